@@ -1,0 +1,387 @@
+"""ORACLE support (test infrastructure) — generate ``tests/golden/*.npz`` by importing the REAL
+reference (``/root/reference``) in the build container and running it on seeded synthetic
+weights/inputs (``esrganplus_amd.synth``).  Also asserts that the functional restatement
+``oracle/ref_torch.py`` reproduces the reference (this is what pins the oracle).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+The reference never travels; only the vectors written here are committed.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from esrganplus_amd import synth          # noqa: E402
+from oracle import ref_import as RI       # noqa: E402
+from oracle import ref_torch as RT        # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+torch.set_grad_enabled(True)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def checks(t):
+    """(sum, abs-sum, L2) in float64 — compact whole-tensor checksums."""
+    a = npy(t).astype(np.float64)
+    return np.array([a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum())])
+
+
+def draw_z(seed, shapes, tag='z'):
+    """Synthetic N(0,1) tensors standing in for GaussianNoise's normal_() draws (block.py:120).
+    They are injected into the reference run with ``inject_z`` so the same numpy-generated z can
+    be rebuilt on the GPU box (no dependence on torch's generator; nothing stored)."""
+    return [synth.normal_like(seed, '%s.%d' % (tag, i), s) for i, s in enumerate(shapes)]
+
+
+class inject_z:
+    """Make the reference's ``self.noise.repeat(*x.size()).normal_()`` return our z tensors, in
+    module execution order (one draw of the full activation shape per noise layer)."""
+
+    def __init__(self, zs):
+        self.zs = list(zs) if zs is not None else None
+
+    def __enter__(self):
+        self.orig = torch.Tensor.normal_
+        if self.zs is None:
+            return self
+        it = iter(self.zs)
+
+        def normal_(t, *a, **k):
+            z = next(it)
+            assert tuple(z.shape) == tuple(t.shape), (z.shape, t.shape)
+            return t.copy_(z)
+        torch.Tensor.normal_ = normal_
+        self.it = it
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.normal_ = self.orig
+        if self.zs is not None and exc[0] is None:
+            assert next(self.it, None) is None, 'not all z consumed'
+
+
+def assert_close(a, b, tol, what):
+    d = (a - b).abs().max().item()
+    print('  restatement vs reference  %-34s max|diff| = %.3e' % (what, d))
+    assert d <= tol, (what, d)
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_rdb():
+    arch, blk = RI.codes_arch()
+    sd = synth.rrdbnet_state_dict(nb=1, seed=11)
+    p = 'model.1.sub.0.RDB1'
+    with RI.cuda_to_cpu():
+        m = blk.ResidualDenseBlock_5C(64)
+    m.load_state_dict({k[len(p) + 1:]: v for k, v in sd.items() if k.startswith(p + '.')})
+    x = synth.normal_like(11, 'rdb.x', (1, 64, 12, 12))
+    gy = synth.normal_like(11, 'rdb.gy', (1, 64, 12, 12))
+    res = {}
+    for mode in ('eval', 'train'):
+        m.train(mode == 'train')
+        xr = x.clone().requires_grad_(True)
+        m.zero_grad()
+        z = draw_z(5, [x.shape], 'rdb.z')[0] if mode == 'train' else None
+        with inject_z(None if z is None else [z]):
+            y = m(xr)
+        (y * gy).sum().backward()
+        # restatement
+        sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith(p)}
+        xo = x.clone().requires_grad_(True)
+        yo = RT.rdb_forward(xo, sdr, p, z)
+        (yo * gy).sum().backward()
+        assert_close(y, yo, 1e-6, 'rdb %s fwd' % mode)
+        assert_close(xr.grad, xo.grad, 1e-5, 'rdb %s grad_x' % mode)
+        assert_close(m.conv5[0].weight.grad, sdr[p + '.conv5.0.weight'].grad, 1e-4,
+                     'rdb %s grad conv5.w' % mode)
+        res['y_' + mode] = npy(y)
+        res['gx_' + mode] = npy(xr.grad)
+        if mode == 'train':
+            res['gw_conv1'] = npy(m.conv1[0].weight.grad)
+            res['gw_conv3'] = npy(m.conv3[0].weight.grad)
+            res['gw_conv5'] = npy(m.conv5[0].weight.grad)
+            res['gb_conv4'] = npy(m.conv4[0].bias.grad)
+            res['gw_conv1x1'] = npy(m.conv1x1.weight.grad)
+    np.savez_compressed(os.path.join(OUT, 'rdb.npz'), **res)
+
+
+def _run_net(net, sd_keys, x, gy, z):
+    net.zero_grad()
+    xr = x.clone().requires_grad_(True)
+    with inject_z(z):
+        y = net(xr)
+    (y * gy).sum().backward()
+    grads = {k: dict(net.named_parameters())[k].grad for k in sd_keys}
+    return y, xr.grad, grads
+
+
+def gen_rrdbnet_small():
+    res = {}
+    for tag, nb, shape, variant in (('a', 1, (1, 3, 16, 20), 'codes'),
+                                    ('b', 2, (2, 3, 24, 24), 'codes'),
+                                    ('c', 1, (1, 3, 13, 18), 'test_image')):
+        sd = synth.rrdbnet_state_dict(nb=nb, seed=20 + nb)
+        net = RI.build_rrdbnet(nb, variant)
+        net.load_state_dict(sd, strict=True)
+        x = synth.image_batch(3, *shape, name='small.x.' + tag)
+        gy = synth.normal_like(3, 'small.gy.' + tag, (shape[0], 3, shape[2] * 4, shape[3] * 4))
+        keys = list(sd.keys())
+        for mode in ('eval', 'train'):
+            net.train(mode == 'train')
+            z = None
+            if mode == 'train':
+                z = draw_z(7, RT.noise_shapes(shape, nb, variant), 'small.z.' + tag)
+            y, gx, grads = _run_net(net, keys, x, gy, z)
+            sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+            xo = x.clone().requires_grad_(True)
+            yo = RT.rrdbnet_forward(xo, sdr, nb, z, variant)
+            (yo * gy).sum().backward()
+            assert_close(y, yo, 2e-6, 'rrdbnet[%s] %s fwd' % (tag, mode))
+            assert_close(gx, xo.grad, 1e-4, 'rrdbnet[%s] %s grad_x' % (tag, mode))
+            gmax = max((grads[k] - sdr[k].grad).abs().max().item() for k in keys)
+            print('  restatement vs reference  rrdbnet[%s] %s param grads max|diff| = %.3e'
+                  % (tag, mode, gmax))
+            assert gmax < 2e-3
+            res['%s_y_%s' % (tag, mode)] = npy(y)
+            res['%s_gx_%s' % (tag, mode)] = npy(gx)
+            res['%s_gchk_%s' % (tag, mode)] = np.stack([checks(grads[k]) for k in keys])
+            if mode == 'train':
+                for k in ('model.0.weight', 'model.1.sub.0.RDB2.conv2.0.weight',
+                          'model.1.sub.0.RDB3.conv1x1.weight', 'model.1.sub.0.RDB1.conv5.0.bias',
+                          'model.6.weight', 'model.10.weight', 'model.10.bias'):
+                    res['%s_g_%s' % (tag, k)] = npy(grads[k])
+    np.savez_compressed(os.path.join(OUT, 'rrdbnet_small.npz'), **res)
+
+
+def gen_rrdbnet_full():
+    from PIL import Image
+    sd = synth.rrdbnet_state_dict(nb=23, seed=0)
+    res = {}
+    for variant in ('codes', 'test_image'):
+        net = RI.build_rrdbnet(23, variant).eval()
+        net.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            x = synth.image_batch(0, 1, 3, 32, 32, name='full.x32')
+            y = net(x)
+            yo = RT.rrdbnet_forward(x, sd, 23, None, variant)
+            assert_close(y, yo, 1e-5, 'rrdbnet nb=23 32x32 (%s)' % variant)
+            if variant == 'codes':
+                res['y32'] = npy(y)
+                y32 = y
+            else:
+                assert_close(y, y32, 0.0, 'test_image copy == codes copy (eval)')
+    # real image, reproducing test_image/test.py:26-40 with PIL instead of cv2
+    img = np.array(Image.open(os.path.join(RI.REF, 'test_image', 'LR', 'baby.png')).convert('RGB'))
+    x = torch.from_numpy(np.transpose(img.astype(np.float64) / 255, (2, 0, 1))).float()[None]
+    with torch.no_grad():
+        y = net(x)
+        yo = RT.rrdbnet_forward(x, sd, 23, None)
+    assert_close(y, yo, 1e-5, 'rrdbnet nb=23 baby.png 128x128')
+    res['baby_lr_rgb'] = img
+    res['baby_y_sub4'] = npy(y)[:, :, ::4, ::4]
+    res['baby_y_chk'] = checks(y)
+    out = y.squeeze().clamp(0, 1).numpy()
+    res['baby_u8_sub4'] = (out * 255.0).round().astype(np.uint8)[:, ::4, ::4]
+    print('  baby.png output range [%.3f, %.3f]' % (y.min().item(), y.max().item()))
+    # odd-shaped natural image (57 wide x 86 tall) — the non-multiple-of-tile edge case
+    img = np.array(Image.open(os.path.join(RI.REF, 'test_image', 'LR', 'woman.png')).convert('RGB'))
+    print('  woman.png shape', img.shape)
+    x = torch.from_numpy(np.transpose(img.astype(np.float64) / 255, (2, 0, 1))).float()[None]
+    with torch.no_grad():
+        y = net(x)
+    res['woman_lr_rgb'] = img
+    res['woman_y_sub4'] = npy(y)[:, :, ::4, ::4]
+    res['woman_y_chk'] = checks(y)
+    np.savez_compressed(os.path.join(OUT, 'rrdbnet_full.npz'), **res)
+
+
+def gen_disc():
+    sd = synth.discriminator_state_dict(seed=4)
+    net = RI.build_discriminator()
+    net.load_state_dict(sd, strict=True)
+    x = synth.image_batch(4, 4, 3, 128, 128, name='disc.x')
+    gy = synth.normal_like(4, 'disc.gy', (4, 1))
+    res = {}
+    # eval forward
+    net.eval()
+    with torch.no_grad():
+        ye = net(x)
+        yo = RT.discriminator_forward(x, {k: v.clone() for k, v in sd.items()}, training=False)
+    assert_close(ye, yo, 1e-4, 'D eval fwd')
+    res['y_eval'] = npy(ye)
+    # train forward + backward, then 3 more forwards (running stats after 4 calls)
+    net.train()
+    xr = x.clone().requires_grad_(True)
+    y = net(xr)
+    (y * gy).sum().backward()
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k
+               else v.clone()) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    yo = RT.discriminator_forward(xo, sdr, training=True)
+    (yo * gy).sum().backward()
+    assert_close(y, yo, 1e-4, 'D train fwd')
+    assert_close(xr.grad, xo.grad, 1e-4, 'D train grad_x')
+    params = dict(net.named_parameters())
+    gmax = max((params[k].grad - sdr[k].grad).abs().max().item() for k in params)
+    print('  restatement vs reference  D param grads max|diff| = %.3e' % gmax)
+    res['y_train'] = npy(y)
+    res['gx_chk'] = checks(xr.grad)
+    res['gx_sub8'] = npy(xr.grad)[:, :, ::8, ::8]
+    keys = list(params.keys())
+    res['gchk'] = np.stack([checks(params[k].grad) for k in keys])
+    for k in ('features.0.weight', 'features.3.weight', 'features.3.bias', 'features.26.bias',
+              'features.27.weight', 'classifier.2.weight', 'classifier.0.bias'):
+        res['g_' + k] = npy(params[k].grad)
+    res['g_features.2.weight_sub'] = npy(params['features.2.weight'].grad)[::4, ::4]
+    with torch.no_grad():
+        for i in range(3):
+            net(x * (0.5 + 0.25 * i))
+            RT.discriminator_forward(x * (0.5 + 0.25 * i), sdr, training=True)
+    bufs = dict(net.named_buffers())
+    for k in ('features.3', 'features.15', 'features.27'):
+        assert_close(bufs[k + '.running_var'], sdr[k + '.running_var'], 1e-5, 'D ' + k + ' rv')
+        res['rm_' + k] = npy(bufs[k + '.running_mean'])
+        res['rv_' + k] = npy(bufs[k + '.running_var'])
+    res['nbt'] = npy(bufs['features.3.num_batches_tracked'])
+    np.savez_compressed(os.path.join(OUT, 'disc.npz'), **res)
+
+
+def _vgg19_features():
+    layers, cin = [], 3
+    for v in synth.VGG19_CFG:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(2, 2))
+        else:
+            layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return nn.Sequential(*layers)
+
+
+def install_vgg_stub(seed):
+    """torchvision is absent; give the stub a ``vgg19`` whose ``features`` is cfg 'E' (the
+    published torchvision layout) loaded with synthetic He weights.  VGG19 parity is therefore
+    NOT pinned by the reference (no weights, no module) — see DESIGN.md."""
+    RI._stub_torchvision()
+
+    def vgg19(pretrained=False):
+        m = types.SimpleNamespace()
+        f = _vgg19_features()
+        f.load_state_dict({k[len('features.'):]: v
+                           for k, v in synth.vgg19_state_dict(seed, 36).items()}, strict=True)
+        m.features = f
+        return m
+    sys.modules['torchvision'].models.vgg19 = vgg19
+    sys.modules['torchvision.models'].vgg19 = vgg19
+
+
+def gen_vgg():
+    install_vgg_stub(6)
+    arch, _ = RI.codes_arch()
+    netF = arch.VGGFeatureExtractor(feature_layer=34, use_bn=False, use_input_norm=True).eval()
+    sd = synth.vgg19_state_dict(6, 34)
+    x = synth.image_batch(6, 2, 3, 128, 128, name='vgg.x')
+    gy = synth.normal_like(6, 'vgg.gy', (2, 512, 8, 8))
+    xr = x.clone().requires_grad_(True)
+    y = netF(xr)
+    (y * gy).sum().backward()
+    xo = x.clone().requires_grad_(True)
+    yo = RT.vgg19_features_forward(xo, sd)
+    (yo * gy).sum().backward()
+    assert_close(y, yo, 1e-4, 'VGG19[:35] fwd')
+    assert_close(xr.grad, xo.grad, 1e-3, 'VGG19[:35] grad_x')
+    print('  VGG feature magnitude: mean|y| = %.3f' % y.abs().mean().item())
+    np.savez_compressed(os.path.join(OUT, 'vgg.npz'), y=npy(y),
+                        gx_sub2=npy(xr.grad)[:, :, ::2, ::2], gx_chk=checks(xr.grad))
+
+
+def gen_train_step():
+    """One real SRRaGANModel.optimize_parameters step (SRRaGAN_model.py:113-186), nb=2, batch 4."""
+    install_vgg_stub(6)
+    sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+    RI.codes_arch()
+    from models import create_model
+    opt = {'model': 'srragan', 'scale': 4, 'gpu_ids': None, 'is_train': True,
+           'path': {'pretrain_model_G': None, 'pretrain_model_D': None},
+           'network_G': {'which_model_G': 'RRDB_net', 'norm_type': None, 'mode': 'CNA', 'nf': 64,
+                         'nb': 2, 'in_nc': 3, 'out_nc': 3, 'gc': 32, 'scale': 4},
+           'network_D': {'which_model_D': 'discriminator_vgg_128', 'norm_type': 'batch',
+                         'act_type': 'leakyrelu', 'mode': 'CNA', 'nf': 64, 'in_nc': 3},
+           'train': {'lr_G': 1e-4, 'weight_decay_G': 0, 'beta1_G': 0.9, 'lr_D': 1e-4,
+                     'weight_decay_D': 0, 'beta1_D': 0.9, 'lr_scheme': 'MultiStepLR',
+                     'lr_steps': [50000, 100000, 200000, 300000], 'lr_gamma': 0.5,
+                     'pixel_criterion': 'l1', 'pixel_weight': 0.01, 'feature_criterion': 'l1',
+                     'feature_weight': 1, 'gan_type': 'vanilla', 'gan_weight': 0.005,
+                     'D_update_ratio': None, 'D_init_iters': None}}
+    with RI.cuda_to_cpu():
+        model = create_model(opt)
+    sdG = synth.rrdbnet_state_dict(nb=2, seed=30)
+    sdD = synth.discriminator_state_dict(seed=31)
+    model.netG.load_state_dict(sdG, strict=True)
+    model.netD.load_state_dict(sdD, strict=True)
+    lr = synth.image_batch(30, 4, 3, 32, 32, name='step.lr')
+    hr = synth.image_batch(30, 4, 3, 128, 128, name='step.hr')
+    model.feed_data({'LR': lr, 'HR': hr})
+    z = draw_z(9, RT.noise_shapes(lr.shape, 2, 'codes'), 'step.z')
+    with inject_z(z):
+        model.optimize_parameters(1)
+    log = model.get_current_log()
+    res = {}
+    for k, v in log.items():
+        res['log_' + k] = np.array(float(v))
+        print('  %-10s %.6e' % (k, float(v)))
+    res['fake_H_chk'] = checks(model.fake_H)
+    res['fake_H_sub4'] = npy(model.fake_H)[:, :, ::4, ::4]
+    g = dict(model.netG.named_parameters())
+    d = dict(model.netD.named_parameters())
+    res['G_new_chk'] = np.stack([checks(g[k]) for k in sdG.keys()])
+    res['D_new_chk'] = np.stack([checks(d[k]) for k in d.keys()])
+    res['G_delta_model.0.weight'] = npy(g['model.0.weight'] - sdG['model.0.weight'])
+    res['D_delta_classifier.2.weight'] = npy(d['classifier.2.weight'] - sdD['classifier.2.weight'])
+    np.savez_compressed(os.path.join(OUT, 'train_step.npz'), **res)
+
+
+def gen_psnr():
+    sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+    RI._stub_torchvision()
+    p = os.path.join(RI.REF, 'codes')
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import importlib
+    util = importlib.import_module('utils.util')
+    res = {}
+    for i, (h, w) in enumerate(((32, 40), (64, 64), (17, 23))):
+        a = synth.image_batch(40 + i, 1, 3, h, w, name='psnr.a')[0] * 1.2 - 0.1
+        b = (a + 0.03 * synth.normal_like(40 + i, 'psnr.n', (3, h, w)))
+        ia, ib = util.tensor2img(a.clone()), util.tensor2img(b.clone())
+        assert (ia == RT.tensor2img(a)).all()
+        ca = (ia / 255.)[4:-4, 4:-4, :] * 255
+        cb = (ib / 255.)[4:-4, 4:-4, :] * 255
+        ps = util.calculate_psnr(ca, cb)
+        assert abs(ps - RT.psnr_sr(a, b, 4)) < 1e-12
+        res['a%d' % i], res['b%d' % i] = npy(a), npy(b)
+        res['img_a%d' % i] = ia
+        res['psnr%d' % i] = np.array(ps)
+        print('  psnr case %d: %.4f dB' % (i, ps))
+    np.savez_compressed(os.path.join(OUT, 'psnr.npz'), **res)
+
+
+if __name__ == '__main__':
+    assert RI.available(), 'reference tree not found — fixtures can only be generated in the build container'
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ['rdb', 'rrdbnet_small', 'rrdbnet_full', 'disc', 'vgg', 'train_step',
+                             'psnr']
+    for w in which:
+        print('[gen_golden]', w)
+        globals()['gen_' + w]()
+    print('done ->', OUT)
