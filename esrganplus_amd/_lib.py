@@ -1,0 +1,163 @@
+"""ctypes binding of libesrgan_hip.so (C ABI declared in include/esrgan_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a kernel launch fails this
+module raises — it never routes through torch ops or the oracle.
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libesrgan_hip.so')
+
+ESR_F16, ESR_F32 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+NOISE_OFF, NOISE_PHILOX, NOISE_EXPLICIT = 0, 1, 2
+OP_CONV, OP_PACK, OP_LAYOUT, OP_NOISE_FILL = 1, 2, 3, 4
+NO_LAYER = 0xFFFFFFFF
+
+
+class esr_g32(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('batch_stride', C.c_int64), ('group_stride', C.c_int64),
+                ('wp', C.c_int32), ('ngroups', C.c_int32)]
+
+
+class esr_conv(C.Structure):
+    _fields_ = [('dtype', C.c_int32), ('ks', C.c_int32), ('stride', C.c_int32),
+                ('upsample', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('cin_groups', C.c_int32), ('cout_blocks', C.c_int32),
+                ('in_', esr_g32), ('out', esr_g32),
+                ('w', C.c_void_p), ('bias', C.c_void_p), ('w1x1', C.c_void_p),
+                ('n1x1_groups', C.c_int32), ('act', C.c_int32),
+                ('aux_out', esr_g32),
+                ('alpha', C.c_float), ('res1', esr_g32),
+                ('beta', C.c_float), ('res2', esr_g32),
+                ('noise_mode', C.c_int32), ('sigma', C.c_float), ('seed', C.c_uint64),
+                ('layer1', C.c_uint32), ('layer2', C.c_uint32),
+                ('z1', esr_g32), ('z2', esr_g32), ('mask', esr_g32), ('out2', esr_g32),
+                ('nchw_out_c', C.c_int32), ('nchw_out', C.c_void_p)]
+
+
+class esr_pack(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('cout', C.c_int32), ('cin', C.c_int32),
+                ('ks', C.c_int32), ('dtype', C.c_int32), ('transpose_flip', C.c_int32),
+                ('cin_offset', C.c_int32), ('cin_count', C.c_int32)]
+
+
+class esr_layout(C.Structure):
+    _fields_ = [('dtype', C.c_int32), ('to_g32', C.c_int32), ('B', C.c_int32), ('C', C.c_int32),
+                ('H', C.c_int32), ('W', C.c_int32), ('nchw', C.c_void_p), ('g32', esr_g32),
+                ('use_affine', C.c_int32), ('mean_c', C.c_float * 4), ('inv_std_c', C.c_float * 4)]
+
+
+class esr_noise_fill(C.Structure):
+    _fields_ = [('dst', C.c_void_p), ('B', C.c_int32), ('C', C.c_int32), ('H', C.c_int32),
+                ('W', C.c_int32), ('seed', C.c_uint64), ('layer', C.c_uint32)]
+
+
+class _op_union(C.Union):
+    _fields_ = [('conv', esr_conv), ('pack', esr_pack), ('layout', esr_layout),
+                ('noise_fill', esr_noise_fill)]
+
+
+class esr_op(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('_pad', C.c_int32), ('u', _op_union)]
+
+
+# every symbol include/esrgan_hip.h declares (tests check the .so exports all of them)
+EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_pack_conv_weights',
+           'esr_convert_layout', 'esr_fill_noise', 'esr_run_ops', 'esr_last_error',
+           'esr_abi_version', 'esr_sizeof_op']
+
+_lib = None
+_lock = threading.Lock()
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libesrgan_hip.so once; raise loudly if it is missing or does not match this binding."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionError(
+                'esrganplus_amd: %s not found — build it with `python -c "import __graft_entry__ as g; '
+                'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU/eager fallback.' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                raise HipExtensionError('libesrgan_hip.so lacks symbol ' + name)
+        L.esr_last_error.restype = C.c_char_p
+        L.esr_sizeof_op.restype = C.c_size_t
+        L.esr_packed_weight_bytes.restype = C.c_size_t
+        L.esr_packed_weight_bytes.argtypes = [C.c_int32] * 4
+        L.esr_g32_dims.restype = None
+        L.esr_g32_dims.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.esr_run_ops.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        for name, st in (('esr_conv_forward', esr_conv), ('esr_pack_conv_weights', esr_pack),
+                         ('esr_convert_layout', esr_layout), ('esr_fill_noise', esr_noise_fill)):
+            getattr(L, name).argtypes = [C.POINTER(st), C.c_void_p]
+        if L.esr_sizeof_op() != C.sizeof(esr_op):
+            raise HipExtensionError('ABI mismatch: sizeof(esr_op) C=%d ctypes=%d'
+                                    % (L.esr_sizeof_op(), C.sizeof(esr_op)))
+        _lib = L
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise HipExtensionError('%s failed (%d): %s' % (what or 'libesrgan_hip', rc,
+                                                        lib().esr_last_error().decode()))
+
+
+def g32_dims(h, w):
+    hp, wp = C.c_int32(), C.c_int32()
+    lib().esr_g32_dims(h, w, C.byref(hp), C.byref(wp))
+    return hp.value, wp.value
+
+
+def packed_weight_bytes(cout, cin, ks, dtype):
+    return lib().esr_packed_weight_bytes(cout, cin, ks, dtype)
+
+
+class OpList:
+    """A recorded launch sequence: a contiguous array of esr_op replayed by ONE C call."""
+
+    def __init__(self):
+        self.ops = []
+        self._arr = None
+        self.keep = []   # tensors referenced by raw pointers in the ops
+
+    def add_conv(self, conv):
+        o = esr_op()
+        o.kind = OP_CONV
+        o.u.conv = conv
+        self.ops.append(o)
+        self._arr = None
+        return len(self.ops) - 1
+
+    def add(self, kind, field, st):
+        o = esr_op()
+        o.kind = kind
+        setattr(o.u, field, st)
+        self.ops.append(o)
+        self._arr = None
+        return len(self.ops) - 1
+
+    def array(self):
+        if self._arr is None:
+            self._arr = (esr_op * len(self.ops))(*self.ops)
+        return self._arr
+
+    def run(self, stream):
+        if not self.ops:
+            return
+        arr = self.array()
+        check(lib().esr_run_ops(C.cast(arr, C.c_void_p), len(self.ops), C.c_void_p(stream)),
+              'esr_run_ops')

@@ -1,0 +1,247 @@
+"""Drop-in for the reference's ``block`` module on the ESRGAN+ hot path
+(codes/models/modules/block.py and test_image/block.py).
+
+Same factory names, constructor arguments, module tree and state-dict keys as the reference, so
+``networks.init_weights`` (networks.py:30-74, matches class names 'Conv'/'BatchNorm2d'), optimizers,
+``load_state_dict`` and checkpoints keep working.  The leaf ``nn.Conv2d`` / ``nn.LeakyReLU`` /
+``nn.Upsample`` modules are *parameter holders only*: arithmetic never runs through them.  The
+composite modules (``ResidualDenseBlock_5C``, ``RRDB``, and ``RRDBNet`` in architecture.py) execute
+as fused HIP launch plans (engine.py -> libesrgan_hip.so) and raise on CPU tensors.
+
+Out of scope here exactly as SURVEY.md §2.1 row 1 marks them: ResNetBlock, pixelshuffle_block,
+ConcatBlock, minibatch_std_concat_layer, reflect/replicate padding, prelu, instance norm, NAC mode.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from . import _lib as L
+
+
+def act(act_type, inplace=True, neg_slope=0.2, n_prelu=1):
+    """block.py:12-25 (leakyrelu / relu on this path)."""
+    t = act_type.lower()
+    if t == 'relu':
+        return nn.ReLU(inplace)
+    if t == 'leakyrelu':
+        return nn.LeakyReLU(neg_slope, inplace)
+    raise NotImplementedError('activation layer [{:s}] is not found'.format(t))
+
+
+def norm(norm_type, nc):
+    """block.py:28-37 (batch norm only: Discriminator_VGG_128)."""
+    t = norm_type.lower()
+    if t == 'batch':
+        return nn.BatchNorm2d(nc, affine=True)
+    raise NotImplementedError('normalization layer [{:s}] is not found'.format(t))
+
+
+def pad(pad_type, padding):
+    """block.py:40-52: only conv-internal zero padding exists on the hot path."""
+    if padding == 0 or pad_type.lower() == 'zero':
+        return None
+    raise NotImplementedError('padding layer [{:s}] is not implemented'.format(pad_type.lower()))
+
+
+def get_valid_padding(kernel_size, dilation):
+    """block.py:55-58."""
+    kernel_size = kernel_size + (kernel_size - 1) * (dilation - 1)
+    return (kernel_size - 1) // 2
+
+
+def sequential(*args):
+    """block.py:95-108: flattening Sequential (fixes the ``model.N`` key numbering)."""
+    if len(args) == 1:
+        if isinstance(args[0], OrderedDict):
+            raise NotImplementedError('sequential does not support OrderedDict input.')
+        return args[0]
+    mods = []
+    for m in args:
+        if isinstance(m, nn.Sequential):
+            mods.extend(m.children())
+        elif isinstance(m, nn.Module):
+            mods.append(m)
+    return nn.Sequential(*mods)
+
+
+def conv_block(in_nc, out_nc, kernel_size, stride=1, dilation=1, groups=1, bias=True,
+               pad_type='zero', norm_type=None, act_type='relu', mode='CNA'):
+    """block.py:125-151 — Conv(zero pad (k-1)//2) -> Norm -> Act holder chain ('CNA' only)."""
+    if mode != 'CNA':
+        raise NotImplementedError('conv mode [{:s}] is outside the ESRGAN+ hot path'.format(mode))
+    if dilation != 1 or groups != 1:
+        raise NotImplementedError('dilation/groups are outside the ESRGAN+ hot path')
+    p = pad(pad_type, get_valid_padding(kernel_size, dilation)) if pad_type else None
+    c = nn.Conv2d(in_nc, out_nc, kernel_size=kernel_size, stride=stride,
+                  padding=get_valid_padding(kernel_size, dilation), dilation=1, bias=bias, groups=1)
+    a = act(act_type) if act_type else None
+    n = norm(norm_type, out_nc) if norm_type else None
+    return sequential(p, c, n, a)
+
+
+def conv1x1(in_planes, out_planes, stride=1):
+    """block.py:153-154 (bias-free)."""
+    return nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
+
+
+def upconv_blcok(in_nc, out_nc, upscale_factor=2, kernel_size=3, stride=1, bias=True,
+                 pad_type='zero', norm_type=None, act_type='relu', mode='nearest'):
+    """block.py:315-322 (sic: reference spelling)."""
+    if upscale_factor != 2 or mode != 'nearest':
+        raise NotImplementedError('only nearest x2 upconv is on the ESRGAN+ hot path')
+    up = nn.Upsample(scale_factor=upscale_factor, mode=mode)
+    return sequential(up, conv_block(in_nc, out_nc, kernel_size, stride, bias=bias,
+                                     pad_type=pad_type, norm_type=norm_type, act_type=act_type))
+
+
+def pixelshuffle_block(*a, **k):
+    raise NotImplementedError('pixelshuffle upsampling is outside the ESRGAN+ hot path '
+                              '(RRDBNet uses upconv, networks.py:99)')
+
+
+class GaussianNoise(nn.Module):
+    """block.py:110-122.  Holds no parameters/buffers (empty state dict, like the reference); the
+    multiplicative noise x*(1+sigma*z) itself is a fused conv epilogue.  Unlike the reference it
+    does not pin a tensor to device 0 at construction, so replicas on any device work."""
+
+    def __init__(self, sigma=0.1, is_relative_detach=False):
+        super().__init__()
+        if is_relative_detach:
+            raise NotImplementedError('is_relative_detach=True is never used by the reference')
+        self.sigma = sigma
+        self.is_relative_detach = is_relative_detach
+
+    def forward(self, x):
+        raise L.HipExtensionError('GaussianNoise is fused into its producer conv; call the '
+                                  'enclosing ResidualDenseBlock_5C / RRDB / RRDBNet instead')
+
+
+class ShortcutBlock(nn.Module):
+    """block.py:78-92 — x + sub(x); executed as the LR_conv epilogue inside RRDBNet's plan."""
+
+    def __init__(self, submodule):
+        super().__init__()
+        self.sub = submodule
+
+    def forward(self, x):
+        raise L.HipExtensionError('ShortcutBlock is fused into RRDBNet.forward; call the network')
+
+    def __repr__(self):
+        return 'Identity + \n|' + self.sub.__repr__().replace('\n', '\n|')
+
+
+class _PlannedModule(nn.Module):
+    """Shared machinery: weight pack + per-shape launch plans + autograd hookup."""
+
+    variant = 'codes'
+
+    def _init_planned(self):
+        self._wp = {}
+        self._plans = {}
+        self.precision = 'fp32'       # 'fp32' (exact path, reference numerics) or 'fp16'
+        self._force_repack = True
+
+    def set_precision(self, precision):
+        """'fp32': v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain) — the <=1e-3 parity path.
+        'fp16': fp16 storage + v_mfma_f32_32x32x16_f16 with fp32 accumulation — the fast path."""
+        if precision not in ('fp16', 'fp32'):
+            raise ValueError(precision)
+        self.precision = precision
+        return self
+
+    def invalidate(self):
+        """Force a weight re-pack on the next forward (needed after ``p.data`` surgery that does
+        not bump the parameter version, e.g. networks.py:32-34)."""
+        self._force_repack = True
+
+    # nn.Module hooks that change parameter values behind our back
+    def apply(self, fn):
+        self._force_repack = True
+        return super().apply(fn)
+
+    def _apply(self, fn, *a, **k):
+        self._force_repack = True
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._force_repack = True
+        return super().load_state_dict(*a, **k)
+
+    def _conv_list(self):
+        raise NotImplementedError
+
+    def _weights(self, device):
+        key = (self.precision, str(device))
+        wp = self._wp.get(key)
+        if wp is None:
+            wp = E.WeightPack(self._conv_list(), self.precision, device)
+            self._wp[key] = wp
+        wp.ensure(E.current_stream(), force=self._force_repack or self.training)
+        self._force_repack = False
+        return wp
+
+
+def _rdb_convs(prefix, m):
+    out = [(prefix + '.conv1x1', m.conv1x1.weight, None)]
+    for k in range(1, 6):
+        c = getattr(m, 'conv%d' % k)[0]
+        out.append((prefix + '.conv%d.0' % k, c.weight, c.bias))
+    return out
+
+
+class ResidualDenseBlock_5C(_PlannedModule):
+    """block.py:232-268 (``gaussian_noise``) / test_image/block.py:195-232 (``noise_input``)."""
+
+    def __init__(self, nc, kernel_size=3, gc=32, stride=1, bias=True, pad_type='zero',
+                 norm_type=None, act_type='leakyrelu', mode='CNA', gaussian_noise=True,
+                 noise_input=None):
+        super().__init__()
+        if noise_input is not None:
+            gaussian_noise = noise_input
+        if (nc, kernel_size, gc, stride, bias, norm_type, act_type.lower(), mode) != \
+                (64, 3, 32, 1, True, None, 'leakyrelu', 'CNA'):
+            raise NotImplementedError('HIP ResidualDenseBlock_5C supports the ESRGAN+ configuration '
+                                      'nc=64, gc=32, 3x3, leakyrelu, CNA')
+        self.noise = GaussianNoise() if gaussian_noise else None
+        self.conv1x1 = conv1x1(nc, gc)
+        for k in range(1, 5):
+            setattr(self, 'conv%d' % k, conv_block(nc + (k - 1) * gc, gc, kernel_size, stride,
+                                                   bias=bias, pad_type=pad_type, norm_type=norm_type,
+                                                   act_type=act_type, mode=mode))
+        self.conv5 = conv_block(nc + 4 * gc, nc, 3, stride, bias=bias, pad_type=pad_type,
+                                norm_type=norm_type, act_type=None, mode=mode)
+        self._init_planned()
+
+    def _conv_list(self):
+        return _rdb_convs('rdb', self)
+
+    def forward(self, x, z=None):
+        from .functional import run_block
+        return run_block(self, 'rdb', x, z)
+
+
+class RRDB(_PlannedModule):
+    """block.py:271-291; ``extra_noise`` selects the test_image/block.py:250,256 variant."""
+
+    def __init__(self, nc, kernel_size=3, gc=32, stride=1, bias=True, pad_type='zero',
+                 norm_type=None, act_type='leakyrelu', mode='CNA', extra_noise=False):
+        super().__init__()
+        for j in (1, 2, 3):
+            setattr(self, 'RDB%d' % j, ResidualDenseBlock_5C(nc, kernel_size, gc, stride, bias,
+                                                             pad_type, norm_type, act_type, mode))
+        if extra_noise:
+            self.noise = GaussianNoise()
+            self.variant = 'test_image'
+        self._init_planned()
+
+    def _conv_list(self):
+        out = []
+        for j in (1, 2, 3):
+            out += _rdb_convs('rrdb.RDB%d' % j, getattr(self, 'RDB%d' % j))
+        return out
+
+    def forward(self, x, z=None):
+        from .functional import run_block
+        return run_block(self, 'rrdb', x, z)

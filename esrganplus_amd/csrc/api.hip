@@ -1,0 +1,56 @@
+// api.hip — error plumbing, geometry helper and the op-list runner of libesrgan_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+void esr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int esr_check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    esr_set_error("%s: %s", what, hipGetErrorString(e));
+    return ESR_ERR_LAUNCH;
+  }
+  return ESR_OK;
+}
+
+extern "C" const char* esr_last_error(void) { return g_err; }
+extern "C" int esr_abi_version(void) { return 1; }
+extern "C" size_t esr_sizeof_op(void) { return sizeof(esr_op); }
+
+extern "C" void esr_g32_dims(int32_t H, int32_t W, int32_t* Hp, int32_t* Wp) {
+  // 1-pixel zero ring + room for the largest tile overhang (rows) and wrap-around reads (cols).
+  if (Hp) *Hp = ((H + 31) / 32) * 32 + 6;
+  if (Wp) *Wp = ((W + 31) / 32) * 32 + 2;
+}
+
+extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
+  if (!ops || n < 0) { esr_set_error("esr_run_ops: invalid arguments"); return ESR_ERR_INVALID; }
+  for (int i = 0; i < n; ++i) {
+    int rc;
+    switch (ops[i].kind) {
+      case ESR_OP_CONV: rc = esr_conv_forward(&ops[i].u.conv, stream); break;
+      case ESR_OP_PACK: rc = esr_pack_conv_weights(&ops[i].u.pack, stream); break;
+      case ESR_OP_LAYOUT: rc = esr_convert_layout(&ops[i].u.layout, stream); break;
+      case ESR_OP_NOISE_FILL: rc = esr_fill_noise(&ops[i].u.noise_fill, stream); break;
+      default: esr_set_error("esr_run_ops: op %d has unknown kind %d", i, ops[i].kind); return ESR_ERR_INVALID;
+    }
+    if (rc != ESR_OK) {
+      char tmp[400];
+      snprintf(tmp, sizeof(tmp), "%s", esr_last_error());
+      esr_set_error("op %d (kind %d): %s", i, ops[i].kind, tmp);
+      return rc;
+    }
+  }
+  return ESR_OK;
+}

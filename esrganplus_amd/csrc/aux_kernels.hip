@@ -1,0 +1,152 @@
+// aux_kernels.hip — weight packing, NCHW<->G32 layout conversion, noise fill.
+#include "common.h"
+
+namespace {
+
+// One thread per 16-byte fragment piece: [cb][chunk][kh][kw][lane] -> 8 halves / 4 floats.
+template <typename T>
+__global__ void pack_kernel(const esr_pack p, int nchunks, int64_t total) {
+  constexpr int CPG = DT<T>::CPG;
+  constexpr int EPL = CPG / 2;   // elements per lane (8 halves / 4 floats)
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  int64_t rest = idx >> 6;
+  const int taps = p.ks * p.ks;
+  const int tap = rest % taps; rest /= taps;
+  const int chunk = rest % nchunks;
+  const int cb = rest / nchunks;
+  const int kh = tap / p.ks, kw = tap % p.ks;
+  const int i = lane & 31, h = lane >> 5;
+  const int co = cb * 32 + esr_pi(i);
+  T v[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int ci = chunk * CPG + EPL * h + e;
+    float x = 0.f;
+    if (co < p.cout && ci < p.cin) {
+      if (!p.transpose_flip) {
+        // src is OIHW [cout][cin][ks][ks]
+        x = p.src[(((int64_t)co * p.cin + ci) * p.ks + kh) * p.ks + kw];
+      } else {
+        // dgrad operand: the conv maps forward-Cout (= our cin) to forward-Cin (= our cout) with
+        // taps rotated 180 degrees; src is the forward OIHW [cin][cout][ks][ks]
+        x = p.src[(((int64_t)ci * p.cout + co) * p.ks + (p.ks - 1 - kh)) * p.ks + (p.ks - 1 - kw)];
+      }
+    }
+    v[e] = (T)x;
+  }
+  T* dst = (T*)p.dst + idx * EPL;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) dst[e] = v[e];
+}
+
+template <typename T>
+__global__ void to_g32_kernel(const esr_layout p) {
+  constexpr int CPG = DT<T>::CPG;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int g = blockIdx.z % p.g32.ngroups, b = blockIdx.z / p.g32.ngroups;
+  if (x >= p.W) return;
+  T v[CPG];
+#pragma unroll
+  for (int e = 0; e < CPG; ++e) {
+    const int c = g * CPG + e;
+    float f = 0.f;
+    if (c < p.C) {
+      f = p.nchw[(((int64_t)b * p.C + c) * p.H + y) * p.W + x];
+      if (p.use_affine && c < 4) f = (f - p.mean_c[c]) * p.inv_std_c[c];
+    }
+    v[e] = (T)f;
+  }
+  char* dst = (char*)p.g32.ptr + b * p.g32.batch_stride + (int64_t)g * p.g32.group_stride +
+              ((int64_t)(y + 1) * p.g32.wp + x + 1) * 32;
+  const u32x4* s = (const u32x4*)v;
+  ((u32x4*)dst)[0] = s[0];
+  ((u32x4*)dst)[1] = s[1];
+}
+
+template <typename T>
+__global__ void from_g32_kernel(const esr_layout p) {
+  constexpr int CPG = DT<T>::CPG;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int g = blockIdx.z % p.g32.ngroups, b = blockIdx.z / p.g32.ngroups;
+  if (x >= p.W) return;
+  const char* src = (const char*)p.g32.ptr + b * p.g32.batch_stride + (int64_t)g * p.g32.group_stride +
+                    ((int64_t)(y + 1) * p.g32.wp + x + 1) * 32;
+  T v[CPG];
+  ((u32x4*)v)[0] = ((const u32x4*)src)[0];
+  ((u32x4*)v)[1] = ((const u32x4*)src)[1];
+#pragma unroll
+  for (int e = 0; e < CPG; ++e) {
+    const int c = g * CPG + e;
+    if (c < p.C) p.nchw[(((int64_t)b * p.C + c) * p.H + y) * p.W + x] = (float)v[e];
+  }
+}
+
+__global__ void noise_fill_kernel(const esr_noise_fill p) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int cq = blockIdx.z % ((p.C + 3) / 4), b = blockIdx.z / ((p.C + 3) / 4);
+  if (x >= p.W) return;
+  float z[4];
+  philox_normal4((uint32_t)((b * p.H + y) * p.W + x), (uint32_t)cq, p.layer, p.seed, z);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = cq * 4 + e;
+    if (c < p.C) p.dst[(((int64_t)b * p.C + c) * p.H + y) * p.W + x] = z[e];
+  }
+}
+
+}  // namespace
+
+extern "C" size_t esr_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ks, int32_t dtype) {
+  const int cpg = dtype == ESR_F16 ? 16 : 8;
+  const size_t cbs = (cout + 31) / 32, chunks = (cin + cpg - 1) / cpg;
+  return cbs * chunks * ks * ks * 1024;
+}
+
+extern "C" int esr_pack_conv_weights(const esr_pack* p, esr_stream_t stream) {
+  if (!p || !p->src || !p->dst || p->cout <= 0 || p->cin <= 0 || (p->ks != 1 && p->ks != 3 && p->ks != 4) ||
+      p->cin_offset != 0 || p->cin_count != 0) {
+    esr_set_error("esr_pack_conv_weights: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  const int cpg = p->dtype == ESR_F16 ? 16 : 8;
+  const int nchunks = (p->cin + cpg - 1) / cpg;
+  const int64_t total = (int64_t)((p->cout + 31) / 32) * nchunks * p->ks * p->ks * 64;
+  const int blocks = (int)((total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (p->dtype == ESR_F16) hipLaunchKernelGGL(pack_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, *p, nchunks, total);
+  else if (p->dtype == ESR_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, *p, nchunks, total);
+  else { esr_set_error("esr_pack_conv_weights: bad dtype"); return ESR_ERR_INVALID; }
+  return esr_check_launch("pack_kernel");
+}
+
+extern "C" int esr_convert_layout(const esr_layout* p, esr_stream_t stream) {
+  if (!p || !p->nchw || !p->g32.ptr || p->B <= 0 || p->C <= 0 || p->H <= 0 || p->W <= 0 || p->g32.ngroups <= 0) {
+    esr_set_error("esr_convert_layout: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((p->W + 63) / 64, p->H, p->B * p->g32.ngroups), block(64);
+  if (p->dtype == ESR_F16) {
+    if (p->to_g32) hipLaunchKernelGGL(to_g32_kernel<_Float16>, grid, block, 0, st, *p);
+    else hipLaunchKernelGGL(from_g32_kernel<_Float16>, grid, block, 0, st, *p);
+  } else if (p->dtype == ESR_F32) {
+    if (p->to_g32) hipLaunchKernelGGL(to_g32_kernel<float>, grid, block, 0, st, *p);
+    else hipLaunchKernelGGL(from_g32_kernel<float>, grid, block, 0, st, *p);
+  } else { esr_set_error("esr_convert_layout: bad dtype"); return ESR_ERR_INVALID; }
+  return esr_check_launch("layout_kernel");
+}
+
+extern "C" int esr_fill_noise(const esr_noise_fill* p, esr_stream_t stream) {
+  if (!p || !p->dst || p->B <= 0 || p->C <= 0 || p->H <= 0 || p->W <= 0) {
+    esr_set_error("esr_fill_noise: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  dim3 grid((p->W + 63) / 64, p->H, p->B * ((p->C + 3) / 4));
+  hipLaunchKernelGGL(noise_fill_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
+  return esr_check_launch("noise_fill_kernel");
+}

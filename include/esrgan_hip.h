@@ -1,0 +1,157 @@
+/* esrgan_hip.h — C ABI of libesrgan_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (ncarraz/ESRGANplus) has no FFI layer: its hot path is expressed as stock
+ * torch.nn modules that dispatch to cuDNN/cuBLAS.  This header is the boundary a maintainer binds
+ * instead (INTEGRATION.md shows the ctypes stub): every entry point replaces the library call made
+ * by the cited reference line.  Plain C types only; all buffers are caller-owned device memory;
+ * every launch goes to the caller's hipStream_t; the library never allocates, never synchronises
+ * and never changes the current device (graph-capture safe).  Every entry returns 0 on success
+ * or a negative esr_status; esr_last_error() gives a per-thread message.
+ *
+ * ---- activation layout "G32" -----------------------------------------------------------------
+ * A tensor of C channels is stored as ngroups = ceil(C / cpg) planes of 32-byte channel groups
+ * (cpg = 16 for fp16, 8 for fp32):   [B][ngroups][Hp][Wp][32 bytes]
+ * Logical pixel (y,x) lives at padded coordinates (y+1, x+1); row 0 / column 0 and everything at
+ * or beyond (H+1, W+1) is ZERO and is never written by any kernel (this is the conv zero padding
+ * of block.py:55-58,137 — the halo is physical, so kernels need no bounds checks on loads).
+ * Hp >= roundup(H,32)+6, Wp >= roundup(W,32)+2 (see esr_g32_dims).
+ */
+#ifndef ESRGAN_HIP_H
+#define ESRGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* esr_stream_t; /* hipStream_t */
+
+enum esr_status {
+  ESR_OK = 0,
+  ESR_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
+  ESR_ERR_LAUNCH = -2,      /* HIP launch error (message in esr_last_error) */
+  ESR_ERR_UNSUPPORTED = -3
+};
+
+enum esr_dtype { ESR_F16 = 0, ESR_F32 = 1 };
+enum esr_act { ESR_ACT_NONE = 0, ESR_ACT_LRELU = 1 /* slope 0.2, block.py:12 */, ESR_ACT_RELU = 2 };
+enum esr_noise { ESR_NOISE_OFF = 0, ESR_NOISE_PHILOX = 1, ESR_NOISE_EXPLICIT = 2 };
+
+/* One G32 tensor view (pointer already offset to the first channel group of interest). */
+typedef struct esr_g32 {
+  void* ptr;
+  int64_t batch_stride; /* bytes */
+  int64_t group_stride; /* bytes */
+  int32_t wp;           /* row pitch in pixels (32-byte units) */
+  int32_t ngroups;      /* groups addressable through this view */
+} esr_g32;
+
+/* Fused convolution.  Replaces nn.Conv2d + LeakyReLU/ReLU + the elementwise tail the reference
+ * runs as separate kernels (conv_block block.py:125-151; RDB tail block.py:263,266,268; RRDB
+ * tail block.py:291 / test_image/block.py:256; ShortcutBlock block.py:84-86; nearest upsample
+ * block.py:315-322 folded into the load).  Epilogue, per output element, in this order:
+ *     v = acc + bias;  v = act(v);  [aux_out = v];  v += acc_1x1;
+ *     v = v*alpha + res1;  v *= (1 + sigma*z1);  v = v*beta + res2;  v *= (1 + sigma*z2)
+ * (each step skipped when its operand is absent).  dgrad mode (mask != NULL) additionally writes
+ *     out2 = v * lrelu'(mask)   (lrelu' = 1 if mask>0 else 0.2; relu' for act==RELU)            */
+typedef struct esr_conv {
+  int32_t dtype;       /* esr_dtype: storage type of every G32 tensor here (accumulate fp32) */
+  int32_t ks;          /* 1, 3 or 4 */
+  int32_t stride;      /* 1, or 2 (ks==4) */
+  int32_t upsample;    /* 1: input is nearest-x2 upsampled on load (ks==3 only) */
+  int32_t B, H, W;     /* OUTPUT logical size */
+  int32_t cin_groups;  /* K loop length: input channel groups read from `in` */
+  int32_t cout_blocks; /* ceil(Cout/32) */
+  esr_g32 in;
+  esr_g32 out;         /* out.ngroups bounds the groups actually stored */
+  const void* w;       /* packed by esr_pack_conv_weights */
+  const float* bias;   /* fp32 [cout_blocks*32] or NULL */
+  const void* w1x1;    /* packed 1x1 (bias-free, block.py:153-154,263) or NULL */
+  int32_t n1x1_groups; /* input groups the 1x1 reads (prefix of `in`) */
+  int32_t act;         /* esr_act */
+  esr_g32 aux_out;     /* ptr NULL = off */
+  float alpha; esr_g32 res1;
+  float beta;  esr_g32 res2;
+  int32_t noise_mode;  /* esr_noise */
+  float sigma;         /* 0.1, block.py:111 */
+  uint64_t seed;       /* philox key */
+  uint32_t layer1, layer2; /* philox stream ids of z1 / z2; layer==0xFFFFFFFF = that noise off */
+  esr_g32 z1, z2;      /* explicit z (G32, same dtype); ptr NULL = off */
+  esr_g32 mask;        /* dgrad: saved activation whose sign gives act' (ptr NULL = off) */
+  esr_g32 out2;        /* dgrad: masked output */
+  int32_t nchw_out_c;  /* >0: ALSO store the first nchw_out_c channels as fp32 NCHW */
+  float* nchw_out;     /* [B][nchw_out_c][H][W] */
+} esr_conv;
+
+/* Weight packing: OIHW fp32 master (the nn.Parameter the reference keeps, e.g. state-dict key
+ * model.1.sub.0.RDB1.conv1.0.weight) -> MFMA A-fragment order
+ *   [cout_block][cin_group][kh][kw][lane 0..63][16 bytes].
+ * transpose_flip=1 packs the dgrad operand (Cin<->Cout swapped, taps rotated 180 degrees). */
+typedef struct esr_pack {
+  const float* src;    /* OIHW fp32 */
+  void* dst;
+  int32_t cout, cin, ks;
+  int32_t dtype;
+  int32_t transpose_flip;
+  int32_t cin_offset;  /* first input channel to pack (dgrad slices), normally 0 */
+  int32_t cin_count;   /* channels to pack starting at cin_offset (0 = all) */
+} esr_pack;
+
+size_t esr_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ks, int32_t dtype);
+
+/* NCHW fp32 <-> G32 (the tensors crossing the nn.Module boundary are NCHW fp32:
+ * test_image/test.py:31-37, SRRaGAN_model.py:103-111). */
+typedef struct esr_layout {
+  int32_t dtype;
+  int32_t to_g32;      /* 1: NCHW -> G32 (pads channels with zeros), 0: G32 -> NCHW */
+  int32_t B, C, H, W;
+  float* nchw;
+  esr_g32 g32;
+  int32_t use_affine;  /* to_g32 only, C <= 4: v = (v - mean_c[c]) * inv_std_c[c]  (VGG input
+                          norm, architecture.py:304-305) */
+  float mean_c[4];
+  float inv_std_c[4];
+} esr_layout;
+
+/* Philox-4x32-10 N(0,1) fill, NCHW fp32 — the exact z the fused noise epilogue uses for
+ * (seed, layer); lets tests feed the same z to the oracle (GaussianNoise, block.py:117-122). */
+typedef struct esr_noise_fill {
+  float* dst; int32_t B, C, H, W; uint64_t seed; uint32_t layer;
+} esr_noise_fill;
+
+enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_NOISE_FILL = 4 };
+
+typedef struct esr_op {
+  int32_t kind;
+  int32_t _pad;
+  union {
+    esr_conv conv;
+    esr_pack pack;
+    esr_layout layout;
+    esr_noise_fill noise_fill;
+  } u;
+} esr_op;
+
+/* Geometry helper: padded plane size for a logical HxW image. */
+void esr_g32_dims(int32_t H, int32_t W, int32_t* Hp, int32_t* Wp);
+
+/* Single-op entry points. */
+int esr_conv_forward(const esr_conv* p, esr_stream_t stream);
+int esr_pack_conv_weights(const esr_pack* p, esr_stream_t stream);
+int esr_convert_layout(const esr_layout* p, esr_stream_t stream);
+int esr_fill_noise(const esr_noise_fill* p, esr_stream_t stream);
+
+/* Run a recorded list of ops back to back on `stream` (one host call per network pass; this is
+ * what RRDBNet.forward — architecture.py:76-78 — becomes). */
+int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream);
+
+const char* esr_last_error(void);
+int esr_abi_version(void);
+size_t esr_sizeof_op(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESRGAN_HIP_H */

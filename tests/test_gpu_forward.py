@@ -1,0 +1,180 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP path, called through the C ABI, against
+the oracle / golden fixtures.  Tolerances: fp32 path <= 1e-3 max-abs (measured
+far tighter), fp16 path judged by PSNR within 0.01 dB and a loose max-abs sanity bound."""
+import numpy as np
+import pytest
+import torch
+
+from esrganplus_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from esrganplus_amd import _lib
+    _lib.lib()   # fail loudly if the HIP extension is missing
+    return torch.device('cuda:0')
+
+
+def zs(seed, shapes, tag):
+    return [synth.normal_like(seed, '%s.%d' % (tag, i), s) for i, s in enumerate(shapes)]
+
+
+CONV_CASES = [
+    # cin, cout, ks, stride, upsample, act, (B,H,W)
+    (64, 32, 3, 1, False, 'leakyrelu', (2, 16, 64)),
+    (96, 32, 3, 1, False, 'leakyrelu', (1, 19, 37)),     # ragged tile edges
+    (192, 64, 3, 1, False, None, (1, 24, 40)),
+    (3, 64, 3, 1, False, None, (2, 9, 33)),              # channel padding 3 -> group
+    (64, 3, 3, 1, False, None, (1, 40, 72)),             # cout padding 3 -> 32
+    (64, 64, 3, 1, True, 'leakyrelu', (1, 12, 20)),      # nearest x2 folded into the load
+    (64, 64, 4, 2, False, 'leakyrelu', (2, 32, 64)),     # discriminator 4x4/s2
+    (128, 256, 3, 1, False, 'relu', (1, 16, 16)),        # VGG-style wide conv
+    (64, 32, 1, 1, False, None, (1, 10, 34)),            # 1x1
+    (32, 32, 3, 1, False, None, (1, 1, 1)),              # degenerate 1x1 image
+]
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16'])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_single_conv(dev, case, precision):
+    from esrganplus_amd import ops
+    cin, cout, ks, stride, ups, act, (B, H, W) = case
+    g = np.random.default_rng(hash(case) % 1000)
+    x = torch.from_numpy(g.standard_normal((B, cin, H, W), dtype=np.float32))
+    w = torch.from_numpy(g.standard_normal((cout, cin, ks, ks), dtype=np.float32)) / np.sqrt(cin * ks * ks)
+    b = torch.from_numpy(g.standard_normal(cout, dtype=np.float32))
+    xi = torch.nn.functional.interpolate(x, scale_factor=2, mode='nearest') if ups else x
+    ref = torch.nn.functional.conv2d(xi, w, b, stride=stride, padding=(ks - 1) // 2)
+    if act == 'leakyrelu':
+        ref = torch.nn.functional.leaky_relu(ref, 0.2)
+    elif act == 'relu':
+        ref = torch.relu(ref)
+    y = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), stride=stride, act=act, upsample=ups,
+                   precision=precision).cpu()
+    assert y.shape == ref.shape
+    tol = 2e-5 if precision == 'fp32' else 3e-2
+    assert (y - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('fp16', 5e-2)])
+def test_rdb_golden(dev, golden, precision, tol):
+    from esrganplus_amd import block as B
+    g = golden('rdb')
+    sd = synth.rrdbnet_state_dict(nb=1, seed=11)
+    p = 'model.1.sub.0.RDB1.'
+    m = B.ResidualDenseBlock_5C(64).to(dev).set_precision(precision)
+    m.load_state_dict({k[len(p):]: v for k, v in sd.items() if k.startswith(p)})
+    x = synth.normal_like(11, 'rdb.x', (1, 64, 12, 12)).to(dev)
+    with torch.no_grad():
+        m.eval()
+        y = m(x).cpu().numpy()
+        assert np.abs(y - g['y_eval']).max() <= tol
+        m.train()
+        z = zs(5, [(1, 64, 12, 12)], 'rdb.z')[0].to(dev)
+        y = m(x, z=z).cpu().numpy()
+        assert np.abs(y - g['y_train']).max() <= tol
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('fp16', 5e-2)])
+@pytest.mark.parametrize('tag,nb,shape,variant', [('a', 1, (1, 3, 16, 20), 'codes'),
+                                                  ('b', 2, (2, 3, 24, 24), 'codes'),
+                                                  ('c', 1, (1, 3, 13, 18), 'test_image')])
+def test_rrdbnet_small_golden(dev, golden, tag, nb, shape, variant, precision, tol):
+    from esrganplus_amd import architecture as arch
+    g = golden('rrdbnet_small')
+    sd = synth.rrdbnet_state_dict(nb=nb, seed=20 + nb)
+    cls = arch.RRDBNet if variant == 'codes' else arch.RRDB_Net
+    net = cls(3, 3, 64, nb).to(dev).set_precision(precision)
+    net.load_state_dict(sd, strict=True)
+    x = synth.image_batch(3, *shape, name='small.x.' + tag).to(dev)
+    from oracle import ref_torch as RT
+    with torch.no_grad():
+        net.eval()
+        y = net(x).cpu().numpy()
+        assert np.abs(y - g[tag + '_y_eval']).max() <= tol
+        net.train()
+        z = [t.to(dev) for t in zs(7, RT.noise_shapes(shape, nb, variant), 'small.z.' + tag)]
+        y = net(x, z=z).cpu().numpy()
+        assert np.abs(y - g[tag + '_y_train']).max() <= tol
+
+
+def test_philox_noise_matches_oracle_with_same_z(dev):
+    """Production noise path: fused Philox z == esr_fill_noise z; oracle fed that z agrees."""
+    from esrganplus_amd import architecture as arch, ops
+    from oracle import ref_torch as RT
+    nb, shape = 1, (2, 3, 12, 20)
+    sd = synth.rrdbnet_state_dict(nb=nb, seed=5)
+    net = arch.RRDB_Net(3, 3, 64, nb).to(dev).train()
+    net.load_state_dict(sd, strict=True)
+    x = synth.image_batch(5, *shape, name='philox.x')
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        y = net(x.to(dev)).cpu()
+    torch.manual_seed(1234)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    z = [ops.philox_normal((2, 64, 12, 20), seed, i, dev).cpu() for i in range(4)]
+    zc = torch.cat([t.flatten() for t in z])
+    assert abs(zc.mean().item()) < 0.02 and abs(zc.std().item() - 1.0) < 0.02
+    with torch.no_grad():
+        ref = RT.rrdbnet_forward(x, sd, nb, z, 'test_image')
+    assert (y - ref).abs().max().item() <= 1e-4
+    torch.manual_seed(99)
+    with torch.no_grad():
+        y2 = net(x.to(dev)).cpu()
+    assert (y2 - y).abs().max().item() > 1e-3     # a different seed gives different noise
+
+
+def _psnr_gate(y_hip, y_ref, hr):
+    from oracle import ref_torch as RT
+    return abs(RT.psnr_sr(y_hip, hr) - RT.psnr_sr(y_ref, hr))
+
+
+def test_rrdbnet_full_nb23(dev, golden):
+    """Config 1: RRDBNet x4 (23 RRDB, nf=64) — 32x32 crop, baby.png 128x128, woman.png 57x86."""
+    from esrganplus_amd import architecture as arch
+    g = golden('rrdbnet_full')
+    sd = synth.rrdbnet_state_dict(nb=23, seed=0)
+    net = arch.RRDB_Net(3, 3, 64, 23, res_scale=1).to(dev).eval()
+    net.load_state_dict(sd, strict=True)
+    x32 = synth.image_batch(0, 1, 3, 32, 32, name='full.x32').to(dev)
+
+    def img(name):
+        a = g[name].astype(np.float64) / 255
+        return torch.from_numpy(np.transpose(a, (2, 0, 1))).float()[None].to(dev)
+
+    with torch.no_grad():
+        y = net(x32).cpu()
+        e = np.abs(y.numpy() - g['y32']).max()
+        print('fp32 nb=23 32x32 max|diff| = %.3e' % e)
+        assert e <= 1e-3
+        for name in ('baby', 'woman'):
+            yb = net(img(name + '_lr_rgb')).cpu()
+            e = np.abs(yb.numpy()[:, :, ::4, ::4] - g[name + '_y_sub4']).max()
+            print('fp32 nb=23 %s max|diff| = %.3e' % (name, e))
+            assert e <= 1e-3
+            chk = g[name + '_y_chk']
+            a = yb.numpy().astype(np.float64)
+            assert abs(a.sum() - chk[0]) <= 1e-5 * chk[1]
+        yb32 = net(img('baby_lr_rgb')).cpu()
+        u8 = (yb32.squeeze().clamp(0, 1).numpy() * 255.0).round().astype(np.uint8)[:, ::4, ::4]
+        assert (np.abs(u8.astype(int) - g['baby_u8_sub4'].astype(int)) <= 1).all()
+        # fp16 path: PSNR gate against a synthetic HR target
+        net.set_precision('fp16')
+        y16 = net(img('baby_lr_rgb')).cpu()
+        hr = synth.image_batch(9, 1, 3, 512, 512, name='full.hr')
+        d = _psnr_gate(y16[0], yb32[0], hr[0])
+        print('fp16 vs fp32: max|diff| = %.3e, |dPSNR| = %.5f dB'
+              % ((y16 - yb32).abs().max().item(), d))
+        assert d <= 0.01
+        assert (y16 - yb32).abs().max().item() <= 3e-2
+
+
+def test_cpu_input_fails_loudly(dev):
+    from esrganplus_amd import architecture as arch, _lib
+    net = arch.RRDBNet(3, 3, 64, 1).to(dev).eval()
+    with pytest.raises(_lib.HipExtensionError):
+        with torch.no_grad():
+            net(torch.rand(1, 3, 8, 8))

@@ -1,0 +1,102 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, ctypes
+struct mirrors match the C structs, drop-in modules keep the reference's state-dict layout, and
+the product path refuses to run without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from esrganplus_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    from esrganplus_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, 'include', 'esrgan_hip.h')).read()
+    declared = set(re.findall(r'\b(esr_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(built.EXPORTS), declared ^ set(built.EXPORTS)
+    L = ctypes.CDLL(built.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_struct_mirror_sizes(built):
+    L = built.lib()
+    assert L.esr_sizeof_op() == ctypes.sizeof(built.esr_op)
+    assert L.esr_abi_version() == 1
+    assert built.packed_weight_bytes(32, 64, 3, built.ESR_F16) == 1 * 4 * 9 * 1024
+    assert built.packed_weight_bytes(64, 192, 3, built.ESR_F32) == 2 * 24 * 9 * 1024
+    assert built.g32_dims(128, 128) == (134, 130)
+    assert built.g32_dims(57, 86)[1] >= 86 + 2
+
+
+def test_invalid_arguments_return_error_codes(built):
+    L = built.lib()
+    c = built.esr_conv()
+    assert L.esr_conv_forward(ctypes.byref(c), None) == -1
+    assert b'invalid' in L.esr_last_error()
+    with pytest.raises(built.HipExtensionError):
+        built.check(-1, 'x')
+
+
+def test_dropin_state_dict_layout():
+    from esrganplus_amd import architecture as arch
+    for nb in (1, 3):
+        sd = synth.rrdbnet_state_dict(nb, 0)
+        for cls in (arch.RRDBNet, arch.RRDB_Net):
+            net = cls(3, 3, 64, nb)
+            assert list(net.state_dict().keys()) == list(sd.keys())
+            for k, v in net.state_dict().items():
+                assert v.shape == sd[k].shape, k
+            net.load_state_dict(sd, strict=True)
+    assert sum(p.numel() for p in arch.RRDBNet(3, 3, 64, 23).parameters()) == 16839299
+
+
+def test_init_weights_by_classname_and_optimizer():
+    """networks.py:30-44 pattern: apply(fn) matching 'Conv' in the class name, then Adam."""
+    from esrganplus_amd import architecture as arch
+    net = arch.RRDBNet(3, 3, 64, 1)
+    seen = []
+
+    def init(m):
+        if m.__class__.__name__.find('Conv') != -1:
+            torch.nn.init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
+            m.weight.data *= 0.1
+            if m.bias is not None:
+                m.bias.data.zero_()
+            seen.append(m)
+    net.apply(init)
+    assert len(seen) == 1 + 3 * 6 + 1 + 4
+    assert net._force_repack
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-4)
+    assert len(opt.param_groups[0]['params']) == 45
+    assert str(net).startswith('RRDBNet(')
+    wrapped = torch.nn.DataParallel(net)
+    assert wrapped.module is net
+
+
+def test_unsupported_configs_raise_like_reference():
+    from esrganplus_amd import architecture as arch, block
+    with pytest.raises(NotImplementedError):
+        arch.RRDBNet(3, 3, 64, 1, upsample_mode='bogus')
+    with pytest.raises(NotImplementedError):
+        block.act('swish')
+    with pytest.raises(NotImplementedError):
+        block.norm('layer', 8)
+
+
+def test_no_cpu_fallback():
+    from esrganplus_amd import architecture as arch, _lib
+    net = arch.RRDBNet(3, 3, 64, 1).eval()
+    with torch.no_grad(), pytest.raises(_lib.HipExtensionError):
+        net(torch.rand(1, 3, 8, 8))
