@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py — HR megapixels/s of the RRDBNet x4 hot path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d "Config 2"): RRDBNet x4 (23 RRDB, nf=64, gc=32)
+fp16 storage / fp32 accumulate, forward only, batch 16 of 128x128 LR tiles -> 512x512 HR, per GPU.
+One "step" = one such forward over one synthetic batch already resident in HBM.
+N>1 (launched by torch.distributed.run): tiles are independent, so every rank runs the same step
+on its own batch (weak scaling, no data-path collective); value = all ranks' HR-Mpix / max time.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, measured with HIP events on the
+launch stream) and `cpu_baseline` (the oracle restatement timed on the host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+NB, BATCH, LR = 23, 16, 128
+MAC_PER_LR_PIXEL = 18068160            # SURVEY.md §8d [probe]: conv MACs of RRDBNet x4 forward
+PEAK_F16_TFLOPS = 2500.0               # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
+
+
+def conv_flops(c):
+    """Algorithmic FLOPs of one fused-conv launch: 2 * MACs of the convolution(s) it replaces
+    (true Cin/Cout, not the padded GEMM the kernel runs)."""
+    return 2.0 * c['B'] * c['H'] * c['W'] * (c['cout'] * c['cin'] * c['ks'] ** 2 + c['extra_mac'])
+
+
+def describe_plan(net, plan):
+    """(kernel-variant name, algorithmic flops) for every op of the recorded plan."""
+    from esrganplus_amd import _lib as L
+    ent = {e.w_ptr: e for e in net._wp[(net.precision, str(next(net.parameters()).device))].entries.values()}
+    out = []
+    for o in plan.ops.ops:
+        if o.kind != L.OP_CONV:
+            out.append(('layout', 0.0))
+            continue
+        c = o.u.conv
+        e = ent[c.w]
+        extra = 0
+        if c.w1x1:
+            extra = 32 * 64          # fused bias-free 1x1 64->32 (block.py:263)
+        cbk = c.cout_blocks
+        if c.upsample:
+            name = 'conv3x3_ups_%s' % ('2x2x1' if cbk == 1 else '2x1x2')
+        elif c.w1x1:
+            name = 'conv3x3_1x1_%s' % ('4x1x1' if c.W <= 32 else '2x2x1')
+        elif cbk == 1:
+            name = 'conv3x3_%s' % ('4x1x1' if c.W <= 32 else '2x2x1')
+        else:
+            name = 'conv3x3_2x1x2'
+        out.append((name, conv_flops(dict(B=c.B, H=c.H, W=c.W, cout=e.cout, cin=e.cin, ks=e.ks,
+                                          extra_mac=extra))))
+    return out
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Oracle (torch restatement == reference bit-for-bit, oracle/gen_golden.py) on host cores:
+    one 128x128 LR tile per forward, fp32, eval."""
+    from esrganplus_amd import synth
+    from oracle import ref_torch as RT
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth.rrdbnet_state_dict(NB, 0)
+    x = synth.image_batch(0, 1, 3, LR, LR, name='bench.cpu')
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        RT.rrdbnet_forward(x, sd, NB)           # warm-up
+        first = time.perf_counter() - t0
+        n = max(1, min(5, int(seconds_budget / max(first, 1e-3))))
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            RT.rrdbnet_forward(x, sd, NB)
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {'value': round((4 * LR) ** 2 / 1e6 / med, 4), 'unit': 'HR-Mpix/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'sample': '%d forwards of one 1x3x128x128 tile, fp32, median %.3f s' % (n, med),
+            'gflops': round(2 * MAC_PER_LR_PIXEL * LR * LR / med / 1e9, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=BATCH)
+    ap.add_argument('--lr', type=int, default=LR)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world == 1:
+        # not under torchrun: re-launch one process per GPU over RCCL
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.execvp(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                                   '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+                                   '--master-port', os.environ.get('MASTER_PORT', '29533'),
+                                   os.path.abspath(__file__)] + sys.argv[1:])
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from esrganplus_amd import architecture as arch, synth, engine as E
+    net = arch.RRDBNet(3, 3, 64, NB).to(dev).eval().set_precision('fp16')
+    net.load_state_dict(synth.rrdbnet_state_dict(NB, 0), strict=True)
+    x = synth.image_batch(100 + rank, args.batch, 3, args.lr, args.lr, name='bench.x').to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
+            y = net(x)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = net(x)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert torch.isfinite(y).all()
+
+    ms_per_step = elapsed / args.steps * 1e3
+    hr_mpix_per_step = world * args.batch * (4 * args.lr) ** 2 / 1e6
+    value = hr_mpix_per_step / (elapsed / args.steps)
+    step_flops = 2.0 * MAC_PER_LR_PIXEL * args.batch * args.lr * args.lr
+
+    res = {'metric': 'HR megapixels/sec (x4 SR) RRDBNet forward', 'value': round(value, 2),
+           'unit': 'HR-Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+           'config': {'workload': 'RRDBNet x4 (23 RRDB, nf=64, gc=32) fp16 forward-only, batch %d of '
+                                  '%dx%d LR tiles per GPU -> %dx%d HR (BASELINE configs[1])'
+                                  % (args.batch, args.lr, args.lr, 4 * args.lr, 4 * args.lr),
+                      'global_batch': world * args.batch, 'parallelism': 'dp%d (independent tiles, no collective)' % world,
+                      'weights': 'synthetic default-init seed 0'},
+           'whole_net_tflops_per_gpu': round(step_flops / (elapsed / args.steps) / 1e12, 1),
+           'whole_net_frac_of_f16_mfma_peak': round(step_flops / (elapsed / args.steps) / 1e12 / PEAK_F16_TFLOPS, 4)}
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: per-op HIP-event timing on the launch stream
+        with torch.no_grad():
+            plan = next(iter(net._plans.values()))
+            desc = describe_plan(net, plan)
+            st = E.current_stream()
+            agg = {}
+            reps = 3
+            for _ in range(reps):
+                ms = plan.ops.run_timed(st)
+                for (name, fl), t in zip(desc, ms):
+                    a = agg.setdefault(name, [0.0, 0.0, 0])
+                    a[0] += t
+                    a[1] += fl
+                    a[2] += 1
+        dom = max((k for k in agg if k != 'layout'), key=lambda k: agg[k][0])
+        tot_ms = sum(a[0] for a in agg.values()) / reps
+        t_ms, fl, n = agg[dom]
+        ach = fl / (t_ms * 1e-3) / 1e12
+        res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_F16_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4), 'traffic': None,
+                           'launches_per_step': n // reps, 'avg_launch_us': round(t_ms / n * 1e3, 2),
+                           'share_of_step_time': round(t_ms / reps / tot_ms, 3)}
+        res['kernels'] = {k: {'launches': a[2] // reps, 'ms_per_step': round(a[0] / reps, 3),
+                              'tflops': round(a[1] / (a[0] * 1e-3) / 1e12, 1) if a[1] else 0.0}
+                          for k, a in sorted(agg.items())}
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -7,6 +7,11 @@ import ctypes as C
 import os
 import threading
 
+# torch bundles its own libamdhip64.so.7; it MUST be the HIP runtime already resident when
+# libesrgan_hip.so is dlopen'ed (same soname -> shared), otherwise our launches would go through a
+# second runtime that does not see torch's device/stream state.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libesrgan_hip.so')
 
@@ -66,7 +71,7 @@ class esr_op(C.Structure):
 
 # every symbol include/esrgan_hip.h declares (tests check the .so exports all of them)
 EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_pack_conv_weights',
-           'esr_convert_layout', 'esr_fill_noise', 'esr_run_ops', 'esr_last_error',
+           'esr_convert_layout', 'esr_fill_noise', 'esr_run_ops', 'esr_run_ops_timed', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op']
 
 _lib = None
@@ -100,6 +105,7 @@ def lib():
         L.esr_g32_dims.restype = None
         L.esr_g32_dims.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.esr_run_ops.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.esr_run_ops_timed.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         for name, st in (('esr_conv_forward', esr_conv), ('esr_pack_conv_weights', esr_pack),
                          ('esr_convert_layout', esr_layout), ('esr_fill_noise', esr_noise_fill)):
             getattr(L, name).argtypes = [C.POINTER(st), C.c_void_p]
@@ -154,6 +160,14 @@ class OpList:
         if self._arr is None:
             self._arr = (esr_op * len(self.ops))(*self.ops)
         return self._arr
+
+    def run_timed(self, stream):
+        """Measurement only: per-op elapsed ms (hipEvents on `stream`; synchronises)."""
+        arr = self.array()
+        ms = (C.c_float * len(self.ops))()
+        check(lib().esr_run_ops_timed(C.cast(arr, C.c_void_p), len(self.ops), C.c_void_p(stream),
+                                      C.cast(ms, C.c_void_p)), 'esr_run_ops_timed')
+        return list(ms)
 
     def run(self, stream):
         if not self.ops:

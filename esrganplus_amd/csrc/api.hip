@@ -54,3 +54,22 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
   }
   return ESR_OK;
 }
+
+extern "C" int esr_run_ops_timed(const esr_op* ops, int32_t n, esr_stream_t stream, float* ms_out) {
+  if (!ops || n <= 0 || !ms_out) { esr_set_error("esr_run_ops_timed: invalid arguments"); return ESR_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t* ev = new hipEvent_t[n + 1];
+  for (int i = 0; i <= n; ++i) hipEventCreate(&ev[i]);
+  int rc = ESR_OK;
+  hipEventRecord(ev[0], st);
+  for (int i = 0; i < n && rc == ESR_OK; ++i) {
+    rc = esr_run_ops(&ops[i], 1, stream);
+    hipEventRecord(ev[i + 1], st);
+  }
+  hipStreamSynchronize(st);
+  if (rc == ESR_OK)
+    for (int i = 0; i < n; ++i) hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
+  for (int i = 0; i <= n; ++i) hipEventDestroy(ev[i]);
+  delete[] ev;
+  return rc;
+}

@@ -15,17 +15,20 @@
 //   B fragment read from LDS feeds up to KS MFMAs (the kh taps of different output rows), each
 //   A fragment up to 8 (the rows).
 // A workgroup is 4 waves arranged WR x WC spatially x NCG cout-blocks.
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 namespace {
 
-template <typename T> __device__ inline void mma(f32x16& acc, const u32x4& a, const u32x4& b);
+template <typename T> __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b);
 
-template <> __device__ inline void mma<_Float16>(f32x16& acc, const u32x4& a, const u32x4& b) {
+template <> __device__ __forceinline__ void mma<_Float16>(f32x16& acc, const u32x4& a, const u32x4& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a),
                                               __builtin_bit_cast(half8, b), acc, 0, 0, 0);
 }
-template <> __device__ inline void mma<float>(f32x16& acc, const u32x4& a, const u32x4& b) {
+template <> __device__ __forceinline__ void mma<float>(f32x16& acc, const u32x4& a, const u32x4& b) {
   const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -36,14 +39,14 @@ template <> __device__ inline void mma<float>(f32x16& acc, const u32x4& a, const
 template <typename T> struct Px16;
 template <> struct Px16<_Float16> {
   // lane half h owns group (2*cb + h): one 32-byte group
-  static __device__ inline void load(const esr_g32& t, int b, int cb, int h, int64_t pix, float v[16]) {
+  static __device__ __forceinline__ void load(const esr_g32& t, int b, int cb, int h, int64_t pix, float v[16]) {
     const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(2 * cb + h) * t.group_stride + pix * 32;
     const u32x4 a = *(const u32x4*)p, c = *(const u32x4*)(p + 16);
     const half8 x = __builtin_bit_cast(half8, a), y = __builtin_bit_cast(half8, c);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { v[i] = (float)x[i]; v[8 + i] = (float)y[i]; }
   }
-  static __device__ inline void store(const esr_g32& t, int b, int cb, int h, int64_t pix, const float v[16]) {
+  static __device__ __forceinline__ void store(const esr_g32& t, int b, int cb, int h, int64_t pix, const float v[16]) {
     if (2 * cb + h >= t.ngroups) return;
     char* p = (char*)t.ptr + b * t.batch_stride + (int64_t)(2 * cb + h) * t.group_stride + pix * 32;
     half8 x, y;
@@ -55,7 +58,7 @@ template <> struct Px16<_Float16> {
 };
 template <> struct Px16<float> {
   // lane half h owns groups (4*cb + 2h) and (4*cb + 2h + 1)
-  static __device__ inline void load(const esr_g32& t, int b, int cb, int h, int64_t pix, float v[16]) {
+  static __device__ __forceinline__ void load(const esr_g32& t, int b, int cb, int h, int64_t pix, float v[16]) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(4 * cb + 2 * h + g) * t.group_stride + pix * 32;
@@ -64,7 +67,7 @@ template <> struct Px16<float> {
       for (int i = 0; i < 4; ++i) { v[8 * g + i] = a[i]; v[8 * g + 4 + i] = c[i]; }
     }
   }
-  static __device__ inline void store(const esr_g32& t, int b, int cb, int h, int64_t pix, const float v[16]) {
+  static __device__ __forceinline__ void store(const esr_g32& t, int b, int cb, int h, int64_t pix, const float v[16]) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       if (4 * cb + 2 * h + g >= t.ngroups) continue;
@@ -90,6 +93,122 @@ struct Geo {
   static constexpr int PAD = (KS - 1) / 2;
 };
 
+// async global -> LDS copy of 16 bytes per lane (LDS-DMA): destination = wave-uniform LDS base
+// + lane*16, source = per-lane global address.  No VGPR round trip, no staging registers.
+__device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Accumulators are 8 NAMED vector members (never an indexable array): every access is resolved at
+// compile time, so the register allocator keeps them in AGPRs for the whole kernel.  (An
+// `f32x16 acc[8]` that is indexed by a not-fully-unrolled loop anywhere — e.g. the epilogue — is
+// demoted to scratch and re-stored after every K step.)
+struct Acc8 { f32x16 a0, a1, a2, a3, a4, a5, a6, a7; };
+
+template <int R> __device__ __forceinline__ f32x16& accsel(Acc8& s) {
+  static_assert(R >= 0 && R < 8, "row");
+  if constexpr (R == 0) return s.a0;
+  else if constexpr (R == 1) return s.a1;
+  else if constexpr (R == 2) return s.a2;
+  else if constexpr (R == 3) return s.a3;
+  else if constexpr (R == 4) return s.a4;
+  else if constexpr (R == 5) return s.a5;
+  else if constexpr (R == 6) return s.a6;
+  else return s.a7;
+}
+
+__device__ __forceinline__ void acc_zero(Acc8& s) {
+  f32x16 z;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) z[e] = 0.f;
+  s.a0 = z; s.a1 = z; s.a2 = z; s.a3 = z; s.a4 = z; s.a5 = z; s.a6 = z; s.a7 = z;
+}
+
+__device__ __forceinline__ f32x16 pick8(const Acc8& s, int r) {   // r is wave-uniform
+  switch (r) {
+    case 0: return s.a0;
+    case 1: return s.a1;
+    case 2: return s.a2;
+    case 3: return s.a3;
+    case 4: return s.a4;
+    case 5: return s.a5;
+    case 6: return s.a6;
+    default: return s.a7;
+  }
+}
+
+template <typename F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
+  sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <typename T>
+__device__ __forceinline__ void noise16(int explicit_z, const esr_g32 zt, uint32_t layer, uint64_t seed, float sigma,
+                                     int b, int cb, int h, int64_t pixoff_z, uint32_t pix, float v[16]) {
+  float z[16];
+  if (explicit_z) {
+    Px16<T>::load(zt, b, cb, h, pixoff_z, z);
+  } else {
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), layer, seed, &z[4 * q]);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) v[e] = v[e] + z[e] * (sigma * v[e]);   // block.py:119-121
+}
+
+// Per-row epilogue (see esr_conv in esrgan_hip.h for the operation order).
+template <typename T>
+__device__ __forceinline__ void epilogue_row(const esr_conv& p, const f32x16& a, const f32x16* a1, const float bias[16],
+                                    int b, int cb, int h, int oy, int ox) {
+  float v[16], tmp[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    float x = a[e] + bias[e];
+    if (p.act == ESR_ACT_LRELU) x = x > 0.f ? x : x * ESR_LRELU_SLOPE;
+    else if (p.act == ESR_ACT_RELU) x = x > 0.f ? x : 0.f;
+    v[e] = x;
+  }
+  if (p.aux_out.ptr) Px16<T>::store(p.aux_out, b, cb, h, (int64_t)(oy + 1) * p.aux_out.wp + ox + 1, v);
+  if (a1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] += (*a1)[e];
+  }
+  if (p.res1.ptr) {
+    Px16<T>::load(p.res1, b, cb, h, (int64_t)(oy + 1) * p.res1.wp + ox + 1, tmp);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = v[e] * p.alpha + tmp[e];
+  }
+  const uint32_t pix = (uint32_t)((b * p.H + oy) * p.W + ox);
+  if ((p.noise_mode == ESR_NOISE_PHILOX && p.layer1 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z1.ptr))
+    noise16<T>(p.noise_mode == ESR_NOISE_EXPLICIT, p.z1, p.layer1, p.seed, p.sigma, b, cb, h, (int64_t)(oy + 1) * p.z1.wp + ox + 1, pix, v);
+  if (p.res2.ptr) {
+    Px16<T>::load(p.res2, b, cb, h, (int64_t)(oy + 1) * p.res2.wp + ox + 1, tmp);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = v[e] * p.beta + tmp[e];
+  }
+  if ((p.noise_mode == ESR_NOISE_PHILOX && p.layer2 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z2.ptr))
+    noise16<T>(p.noise_mode == ESR_NOISE_EXPLICIT, p.z2, p.layer2, p.seed, p.sigma, b, cb, h, (int64_t)(oy + 1) * p.z2.wp + ox + 1, pix, v);
+  if (p.out.ptr) Px16<T>::store(p.out, b, cb, h, (int64_t)(oy + 1) * p.out.wp + ox + 1, v);
+  if (p.mask.ptr) {
+    Px16<T>::load(p.mask, b, cb, h, (int64_t)(oy + 1) * p.mask.wp + ox + 1, tmp);
+    const float neg = p.act == ESR_ACT_RELU ? 0.f : ESR_LRELU_SLOPE;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tmp[e] = tmp[e] > 0.f ? v[e] : v[e] * neg;
+    Px16<T>::store(p.out2, b, cb, h, (int64_t)(oy + 1) * p.out2.wp + ox + 1, tmp);
+  }
+  if (p.nchw_out_c > 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ch = cb * 32 + 16 * h + e;
+      if (ch < p.nchw_out_c) p.nchw_out[(((int64_t)b * p.nchw_out_c + ch) * p.H + oy) * p.W + ox] = v[e];
+    }
+  }
+}
+
 template <typename T, int KS, int S, bool UPS, int WR, int WC, int NCG, bool HAS1X1>
 __global__ __launch_bounds__(256, 1) void conv_kernel(const esr_conv p) {
   using G = Geo<KS, S, UPS, WR, WC>;
@@ -107,10 +226,9 @@ __global__ __launch_bounds__(256, 1) void conv_kernel(const esr_conv p) {
   // ---- XCD-aware tile mapping: block b runs on XCD b%8; give every XCD a contiguous run of
   // tiles (neighbouring tiles share halo rows -> they hit the same private L2).
   const int tiles_x = (p.W + G::TW - 1) / G::TW, tiles_y = (p.H + G::TH - 1) / G::TH;
-  const int nwg = gridDim.x;
   int t;
   {
-    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
@@ -118,115 +236,107 @@ __global__ __launch_bounds__(256, 1) void conv_kernel(const esr_conv p) {
   const bool cb_ok = cb < p.cout_blocks;
   const int oy0 = ty * G::TH, ox0 = tx * G::TW;     // output tile origin (logical)
 
-  // ---- staging map: slot s = tid + 256*i of the stage <- 16 bytes of the input tile.
-  // LDS image: [row][col][2 halves], the halves of pixel col swapped when (col>>3)&1 so that the
-  // 16 lanes of a ds_read_b128 group cover 16 distinct 16-byte bank slots.
+  // ---- staging map: LDS slot s = tid + 256*i (16 bytes) <- input tile, by LDS-DMA.
+  // LDS image: [row][col][2 halves]; the two 16-byte halves of pixel `col` are swapped when
+  // (col>>3)&1 so that the 16 lanes of a ds_read_b128 group cover 16 distinct bank slots.  The
+  // DMA destination is lane-linear, so the swizzle is applied to the SOURCE address.
   const int iy0 = UPS ? oy0 / 2 : oy0 * S + 1 - G::PAD;   // padded coords of tile origin
   const int ix0 = UPS ? ox0 / 2 : ox0 * S + 1 - G::PAD;
   int goff[G::NLD];
 #pragma unroll
   for (int i = 0; i < G::NLD; ++i) {
     int s = tid + 256 * i;
-    if (s >= G::NSLOT) s = G::NSLOT - 1;            // clamp (duplicate write of the same data)
+    if (s >= G::NSLOT) s = G::NSLOT - 1;            // tail lanes land in the stage's padding
     const int row = s / (2 * G::IW), rem = s - row * 2 * G::IW;
     const int col = rem >> 1, hs = rem & 1, half = hs ^ ((col >> 3) & 1);
     goff[i] = ((iy0 + row) * p.in.wp + ix0 + col) * 32 + half * 16;
   }
   const char* in_b = (const char*)p.in.ptr + b * p.in.batch_stride;
+  char* const lds_w = smem + wave * 1024;           // this wave's 64-slot window inside a stage
 
   // ---- B-fragment (activation) read offsets, one per kw tap
   int colofs[KS];
 #pragma unroll
   for (int kw = 0; kw < KS; ++kw) {
     const int col = UPS ? (((wc * 32 + j + kw - 1) >> 1) + 1) : ((wc * 32 + j) * S + kw);
-    colofs[kw] = col * 32 + ((h ^ ((col >> 3) & 1)) << 4);
+    colofs[kw] = col * 32 + ((h ^ ((col >> 3) & 1)) << 4) + (UPS ? wr * 4 : wr * 8 * S) * G::IW * 32;
   }
-  constexpr int WROW0 = 0;  // wave row base is added below (depends on wr)
-  const int rowbase = (UPS ? wr * 4 : wr * 8 * S) * G::IW * 32 + WROW0;
 
   // ---- A-fragment (weight) pointer: [cb][chunk][tap][lane][16B]
   const int nchunks = p.cin_groups;
   const char* wp = (const char*)p.w + ((int64_t)(cb_ok ? cb : 0) * nchunks * (KS * KS) * 64 + lane) * 16;
   const char* w1p = HAS1X1 ? (const char*)p.w1x1 + ((int64_t)(cb_ok ? cb : 0) * p.n1x1_groups * 64 + lane) * 16 : nullptr;
 
-  f32x16 acc[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
-  f32x16 acc1[HAS1X1 ? 8 : 1];
-  if constexpr (HAS1X1) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc1[r][e] = 0.f;
-  }
+  Acc8 acc, acc1;
+  acc_zero(acc);
+  if constexpr (HAS1X1) acc_zero(acc1);
 
-  u32x4 stg[G::NLD];
   u32x4 wf[KS * KS], wn[KS * KS];
-  u32x4 w1f, w1n;
+  u32x4 w1f = {0, 0, 0, 0}, w1n = {0, 0, 0, 0};
+
+  const int64_t in_gs = p.in.group_stride;
+  const int n1x1 = HAS1X1 ? p.n1x1_groups : 0;
+  auto stage_in = [&](int chunk, int st) {
+    const char* src = in_b + (int64_t)chunk * in_gs;
+    char* dst = lds_w + st * G::STAGE;
+#pragma unroll
+    for (int i = 0; i < G::NLD; ++i)   // only the last round can run past the tile
+      if (i < G::NLD - 1 || wave * 64 + 256 * i < ((G::NSLOT + 63) / 64) * 64) dma16(src + goff[i], dst + 4096 * i);
+  };
 
   // prologue: chunk 0
-  {
-    const char* src = in_b;
+  stage_in(0, 0);
 #pragma unroll
-    for (int i = 0; i < G::NLD; ++i) stg[i] = *(const u32x4*)(src + goff[i]);
-#pragma unroll
-    for (int tp = 0; tp < KS * KS; ++tp) wf[tp] = *(const u32x4*)(wp + tp * 1024);
-    if (HAS1X1) w1f = *(const u32x4*)w1p;
-#pragma unroll
-    for (int i = 0; i < G::NLD; ++i)
-      if (tid + 256 * i < G::NSLOT) *(u32x4*)(smem + (tid + 256 * i) * 16) = stg[i];
-    __syncthreads();
-  }
+  for (int tp = 0; tp < KS * KS; ++tp) wf[tp] = *(const u32x4*)(wp + tp * 1024);
+  if (HAS1X1) w1f = *(const u32x4*)w1p;
+  __syncthreads();
 
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
-    if (more) {   // prefetch chunk c+1: activations -> staging registers, weights -> wn
-      const char* src = in_b + (int64_t)(c + 1) * p.in.group_stride;
-#pragma unroll
-      for (int i = 0; i < G::NLD; ++i) stg[i] = *(const u32x4*)(src + goff[i]);
+    if (more) {   // prefetch chunk c+1: activations by LDS-DMA, weights into wn
+      stage_in(c + 1, (c + 1) & 1);
       const char* wsrc = wp + (int64_t)(c + 1) * (KS * KS) * 1024;
 #pragma unroll
       for (int tp = 0; tp < KS * KS; ++tp) wn[tp] = *(const u32x4*)(wsrc + tp * 1024);
-      if (HAS1X1 && c + 1 < p.n1x1_groups) w1n = *(const u32x4*)(w1p + (int64_t)(c + 1) * 1024);
+      if (HAS1X1 && c + 1 < n1x1) w1n = *(const u32x4*)(w1p + (int64_t)(c + 1) * 1024);
     }
 
-    const char* lds = smem + (c & 1) * G::STAGE + rowbase;
-    const bool do1x1 = HAS1X1 && c < p.n1x1_groups;
+    const char* lds = smem + (c & 1) * G::STAGE;
+    const bool do1x1 = HAS1X1 && c < n1x1;
+    sfor<G::WIH>([&](auto IR) __attribute__((always_inline)) {
+      constexpr int ir = decltype(IR)::value;
+      u32x4 bf[KS];
 #pragma unroll
-    for (int ir = 0; ir < G::WIH; ++ir) {
-#pragma unroll
-      for (int kw = 0; kw < KS; ++kw) {
-        const u32x4 bf = *(const u32x4*)(lds + colofs[kw] + ir * G::IW * 32);
-#pragma unroll
-        for (int kh = 0; kh < KS; ++kh) {
-          if (UPS) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-              if ((((r + kh - 1) >> 1) + 1) == ir) mma<T>(acc[r], wf[kh * KS + kw], bf);
+      for (int kw = 0; kw < KS; ++kw) bf[kw] = *(const u32x4*)(lds + colofs[kw] + ir * G::IW * 32);
+      sfor<KS>([&](auto KW) __attribute__((always_inline)) {
+        constexpr int kw = decltype(KW)::value;
+        sfor<KS>([&](auto KH) __attribute__((always_inline)) {
+          constexpr int kh = decltype(KH)::value;
+          if constexpr (UPS) {
+            sfor<8>([&](auto R) __attribute__((always_inline)) {
+              constexpr int r = decltype(R)::value;
+              if constexpr ((((r + kh - 1) >> 1) + 1) == ir) mma<T>(accsel<r>(acc), wf[kh * KS + kw], bf[kw]);
+            });
           } else {
-            const int tt = ir - kh;
-            if (tt >= 0 && tt % S == 0 && tt / S < 8) mma<T>(acc[tt / S], wf[kh * KS + kw], bf);
+            constexpr int tt = ir - kh;
+            if constexpr (tt >= 0 && tt % S == 0 && tt / S < 8) mma<T>(accsel<tt / S>(acc), wf[kh * KS + kw], bf[kw]);
+          }
+        });
+        if constexpr (HAS1X1 && !UPS && S == 1 && kw == G::PAD) {   // centre tap feeds the 1x1 residual conv
+          constexpr int r = ir - G::PAD;
+          if constexpr (r >= 0 && r < 8) {
+            if (do1x1) mma<T>(accsel<r>(acc1), w1f, bf[kw]);
           }
         }
-        if constexpr (HAS1X1 && !UPS && S == 1) {   // centre tap feeds the 1x1 residual conv
-          const int r = ir - G::PAD;
-          if (kw == G::PAD && r >= 0 && r < 8 && do1x1) mma<T>(acc1[r], w1f, bf);
-        }
-      }
-    }
+      });
+    });
 
     if (more) {
-#pragma unroll
-      for (int i = 0; i < G::NLD; ++i)
-        if (tid + 256 * i < G::NSLOT)
-          *(u32x4*)(smem + ((c + 1) & 1) * G::STAGE + (tid + 256 * i) * 16) = stg[i];
 #pragma unroll
       for (int tp = 0; tp < KS * KS; ++tp) wf[tp] = wn[tp];
       if (HAS1X1) w1f = w1n;
     }
-    __syncthreads();
+    __syncthreads();   // drains the DMA (vmcnt(0)) and fences LDS for the next stage
   }
 
   if (!cb_ok) return;
@@ -236,70 +346,17 @@ __global__ __launch_bounds__(256, 1) void conv_kernel(const esr_conv p) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) bias[e] = p.bias ? p.bias[cb * 32 + 16 * h + e] : 0.f;
   const int ox = ox0 + wc * 32 + j;
-  const bool x_ok = ox < p.W;
-#pragma unroll
+  if (ox >= p.W) return;
+#pragma unroll 1
   for (int r = 0; r < 8; ++r) {
     const int oy = oy0 + wr * 8 + r;
-    if (!(x_ok && oy < p.H)) continue;
-    float v[16], tmp[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      float a = acc[r][e] + bias[e];
-      if (p.act == ESR_ACT_LRELU) a = a > 0.f ? a : a * ESR_LRELU_SLOPE;
-      else if (p.act == ESR_ACT_RELU) a = a > 0.f ? a : 0.f;
-      v[e] = a;
-    }
-    if (p.aux_out.ptr) Px16<T>::store(p.aux_out, b, cb, h, (int64_t)(oy + 1) * p.aux_out.wp + ox + 1, v);
+    if (oy >= p.H) break;
+    const f32x16 a = pick8(acc, r);
     if constexpr (HAS1X1) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] += acc1[r][e];
-    }
-    if (p.res1.ptr) {
-      Px16<T>::load(p.res1, b, cb, h, (int64_t)(oy + 1) * p.res1.wp + ox + 1, tmp);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = v[e] * p.alpha + tmp[e];
-    }
-    const uint32_t pix = (uint32_t)((b * p.H + oy) * p.W + ox);
-    if ((p.noise_mode == ESR_NOISE_PHILOX && p.layer1 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z1.ptr)) {
-      if (p.noise_mode == ESR_NOISE_EXPLICIT) {
-        Px16<T>::load(p.z1, b, cb, h, (int64_t)(oy + 1) * p.z1.wp + ox + 1, tmp);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer1, p.seed, &tmp[4 * q]);
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);   // block.py:119-121
-    }
-    if (p.res2.ptr) {
-      Px16<T>::load(p.res2, b, cb, h, (int64_t)(oy + 1) * p.res2.wp + ox + 1, tmp);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = v[e] * p.beta + tmp[e];
-    }
-    if ((p.noise_mode == ESR_NOISE_PHILOX && p.layer2 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z2.ptr)) {
-      if (p.noise_mode == ESR_NOISE_EXPLICIT) {
-        Px16<T>::load(p.z2, b, cb, h, (int64_t)(oy + 1) * p.z2.wp + ox + 1, tmp);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer2, p.seed, &tmp[4 * q]);
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
-    }
-    if (p.out.ptr) Px16<T>::store(p.out, b, cb, h, (int64_t)(oy + 1) * p.out.wp + ox + 1, v);
-    if (p.mask.ptr) {
-      Px16<T>::load(p.mask, b, cb, h, (int64_t)(oy + 1) * p.mask.wp + ox + 1, tmp);
-      const float neg = p.act == ESR_ACT_RELU ? 0.f : ESR_LRELU_SLOPE;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) tmp[e] = tmp[e] > 0.f ? v[e] : v[e] * neg;
-      Px16<T>::store(p.out2, b, cb, h, (int64_t)(oy + 1) * p.out2.wp + ox + 1, tmp);
-    }
-    if (p.nchw_out_c > 0) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int ch = cb * 32 + 16 * h + e;
-        if (ch < p.nchw_out_c)
-          p.nchw_out[(((int64_t)b * p.nchw_out_c + ch) * p.H + oy) * p.W + ox] = v[e];
-      }
+      const f32x16 a1 = pick8(acc1, r);
+      epilogue_row<T>(p, a, &a1, bias, b, cb, h, oy, ox);
+    } else {
+      epilogue_row<T>(p, a, nullptr, bias, b, cb, h, oy, ox);
     }
   }
 }

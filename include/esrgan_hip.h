@@ -147,6 +147,11 @@ int esr_fill_noise(const esr_noise_fill* p, esr_stream_t stream);
  * what RRDBNet.forward — architecture.py:76-78 — becomes). */
 int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream);
 
+/* Measurement-only variant (bench.py): brackets every op with hipEvents on `stream`, waits for the
+ * stream, and writes each op's elapsed milliseconds to ms_out[n].  This is the one entry point that
+ * creates events and synchronises; never call it under graph capture. */
+int esr_run_ops_timed(const esr_op* ops, int32_t n, esr_stream_t stream, float* ms_out);
+
 const char* esr_last_error(void);
 int esr_abi_version(void);
 size_t esr_sizeof_op(void);
