@@ -10,11 +10,11 @@
 //   B operand = activations: a (rows x cols) halo tile of ONE 32-byte channel group is staged in
 //               LDS per K step; the 3x3 (or 4x4/s2, or upsampled) taps are just shifted
 //               ds_read_b128 addresses into that tile — nothing is ever im2col'ed.
-//   One wave owns 8 output rows x 32 output pixels x 32 couts = 8 MFMA 32x32 accumulators
+//   One wave owns 4 output rows x 32 output pixels x 32*NCW couts = 4*NCW MFMA 32x32 accumulators
 //   (v_mfma_f32_32x32x16_f16, or 4x v_mfma_f32_32x32x2_f32 for the exact-fp32 path).  Each
 //   B fragment read from LDS feeds up to KS MFMAs (the kh taps of different output rows), each
 //   A fragment up to 8 (the rows).
-// A workgroup is 4 waves arranged WR x WC spatially x NCG cout-blocks.
+// A workgroup is 8 waves arranged WR x WC spatially x NCG cout-groups (2 waves per SIMD).
 #include <type_traits>
 #include <utility>
 
@@ -81,18 +81,6 @@ template <> struct Px16<float> {
   }
 };
 
-template <int KS, int S, bool UPS, int WR, int WC>
-struct Geo {
-  static constexpr int TH = 8 * WR, TW = 32 * WC;                       // output tile
-  static constexpr int IH = UPS ? TH / 2 + 2 : (TH - 1) * S + KS;      // staged input tile
-  static constexpr int IW = UPS ? TW / 2 + 2 : (TW - 1) * S + KS;
-  static constexpr int WIH = UPS ? 6 : 7 * S + KS;                      // input rows one wave touches
-  static constexpr int STAGE = ((IH * IW * 32 + 1023) / 1024) * 1024;   // bytes per LDS stage
-  static constexpr int NSLOT = IH * IW * 2;                             // 16-byte slots per stage
-  static constexpr int NLD = (NSLOT + 255) / 256;
-  static constexpr int PAD = (KS - 1) / 2;
-};
-
 // async global -> LDS copy of 16 bytes per lane (LDS-DMA): destination = wave-uniform LDS base
 // + lane*16, source = per-lane global address.  No VGPR round trip, no staging registers.
 __device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
@@ -146,73 +134,154 @@ template <int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
   sfor_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <typename T>
-__device__ __forceinline__ void noise16(int explicit_z, const esr_g32 zt, uint32_t layer, uint64_t seed, float sigma,
-                                     int b, int cb, int h, int64_t pixoff_z, uint32_t pix, float v[16]) {
-  float z[16];
-  if (explicit_z) {
-    Px16<T>::load(zt, b, cb, h, pixoff_z, z);
-  } else {
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), layer, seed, &z[4 * q]);
+// Raw (storage-typed) 16-channel pixel: 32 bytes for fp16, 64 for fp32.
+template <typename T> struct Raw16;
+template <> struct Raw16<_Float16> {
+  u32x4 q[2];
+  __device__ __forceinline__ void load(const esr_g32& t, int b, int cb, int h, int64_t pix) {
+    const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(2 * cb + h) * t.group_stride + pix * 32;
+    q[0] = *(const u32x4*)p; q[1] = *(const u32x4*)(p + 16);
   }
+  __device__ __forceinline__ void get(float v[16]) const {
+    const half8 x = __builtin_bit_cast(half8, q[0]), y = __builtin_bit_cast(half8, q[1]);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) v[e] = v[e] + z[e] * (sigma * v[e]);   // block.py:119-121
-}
-
-// Per-row epilogue (see esr_conv in esrgan_hip.h for the operation order).
-template <typename T>
-__device__ __forceinline__ void epilogue_row(const esr_conv& p, const f32x16& a, const f32x16* a1, const float bias[16],
-                                    int b, int cb, int h, int oy, int ox) {
-  float v[16], tmp[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    float x = a[e] + bias[e];
-    if (p.act == ESR_ACT_LRELU) x = x > 0.f ? x : x * ESR_LRELU_SLOPE;
-    else if (p.act == ESR_ACT_RELU) x = x > 0.f ? x : 0.f;
-    v[e] = x;
+    for (int i = 0; i < 8; ++i) { v[i] = (float)x[i]; v[8 + i] = (float)y[i]; }
   }
-  if (p.aux_out.ptr) Px16<T>::store(p.aux_out, b, cb, h, (int64_t)(oy + 1) * p.aux_out.wp + ox + 1, v);
-  if (a1) {
+};
+template <> struct Raw16<float> {
+  f32x4 q[4];
+  __device__ __forceinline__ void load(const esr_g32& t, int b, int cb, int h, int64_t pix) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] += (*a1)[e];
-  }
-  if (p.res1.ptr) {
-    Px16<T>::load(p.res1, b, cb, h, (int64_t)(oy + 1) * p.res1.wp + ox + 1, tmp);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = v[e] * p.alpha + tmp[e];
-  }
-  const uint32_t pix = (uint32_t)((b * p.H + oy) * p.W + ox);
-  if ((p.noise_mode == ESR_NOISE_PHILOX && p.layer1 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z1.ptr))
-    noise16<T>(p.noise_mode == ESR_NOISE_EXPLICIT, p.z1, p.layer1, p.seed, p.sigma, b, cb, h, (int64_t)(oy + 1) * p.z1.wp + ox + 1, pix, v);
-  if (p.res2.ptr) {
-    Px16<T>::load(p.res2, b, cb, h, (int64_t)(oy + 1) * p.res2.wp + ox + 1, tmp);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = v[e] * p.beta + tmp[e];
-  }
-  if ((p.noise_mode == ESR_NOISE_PHILOX && p.layer2 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z2.ptr))
-    noise16<T>(p.noise_mode == ESR_NOISE_EXPLICIT, p.z2, p.layer2, p.seed, p.sigma, b, cb, h, (int64_t)(oy + 1) * p.z2.wp + ox + 1, pix, v);
-  if (p.out.ptr) Px16<T>::store(p.out, b, cb, h, (int64_t)(oy + 1) * p.out.wp + ox + 1, v);
-  if (p.mask.ptr) {
-    Px16<T>::load(p.mask, b, cb, h, (int64_t)(oy + 1) * p.mask.wp + ox + 1, tmp);
-    const float neg = p.act == ESR_ACT_RELU ? 0.f : ESR_LRELU_SLOPE;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) tmp[e] = tmp[e] > 0.f ? v[e] : v[e] * neg;
-    Px16<T>::store(p.out2, b, cb, h, (int64_t)(oy + 1) * p.out2.wp + ox + 1, tmp);
-  }
-  if (p.nchw_out_c > 0) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int ch = cb * 32 + 16 * h + e;
-      if (ch < p.nchw_out_c) p.nchw_out[(((int64_t)b * p.nchw_out_c + ch) * p.H + oy) * p.W + ox] = v[e];
+    for (int g = 0; g < 2; ++g) {
+      const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(4 * cb + 2 * h + g) * t.group_stride + pix * 32;
+      q[2 * g] = *(const f32x4*)p; q[2 * g + 1] = *(const f32x4*)(p + 16);
     }
   }
+  __device__ __forceinline__ void get(float v[16]) const {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[4 * g + i] = q[g][i];
+  }
+};
+
+// Epilogue of one 32-cout block of a wave (R rows x 1 pixel x 16 couts per lane); operation order
+// as documented on esr_conv in esrgan_hip.h.  Two phases: (1) issue EVERY global load of all R rows
+// (bias, residuals, explicit z, mask) back to back, (2) compute and store.  With one or two waves
+// per SIMD a load->use->store chain per row would expose R full memory latencies.
+template <typename T, int R, int NCW, int CW, bool HAS1X1>
+__device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc8& acc1, int b, int cb, int h,
+                                               int oyb, int ox) {
+  const bool n1 = (p.noise_mode == ESR_NOISE_PHILOX && p.layer1 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z1.ptr);
+  const bool n2 = (p.noise_mode == ESR_NOISE_PHILOX && p.layer2 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z2.ptr);
+  const bool xz = p.noise_mode == ESR_NOISE_EXPLICIT;
+  f32x4 bq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bq[i] = p.bias ? *(const f32x4*)(p.bias + cb * 32 + 16 * h + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+  Raw16<T> r1[R], r2[R];   // prefetched; explicit-z / mask operands (test & dgrad modes) load in phase 2
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int oy = oyb + r < p.H ? oyb + r : p.H - 1;     // clamp: rows past the image are not stored
+    if (p.res1.ptr) r1[r].load(p.res1, b, cb, h, (int64_t)(oy + 1) * p.res1.wp + ox + 1);
+    if (p.res2.ptr) r2[r].load(p.res2, b, cb, h, (int64_t)(oy + 1) * p.res2.wp + ox + 1);
+  }
+  sfor<R>([&](auto RR) __attribute__((always_inline)) {
+    constexpr int r = decltype(RR)::value;
+    const int oy = oyb + r;
+    if (oy >= p.H) return;
+    const f32x16 a = accsel<r * NCW + CW>(acc);
+    float v[16], tmp[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float x = a[e] + bq[e >> 2][e & 3];
+      if (p.act == ESR_ACT_LRELU) x = x > 0.f ? x : x * ESR_LRELU_SLOPE;
+      else if (p.act == ESR_ACT_RELU) x = x > 0.f ? x : 0.f;
+      v[e] = x;
+    }
+    if (p.aux_out.ptr) Px16<T>::store(p.aux_out, b, cb, h, (int64_t)(oy + 1) * p.aux_out.wp + ox + 1, v);
+    if constexpr (HAS1X1) {
+      const f32x16 a1 = accsel<r>(acc1);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += a1[e];
+    }
+    if (p.res1.ptr) {
+      r1[r].get(tmp);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = v[e] * p.alpha + tmp[e];
+    }
+    const uint32_t pix = (uint32_t)((b * p.H + oy) * p.W + ox);
+    if (n1) {
+      if (xz) Px16<T>::load(p.z1, b, cb, h, (int64_t)(oy + 1) * p.z1.wp + ox + 1, tmp);
+      else {
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer1, p.seed, &tmp[4 * q]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);   // block.py:119-121
+    }
+    if (p.res2.ptr) {
+      r2[r].get(tmp);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = v[e] * p.beta + tmp[e];
+    }
+    if (n2) {
+      if (xz) Px16<T>::load(p.z2, b, cb, h, (int64_t)(oy + 1) * p.z2.wp + ox + 1, tmp);
+      else {
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer2, p.seed, &tmp[4 * q]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
+    }
+    if (p.out.ptr) Px16<T>::store(p.out, b, cb, h, (int64_t)(oy + 1) * p.out.wp + ox + 1, v);
+    if (p.mask.ptr) {
+      Px16<T>::load(p.mask, b, cb, h, (int64_t)(oy + 1) * p.mask.wp + ox + 1, tmp);
+      const float neg = p.act == ESR_ACT_RELU ? 0.f : ESR_LRELU_SLOPE;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tmp[e] = tmp[e] > 0.f ? v[e] : v[e] * neg;
+      Px16<T>::store(p.out2, b, cb, h, (int64_t)(oy + 1) * p.out2.wp + ox + 1, tmp);
+    }
+    if (p.nchw_out_c > 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ch = cb * 32 + 16 * h + e;
+        if (ch < p.nchw_out_c) p.nchw_out[(((int64_t)b * p.nchw_out_c + ch) * p.H + oy) * p.W + ox] = v[e];
+      }
+    }
+  });
 }
 
-template <typename T, int KS, int S, bool UPS, int WR, int WC, int NCG, bool HAS1X1>
-__global__ __launch_bounds__(256, 1) void conv_kernel(const esr_conv p) {
-  using G = Geo<KS, S, UPS, WR, WC>;
-  static_assert(WR * WC * NCG == 4, "4 waves per workgroup");
+// ------------------------------------------------------------------------------------------------
+// Tile geometry.  A workgroup = 8 waves = WR x WC spatial waves x NCG cout-groups; every wave owns
+// R=4 output rows x 32 output pixels x NCW blocks of 32 couts (R*NCW <= 8 MFMA accumulators).
+// ------------------------------------------------------------------------------------------------
+template <int KS, int S, bool UPS, int WR, int WC, int NCG, int NCW, bool WLDS>
+struct Geo {
+  static constexpr int R = 4;
+  static constexpr int NW = WR * WC * NCG;                               // waves per workgroup
+  static constexpr int NT = NW * 64;
+  static constexpr int TH = R * WR, TW = 32 * WC;                        // output tile
+  static constexpr int IH = UPS ? TH / 2 + 2 : (TH - 1) * S + KS;       // staged input tile
+  static constexpr int IW = UPS ? TW / 2 + 2 : (TW - 1) * S + KS;
+  static constexpr int WIH = UPS ? R / 2 + 2 : (R - 1) * S + KS;        // input rows one wave reads
+  static constexpr int NSLOT = IH * IW * 2;                              // 16-byte slots (activations)
+  static constexpr int ACT = ((NSLOT * 16 + 1023) / 1024) * 1024;        // bytes, padded to a wave DMA
+  static constexpr int NLD = (NSLOT + NT - 1) / NT;                      // DMA rounds per thread
+  static constexpr int WSLOT = WLDS ? NCG * NCW * KS * KS * 64 : 0;      // 16-byte slots (weights)
+  static constexpr int WLD = (WSLOT + NT - 1) / NT;
+  static constexpr int STAGE = ACT + WSLOT * 16;
+  static constexpr int PAD = (KS - 1) / 2;
+  static constexpr int NTAP = KS * KS;
+  static_assert(NW == 8, "8 waves per workgroup");
+  static_assert(R * NCW <= 8, "accumulator budget");
+  static_assert(2 * STAGE <= 160 * 1024, "LDS budget");
+};
+
+template <typename T, int KS, int S, bool UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
+__global__ __launch_bounds__(512, 2) void conv_kernel(const esr_conv p) {
+  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS>;
+  constexpr int R = G::R;
+  static_assert(!HAS1X1 || (NCW == 1 && KS == 3 && S == 1 && !UPS), "fused 1x1 only on the N=32 3x3 conv");
   __shared__ __attribute__((aligned(16))) char smem[2 * G::STAGE];
 
   const int tid = threadIdx.x;
@@ -223,8 +292,8 @@ __global__ __launch_bounds__(256, 1) void conv_kernel(const esr_conv p) {
   const int wr = (wave / NCG) / WC;
   const int j = lane & 31, h = lane >> 5;
 
-  // ---- XCD-aware tile mapping: block b runs on XCD b%8; give every XCD a contiguous run of
-  // tiles (neighbouring tiles share halo rows -> they hit the same private L2).
+  // ---- XCD-aware tile mapping: block b runs on XCD b%8; give every XCD a contiguous run of tiles
+  // (= whole images) so the activations it wrote in the previous launch are in ITS L2 / nearby MALL.
   const int tiles_x = (p.W + G::TW - 1) / G::TW, tiles_y = (p.H + G::TH - 1) / G::TH;
   int t;
   {
@@ -232,141 +301,183 @@ __global__ __launch_bounds__(256, 1) void conv_kernel(const esr_conv p) {
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
-  const int cb = blockIdx.y * NCG + cg;             // 32-cout block of this wave
-  const bool cb_ok = cb < p.cout_blocks;
-  const int oy0 = ty * G::TH, ox0 = tx * G::TW;     // output tile origin (logical)
+  const int cb0 = (blockIdx.y * NCG + cg) * NCW;     // first 32-cout block of this wave
+  const int oy0 = ty * G::TH, ox0 = tx * G::TW;      // output tile origin (logical)
 
-  // ---- staging map: LDS slot s = tid + 256*i (16 bytes) <- input tile, by LDS-DMA.
-  // LDS image: [row][col][2 halves]; the two 16-byte halves of pixel `col` are swapped when
-  // (col>>3)&1 so that the 16 lanes of a ds_read_b128 group cover 16 distinct bank slots.  The
-  // DMA destination is lane-linear, so the swizzle is applied to the SOURCE address.
-  const int iy0 = UPS ? oy0 / 2 : oy0 * S + 1 - G::PAD;   // padded coords of tile origin
+  // ---- activation staging map: LDS slot s = tid + NT*i (16 bytes) <- input tile, by LDS-DMA.
+  // LDS image [row][col][2 halves]; the two 16-byte halves of pixel `col` are swapped when
+  // (col>>3)&1 so the 16 lanes of a ds_read_b128 group cover 16 distinct bank slots.  The DMA
+  // destination is lane-linear, so the swizzle is applied to the SOURCE address.
+  const int iy0 = UPS ? oy0 / 2 : oy0 * S + 1 - G::PAD;   // padded coords of the tile origin
   const int ix0 = UPS ? ox0 / 2 : ox0 * S + 1 - G::PAD;
   int goff[G::NLD];
 #pragma unroll
   for (int i = 0; i < G::NLD; ++i) {
-    int s = tid + 256 * i;
-    if (s >= G::NSLOT) s = G::NSLOT - 1;            // tail lanes land in the stage's padding
+    int s = tid + G::NT * i;
+    if (s >= G::NSLOT) s = G::NSLOT - 1;             // tail lanes land in the stage's padding
     const int row = s / (2 * G::IW), rem = s - row * 2 * G::IW;
     const int col = rem >> 1, hs = rem & 1, half = hs ^ ((col >> 3) & 1);
     goff[i] = ((iy0 + row) * p.in.wp + ix0 + col) * 32 + half * 16;
   }
   const char* in_b = (const char*)p.in.ptr + b * p.in.batch_stride;
-  char* const lds_w = smem + wave * 1024;           // this wave's 64-slot window inside a stage
+  const int64_t in_gs = p.in.group_stride;
+  char* const lds_wv = smem + wave * 1024;           // this wave's 64-slot DMA window
 
   // ---- B-fragment (activation) read offsets, one per kw tap
   int colofs[KS];
 #pragma unroll
   for (int kw = 0; kw < KS; ++kw) {
     const int col = UPS ? (((wc * 32 + j + kw - 1) >> 1) + 1) : ((wc * 32 + j) * S + kw);
-    colofs[kw] = col * 32 + ((h ^ ((col >> 3) & 1)) << 4) + (UPS ? wr * 4 : wr * 8 * S) * G::IW * 32;
+    colofs[kw] = col * 32 + ((h ^ ((col >> 3) & 1)) << 4) + (UPS ? wr * (R / 2) : wr * R * S) * G::IW * 32;
   }
 
-  // ---- A-fragment (weight) pointer: [cb][chunk][tap][lane][16B]
+  // ---- weights: packed [cout_block][chunk][tap][lane][16 B]
   const int nchunks = p.cin_groups;
-  const char* wp = (const char*)p.w + ((int64_t)(cb_ok ? cb : 0) * nchunks * (KS * KS) * 64 + lane) * 16;
-  const char* w1p = HAS1X1 ? (const char*)p.w1x1 + ((int64_t)(cb_ok ? cb : 0) * p.n1x1_groups * 64 + lane) * 16 : nullptr;
+  const int64_t w_cb_stride = (int64_t)nchunks * G::NTAP * 1024;
+  const char* const wbase = (const char*)p.w;
+  const int n1x1 = HAS1X1 ? p.n1x1_groups : 0;
+  const char* const w1p = HAS1X1 ? (const char*)p.w1x1 + ((int64_t)cb0 * n1x1 * 64 + lane) * 16 : nullptr;
+  // register-resident weight path (WLDS == false)
+  const char* wreg[NCW];
+#pragma unroll
+  for (int cw = 0; cw < NCW; ++cw) {
+    const int cb = cb0 + cw < p.cout_blocks ? cb0 + cw : 0;
+    wreg[cw] = wbase + cb * w_cb_stride + lane * 16;
+  }
 
   Acc8 acc, acc1;
   acc_zero(acc);
   if constexpr (HAS1X1) acc_zero(acc1);
 
-  u32x4 wf[KS * KS], wn[KS * KS];
+  u32x4 wf[WLDS ? 1 : NCW * G::NTAP], wn[WLDS ? 1 : NCW * G::NTAP];
   u32x4 w1f = {0, 0, 0, 0}, w1n = {0, 0, 0, 0};
 
-  const int64_t in_gs = p.in.group_stride;
-  const int n1x1 = HAS1X1 ? p.n1x1_groups : 0;
-  auto stage_in = [&](int chunk, int st) {
+  auto stage_in = [&](int chunk, int st) __attribute__((always_inline)) {
     const char* src = in_b + (int64_t)chunk * in_gs;
-    char* dst = lds_w + st * G::STAGE;
+    char* dst = lds_wv + st * G::STAGE;
 #pragma unroll
     for (int i = 0; i < G::NLD; ++i)   // only the last round can run past the tile
-      if (i < G::NLD - 1 || wave * 64 + 256 * i < ((G::NSLOT + 63) / 64) * 64) dma16(src + goff[i], dst + 4096 * i);
+      if (i < G::NLD - 1 || wave * 64 + G::NT * i < G::ACT / 16) dma16(src + goff[i], dst + G::NT * 16 * i);
+    if constexpr (WLDS) {
+      // weight fragments of this K step for all NCG*NCW cout blocks of the workgroup: a linear copy
+#pragma unroll
+      for (int i = 0; i < G::WLD; ++i) {
+        const int s0 = wave * 64 + G::NT * i;        // wave-uniform first slot
+        if (i < G::WLD - 1 || s0 < G::WSLOT) {
+          const int blk = s0 / (G::NTAP * 64);        // which cout block of the WG (wave-uniform)
+          int cb = blockIdx.y * NCG * NCW + blk;
+          if (cb >= p.cout_blocks) cb = 0;
+          const char* wsrc = wbase + cb * w_cb_stride + (int64_t)chunk * G::NTAP * 1024 +
+                             (s0 - blk * G::NTAP * 64 + lane) * 16;
+          dma16(wsrc, dst + G::ACT + G::NT * 16 * i);
+        }
+      }
+    }
   };
 
   // prologue: chunk 0
   stage_in(0, 0);
+  if constexpr (!WLDS) {
 #pragma unroll
-  for (int tp = 0; tp < KS * KS; ++tp) wf[tp] = *(const u32x4*)(wp + tp * 1024);
+    for (int cw = 0; cw < NCW; ++cw)
+#pragma unroll
+      for (int tp = 0; tp < G::NTAP; ++tp) wf[cw * G::NTAP + tp] = *(const u32x4*)(wreg[cw] + tp * 1024);
+  }
   if (HAS1X1) w1f = *(const u32x4*)w1p;
   __syncthreads();
 
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
-    if (more) {   // prefetch chunk c+1: activations by LDS-DMA, weights into wn
+    if (more) {   // prefetch K step c+1 (LDS-DMA; register weights into wn)
       stage_in(c + 1, (c + 1) & 1);
-      const char* wsrc = wp + (int64_t)(c + 1) * (KS * KS) * 1024;
+      if constexpr (!WLDS) {
 #pragma unroll
-      for (int tp = 0; tp < KS * KS; ++tp) wn[tp] = *(const u32x4*)(wsrc + tp * 1024);
+        for (int cw = 0; cw < NCW; ++cw)
+#pragma unroll
+          for (int tp = 0; tp < G::NTAP; ++tp)
+            wn[cw * G::NTAP + tp] = *(const u32x4*)(wreg[cw] + (int64_t)(c + 1) * G::NTAP * 1024 + tp * 1024);
+      }
       if (HAS1X1 && c + 1 < n1x1) w1n = *(const u32x4*)(w1p + (int64_t)(c + 1) * 1024);
     }
 
     const char* lds = smem + (c & 1) * G::STAGE;
+    const char* ldw = lds + G::ACT + ((cg * NCW) * G::NTAP * 64 + lane) * 16;   // this wave's A fragments
     const bool do1x1 = HAS1X1 && c < n1x1;
-    sfor<G::WIH>([&](auto IR) __attribute__((always_inline)) {
-      constexpr int ir = decltype(IR)::value;
-      u32x4 bf[KS];
+
+    // kw-major: the KS*NCW A fragments of column tap kw stay in registers while the wave walks its
+    // WIH input rows; each B fragment read feeds up to KS*NCW MFMAs.
+    sfor<KS>([&](auto KW) __attribute__((always_inline)) {
+      constexpr int kw = decltype(KW)::value;
+      u32x4 af[KS * NCW];
 #pragma unroll
-      for (int kw = 0; kw < KS; ++kw) bf[kw] = *(const u32x4*)(lds + colofs[kw] + ir * G::IW * 32);
-      sfor<KS>([&](auto KW) __attribute__((always_inline)) {
-        constexpr int kw = decltype(KW)::value;
+      for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+        for (int cw = 0; cw < NCW; ++cw) {
+          if constexpr (WLDS) af[kh * NCW + cw] = *(const u32x4*)(ldw + (cw * G::NTAP + kh * KS + kw) * 1024);
+          else af[kh * NCW + cw] = wf[cw * G::NTAP + kh * KS + kw];
+        }
+      sfor<G::WIH>([&](auto IR) __attribute__((always_inline)) {
+        constexpr int ir = decltype(IR)::value;
+        const u32x4 bf = *(const u32x4*)(lds + colofs[kw] + ir * G::IW * 32);
         sfor<KS>([&](auto KH) __attribute__((always_inline)) {
           constexpr int kh = decltype(KH)::value;
           if constexpr (UPS) {
-            sfor<8>([&](auto R) __attribute__((always_inline)) {
-              constexpr int r = decltype(R)::value;
-              if constexpr ((((r + kh - 1) >> 1) + 1) == ir) mma<T>(accsel<r>(acc), wf[kh * KS + kw], bf[kw]);
+            sfor<R>([&](auto RR) __attribute__((always_inline)) {
+              constexpr int r = decltype(RR)::value;
+              if constexpr ((((r + kh - 1) >> 1) + 1) == ir) {
+                sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
+                  constexpr int cw = decltype(CW)::value;
+                  mma<T>(accsel<r * NCW + cw>(acc), af[kh * NCW + cw], bf);
+                });
+              }
             });
           } else {
             constexpr int tt = ir - kh;
-            if constexpr (tt >= 0 && tt % S == 0 && tt / S < 8) mma<T>(accsel<tt / S>(acc), wf[kh * KS + kw], bf[kw]);
+            if constexpr (tt >= 0 && tt % S == 0 && tt / S < R) {
+              sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
+                constexpr int cw = decltype(CW)::value;
+                mma<T>(accsel<(tt / S) * NCW + cw>(acc), af[kh * NCW + cw], bf);
+              });
+            }
           }
         });
-        if constexpr (HAS1X1 && !UPS && S == 1 && kw == G::PAD) {   // centre tap feeds the 1x1 residual conv
+        if constexpr (HAS1X1 && kw == G::PAD) {   // centre tap also feeds the fused 1x1 conv
           constexpr int r = ir - G::PAD;
-          if constexpr (r >= 0 && r < 8) {
-            if (do1x1) mma<T>(accsel<r>(acc1), w1f, bf[kw]);
+          if constexpr (r >= 0 && r < R) {
+            if (do1x1) mma<T>(accsel<r>(acc1), w1f, bf);
           }
         }
       });
     });
 
     if (more) {
+      if constexpr (!WLDS) {
 #pragma unroll
-      for (int tp = 0; tp < KS * KS; ++tp) wf[tp] = wn[tp];
+        for (int tp = 0; tp < NCW * G::NTAP; ++tp) wf[tp] = wn[tp];
+      }
       if (HAS1X1) w1f = w1n;
     }
     __syncthreads();   // drains the DMA (vmcnt(0)) and fences LDS for the next stage
   }
 
-  if (!cb_ok) return;
-
   // ---------------------------------------------------------------- epilogue
-  float bias[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) bias[e] = p.bias ? p.bias[cb * 32 + 16 * h + e] : 0.f;
   const int ox = ox0 + wc * 32 + j;
   if (ox >= p.W) return;
-#pragma unroll 1
-  for (int r = 0; r < 8; ++r) {
-    const int oy = oy0 + wr * 8 + r;
-    if (oy >= p.H) break;
-    const f32x16 a = pick8(acc, r);
-    if constexpr (HAS1X1) {
-      const f32x16 a1 = pick8(acc1, r);
-      epilogue_row<T>(p, a, &a1, bias, b, cb, h, oy, ox);
-    } else {
-      epilogue_row<T>(p, a, nullptr, bias, b, cb, h, oy, ox);
-    }
-  }
+  const int oyb = oy0 + wr * R;
+  sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
+    constexpr int cw = decltype(CW)::value;
+    const int cb = cb0 + cw;
+    if (cb >= p.cout_blocks) return;
+    epilogue_block<T, R, NCW, cw, HAS1X1>(p, acc, acc1, b, cb, h, oyb, ox);
+  });
 }
 
-template <typename T, int KS, int S, bool UPS, int WR, int WC, int NCG, bool HAS1X1>
+template <typename T, int KS, int S, bool UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
 int launch(const esr_conv& p, hipStream_t st) {
-  using G = Geo<KS, S, UPS, WR, WC>;
+  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS>;
   const int tiles = ((p.W + G::TW - 1) / G::TW) * ((p.H + G::TH - 1) / G::TH) * p.B;
-  dim3 grid(tiles, (p.cout_blocks + NCG - 1) / NCG);
-  hipLaunchKernelGGL((conv_kernel<T, KS, S, UPS, WR, WC, NCG, HAS1X1>), grid, dim3(256), 0, st, p);
+  dim3 grid(tiles, (p.cout_blocks + NCG * NCW - 1) / (NCG * NCW));
+  hipLaunchKernelGGL((conv_kernel<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>), grid, dim3(G::NT), 0, st, p);
   return esr_check_launch("conv_kernel");
 }
 
@@ -374,25 +485,24 @@ template <typename T>
 int dispatch(const esr_conv& p, hipStream_t st) {
   const bool has1 = p.w1x1 != nullptr;
   const int cbk = p.cout_blocks;
+  const bool narrow = p.W <= 32;
   if (p.ks == 3 && p.stride == 1 && !p.upsample) {
     if (has1) {
       if (cbk != 1) { esr_set_error("conv: fused 1x1 needs cout_blocks==1"); return ESR_ERR_UNSUPPORTED; }
-      return p.W <= 32 ? launch<T, 3, 1, false, 4, 1, 1, true>(p, st) : launch<T, 3, 1, false, 2, 2, 1, true>(p, st);
+      return narrow ? launch<T, 3, 1, false, 8, 1, 1, 1, true, true>(p, st) : launch<T, 3, 1, false, 4, 2, 1, 1, true, true>(p, st);
     }
-    if (cbk == 1) return p.W <= 32 ? launch<T, 3, 1, false, 4, 1, 1, false>(p, st) : launch<T, 3, 1, false, 2, 2, 1, false>(p, st);
-    if (cbk < 4 || cbk % 4) return launch<T, 3, 1, false, 2, 1, 2, false>(p, st);
-    return launch<T, 3, 1, false, 1, 1, 4, false>(p, st);
+    if (cbk == 1) return narrow ? launch<T, 3, 1, false, 8, 1, 1, 1, true, false>(p, st) : launch<T, 3, 1, false, 4, 2, 1, 1, true, false>(p, st);
+    if (cbk <= 3) return narrow ? launch<T, 3, 1, false, 8, 1, 1, 2, true, false>(p, st) : launch<T, 3, 1, false, 4, 2, 1, 2, true, false>(p, st);
+    return launch<T, 3, 1, false, 2, 1, 4, 1, false, false>(p, st);     // wide convs (D / VGG)
   }
   if (has1) { esr_set_error("conv: fused 1x1 only with 3x3/s1"); return ESR_ERR_UNSUPPORTED; }
   if (p.ks == 3 && p.stride == 1 && p.upsample) {
     if ((p.H | p.W) & 1) { esr_set_error("conv: upsample needs even output size"); return ESR_ERR_INVALID; }
-    return cbk == 1 ? launch<T, 3, 1, true, 2, 2, 1, false>(p, st) : launch<T, 3, 1, true, 2, 1, 2, false>(p, st);
+    return cbk == 1 ? launch<T, 3, 1, true, 4, 2, 1, 1, true, false>(p, st) : launch<T, 3, 1, true, 4, 2, 1, 2, true, false>(p, st);
   }
-  if (p.ks == 4 && p.stride == 2 && !p.upsample) {
-    return (cbk < 4 || cbk % 4) ? launch<T, 4, 2, false, 1, 2, 2, false>(p, st) : launch<T, 4, 2, false, 1, 1, 4, false>(p, st);
-  }
+  if (p.ks == 4 && p.stride == 2 && !p.upsample) return launch<T, 4, 2, false, 2, 1, 4, 1, false, false>(p, st);
   if (p.ks == 1 && p.stride == 1 && !p.upsample) {
-    return cbk == 1 ? launch<T, 1, 1, false, 2, 2, 1, false>(p, st) : launch<T, 1, 1, false, 2, 1, 2, false>(p, st);
+    return cbk == 1 ? launch<T, 1, 1, false, 4, 2, 1, 1, true, false>(p, st) : launch<T, 1, 1, false, 4, 2, 1, 2, true, false>(p, st);
   }
   esr_set_error("conv: unsupported ks=%d stride=%d upsample=%d", p.ks, p.stride, p.upsample);
   return ESR_ERR_UNSUPPORTED;
