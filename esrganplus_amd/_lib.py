@@ -40,7 +40,8 @@ class esr_conv(C.Structure):
                 ('noise_mode', C.c_int32), ('sigma', C.c_float), ('seed', C.c_uint64),
                 ('layer1', C.c_uint32), ('layer2', C.c_uint32),
                 ('z1', esr_g32), ('z2', esr_g32), ('mask', esr_g32), ('out2', esr_g32),
-                ('nchw_out_c', C.c_int32), ('nchw_out', C.c_void_p)]
+                ('nchw_out_c', C.c_int32), ('nchw_out', C.c_void_p),
+                ('debug_flags', C.c_int32), ('_reserved', C.c_int32)]
 
 
 class esr_pack(C.Structure):

@@ -254,8 +254,12 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
 // ------------------------------------------------------------------------------------------------
 // Tile geometry.  A workgroup = 8 waves = WR x WC spatial waves x NCG cout-groups; every wave owns
 // R=4 output rows x 32 output pixels x NCW blocks of 32 couts (R*NCW <= 8 MFMA accumulators).
+// LDS holds an NST-deep ring of K-step stages; one stage = the activation halo tile of ONE 32-byte
+// channel group [+ the A fragments (weights) of that K step for every cout block of the workgroup].
+// Every wave issues exactly NDMA LDS-DMA instructions per K step (tail rounds re-copy an earlier
+// window), so a counted `s_waitcnt vmcnt(NDMA)` retires exactly one stage.
 // ------------------------------------------------------------------------------------------------
-template <int KS, int S, bool UPS, int WR, int WC, int NCG, int NCW, bool WLDS>
+template <int KS, int S, bool UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
 struct Geo {
   static constexpr int R = 4;
   static constexpr int NW = WR * WC * NCG;                               // waves per workgroup
@@ -265,24 +269,31 @@ struct Geo {
   static constexpr int IW = UPS ? TW / 2 + 2 : (TW - 1) * S + KS;
   static constexpr int WIH = UPS ? R / 2 + 2 : (R - 1) * S + KS;        // input rows one wave reads
   static constexpr int NSLOT = IH * IW * 2;                              // 16-byte slots (activations)
-  static constexpr int ACT = ((NSLOT * 16 + 1023) / 1024) * 1024;        // bytes, padded to a wave DMA
-  static constexpr int NLD = (NSLOT + NT - 1) / NT;                      // DMA rounds per thread
-  static constexpr int WSLOT = WLDS ? NCG * NCW * KS * KS * 64 : 0;      // 16-byte slots (weights)
-  static constexpr int WLD = (WSLOT + NT - 1) / NT;
-  static constexpr int STAGE = ACT + WSLOT * 16;
-  static constexpr int PAD = (KS - 1) / 2;
+  static constexpr int NLD = (NSLOT + NT - 1) / NT;                      // activation DMA rounds
+  static constexpr int ACT = NLD * NT * 16;                              // bytes (tail lanes -> padding)
   static constexpr int NTAP = KS * KS;
+  static constexpr int WWIN = WLDS ? NCG * NCW * NTAP + (HAS1X1 ? 1 : 0) : 0;   // 1 KB weight windows
+  static constexpr int WLD = (WWIN + NW - 1) / NW;                        // weight DMA rounds
+  static constexpr int NDMA = NLD + WLD;
+  static constexpr int STAGE = ACT + WWIN * 1024;
+  static constexpr int NST = (3 * STAGE <= 160 * 1024) ? 3 : 2;          // ring depth
+  static constexpr int PAD = (KS - 1) / 2;
   static_assert(NW == 8, "8 waves per workgroup");
   static_assert(R * NCW <= 8, "accumulator budget");
   static_assert(2 * STAGE <= 160 * 1024, "LDS budget");
 };
 
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <typename T, int KS, int S, bool UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
 __global__ __launch_bounds__(512, 2) void conv_kernel(const esr_conv p) {
-  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS>;
+  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>;
   constexpr int R = G::R;
-  static_assert(!HAS1X1 || (NCW == 1 && KS == 3 && S == 1 && !UPS), "fused 1x1 only on the N=32 3x3 conv");
-  __shared__ __attribute__((aligned(16))) char smem[2 * G::STAGE];
+  constexpr int NST = G::NST;
+  static_assert(!HAS1X1 || (NCW == 1 && NCG == 1 && KS == 3 && S == 1 && !UPS && WLDS), "fused 1x1 only on the N=32 3x3 conv");
+  __shared__ __attribute__((aligned(16))) char smem[NST * G::STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const esr_conv p) {
 #pragma unroll
   for (int i = 0; i < G::NLD; ++i) {
     int s = tid + G::NT * i;
-    if (s >= G::NSLOT) s = G::NSLOT - 1;             // tail lanes land in the stage's padding
+    if (s >= G::NSLOT) s = G::NSLOT - 1;             // tail lanes: harmless re-copy into the padding
     const int row = s / (2 * G::IW), rem = s - row * 2 * G::IW;
     const int col = rem >> 1, hs = rem & 1, half = hs ^ ((col >> 3) & 1);
     goff[i] = ((iy0 + row) * p.in.wp + ix0 + col) * 32 + half * 16;
@@ -336,7 +347,27 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const esr_conv p) {
   const int64_t w_cb_stride = (int64_t)nchunks * G::NTAP * 1024;
   const char* const wbase = (const char*)p.w;
   const int n1x1 = HAS1X1 ? p.n1x1_groups : 0;
-  const char* const w1p = HAS1X1 ? (const char*)p.w1x1 + ((int64_t)cb0 * n1x1 * 64 + lane) * 16 : nullptr;
+  // LDS weight windows this wave copies each K step: window q = wave + 8*i (wrapping -> duplicate)
+  const char* wsrc[G::WLD > 0 ? G::WLD : 1];
+  int wdst[G::WLD > 0 ? G::WLD : 1];
+  int64_t wstep[G::WLD > 0 ? G::WLD : 1];
+  if constexpr (WLDS) {
+#pragma unroll
+    for (int i = 0; i < G::WLD; ++i) {
+      const int q = (wave + G::NW * i) % G::WWIN;
+      wdst[i] = G::ACT + q * 1024;
+      if (HAS1X1 && q == G::WWIN - 1) {              // the fused 1x1's A fragment: [cb][chunk][lane]
+        wsrc[i] = (const char*)p.w1x1 + ((int64_t)cb0 * n1x1 * 64 + lane) * 16;
+        wstep[i] = 1024;
+      } else {
+        const int blk = q / G::NTAP;                  // cout block within the workgroup
+        int cb = blockIdx.y * NCG * NCW + blk;
+        if (cb >= p.cout_blocks) cb = 0;
+        wsrc[i] = wbase + cb * w_cb_stride + ((q - blk * G::NTAP) * 64 + lane) * 16;
+        wstep[i] = (int64_t)G::NTAP * 1024;
+      }
+    }
+  }
   // register-resident weight path (WLDS == false)
   const char* wreg[NCW];
 #pragma unroll
@@ -345,124 +376,137 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const esr_conv p) {
     wreg[cw] = wbase + cb * w_cb_stride + lane * 16;
   }
 
+  const int dbg = p.debug_flags;
   Acc8 acc, acc1;
   acc_zero(acc);
   if constexpr (HAS1X1) acc_zero(acc1);
 
   u32x4 wf[WLDS ? 1 : NCW * G::NTAP], wn[WLDS ? 1 : NCW * G::NTAP];
-  u32x4 w1f = {0, 0, 0, 0}, w1n = {0, 0, 0, 0};
 
   auto stage_in = [&](int chunk, int st) __attribute__((always_inline)) {
     const char* src = in_b + (int64_t)chunk * in_gs;
     char* dst = lds_wv + st * G::STAGE;
+    if (!(dbg & 4)) {
 #pragma unroll
-    for (int i = 0; i < G::NLD; ++i)   // only the last round can run past the tile
-      if (i < G::NLD - 1 || wave * 64 + G::NT * i < G::ACT / 16) dma16(src + goff[i], dst + G::NT * 16 * i);
+      for (int i = 0; i < G::NLD; ++i) dma16(src + goff[i], dst + G::NT * 16 * i);
+    }
     if constexpr (WLDS) {
-      // weight fragments of this K step for all NCG*NCW cout blocks of the workgroup: a linear copy
 #pragma unroll
       for (int i = 0; i < G::WLD; ++i) {
-        const int s0 = wave * 64 + G::NT * i;        // wave-uniform first slot
-        if (i < G::WLD - 1 || s0 < G::WSLOT) {
-          const int blk = s0 / (G::NTAP * 64);        // which cout block of the WG (wave-uniform)
-          int cb = blockIdx.y * NCG * NCW + blk;
-          if (cb >= p.cout_blocks) cb = 0;
-          const char* wsrc = wbase + cb * w_cb_stride + (int64_t)chunk * G::NTAP * 1024 +
-                             (s0 - blk * G::NTAP * 64 + lane) * 16;
-          dma16(wsrc, dst + G::ACT + G::NT * 16 * i);
-        }
+        const int cc = (HAS1X1 && wstep[i] == 1024 && chunk >= n1x1) ? 0 : chunk;   // 1x1 has fewer K steps
+        dma16(wsrc[i] + cc * wstep[i], smem + st * G::STAGE + wdst[i]);
       }
     }
   };
 
-  // prologue: chunk 0
+  // prologue: fill NST-1 stages
   stage_in(0, 0);
+  if constexpr (NST == 3) { if (nchunks > 1) stage_in(1, 1); }
   if constexpr (!WLDS) {
 #pragma unroll
     for (int cw = 0; cw < NCW; ++cw)
 #pragma unroll
       for (int tp = 0; tp < G::NTAP; ++tp) wf[cw * G::NTAP + tp] = *(const u32x4*)(wreg[cw] + tp * 1024);
   }
-  if (HAS1X1) w1f = *(const u32x4*)w1p;
-  __syncthreads();
 
+  int st = 0;   // ring slot of K step c
   for (int c = 0; c < nchunks; ++c) {
-    const bool more = c + 1 < nchunks;
-    if (more) {   // prefetch K step c+1 (LDS-DMA; register weights into wn)
-      stage_in(c + 1, (c + 1) & 1);
-      if constexpr (!WLDS) {
+    // ---- retire K step c: its DMAs were issued before those of step c+1 (in-order return)
+    if constexpr (WLDS) {
+      if (NST == 3 && c + 1 < nchunks) wait_vmcnt<G::NDMA>(); else wait_vmcnt<0>();
+    } else {
+      wait_vmcnt<0>();   // mixed VGPR loads + DMA: plain drain
+    }
+    __builtin_amdgcn_s_barrier();   // step c visible to all waves; all waves done reading slot (c-1)
+    // ---- refill the slot that step c-1 just vacated with step c+NST-1
+    const int cn = c + NST - 1;
+    if (cn < nchunks) {
+      int sn = st + NST - 1; if (sn >= NST) sn -= NST;
+      stage_in(cn, sn);
+    }
+    if constexpr (!WLDS) {
+      if (c + 1 < nchunks) {
 #pragma unroll
         for (int cw = 0; cw < NCW; ++cw)
 #pragma unroll
           for (int tp = 0; tp < G::NTAP; ++tp)
             wn[cw * G::NTAP + tp] = *(const u32x4*)(wreg[cw] + (int64_t)(c + 1) * G::NTAP * 1024 + tp * 1024);
       }
-      if (HAS1X1 && c + 1 < n1x1) w1n = *(const u32x4*)(w1p + (int64_t)(c + 1) * 1024);
     }
 
-    const char* lds = smem + (c & 1) * G::STAGE;
+    const char* lds = smem + st * G::STAGE;
     const char* ldw = lds + G::ACT + ((cg * NCW) * G::NTAP * 64 + lane) * 16;   // this wave's A fragments
     const bool do1x1 = HAS1X1 && c < n1x1;
 
     // kw-major: the KS*NCW A fragments of column tap kw stay in registers while the wave walks its
-    // WIH input rows; each B fragment read feeds up to KS*NCW MFMAs.
-    sfor<KS>([&](auto KW) __attribute__((always_inline)) {
+    // WIH input rows; each B fragment read feeds up to KS*NCW MFMAs.  Fragments of tap kw+1 are
+    // read from LDS while the MFMAs of tap kw run.
+    u32x4 af[2][KS * NCW], bf[2][G::WIH], a1f;
+    auto read_step = [&](auto KW, u32x4 (&a)[KS * NCW], u32x4 (&bq)[G::WIH]) __attribute__((always_inline)) {
       constexpr int kw = decltype(KW)::value;
-      u32x4 af[KS * NCW];
 #pragma unroll
       for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
         for (int cw = 0; cw < NCW; ++cw) {
-          if constexpr (WLDS) af[kh * NCW + cw] = *(const u32x4*)(ldw + (cw * G::NTAP + kh * KS + kw) * 1024);
-          else af[kh * NCW + cw] = wf[cw * G::NTAP + kh * KS + kw];
+          if constexpr (WLDS) a[kh * NCW + cw] = *(const u32x4*)(ldw + (cw * G::NTAP + kh * KS + kw) * 1024);
+          else a[kh * NCW + cw] = wf[cw * G::NTAP + kh * KS + kw];
         }
-      sfor<G::WIH>([&](auto IR) __attribute__((always_inline)) {
-        constexpr int ir = decltype(IR)::value;
-        const u32x4 bf = *(const u32x4*)(lds + colofs[kw] + ir * G::IW * 32);
-        sfor<KS>([&](auto KH) __attribute__((always_inline)) {
-          constexpr int kh = decltype(KH)::value;
-          if constexpr (UPS) {
-            sfor<R>([&](auto RR) __attribute__((always_inline)) {
-              constexpr int r = decltype(RR)::value;
-              if constexpr ((((r + kh - 1) >> 1) + 1) == ir) {
+#pragma unroll
+      for (int ir = 0; ir < G::WIH; ++ir) bq[ir] = *(const u32x4*)(lds + colofs[kw] + ir * G::IW * 32);
+    };
+    if (!(dbg & 2)) {
+      read_step(std::integral_constant<int, 0>{}, af[0], bf[0]);
+      if constexpr (HAS1X1) a1f = *(const u32x4*)(lds + G::ACT + ((G::WWIN - 1) * 64 + lane) * 16);
+      sfor<KS>([&](auto KW) __attribute__((always_inline)) {
+        constexpr int kw = decltype(KW)::value;
+        constexpr int cur = kw & 1;
+        if constexpr (kw + 1 < KS) read_step(std::integral_constant<int, kw + 1>{}, af[cur ^ 1], bf[cur ^ 1]);
+        sfor<G::WIH>([&](auto IR) __attribute__((always_inline)) {
+          constexpr int ir = decltype(IR)::value;
+          sfor<KS>([&](auto KH) __attribute__((always_inline)) {
+            constexpr int kh = decltype(KH)::value;
+            if constexpr (UPS) {
+              sfor<R>([&](auto RR) __attribute__((always_inline)) {
+                constexpr int r = decltype(RR)::value;
+                if constexpr ((((r + kh - 1) >> 1) + 1) == ir) {
+                  sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
+                    constexpr int cw = decltype(CW)::value;
+                    mma<T>(accsel<r * NCW + cw>(acc), af[cur][kh * NCW + cw], bf[cur][ir]);
+                  });
+                }
+              });
+            } else {
+              constexpr int tt = ir - kh;
+              if constexpr (tt >= 0 && tt % S == 0 && tt / S < R) {
                 sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
                   constexpr int cw = decltype(CW)::value;
-                  mma<T>(accsel<r * NCW + cw>(acc), af[kh * NCW + cw], bf);
+                  mma<T>(accsel<(tt / S) * NCW + cw>(acc), af[cur][kh * NCW + cw], bf[cur][ir]);
                 });
               }
-            });
-          } else {
-            constexpr int tt = ir - kh;
-            if constexpr (tt >= 0 && tt % S == 0 && tt / S < R) {
-              sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
-                constexpr int cw = decltype(CW)::value;
-                mma<T>(accsel<(tt / S) * NCW + cw>(acc), af[kh * NCW + cw], bf);
-              });
+            }
+          });
+          if constexpr (HAS1X1 && kw == G::PAD) {   // centre tap also feeds the fused 1x1 conv
+            constexpr int r = ir - G::PAD;
+            if constexpr (r >= 0 && r < R) {
+              if (do1x1) mma<T>(accsel<r>(acc1), a1f, bf[cur][ir]);
             }
           }
         });
-        if constexpr (HAS1X1 && kw == G::PAD) {   // centre tap also feeds the fused 1x1 conv
-          constexpr int r = ir - G::PAD;
-          if constexpr (r >= 0 && r < R) {
-            if (do1x1) mma<T>(accsel<r>(acc1), w1f, bf);
-          }
-        }
       });
-    });
+    }
 
-    if (more) {
-      if constexpr (!WLDS) {
+    if constexpr (!WLDS) {
+      if (c + 1 < nchunks) {
 #pragma unroll
         for (int tp = 0; tp < NCW * G::NTAP; ++tp) wf[tp] = wn[tp];
       }
-      if (HAS1X1) w1f = w1n;
     }
-    __syncthreads();   // drains the DMA (vmcnt(0)) and fences LDS for the next stage
+    if (++st == NST) st = 0;
   }
 
   // ---------------------------------------------------------------- epilogue
   const int ox = ox0 + wc * 32 + j;
-  if (ox >= p.W) return;
+  if (ox >= p.W || (dbg & 1)) return;
   const int oyb = oy0 + wr * R;
   sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
     constexpr int cw = decltype(CW)::value;
@@ -474,7 +518,7 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const esr_conv p) {
 
 template <typename T, int KS, int S, bool UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
 int launch(const esr_conv& p, hipStream_t st) {
-  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS>;
+  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>;
   const int tiles = ((p.W + G::TW - 1) / G::TW) * ((p.H + G::TH - 1) / G::TH) * p.B;
   dim3 grid(tiles, (p.cout_blocks + NCG * NCW - 1) / (NCG * NCW));
   hipLaunchKernelGGL((conv_kernel<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>), grid, dim3(G::NT), 0, st, p);

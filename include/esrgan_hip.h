@@ -83,6 +83,8 @@ typedef struct esr_conv {
   esr_g32 out2;        /* dgrad: masked output */
   int32_t nchw_out_c;  /* >0: ALSO store the first nchw_out_c channels as fp32 NCHW */
   float* nchw_out;     /* [B][nchw_out_c][H][W] */
+  int32_t debug_flags; /* measurement only: 1 = skip epilogue, 2 = skip MFMAs, 4 = skip activation DMA */
+  int32_t _reserved;
 } esr_conv;
 
 /* Weight packing: OIHW fp32 master (the nn.Parameter the reference keeps, e.g. state-dict key
