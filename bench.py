@@ -48,43 +48,67 @@ def describe_plan(net, plan):
         if c.w1x1:
             extra = 32 * 64          # fused bias-free 1x1 64->32 (block.py:263)
         cbk = c.cout_blocks
+        # kernel variants of conv_mfma.hip: <ks, cout per wave (32*NCW), extras>
+        name = 'conv%dx%d_c%d' % (c.ks, c.ks, 32 if cbk == 1 else 64)
         if c.upsample:
-            name = 'conv3x3_ups_%s' % ('2x2x1' if cbk == 1 else '2x1x2')
-        elif c.w1x1:
-            name = 'conv3x3_1x1_%s' % ('4x1x1' if c.W <= 32 else '2x2x1')
-        elif cbk == 1:
-            name = 'conv3x3_%s' % ('4x1x1' if c.W <= 32 else '2x2x1')
-        else:
-            name = 'conv3x3_2x1x2'
+            name += '_ups'
+        if c.w1x1:
+            name += '_1x1'
         out.append((name, conv_flops(dict(B=c.B, H=c.H, W=c.W, cout=e.cout, cin=e.cin, ks=e.ks,
                                           extra_mac=extra))))
     return out
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """Oracle (torch restatement == reference bit-for-bit, oracle/gen_golden.py) on host cores:
-    one 128x128 LR tile per forward, fp32, eval."""
+def host_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (a box that
+    reports 256 CPUs but grants a few cores' worth of quota must not get 256 oneDNN threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Oracle (torch restatement == reference bit-for-bit, oracle/gen_golden.py) on the host cores:
+    RRDBNet x4 fp32 eval forward.  Calibrates on a 32x32 LR tile, then times the largest LR tile
+    (128, 64 or 32 square — same MACs per pixel) whose forwards fit the time budget."""
     from esrganplus_amd import synth
     from oracle import ref_torch as RT
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = synth.rrdbnet_state_dict(NB, 0)
-    x = synth.image_batch(0, 1, 3, LR, LR, name='bench.cpu')
-    with torch.no_grad():
+
+    def timed(n):
+        x = synth.image_batch(0, 1, 3, n, n, name='bench.cpu')
         t0 = time.perf_counter()
-        RT.rrdbnet_forward(x, sd, NB)           # warm-up
-        first = time.perf_counter() - t0
-        n = max(1, min(5, int(seconds_budget / max(first, 1e-3))))
-        ts = []
-        for _ in range(n):
-            t0 = time.perf_counter()
+        with torch.no_grad():
             RT.rrdbnet_forward(x, sd, NB)
-            ts.append(time.perf_counter() - t0)
-    ts.sort()
+        return time.perf_counter() - t0
+
+    timed(32)                                   # warm-up (oneDNN primitive creation)
+    t32 = timed(32)
+    size = 128 if t32 * 16 * 3 <= seconds_budget else (64 if t32 * 4 * 3 <= seconds_budget else 32)
+    est = t32 * (size // 32) ** 2
+    n = max(1, min(5, int(seconds_budget / max(est, 1e-3)) - 1))
+    timed(size)
+    ts = sorted(timed(size) for _ in range(n))
     med = ts[len(ts) // 2]
-    return {'value': round((4 * LR) ** 2 / 1e6 / med, 4), 'unit': 'HR-Mpix/s', 'cores': torch.get_num_threads(),
-            'kind': 'port', 'sample': '%d forwards of one 1x3x128x128 tile, fp32, median %.3f s' % (n, med),
-            'gflops': round(2 * MAC_PER_LR_PIXEL * LR * LR / med / 1e9, 1)}
+    return {'value': round((4 * size) ** 2 / 1e6 / med, 4), 'unit': 'HR-Mpix/s', 'cores': cores,
+            'kind': 'port',
+            'sample': '%d forwards of one 1x3x%dx%d LR tile, fp32 eval, median %.3f s' % (n, size, size, med),
+            'gflops': round(2 * MAC_PER_LR_PIXEL * size * size / med / 1e9, 1)}
 
 
 def main():

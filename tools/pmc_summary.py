@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Aggregate rocprofv3 --pmc counter_collection CSVs per kernel (sum / per-dispatch mean)."""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r'conv_kernelI(DF16_|f)Li(\d)ELi(\d)ELb(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)', name)
+    if m:
+        t, ks, s, ups, wr, wc, ncg, ncw, wlds, h1 = m.groups()
+        return 'conv<%s,k%s,s%s,ups%s,%sx%sx%s,ncw%s,wlds%s,1x1=%s>' % ('f16' if t != 'f' else 'f32', ks, s, ups, wr, wc, ncg, ncw, wlds, h1)
+    return name[:60]
+
+
+def main(root):
+    agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for f in sorted(glob.glob(os.path.join(root, 'pmc_*', '*counter_collection.csv'))):
+        for r in csv.DictReader(open(f)):
+            a = agg[short(r['Kernel_Name'])][r['Counter_Name']]
+            a[0] += float(r['Counter_Value'])
+            a[1] += 1
+    for k in sorted(agg, key=lambda k: -agg[k].get('SQ_BUSY_CYCLES', [0, 0])[0]):
+        if not k.startswith('conv<'):
+            continue
+        c = agg[k]
+        n = max(v[1] for v in c.values())
+        print(k, 'dispatches', n)
+        for name in sorted(c):
+            print('    %-28s mean/dispatch %16.1f' % (name, c[name][0] / c[name][1]))
+        if 'FETCH_SIZE' in c:
+            # gfx950: FETCH_SIZE (KB) under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM)
+            fk = c['FETCH_SIZE'][0] / c['FETCH_SIZE'][1]
+            wk = c['WRITE_SIZE'][0] / c['WRITE_SIZE'][1] if 'WRITE_SIZE' in c else float('nan')
+            print('    => HBM-side read ~ %.1f MB (2x-corrected FETCH_SIZE), write ~ %.1f MB per dispatch' % (2 * fk / 1024, wk / 1024))
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and 'GRBM_GUI_ACTIVE' in c:
+            print('    => MFMA busy / (GUI_ACTIVE * 1024 SIMDs) = %.3f' % (c['SQ_VALU_MFMA_BUSY_CYCLES'][0] / (c['GRBM_GUI_ACTIVE'][0] * 1024)))
+        if 'TCC_HIT_sum' in c:
+            h, m = c['TCC_HIT_sum'][0], c['TCC_MISS_sum'][0]
+            print('    => L2 hit rate %.3f' % (h / max(h + m, 1)))
+        if 'SQ_LDS_BANK_CONFLICT' in c:
+            print('    => LDS bank-conflict cycles / LDS active cycles = %.3f' % (c['SQ_LDS_BANK_CONFLICT'][0] / max(c['SQ_LDS_IDX_ACTIVE'][0], 1)))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
