@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, 'libesrgan_hip.so')
 ESR_F16, ESR_F32 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 NOISE_OFF, NOISE_PHILOX, NOISE_EXPLICIT = 0, 1, 2
-OP_CONV, OP_PACK, OP_LAYOUT, OP_NOISE_FILL = 1, 2, 3, 4
+OP_CONV, OP_PACK, OP_LAYOUT, OP_NOISE_FILL, OP_WGRAD = 1, 2, 3, 4, 5
 NO_LAYER = 0xFFFFFFFF
 
 
@@ -41,13 +41,23 @@ class esr_conv(C.Structure):
                 ('layer1', C.c_uint32), ('layer2', C.c_uint32),
                 ('z1', esr_g32), ('z2', esr_g32), ('mask', esr_g32), ('out2', esr_g32),
                 ('nchw_out_c', C.c_int32), ('nchw_out', C.c_void_p),
-                ('debug_flags', C.c_int32), ('_reserved', C.c_int32)]
+                ('debug_flags', C.c_int32), ('mask_cb_begin', C.c_int32), ('gamma', C.c_float),
+                ('layer3', C.c_uint32), ('z3', esr_g32), ('out3', esr_g32),
+                ('mask_act', C.c_int32), ('_pad2', C.c_int32)]
 
 
 class esr_pack(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('cout', C.c_int32), ('cin', C.c_int32),
                 ('ks', C.c_int32), ('dtype', C.c_int32), ('transpose_flip', C.c_int32),
-                ('cin_offset', C.c_int32), ('cin_count', C.c_int32)]
+                ('sum_dst', C.c_int32), ('sum_src', C.c_int32), ('sum_count', C.c_int32),
+                ('ups_dgrad', C.c_int32)]
+
+
+class esr_wgrad(C.Structure):
+    _fields_ = [('dtype', C.c_int32), ('ks', C.c_int32), ('stride', C.c_int32),
+                ('upsample', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('cout', C.c_int32), ('cin', C.c_int32), ('g', esr_g32), ('in_', esr_g32),
+                ('dw', C.c_void_p), ('dbias', C.c_void_p), ('scale', C.c_float), ('_pad', C.c_int32)]
 
 
 class esr_layout(C.Structure):
@@ -63,7 +73,7 @@ class esr_noise_fill(C.Structure):
 
 class _op_union(C.Union):
     _fields_ = [('conv', esr_conv), ('pack', esr_pack), ('layout', esr_layout),
-                ('noise_fill', esr_noise_fill)]
+                ('noise_fill', esr_noise_fill), ('wgrad', esr_wgrad)]
 
 
 class esr_op(C.Structure):
@@ -72,7 +82,7 @@ class esr_op(C.Structure):
 
 # every symbol include/esrgan_hip.h declares (tests check the .so exports all of them)
 EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_pack_conv_weights',
-           'esr_convert_layout', 'esr_fill_noise', 'esr_run_ops', 'esr_run_ops_timed', 'esr_last_error',
+           'esr_convert_layout', 'esr_fill_noise', 'esr_conv_wgrad', 'esr_run_ops', 'esr_run_ops_timed', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op']
 
 _lib = None
@@ -108,7 +118,8 @@ def lib():
         L.esr_run_ops.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.esr_run_ops_timed.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         for name, st in (('esr_conv_forward', esr_conv), ('esr_pack_conv_weights', esr_pack),
-                         ('esr_convert_layout', esr_layout), ('esr_fill_noise', esr_noise_fill)):
+                         ('esr_convert_layout', esr_layout), ('esr_fill_noise', esr_noise_fill),
+                         ('esr_conv_wgrad', esr_wgrad)):
             getattr(L, name).argtypes = [C.POINTER(st), C.c_void_p]
         if L.esr_sizeof_op() != C.sizeof(esr_op):
             raise HipExtensionError('ABI mismatch: sizeof(esr_op) C=%d ctypes=%d'

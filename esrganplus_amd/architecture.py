@@ -53,6 +53,14 @@ class _RRDBNetBase(B._PlannedModule):
             out.append(('model.%d' % idx, m[idx].weight, m[idx].bias))
         return out
 
+    def _dgrad_special(self):
+        sp = {'model.3': {'ups': True}, 'model.6': {'ups': True}}
+        for i in range(self.nb):
+            for j in (1, 2, 3):
+                # x4 = lrelu(a4) + x2 (block.py:266): dL/dx2 also receives conv5's x4 slice
+                sp['model.1.sub.%d.RDB%d.conv5.0' % (i, j)] = {'sum': (96, 160, 32)}
+        return sp
+
     def forward(self, x, z=None):
         """x: NCHW float32 in [0,1] on the MI355X -> [B, out_nc, 4H, 4W] float32.
         ``z`` (training mode only): explicit N(0,1) tensors, one [B,64,H,W] per noise layer in

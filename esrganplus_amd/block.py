@@ -172,6 +172,18 @@ class _PlannedModule(nn.Module):
     def _conv_list(self):
         raise NotImplementedError
 
+    def _dgrad_special(self):
+        return {}
+
+    def _dgrad_weights(self, device):
+        key = ('dgrad', self.precision, str(device))
+        dp = self._wp.get(key)
+        if dp is None:
+            convs = [(k, w) for k, w, _ in self._conv_list()]
+            dp = E.DgradPack(convs, self.precision, device, self._dgrad_special())
+            self._wp[key] = dp
+        return dp
+
     def _weights(self, device):
         key = (self.precision, str(device))
         wp = self._wp.get(key)

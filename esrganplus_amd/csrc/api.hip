@@ -43,6 +43,7 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       case ESR_OP_PACK: rc = esr_pack_conv_weights(&ops[i].u.pack, stream); break;
       case ESR_OP_LAYOUT: rc = esr_convert_layout(&ops[i].u.layout, stream); break;
       case ESR_OP_NOISE_FILL: rc = esr_fill_noise(&ops[i].u.noise_fill, stream); break;
+      case ESR_OP_WGRAD: rc = esr_conv_wgrad(&ops[i].u.wgrad, stream); break;
       default: esr_set_error("esr_run_ops: op %d has unknown kind %d", i, ops[i].kind); return ESR_ERR_INVALID;
     }
     if (rc != ESR_OK) {

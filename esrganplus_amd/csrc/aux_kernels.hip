@@ -20,18 +20,31 @@ __global__ void pack_kernel(const esr_pack p, int nchunks, int64_t total) {
   const int i = lane & 31, h = lane >> 5;
   const int co = cb * 32 + esr_pi(i);
   T v[EPL];
+  // NB: in transpose_flip mode p.ks is the OUTPUT kernel size (4 when ups_dgrad).
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
     const int ci = chunk * CPG + EPL * h + e;
     float x = 0.f;
-    if (co < p.cout && ci < p.cin) {
-      if (!p.transpose_flip) {
-        // src is OIHW [cout][cin][ks][ks]
-        x = p.src[(((int64_t)co * p.cin + ci) * p.ks + kh) * p.ks + kw];
-      } else {
-        // dgrad operand: the conv maps forward-Cout (= our cin) to forward-Cin (= our cout) with
-        // taps rotated 180 degrees; src is the forward OIHW [cin][cout][ks][ks]
-        x = p.src[(((int64_t)ci * p.cout + co) * p.ks + (p.ks - 1 - kh)) * p.ks + (p.ks - 1 - kw)];
+    if (!p.transpose_flip) {
+      // src is OIHW [cout][cin][ks][ks]
+      if (co < p.cout && ci < p.cin) x = p.src[(((int64_t)co * p.cin + ci) * p.ks + kh) * p.ks + kw];
+    } else {
+      // dgrad operand.  Here `co` runs over the FORWARD conv's input channels (p.cin of them) and
+      // `ci` over its output channels (p.cout); src is the forward OIHW [p.cout][p.cin][3|ks][..].
+      if (co < p.cin && ci < p.cout) {
+        if (!p.ups_dgrad) {
+          const int fk = p.ks - 1 - kh, fw = p.ks - 1 - kw;        // taps rotated 180 degrees
+          x = p.src[(((int64_t)ci * p.cin + co) * p.ks + fk) * p.ks + fw];
+          if (p.sum_count > 0 && co >= p.sum_dst && co < p.sum_dst + p.sum_count)
+            x += p.src[(((int64_t)ci * p.cin + (co - p.sum_dst + p.sum_src)) * p.ks + fk) * p.ks + fw];
+        } else {
+          // adjoint of nearest-x2 + conv3x3 as a 4x4/s2/p1 conv over g: tap ky collects the forward
+          // rows {2}, {1,2}, {0,1}, {0} for ky = 0..3 (same for kx) — see DESIGN.md
+          const int r0 = kh == 0 ? 2 : (kh == 1 ? 1 : 0), r1 = kh == 0 ? 2 : (kh == 1 ? 2 : (kh == 2 ? 1 : 0));
+          const int c0 = kw == 0 ? 2 : (kw == 1 ? 1 : 0), c1 = kw == 0 ? 2 : (kw == 1 ? 2 : (kw == 2 ? 1 : 0));
+          for (int r = r0; r <= r1; ++r)
+            for (int c = c0; c <= c1; ++c) x += p.src[(((int64_t)ci * p.cin + co) * 3 + r) * 3 + c];
+        }
       }
     }
     v[e] = (T)x;
@@ -109,13 +122,16 @@ extern "C" size_t esr_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ks,
 
 extern "C" int esr_pack_conv_weights(const esr_pack* p, esr_stream_t stream) {
   if (!p || !p->src || !p->dst || p->cout <= 0 || p->cin <= 0 || (p->ks != 1 && p->ks != 3 && p->ks != 4) ||
-      p->cin_offset != 0 || p->cin_count != 0) {
+      (p->ups_dgrad && !(p->transpose_flip && p->ks == 4))) {
     esr_set_error("esr_pack_conv_weights: invalid arguments");
     return ESR_ERR_INVALID;
   }
   const int cpg = p->dtype == ESR_F16 ? 16 : 8;
-  const int nchunks = (p->cin + cpg - 1) / cpg;
-  const int64_t total = (int64_t)((p->cout + 31) / 32) * nchunks * p->ks * p->ks * 64;
+  // packed geometry: rows = the packed conv's couts, K = its cins
+  const int rows = p->transpose_flip ? p->cin : p->cout;
+  const int kdim = p->transpose_flip ? p->cout : p->cin;
+  const int nchunks = (kdim + cpg - 1) / cpg;
+  const int64_t total = (int64_t)((rows + 31) / 32) * nchunks * p->ks * p->ks * 64;
   const int blocks = (int)((total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
   if (p->dtype == ESR_F16) hipLaunchKernelGGL(pack_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, *p, nchunks, total);

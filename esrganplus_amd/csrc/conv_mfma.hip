@@ -40,6 +40,11 @@ template <typename T> struct Px16;
 template <> struct Px16<_Float16> {
   // lane half h owns group (2*cb + h): one 32-byte group
   static __device__ __forceinline__ void load(const esr_g32& t, int b, int cb, int h, int64_t pix, float v[16]) {
+    if (2 * cb + h >= t.ngroups) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = 0.f;
+      return;
+    }
     const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(2 * cb + h) * t.group_stride + pix * 32;
     const u32x4 a = *(const u32x4*)p, c = *(const u32x4*)(p + 16);
     const half8 x = __builtin_bit_cast(half8, a), y = __builtin_bit_cast(half8, c);
@@ -61,8 +66,11 @@ template <> struct Px16<float> {
   static __device__ __forceinline__ void load(const esr_g32& t, int b, int cb, int h, int64_t pix, float v[16]) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(4 * cb + 2 * h + g) * t.group_stride + pix * 32;
-      const f32x4 a = *(const f32x4*)p, c = *(const f32x4*)(p + 16);
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+      if (4 * cb + 2 * h + g < t.ngroups) {
+        const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(4 * cb + 2 * h + g) * t.group_stride + pix * 32;
+        a = *(const f32x4*)p; c = *(const f32x4*)(p + 16);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) { v[8 * g + i] = a[i]; v[8 * g + 4 + i] = c[i]; }
     }
@@ -139,6 +147,7 @@ template <typename T> struct Raw16;
 template <> struct Raw16<_Float16> {
   u32x4 q[2];
   __device__ __forceinline__ void load(const esr_g32& t, int b, int cb, int h, int64_t pix) {
+    if (2 * cb + h >= t.ngroups) { q[0] = u32x4{0, 0, 0, 0}; q[1] = u32x4{0, 0, 0, 0}; return; }
     const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(2 * cb + h) * t.group_stride + pix * 32;
     q[0] = *(const u32x4*)p; q[1] = *(const u32x4*)(p + 16);
   }
@@ -153,8 +162,11 @@ template <> struct Raw16<float> {
   __device__ __forceinline__ void load(const esr_g32& t, int b, int cb, int h, int64_t pix) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(4 * cb + 2 * h + g) * t.group_stride + pix * 32;
-      q[2 * g] = *(const f32x4*)p; q[2 * g + 1] = *(const f32x4*)(p + 16);
+      q[2 * g] = f32x4{0.f, 0.f, 0.f, 0.f}; q[2 * g + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (4 * cb + 2 * h + g < t.ngroups) {
+        const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(4 * cb + 2 * h + g) * t.group_stride + pix * 32;
+        q[2 * g] = *(const f32x4*)p; q[2 * g + 1] = *(const f32x4*)(p + 16);
+      }
     }
   }
   __device__ __forceinline__ void get(float v[16]) const {
@@ -174,6 +186,7 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
                                                int oyb, int ox) {
   const bool n1 = (p.noise_mode == ESR_NOISE_PHILOX && p.layer1 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z1.ptr);
   const bool n2 = (p.noise_mode == ESR_NOISE_PHILOX && p.layer2 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z2.ptr);
+  const bool n3 = (p.noise_mode == ESR_NOISE_PHILOX && p.layer3 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z3.ptr);
   const bool xz = p.noise_mode == ESR_NOISE_EXPLICIT;
   f32x4 bq[4];
 #pragma unroll
@@ -204,10 +217,12 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] += a1[e];
     }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] *= p.alpha;
     if (p.res1.ptr) {
       r1[r].get(tmp);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = v[e] * p.alpha + tmp[e];
+      for (int e = 0; e < 16; ++e) v[e] += tmp[e];
     }
     const uint32_t pix = (uint32_t)((b * p.H + oy) * p.W + ox);
     if (n1) {
@@ -234,12 +249,27 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
       for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
     }
     if (p.out.ptr) Px16<T>::store(p.out, b, cb, h, (int64_t)(oy + 1) * p.out.wp + ox + 1, v);
-    if (p.mask.ptr) {
-      Px16<T>::load(p.mask, b, cb, h, (int64_t)(oy + 1) * p.mask.wp + ox + 1, tmp);
-      const float neg = p.act == ESR_ACT_RELU ? 0.f : ESR_LRELU_SLOPE;
+    if (p.mask.ptr && cb >= p.mask_cb_begin) {
+      const int mb = cb - p.mask_cb_begin;
+      Px16<T>::load(p.mask, b, mb, h, (int64_t)(oy + 1) * p.mask.wp + ox + 1, tmp);
+      const float neg = p.mask_act == ESR_ACT_RELU ? 0.f : ESR_LRELU_SLOPE;
 #pragma unroll
       for (int e = 0; e < 16; ++e) tmp[e] = tmp[e] > 0.f ? v[e] : v[e] * neg;
-      Px16<T>::store(p.out2, b, cb, h, (int64_t)(oy + 1) * p.out2.wp + ox + 1, tmp);
+      Px16<T>::store(p.out2, b, mb, h, (int64_t)(oy + 1) * p.out2.wp + ox + 1, tmp);
+    }
+    if (p.out3.ptr) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] *= p.gamma;
+      if (n3) {
+        if (xz) Px16<T>::load(p.z3, b, cb, h, (int64_t)(oy + 1) * p.z3.wp + ox + 1, tmp);
+        else {
+#pragma unroll 1
+          for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer3, p.seed, &tmp[4 * q]);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
+      }
+      Px16<T>::store(p.out3, b, cb, h, (int64_t)(oy + 1) * p.out3.wp + ox + 1, v);
     }
     if (p.nchw_out_c > 0) {
 #pragma unroll
@@ -559,11 +589,8 @@ extern "C" int esr_conv_forward(const esr_conv* p, esr_stream_t stream) {
     esr_set_error("esr_conv_forward: invalid arguments");
     return ESR_ERR_INVALID;
   }
-  if (p->noise_mode == ESR_NOISE_EXPLICIT && !p->z1.ptr && !p->z2.ptr) {
-    esr_set_error("esr_conv_forward: explicit noise without z tensors");
-    return ESR_ERR_INVALID;
-  }
   if (p->mask.ptr && !p->out2.ptr) { esr_set_error("esr_conv_forward: mask without out2"); return ESR_ERR_INVALID; }
+
   hipStream_t st = (hipStream_t)stream;
   if (p->dtype == ESR_F16) return dispatch<_Float16>(*p, st);
   if (p->dtype == ESR_F32) return dispatch<float>(*p, st);

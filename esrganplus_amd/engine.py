@@ -171,6 +171,9 @@ def _conv(dtype_e, B, H, W, src, src_ch, dst, cw, act=L.ACT_NONE, ks=None, strid
     c.noise_mode = L.NOISE_OFF
     c.layer1 = L.NO_LAYER
     c.layer2 = L.NO_LAYER
+    c.layer3 = L.NO_LAYER
+    c.gamma = 1.0
+    c.mask_act = L.ACT_LRELU
     return c
 
 
@@ -379,3 +382,307 @@ def build_block_plan(kind, wp, B, H, W, dtype, device, noise, variant, explicit_
 def build_rrdbnet_plan(wp, nb, in_nc, out_nc, B, H, W, dtype, device, noise, variant, explicit_z):
     bld = Builder(wp, B, H, W, dtype, device, noise, variant)
     return bld.rrdbnet(nb, in_nc, out_nc, explicit_z)
+
+
+# =================================================================================================
+# Training path: forward that keeps every activation + the matching backward launch list
+# =================================================================================================
+class DgradPack:
+    """Packed operands of the input-gradient convolutions: Cin<->Cout transposed, taps rotated 180
+    degrees (esr_pack.transpose_flip); conv5 of an RDB additionally folds the x4->x2 identity path
+    (block.py:266) into its x2 output slice, and the upconvs get the 4x4/stride-2 adjoint kernel."""
+
+    def __init__(self, convs, dtype, device, special):
+        # convs: list of (key, weight_param); special: key -> dict(sum=(dst,src,count)) / dict(ups=True)
+        self.esr_dtype, self.tdtype, self.cpg = _dt(dtype)
+        self.convs, self.special = convs, special
+        self.entries = {}
+        total, offs = 0, []
+        for key, w in convs:
+            cout, cin, ks, _ = w.shape
+            ks_out = 4 if special.get(key, {}).get('ups') else ks
+            offs.append(total)
+            total += L.packed_weight_bytes(cin, cout, ks_out, self.esr_dtype)
+        self.arena = torch.zeros(total, dtype=torch.uint8, device=device)
+        for (key, w), off in zip(convs, offs):
+            e = ConvW()
+            e.key = key
+            fc, fi, ks = w.shape[:3]
+            e.cout, e.cin = fi, fc                  # the dgrad conv maps fwd-Cout -> fwd-Cin
+            e.ks = 4 if special.get(key, {}).get('ups') else ks
+            e.w_ptr, e.bias_ptr, e.has_bias = self.arena.data_ptr() + off, None, False
+            self.entries[key] = e
+        self._ptrs = None
+        self.ops = None
+
+    def ensure(self, stream):
+        ptrs = tuple(w.data_ptr() for _, w in self.convs)
+        if ptrs != self._ptrs:
+            ops = L.OpList()
+            for key, w in self.convs:
+                e = self.entries[key]
+                sp = self.special.get(key, {})
+                pk = L.esr_pack()
+                pk.src, pk.dst = w.data_ptr(), e.w_ptr
+                pk.cout, pk.cin = w.shape[0], w.shape[1]
+                pk.ks = e.ks
+                pk.dtype = self.esr_dtype
+                pk.transpose_flip = 1
+                if 'sum' in sp:
+                    pk.sum_dst, pk.sum_src, pk.sum_count = sp['sum']
+                pk.ups_dgrad = 1 if sp.get('ups') else 0
+                ops.add(L.OP_PACK, 'pack', pk)
+            self.ops, self._ptrs = ops, ptrs
+        self.ops.run(stream)      # weights change every optimizer step: always re-pack
+
+
+class TrainPlan:
+    """Forward (all activations kept) + backward launch lists of RRDBNet for one input shape."""
+
+    def __init__(self):
+        self.fwd = Plan()
+        self.bwd = L.OpList()
+        self.bufs = []
+        self.busy = False
+        self.gy_op = None            # layout op importing dL/dy (NCHW fp32) in the backward list
+        self.bwd_noise_ops = []      # backward conv ops that need (noise_mode, seed)
+        self.grad_flat = None        # fp32 flat gradient buffer; views per parameter
+        self.grad_views = None
+
+
+def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, device, noise, variant,
+                             explicit_z):
+    """RRDBNet forward keeping every RDB concat buffer (+ pre-residual activations of conv2/conv4,
+    whose signs are the LeakyReLU masks) and the backward pass:
+      * input gradients = the same fused conv kernel over transposed/rotated weights, with the
+        LeakyReLU-mask / noise / residual-scale backward applied in its epilogue;
+      * weight/bias gradients = esr_conv_wgrad."""
+    dt_e, tdtype, cpg = _dt(dtype)
+    TP = TrainPlan()
+    P = TP.fwd
+    e = wp.entries
+    d = dt_e
+    per = 4 if variant == 'test_image' else 3
+    n_noise = per * nb if noise else 0
+
+    def buf(C_, h=H, w=W):
+        b = G32(B, C_, h, w, dtype, device)
+        TP.bufs.append(b)
+        return b
+
+    def imp(ops, dst, C_):
+        lo = L.esr_layout()
+        lo.dtype, lo.to_g32 = dt_e, 1
+        lo.B, lo.C, lo.H, lo.W = B, C_, dst.H, dst.W
+        lo.g32 = dst.view(0, C_)
+        return ops.add(L.OP_LAYOUT, 'layout', lo)
+
+    zb = []
+    if noise and explicit_z:
+        for _ in range(n_noise):
+            z = buf(64)
+            P.z_ops.append(imp(P.ops, z, 64))
+            zb.append(z)
+
+    def set_noise(c, slot, lid):
+        """slot 1/2/3 of conv c multiplies by (1 + sigma * z[lid])."""
+        if not noise or lid is None:
+            return
+        setattr(c, 'layer%d' % slot, lid)
+        if zb:
+            setattr(c, 'z%d' % slot, zb[lid].view(0, 64))
+
+    # ------------------------------------------------------------------ forward
+    xin, fea = buf(in_nc), buf(64)
+    S = [[buf(192) for _ in range(3)] for _ in range(nb)]
+    AUX = [[buf(64) for _ in range(3)] for _ in range(nb)]
+    XF = buf(64)                                   # output of the last RRDB
+    P.in_op = imp(P.ops, xin, in_nc)
+    c = _conv(d, B, H, W, xin.view(0), in_nc, (S[0][0] if nb else XF).view(0, 64), e['model.0'])
+    c.aux_out = fea.view(0, 64)
+    P.ops.add_conv(c)
+    for i in range(nb):
+        for j in range(3):
+            bf, ax = S[i][j], AUX[i][j]
+            bn = S[i][j + 1] if j < 2 else (S[i + 1][0] if i + 1 < nb else XF)
+            p = 'model.1.sub.%d.RDB%d' % (i, j + 1)
+            P.ops.add_conv(_conv(d, B, H, W, bf.view(0), 64, bf.view(64, 32), e[p + '.conv1.0'], L.ACT_LRELU))
+            c = _conv(d, B, H, W, bf.view(0), 96, bf.view(96, 32), e[p + '.conv2.0'], L.ACT_LRELU)
+            c.w1x1, c.n1x1_groups = e[p + '.conv1x1'].w_ptr, 64 // cpg
+            c.aux_out = ax.view(0, 32)
+            P.ops.add_conv(c)
+            P.ops.add_conv(_conv(d, B, H, W, bf.view(0), 128, bf.view(128, 32), e[p + '.conv3.0'], L.ACT_LRELU))
+            c = _conv(d, B, H, W, bf.view(0), 160, bf.view(160, 32), e[p + '.conv4.0'], L.ACT_LRELU)
+            c.res1, c.alpha = bf.view(96, 32), 1.0
+            c.aux_out = ax.view(32, 32)
+            P.ops.add_conv(c)
+            c = _conv(d, B, H, W, bf.view(0), 192, bn.view(0, 64), e[p + '.conv5.0'], L.ACT_NONE)
+            c.res1, c.alpha = bf.view(0, 64), 0.2
+            set_noise(c, 1, per * i + j)
+            if j == 2:
+                c.res2, c.beta = S[i][0].view(0, 64), 0.2
+                if variant == 'test_image':
+                    set_noise(c, 2, per * i + 3)
+            k = P.ops.add_conv(c)
+            if noise:
+                P.noise_ops.append(k)
+    T_ = buf(64)
+    c = _conv(d, B, H, W, XF.view(0), 64, T_.view(0, 64), e['model.1.sub.%d' % nb])
+    c.res1, c.alpha = fea.view(0, 64), 1.0
+    P.ops.add_conv(c)
+    U1, U2, U3 = buf(64, 2 * H, 2 * W), buf(64, 4 * H, 4 * W), buf(64, 4 * H, 4 * W)
+    P.ops.add_conv(_conv(d, B, 2 * H, 2 * W, T_.view(0), 64, U1.view(0, 64), e['model.3'], L.ACT_LRELU, upsample=1))
+    P.ops.add_conv(_conv(d, B, 4 * H, 4 * W, U1.view(0), 64, U2.view(0, 64), e['model.6'], L.ACT_LRELU, upsample=1))
+    P.ops.add_conv(_conv(d, B, 4 * H, 4 * W, U2.view(0), 64, U3.view(0, 64), e['model.8'], L.ACT_LRELU))
+    c = _conv(d, B, 4 * H, 4 * W, U3.view(0), 64, None, e['model.10'])
+    c.nchw_out_c = out_nc
+    P.out_op = P.ops.add_conv(c)
+    P.out_shape = (B, out_nc, 4 * H, 4 * W)
+
+    # ------------------------------------------------------------------ gradient storage
+    plist = [(k, w, b_) for k, w, b_ in net._conv_list()]
+    sizes = []
+    for k, w, b_ in plist:
+        sizes.append(w.numel())
+        if b_ is not None:
+            sizes.append(b_.numel())
+    TP.grad_flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+    views, off, gptr = [], 0, {}
+    for k, w, b_ in plist:
+        gw = TP.grad_flat[off:off + w.numel()].view_as(w)
+        off += w.numel()
+        gb = None
+        if b_ is not None:
+            gb = TP.grad_flat[off:off + b_.numel()].view_as(b_)
+            off += b_.numel()
+        views.append((gw, gb))
+        gptr[k] = (gw.data_ptr(), gb.data_ptr() if gb is not None else None)
+    TP.grad_views = views
+
+    # ------------------------------------------------------------------ backward
+    Bk = TP.bwd
+    de = dp.entries
+
+    def dconv(Ho, Wo, src, src_ch, dst, key, **kw):
+        c = _conv(d, B, Ho, Wo, src, src_ch, dst, de[key], L.ACT_NONE, **kw)
+        c.bias = None
+        return c
+
+    def add_b(c, noisy=False):
+        k = Bk.add_conv(c)
+        if noisy and noise:
+            TP.bwd_noise_ops.append(k)
+        return k
+
+    def wgrad(key, g, gin, Hh, Ww, cout, cin, ks=3, ups=0, scale=1.0):
+        wg = L.esr_wgrad()
+        wg.dtype, wg.ks, wg.stride, wg.upsample = dt_e, ks, 1, ups
+        wg.B, wg.H, wg.W = B, Hh, Ww
+        wg.cout, wg.cin = cout, cin
+        wg.g, wg.in_ = g, gin
+        wg.dw, wg.dbias = gptr[key]
+        wg.scale = scale
+        Bk.add(L.OP_WGRAD, 'wgrad', wg)
+
+    GY = buf(out_nc, 4 * H, 4 * W)
+    TP.gy_op = imp(Bk, GY, out_nc)
+    GA8, GA6 = buf(64, 4 * H, 4 * W), buf(64, 4 * H, 4 * W)
+    GA3 = buf(64, 2 * H, 2 * W)
+    GTt = buf(64)                                   # dL/dT (trunk output)
+    gA = [buf(64), buf(64)]                         # RRDB skip gradient A(i), ping-pong
+    gT = [buf(64), buf(64)]                         # g_t of the current RDB, ping-pong
+    G, GA = buf(192), buf(128)
+    GF = buf(64)                                    # dL/dfea
+
+    # HR_conv1 (model.10): u3 -> y
+    wgrad('model.10', GY.view(0, out_nc), U3.view(0, 64), 4 * H, 4 * W, out_nc, 64)
+    c = dconv(4 * H, 4 * W, GY.view(0), out_nc, None, 'model.10')
+    c.mask, c.out2, c.mask_cb_begin = U3.view(0, 64), GA8.view(0, 64), 0
+    add_b(c)
+    # HR_conv0 (model.8): u2 -> u3 (lrelu)
+    wgrad('model.8', GA8.view(0, 64), U2.view(0, 64), 4 * H, 4 * W, 64, 64)
+    c = dconv(4 * H, 4 * W, GA8.view(0), 64, None, 'model.8')
+    c.mask, c.out2 = U2.view(0, 64), GA6.view(0, 64)
+    add_b(c)
+    # upconv 2 (model.6): up(u1) -> u2 ; adjoint = 4x4/s2 conv
+    wgrad('model.6', GA6.view(0, 64), U1.view(0, 64), 4 * H, 4 * W, 64, 64, ups=1)
+    c = dconv(2 * H, 2 * W, GA6.view(0), 64, None, 'model.6', ks=4, stride=2)
+    c.mask, c.out2 = U1.view(0, 64), GA3.view(0, 64)
+    add_b(c)
+    # upconv 1 (model.3): up(T) -> u1
+    wgrad('model.3', GA3.view(0, 64), T_.view(0, 64), 2 * H, 2 * W, 64, 64, ups=1)
+    add_b(dconv(H, W, GA3.view(0), 64, GTt.view(0, 64), 'model.3', ks=4, stride=2))
+    # LR_conv (model.1.sub.nb): XF -> T - fea
+    lrk = 'model.1.sub.%d' % nb
+    wgrad(lrk, GTt.view(0, 64), XF.view(0, 64), H, W, 64, 64)
+    c = dconv(H, W, GTt.view(0), 64, gA[0].view(0, 64) if nb else GF.view(0, 64), lrk)
+    if nb:
+        if variant == 'test_image':
+            set_noise(c, 2, per * (nb - 1) + 3)
+        c.out3, c.gamma = gT[0].view(0, 64), 0.2
+        set_noise(c, 3, per * (nb - 1) + 2)
+    else:
+        c.res1 = GTt.view(0, 64)                    # fea feeds both the trunk and the shortcut
+    add_b(c, noisy=bool(nb))
+    ca, ct = 0, 0
+    for i in range(nb - 1, -1, -1):
+        for j in (2, 1, 0):
+            bf, ax = S[i][j], AUX[i][j]
+            p = 'model.1.sub.%d.RDB%d' % (i, j + 1)
+            gt = gT[ct]
+            # conv5: g_x5 = 0.2 g_t ; G = conv5^T(g_x5) (+ g_t on the x channels: d(0.2x5+x)/dx)
+            wgrad(p + '.conv5.0', gt.view(0, 64), bf.view(0, 192), H, W, 64, 192, scale=0.2)
+            c = dconv(H, W, gt.view(0), 64, G.view(0, 192), p + '.conv5.0')
+            c.alpha, c.res1 = 0.2, gt.view(0, 64)
+            c.mask, c.out2, c.mask_cb_begin = ax.view(32, 32), GA.view(96, 32), 5
+            add_b(c)
+            # conv4
+            wgrad(p + '.conv4.0', GA.view(96, 32), bf.view(0, 160), H, W, 32, 160)
+            c = dconv(H, W, GA.view(96), 32, G.view(0, 160), p + '.conv4.0')
+            c.res1 = G.view(0, 160)
+            c.mask, c.out2, c.mask_cb_begin = bf.view(128, 32), GA.view(64, 32), 4
+            add_b(c)
+            # conv3
+            wgrad(p + '.conv3.0', GA.view(64, 32), bf.view(0, 128), H, W, 32, 128)
+            c = dconv(H, W, GA.view(64), 32, G.view(0, 128), p + '.conv3.0')
+            c.res1 = G.view(0, 128)
+            c.mask, c.out2, c.mask_cb_begin = ax.view(0, 32), GA.view(32, 32), 3
+            add_b(c)
+            # conv2
+            wgrad(p + '.conv2.0', GA.view(32, 32), bf.view(0, 96), H, W, 32, 96)
+            c = dconv(H, W, GA.view(32), 32, G.view(0, 96), p + '.conv2.0')
+            c.res1 = G.view(0, 96)
+            c.mask, c.out2, c.mask_cb_begin = bf.view(64, 32), GA.view(0, 32), 2
+            add_b(c)
+            # conv1x1 (x2 = lrelu(a2) + conv1x1(x)): raw g_x2 = G[96:128]
+            wgrad(p + '.conv1x1', G.view(96, 32), bf.view(0, 64), H, W, 32, 64, ks=1)
+            c = dconv(H, W, G.view(96), 32, G.view(0, 64), p + '.conv1x1')
+            c.res1 = G.view(0, 64)
+            if i == 0 and j == 0:
+                c.res2, c.beta = GTt.view(0, 64), 1.0    # trunk shortcut: fea also feeds T directly
+            add_b(c)
+            # conv1: closes the block: g_x = conv1^T(g_a1) + G[x]  (+ RRDB skip for RDB1)
+            wgrad(p + '.conv1.0', GA.view(0, 32), bf.view(0, 64), H, W, 32, 64)
+            c = dconv(H, W, GA.view(0), 32, None, p + '.conv1.0')
+            c.res1 = G.view(0, 64)
+            if j > 0:
+                # g_x = g_y of RDB j (previous in forward order) -> its g_t = g_y * n
+                c.out = gT[ct ^ 1].view(0, 64)
+                set_noise(c, 2, per * i + j - 1)
+                ct ^= 1
+            else:
+                c.res2, c.beta = gA[ca].view(0, 64), 1.0
+                if i > 0:
+                    c.out = gA[ca ^ 1].view(0, 64)
+                    if variant == 'test_image':
+                        set_noise(c, 2, per * (i - 1) + 3)
+                    c.out3, c.gamma = gT[ct ^ 1].view(0, 64), 0.2
+                    set_noise(c, 3, per * (i - 1) + 2)
+                    ca ^= 1
+                    ct ^= 1
+                else:
+                    c.out = GF.view(0, 64)
+            add_b(c, noisy=True)
+    # fea_conv (model.0): weight gradient only (the LR input image needs no gradient)
+    wgrad('model.0', GF.view(0, 64), xin.view(0, in_nc), H, W, 64, in_nc)
+    return TP

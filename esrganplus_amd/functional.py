@@ -63,10 +63,107 @@ def run_block(mod, kind, x, z=None):
     return out
 
 
+class _PlanLease:
+    """Marks a TrainPlan busy while an autograd graph still references its saved activations."""
+
+    def __init__(self, tp):
+        self.tp = tp
+        tp.busy = True
+
+    def release(self):
+        if self.tp is not None:
+            self.tp.busy = False
+            self.tp = None
+
+    def __del__(self):
+        self.release()
+
+
+def _train_plan(net, wp, dp, B, H, W, dev, noise, explicit):
+    key = ('train', B, H, W, net.precision, noise, explicit, wp.generation, str(dev))
+    pool = net._plans.setdefault(key, [])
+    for tp in pool:
+        if not tp.busy:
+            return tp
+    tp = E.build_rrdbnet_train_plan(net, wp, dp, net.nb, net.in_nc, net.out_nc, B, H, W,
+                                    net.precision, dev, noise, net.variant, explicit)
+    pool.append(tp)
+    return tp
+
+
+class _RRDBNetFn(torch.autograd.Function):
+    """RRDBNet forward/backward as ONE autograd node (architecture.py:76-78 + the implicit
+    autograd backward triggered at SRRaGAN_model.py:140)."""
+
+    @staticmethod
+    def forward(ctx, x, net, zs, *params):
+        xin = _prep_input(x, 'input')
+        B, _, H, W = xin.shape
+        dev = xin.device
+        st = E.current_stream()
+        wp = net._weights(dev)
+        dp = net._dgrad_weights(dev)
+        dp.ensure(st)
+        noise = bool(net.training)
+        tp = _train_plan(net, wp, dp, B, H, W, dev, noise, zs is not None)
+        ctx.lease = _PlanLease(tp)
+        ctx.seed = _draw_seed() if (noise and zs is None) else 0
+        ctx.explicit = zs is not None
+        ctx.noise = noise
+        ctx.n_params = len(params)
+        out = torch.empty(tp.fwd.out_shape, dtype=torch.float32, device=dev)
+        tp.fwd.run(xin, out, st, ctx.seed, zs)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        tp = ctx.lease.tp
+        if tp is None:
+            raise RuntimeError('RRDBNet backward called twice (retain_graph is not supported: the '
+                               'saved activations live in a reusable launch plan)')
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError('gradient w.r.t. the LR input image is not provided')
+        gy = gy.detach().contiguous().float()
+        st = E.current_stream()
+        tp.grad_flat.zero_()
+        arr = tp.bwd.array()
+        arr[tp.gy_op].u.layout.nchw = gy.data_ptr()
+        mode = L.NOISE_OFF
+        if ctx.noise:
+            mode = L.NOISE_EXPLICIT if ctx.explicit else L.NOISE_PHILOX
+        for i in tp.bwd_noise_ops:
+            arr[i].u.conv.noise_mode = mode
+            arr[i].u.conv.seed = ctx.seed
+        tp.bwd.run(st)
+        flat = tp.grad_flat.clone()
+        ctx.lease.release()
+        grads, off = [], 0
+        for gw, gb in tp.grad_views:
+            grads.append(flat[off:off + gw.numel()].view_as(gw))
+            off += gw.numel()
+            if gb is not None:
+                grads.append(flat[off:off + gb.numel()].view_as(gb))
+                off += gb.numel()
+        assert len(grads) == ctx.n_params
+        grads = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:])]
+        return (None, None, None) + tuple(grads)
+
+
 def run_rrdbnet(net, x, z=None):
     """RRDBNet.forward (architecture.py:76-78) on the HIP path."""
     if _needs_grad(net, x):
-        raise NotImplementedError('RRDBNet backward is not wired yet; call under torch.no_grad()')
+        E.require_cuda(x, 'input')
+        B, C_, H, W = x.shape
+        if C_ != net.in_nc:
+            raise ValueError('expected %d input channels, got %d' % (net.in_nc, C_))
+        per = 4 if net.variant == 'test_image' else 3
+        zs = _zs_list(z, per * net.nb, (B, 64, H, W), x.device) if net.training else None
+        params = []
+        for _, w, b in net._conv_list():
+            params.append(w)
+            if b is not None:
+                params.append(b)
+        return _RRDBNetFn.apply(x, net, zs, *params)
     xin = _prep_input(x, 'input')
     B, C_, H, W = xin.shape
     if C_ != net.in_nc:

@@ -53,9 +53,13 @@ typedef struct esr_g32 {
  * tail block.py:291 / test_image/block.py:256; ShortcutBlock block.py:84-86; nearest upsample
  * block.py:315-322 folded into the load).  Epilogue, per output element, in this order:
  *     v = acc + bias;  v = act(v);  [aux_out = v];  v += acc_1x1;
- *     v = v*alpha + res1;  v *= (1 + sigma*z1);  v = v*beta + res2;  v *= (1 + sigma*z2)
- * (each step skipped when its operand is absent).  dgrad mode (mask != NULL) additionally writes
- *     out2 = v * lrelu'(mask)   (lrelu' = 1 if mask>0 else 0.2; relu' for act==RELU)            */
+ *     v = v*alpha + res1;  v *= (1 + sigma*z1);  v = v*beta + res2;  v *= (1 + sigma*z2);  out = v
+ * (each step skipped when its operand is absent; a residual / z view with fewer channel groups
+ * than the output contributes zero to the channels it does not cover).  Backward chains add
+ *     out2 = v * act'(mask)      for cout blocks >= mask_cb_begin (act' = 1 if mask>0 else 0.2 / 0)
+ *     out3 = v * gamma * (1 + sigma*z3)
+ * which is how dgrad launches also apply the LeakyReLU / GaussianNoise / residual-scale backward
+ * of block.py:262-268,291 without extra elementwise passes.                                    */
 typedef struct esr_conv {
   int32_t dtype;       /* esr_dtype: storage type of every G32 tensor here (accumulate fp32) */
   int32_t ks;          /* 1, 3 or 4 */
@@ -84,7 +88,13 @@ typedef struct esr_conv {
   int32_t nchw_out_c;  /* >0: ALSO store the first nchw_out_c channels as fp32 NCHW */
   float* nchw_out;     /* [B][nchw_out_c][H][W] */
   int32_t debug_flags; /* measurement only: 1 = skip epilogue, 2 = skip MFMAs, 4 = skip activation DMA */
-  int32_t _reserved;
+  int32_t mask_cb_begin; /* mask/out2 apply to cout blocks >= this one, indexed from it */
+  float gamma;          /* third stage (backward chains): out3 = v * gamma * (1 + sigma*z3) */
+  uint32_t layer3;      /* philox stream id of z3 (0xFFFFFFFF = no noise on out3) */
+  esr_g32 z3;           /* explicit z3 */
+  esr_g32 out3;         /* ptr NULL = off */
+  int32_t mask_act;     /* esr_act whose derivative the mask selects (LRELU: 1 / 0.2, RELU: 1 / 0) */
+  int32_t _pad2;
 } esr_conv;
 
 /* Weight packing: OIHW fp32 master (the nn.Parameter the reference keeps, e.g. state-dict key
@@ -96,9 +106,12 @@ typedef struct esr_pack {
   void* dst;
   int32_t cout, cin, ks;
   int32_t dtype;
-  int32_t transpose_flip;
-  int32_t cin_offset;  /* first input channel to pack (dgrad slices), normally 0 */
-  int32_t cin_count;   /* channels to pack starting at cin_offset (0 = all) */
+  int32_t transpose_flip; /* 1: dgrad operand; `cout`/`cin` below are still the FORWARD conv's */
+  int32_t sum_dst;     /* transpose_flip only: dgrad output channels [sum_dst, sum_dst+sum_count) */
+  int32_t sum_src;     /*   additionally receive the weights of forward input channels             */
+  int32_t sum_count;   /*   [sum_src, sum_src+sum_count) (x4 = lrelu(a4) + x2, block.py:266)      */
+  int32_t ups_dgrad;   /* 1 (with transpose_flip, ks==3): emit the 4x4/stride-2 kernel that is the
+                          exact adjoint of nearest-x2-upsample + 3x3 conv (block.py:315-322)       */
 } esr_pack;
 
 size_t esr_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ks, int32_t dtype);
@@ -123,7 +136,22 @@ typedef struct esr_noise_fill {
   float* dst; int32_t B, C, H, W; uint64_t seed; uint32_t layer;
 } esr_noise_fill;
 
-enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_NOISE_FILL = 4 };
+/* Weight + bias gradient of a fused conv (autograd's conv backward-weight; SRRaGAN_model.py:140).
+ * Accumulates with fp32 atomics: the caller zeroes dw / dbias first. */
+typedef struct esr_wgrad {
+  int32_t dtype, ks, stride, upsample;
+  int32_t B, H, W;     /* size of g (= conv OUTPUT) */
+  int32_t cout, cin;   /* true channel counts of dw [cout][cin][ks][ks] */
+  esr_g32 g;           /* upstream gradient wrt the conv's pre-activation output */
+  esr_g32 in;          /* the conv's saved input */
+  float* dw;
+  float* dbias;        /* may be NULL */
+  float scale;
+  int32_t _pad;
+} esr_wgrad;
+
+enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_NOISE_FILL = 4,
+                   ESR_OP_WGRAD = 5 };
 
 typedef struct esr_op {
   int32_t kind;
@@ -133,6 +161,7 @@ typedef struct esr_op {
     esr_pack pack;
     esr_layout layout;
     esr_noise_fill noise_fill;
+    esr_wgrad wgrad;
   } u;
 } esr_op;
 
@@ -144,6 +173,7 @@ int esr_conv_forward(const esr_conv* p, esr_stream_t stream);
 int esr_pack_conv_weights(const esr_pack* p, esr_stream_t stream);
 int esr_convert_layout(const esr_layout* p, esr_stream_t stream);
 int esr_fill_noise(const esr_noise_fill* p, esr_stream_t stream);
+int esr_conv_wgrad(const esr_wgrad* p, esr_stream_t stream);
 
 /* Run a recorded list of ops back to back on `stream` (one host call per network pass; this is
  * what RRDBNet.forward — architecture.py:76-78 — becomes). */
