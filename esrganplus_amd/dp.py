@@ -1,0 +1,157 @@
+"""Process-per-GPU data parallelism over RCCL/xGMI (torch.distributed backend "nccl" == RCCL).
+
+The reference's only multi-GPU mechanism is single-process ``nn.DataParallel``
+(codes/models/networks.py:105-107,136-137,152-153), which re-broadcasts parameters every forward,
+gathers outputs to device 0 and cannot run with the noise layers (block.py:115 pins them to cuda:0).
+Here every rank owns one MI355X and a full replica; per optimizer there is exactly ONE exchange:
+the mean all-reduce of that network's gradients.
+
+* ``RRDBNet`` / ``Discriminator`` backward are single autograd nodes that emit ALL parameter
+  gradients as views of one flat fp32 tensor, so the exchange all-reduces slices ("buckets") of that
+  tensor in place — no gather/scatter copies.  Buckets are issued asynchronously on RCCL's stream
+  (largest-first = reverse execution order) and only waited for right before ``optimizer.step()``,
+  so the G-gradient exchange overlaps the discriminator's forward/backward and vice versa.
+* xGMI is point-to-point (7 links x ~153 GB/s per GPU): bucket size defaults to 32 MiB so each
+  ring/tree step moves >= 4 MiB per link — large enough to be bandwidth- rather than latency-bound.
+* The relativistic-average GAN terms use the mean of D's logits over the GLOBAL batch
+  (SRRaGAN_model.py:136-137,151-152; under DataParallel the loss is formed on gathered outputs):
+  ``global_mean`` all-reduces [sum, count] and is differentiable.
+* D's BatchNorm keeps per-replica statistics, exactly as under DataParallel (no SyncBN).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1 or dist.is_initialized():
+        return world
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    kw = {}
+    if backend == 'nccl':
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local)
+        kw['device_id'] = torch.device('cuda', local)
+    dist.init_process_group(backend, **kw)
+    return world
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def broadcast_parameters(module, src=0):
+    """One-time parameter/buffer sync at start-up (replicas then stay identical because every rank
+    applies the same averaged gradients) — replaces DataParallel's per-forward broadcast."""
+    if world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src)
+
+
+class GradExchange:
+    """Mean all-reduce of a module's gradients, bucketed, asynchronous."""
+
+    def __init__(self, module, bucket_bytes=32 << 20):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.bucket_bytes = bucket_bytes
+        self.handles = []
+        self._staged = []
+
+    def _flat_groups(self):
+        """Group parameter grads by underlying storage: grads that are views of one flat tensor
+        (our fused backward nodes) are reduced in place, slice by slice."""
+        groups = {}
+        for p in self.params:
+            if p.grad is None:
+                continue
+            st = p.grad.untyped_storage()
+            groups.setdefault(st.data_ptr(), []).append(p)
+        return groups
+
+    def start(self):
+        """Issue the all-reduces (async).  Call right after ``loss.backward()``."""
+        self.handles, self._staged = [], []
+        if world_size() == 1:
+            return
+        ws = float(world_size())
+        for _, ps in self._flat_groups().items():
+            g0 = ps[0].grad
+            esz = g0.element_size()
+            if len(ps) > 1:
+                # contiguous span covered by these views inside the shared storage
+                lo = min(p.grad.storage_offset() for p in ps)
+                hi = max(p.grad.storage_offset() + p.grad.numel() for p in ps)
+                covered = sum(p.grad.numel() for p in ps)
+                if covered == hi - lo:
+                    flat = torch.empty(0, dtype=g0.dtype, device=g0.device).set_(
+                        g0.untyped_storage(), lo, (hi - lo,))
+                    step = max(1, self.bucket_bytes // esz)
+                    # last slices first: they belong to the layers whose backward finished first
+                    for s in range(((hi - lo - 1) // step) * step, -1, -step):
+                        chunk = flat[s:s + step]
+                        chunk.div_(ws)
+                        self.handles.append(dist.all_reduce(chunk, async_op=True))
+                    continue
+            # generic path: stage into a bucket, reduce, copy back on wait()
+            bucket, size = [], 0
+            for p in reversed(ps):
+                bucket.append(p)
+                size += p.grad.numel() * esz
+                if size >= self.bucket_bytes:
+                    self._launch_bucket(bucket, ws)
+                    bucket, size = [], 0
+            if bucket:
+                self._launch_bucket(bucket, ws)
+
+    def _launch_bucket(self, ps, ws):
+        flat = torch.cat([p.grad.reshape(-1) for p in ps]).div_(ws)
+        self.handles.append(dist.all_reduce(flat, async_op=True))
+        self._staged.append((flat, ps))
+
+    def wait(self):
+        """Block the current stream on the exchange; call right before ``optimizer.step()``."""
+        for h in self.handles:
+            h.wait()
+        for flat, ps in self._staged:
+            off = 0
+            for p in ps:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        self.handles, self._staged = [], []
+
+
+class _GlobalMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        s = torch.stack([x.sum(), x.new_tensor(float(x.numel()))])
+        if world_size() > 1:
+            dist.all_reduce(s)
+        ctx.save_for_backward(s[1:2])
+        ctx.shape = x.shape
+        return s[0] / s[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        (n,) = ctx.saved_tensors
+        # d(mean_global)/dx_local = 1/N_global for every local element, and EVERY rank's loss depends
+        # on the mean, so the upstream gradient is summed over ranks first.  With per-rank losses =
+        # local means and parameter gradients averaged over ranks (GradExchange) this reproduces the
+        # gradient of the reference's single global-batch loss.
+        if world_size() > 1:
+            g = g.clone()
+            dist.all_reduce(g)
+        return (g / n).expand(ctx.shape)
+
+
+def global_mean(x):
+    """mean of ``x`` over the batch of ALL ranks (== torch.mean on one rank), differentiable."""
+    return _GlobalMean.apply(x)

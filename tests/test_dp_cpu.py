@@ -1,0 +1,82 @@
+"""World-size-2 CPU tests (gloo) of the data-parallel exchange logic: bucketed mean all-reduce of
+flat-view gradients and of ordinary gradients, and the differentiable global-batch mean used by the
+relativistic GAN loss.  No GPU, no HIP."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from esrganplus_amd import dp
+    try:
+        assert dp.init_from_env('gloo') == world
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4))
+        dp.broadcast_parameters(net)
+        # (a) grads as views of ONE flat tensor (what the fused HIP backward nodes produce)
+        ps = list(net.parameters())
+        flat = torch.arange(sum(p.numel() for p in ps), dtype=torch.float32) * (rank + 1)
+        off = 0
+        for p in ps:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        ex = dp.GradExchange(net, bucket_bytes=64)      # tiny buckets -> several slices
+        ex.start()
+        ex.wait()
+        want = torch.arange(flat.numel(), dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+        assert torch.allclose(flat, want), 'flat-view exchange'
+        assert ps[0].grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+        # (b) ordinary, separately allocated grads
+        for p in ps:
+            p.grad = torch.full_like(p, float(rank + 1))
+        ex.start()
+        ex.wait()
+        for p in ps:
+            assert torch.allclose(p.grad, torch.full_like(p, (world + 1) / 2.0)), 'generic exchange'
+        # (c) global mean: forward value and gradient equal the single-process global-batch result
+        xs = [torch.tensor([[1.0], [2.0], [4.0]]) * (r + 1) for r in range(world)]
+        x = xs[rank].clone().requires_grad_(True)
+        m = dp.global_mean(x)
+        loss = ((x - m) ** 2).mean()
+        loss.backward()
+        xa = torch.cat(xs).requires_grad_(True)
+        la = sum((((xa[3 * r:3 * r + 3] - xa.mean()) ** 2).mean()) for r in range(world)) / world
+        la.backward()
+        assert torch.allclose(m, xa.mean().detach())
+        # per-rank grads are later averaged over ranks: local grad == world * d(la)/dx_local
+        assert torch.allclose(x.grad, world * xa.grad[3 * rank:3 * rank + 3], atol=1e-6), 'global_mean grad'
+        q.put((rank, 'ok'))
+    except Exception as e:   # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_dp_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
