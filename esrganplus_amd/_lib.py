@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_HERE, 'libesrgan_hip.so')
 ESR_F16, ESR_F32 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 NOISE_OFF, NOISE_PHILOX, NOISE_EXPLICIT = 0, 1, 2
-OP_CONV, OP_PACK, OP_LAYOUT, OP_NOISE_FILL, OP_WGRAD = 1, 2, 3, 4, 5
+OP_CONV, OP_PACK, OP_LAYOUT, OP_NOISE_FILL, OP_WGRAD, OP_BN, OP_POOL, OP_LINEAR = 1, 2, 3, 4, 5, 6, 7, 8
+BN_STATS, BN_FINALIZE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_FINAL, BN_BWD_APPLY = 0, 1, 2, 3, 4, 5
 NO_LAYER = 0xFFFFFFFF
 
 
@@ -71,9 +72,34 @@ class esr_noise_fill(C.Structure):
                 ('W', C.c_int32), ('seed', C.c_uint64), ('layer', C.c_uint32)]
 
 
+class esr_bn(C.Structure):
+    _fields_ = [('dtype', C.c_int32), ('mode', C.c_int32), ('B', C.c_int32), ('C', C.c_int32),
+                ('H', C.c_int32), ('W', C.c_int32), ('training', C.c_int32), ('act', C.c_int32),
+                ('momentum', C.c_float), ('eps', C.c_float),
+                ('x', esr_g32), ('y', esr_g32), ('g', esr_g32), ('gx', esr_g32),
+                ('sums', C.c_void_p), ('mean', C.c_void_p), ('invstd', C.c_void_p),
+                ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p),
+                ('running_var', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p)]
+
+
+class esr_pool(C.Structure):
+    _fields_ = [('dtype', C.c_int32), ('mode', C.c_int32), ('B', C.c_int32), ('C', C.c_int32),
+                ('H', C.c_int32), ('W', C.c_int32), ('relu_mask', C.c_int32), ('_pad', C.c_int32),
+                ('x', esr_g32), ('y', esr_g32), ('g', esr_g32), ('gx', esr_g32)]
+
+
+class esr_linear(C.Structure):
+    _fields_ = [('mode', C.c_int32), ('B', C.c_int32), ('I', C.c_int32), ('O', C.c_int32),
+                ('act', C.c_int32), ('_pad', C.c_int32),
+                ('x', C.c_void_p), ('w', C.c_void_p), ('b', C.c_void_p), ('y', C.c_void_p),
+                ('g', C.c_void_p), ('ysaved', C.c_void_p), ('gx', C.c_void_p), ('dw', C.c_void_p),
+                ('db', C.c_void_p)]
+
+
 class _op_union(C.Union):
     _fields_ = [('conv', esr_conv), ('pack', esr_pack), ('layout', esr_layout),
-                ('noise_fill', esr_noise_fill), ('wgrad', esr_wgrad)]
+                ('noise_fill', esr_noise_fill), ('wgrad', esr_wgrad), ('bn', esr_bn),
+                ('pool', esr_pool), ('linear', esr_linear)]
 
 
 class esr_op(C.Structure):
@@ -82,7 +108,8 @@ class esr_op(C.Structure):
 
 # every symbol include/esrgan_hip.h declares (tests check the .so exports all of them)
 EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_pack_conv_weights',
-           'esr_convert_layout', 'esr_fill_noise', 'esr_conv_wgrad', 'esr_run_ops', 'esr_run_ops_timed', 'esr_last_error',
+           'esr_convert_layout', 'esr_fill_noise', 'esr_conv_wgrad', 'esr_batchnorm', 'esr_maxpool2',
+           'esr_linear_op', 'esr_run_ops', 'esr_run_ops_timed', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op']
 
 _lib = None
@@ -119,7 +146,8 @@ def lib():
         L.esr_run_ops_timed.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         for name, st in (('esr_conv_forward', esr_conv), ('esr_pack_conv_weights', esr_pack),
                          ('esr_convert_layout', esr_layout), ('esr_fill_noise', esr_noise_fill),
-                         ('esr_conv_wgrad', esr_wgrad)):
+                         ('esr_conv_wgrad', esr_wgrad), ('esr_batchnorm', esr_bn),
+                         ('esr_maxpool2', esr_pool), ('esr_linear_op', esr_linear)):
             getattr(L, name).argtypes = [C.POINTER(st), C.c_void_p]
         if L.esr_sizeof_op() != C.sizeof(esr_op):
             raise HipExtensionError('ABI mismatch: sizeof(esr_op) C=%d ctypes=%d'

@@ -90,3 +90,200 @@ class RRDB_Net(_RRDBNetBase):
 class SRResNet(nn.Module):
     def __init__(self, *a, **k):
         raise NotImplementedError('SRResNet is outside the ESRGAN+ hot path (SURVEY.md §2.1 row 2)')
+
+
+# =================================================================================================
+# Discriminator_VGG_128 and VGGFeatureExtractor (the rest of the ESRGAN+ train step)
+# =================================================================================================
+import torch  # noqa: E402
+
+from . import _lib as L  # noqa: E402
+from . import convnet as CN  # noqa: E402
+from . import engine as E  # noqa: E402
+
+
+class _SeqNet(B._PlannedModule):
+    """Shared forward/backward driver of the feed-forward plans."""
+
+    def _spec(self):
+        raise NotImplementedError
+
+    def _head(self):
+        return None
+
+    def _input_affine(self):
+        return None
+
+    def _pspec(self):
+        raise NotImplementedError
+
+    def _dgrad_special(self):
+        return {s['conv']: {'ts2': True} for s in self._spec() if 'conv' in s and s['stride'] == 2}
+
+    def _run_forward(self, x, need_bwd):
+        E.require_cuda(x, 'input')
+        xin = x.detach().contiguous().float()
+        Bn, C_, H, W = xin.shape
+        dev = xin.device
+        st = E.current_stream()
+        wp = self._weights(dev)
+        dp = None
+        want_w = any(p.requires_grad for p in self.parameters())
+        if need_bwd:
+            dp = self._dgrad_weights(dev)
+            dp.ensure(st)
+        training = bool(self.training) and self._has_bn
+        key = ('seq', Bn, H, W, self.precision, training, need_bwd, want_w, wp.generation, str(dev))
+        pool = self._plans.setdefault(key, [])
+        plan = next((p for p in pool if not p.busy), None)
+        if plan is None:
+            plan = CN.build_seq_plan(self._spec(), wp, dp, self._pspec(), want_w, Bn, H, W, self.precision,
+                                     dev, training, need_bwd, self._input_affine(), self._head())
+            pool.append(plan)
+        lease = CN._Lease(plan) if need_bwd else None
+        arr = plan.fwd.array()
+        arr[plan.in_op].u.layout.nchw = xin.data_ptr()
+        if training:
+            plan.sums_f.zero_()
+        plan.fwd.run(st)
+        if training:
+            with torch.no_grad():
+                for m in self.modules():
+                    if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None:
+                        m.num_batches_tracked += 1
+        plan.keep_x = xin
+        return plan.out_tensor.clone(), lease
+
+    def forward(self, x):
+        need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not need:
+            return self._run_forward(x, need_bwd=False)[0]
+        return CN.SeqNetFn.apply(x, self, *[t for _, t in self._pspec()])
+
+
+class Discriminator_VGG_128(_SeqNet):
+    """codes/models/modules/architecture.py:87-129 — VGG-style discriminator for 128x128 inputs:
+    10 convs (3x3/s1 and 4x4/s2, 64..512 ch), 9 BatchNorm2d (batch statistics in train mode),
+    LeakyReLU(0.2), flatten, Linear(8192,100), LeakyReLU, Linear(100,1).  State-dict keys as the
+    reference."""
+
+    _has_bn = True
+
+    def __init__(self, in_nc, base_nf, norm_type='batch', act_type='leakyrelu', mode='CNA'):
+        super().__init__()
+        if (base_nf, norm_type, act_type.lower(), mode) != (64, 'batch', 'leakyrelu', 'CNA'):
+            raise NotImplementedError('HIP Discriminator_VGG_128 supports base_nf=64, batch norm, '
+                                      'leakyrelu, CNA (train_ESRGANplus.json:46-53)')
+        nf = base_nf
+        chans = [(in_nc, nf, 3, 1, None), (nf, nf, 4, 2, norm_type), (nf, 2 * nf, 3, 1, norm_type),
+                 (2 * nf, 2 * nf, 4, 2, norm_type), (2 * nf, 4 * nf, 3, 1, norm_type),
+                 (4 * nf, 4 * nf, 4, 2, norm_type), (4 * nf, 8 * nf, 3, 1, norm_type),
+                 (8 * nf, 8 * nf, 4, 2, norm_type), (8 * nf, 8 * nf, 3, 1, norm_type),
+                 (8 * nf, 8 * nf, 4, 2, norm_type)]
+        self.features = B.sequential(*[B.conv_block(ci, co, kernel_size=k, stride=s, norm_type=nt,
+                                                    act_type=act_type, mode=mode)
+                                       for ci, co, k, s, nt in chans])
+        self.classifier = nn.Sequential(nn.Linear(512 * 4 * 4, 100), nn.LeakyReLU(0.2, True),
+                                        nn.Linear(100, 1))
+        self.in_nc = in_nc
+        self._init_planned()
+
+    def _layers(self):
+        out, mods, i = [], list(self.features.children()), 0
+        while i < len(mods):
+            conv = mods[i]
+            bn = mods[i + 1] if isinstance(mods[i + 1], nn.BatchNorm2d) else None
+            out.append((i, conv, (i + 1, bn) if bn is not None else None))
+            i += 3 if bn is not None else 2
+        return out
+
+    def _conv_list(self):
+        return [('features.%d' % i, c.weight, c.bias) for i, c, _ in self._layers()]
+
+    def _spec(self):
+        spec = []
+        for i, c, bn in self._layers():
+            d = {'conv': 'features.%d' % i, 'cin': c.in_channels, 'cout': c.out_channels,
+                 'ks': c.kernel_size[0], 'stride': c.stride[0], 'act': L.ACT_LRELU, 'bn': None}
+            if bn is not None:
+                m = bn[1]
+                d['bn'] = dict(weight=m.weight, bias=m.bias, rm=m.running_mean, rv=m.running_var)
+            spec.append(d)
+        return spec
+
+    def _head(self):
+        c = self.classifier
+        return dict(w1=c[0].weight, b1=c[0].bias, w2=c[2].weight, b2=c[2].bias)
+
+    def _pspec(self):
+        ps, k = [], 0
+        for i, c, bn in self._layers():
+            ps += [('features.%d.weight' % i, c.weight), ('features.%d.bias' % i, c.bias)]
+            if bn is not None:
+                ps += [('bn%d.weight' % k, bn[1].weight), ('bn%d.bias' % k, bn[1].bias)]
+                k += 1
+        c = self.classifier
+        ps += [('head1.weight', c[0].weight), ('head1.bias', c[0].bias),
+               ('head2.weight', c[2].weight), ('head2.bias', c[2].bias)]
+        return ps
+
+
+VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M',
+             512, 512, 512, 512, 'M']
+
+
+class VGGFeatureExtractor(_SeqNet):
+    """architecture.py:279-307: ``(x - mean)/std`` then torchvision VGG19 ``features[:feature_layer+1]``
+    (cfg 'E'; feature_layer=34 -> conv5_4 before its ReLU), frozen.  The reference pulls ImageNet
+    weights through ``torchvision.models.vgg19(pretrained=True)``; there is no network here, so the
+    conv weights are whatever the caller loads (``load_state_dict`` with keys ``features.N.weight``)."""
+
+    _has_bn = False
+
+    def __init__(self, feature_layer=34, use_bn=False, use_input_norm=True, device=torch.device('cpu')):
+        super().__init__()
+        if use_bn:
+            raise NotImplementedError('vgg19_bn is not used by the ESRGAN+ recipe (networks.py:145-150)')
+        layers, cin = [], 3
+        for v in VGG19_CFG:
+            if v == 'M':
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        self.features = nn.Sequential(*layers[:feature_layer + 1])
+        self.use_input_norm = use_input_norm
+        if use_input_norm:
+            self.register_buffer('mean', torch.Tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1).to(device))
+            self.register_buffer('std', torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1).to(device))
+        for p in self.features.parameters():       # architecture.py:300-301
+            p.requires_grad = False
+        self._init_planned()
+
+    def _conv_list(self):
+        return [('features.%d' % i, m.weight, m.bias) for i, m in enumerate(self.features)
+                if isinstance(m, nn.Conv2d)]
+
+    def _spec(self):
+        spec, mods = [], list(self.features.children())
+        for i, m in enumerate(mods):
+            if isinstance(m, nn.Conv2d):
+                act = L.ACT_RELU if (i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)) else L.ACT_NONE
+                spec.append({'conv': 'features.%d' % i, 'cin': m.in_channels, 'cout': m.out_channels,
+                             'ks': 3, 'stride': 1, 'act': act, 'bn': None})
+            elif isinstance(m, nn.MaxPool2d):
+                spec.append({'pool': True})
+        return spec
+
+    def _input_affine(self):
+        if not self.use_input_norm:
+            return None
+        mean = [float(v) for v in self.mean.flatten().tolist()]
+        inv = [1.0 / float(v) for v in self.std.flatten().tolist()]
+        return (mean, inv)
+
+    def _pspec(self):
+        ps = []
+        for k, w, b in self._conv_list():
+            ps += [(k + '.weight', w), (k + '.bias', b)]
+        return ps

@@ -1,0 +1,308 @@
+"""Launch plans (forward + backward) for the two feed-forward conv nets of the ESRGAN+ train step:
+``Discriminator_VGG_128`` (codes/models/modules/architecture.py:87-129) and the VGG19 feature
+extractor (architecture.py:279-307; body = torchvision cfg 'E' ``features[:35]``).
+
+Same mechanics as engine.py: G32 buffers, fused-conv launches, one ``esr_run_ops`` per pass.
+Convs keep their LeakyReLU / ReLU in the epilogue; BatchNorm2d runs as stats -> finalize -> apply
+passes over the conv output; the backward applies activation masks inside the producing kernels
+(conv epilogue ``out2``, BN backward, max-pool backward).
+"""
+import torch
+
+from . import _lib as L
+from . import engine as E
+
+BN_MOMENTUM, BN_EPS = 0.1, 1e-5      # nn.BatchNorm2d defaults (block.py:31)
+
+
+class _Lease(object):
+    def __init__(self, plan):
+        self.plan = plan
+        plan.busy = True
+
+    def release(self):
+        if self.plan is not None:
+            self.plan.busy = False
+            self.plan = None
+
+    def __del__(self):
+        self.release()
+
+
+def _lin(mode, B_, I, O, act, **kw):
+    o = L.esr_linear()
+    o.mode, o.B, o.I, o.O, o.act = mode, B_, I, O, act
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class SeqPlan:
+    """Forward/backward launch lists of a conv -> [bn] -> act -> [pool] chain (+ optional linear
+    head) for one input shape."""
+
+    def __init__(self):
+        self.fwd, self.bwd = L.OpList(), L.OpList()
+        self.bufs, self.keep = [], []
+        self.busy = False
+        self.in_op = self.out_tensor = None
+        self.gy_tensor = None           # fp32 tensor the upstream gradient is copied into
+        self.gx_tensor = None           # fp32 NCHW gradient w.r.t. the input image
+        self.sums_f = self.sums_b = None
+        self.grad_flat, self.grad_views = None, None
+        self.bn_layers = []
+
+
+def _g32(plan, B, C_, H, W, dtype, dev):
+    b = E.G32(B, C_, H, W, dtype, dev)
+    plan.bufs.append(b)
+    return b
+
+
+def _layout(ops, dt_e, to_g32, B, C_, buf, nchw_ptr=None, affine=None):
+    lo = L.esr_layout()
+    lo.dtype, lo.to_g32 = dt_e, to_g32
+    lo.B, lo.C, lo.H, lo.W = B, C_, buf.H, buf.W
+    lo.g32 = buf.view(0, C_)
+    if nchw_ptr is not None:
+        lo.nchw = nchw_ptr
+    if affine is not None:
+        lo.use_affine = 1
+        for i in range(len(affine[0])):
+            lo.mean_c[i] = affine[0][i]
+            lo.inv_std_c[i] = affine[1][i]
+    return ops.add(L.OP_LAYOUT, 'layout', lo)
+
+
+def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, training, need_bwd,
+                   input_affine=None, head=None):
+    """spec: list of dicts, in execution order:
+         {'conv': key, 'cin', 'cout', 'ks', 'stride', 'act': ACT_*, 'bn': None | dict(weight,bias,rm,rv)}
+         {'pool': True}
+       head: None | dict(w1,b1,w2,b2) — flatten + Linear(.,100) + LeakyReLU + Linear(100,1)
+       pspec: [(name, tensor)] in autograd-argument order; names '<convkey>.weight|bias',
+       'bn<k>.weight|bias', 'head1|head2.weight|bias'.  want_wgrad: emit parameter-gradient launches.
+    """
+    dt_e, tdtype, cpg = E._dt(dtype)
+    P = SeqPlan()
+    f, bk = P.fwd, P.bwd
+    e = wp.entries
+    params_grad = {}
+    P.grad_views = [(t.numel(), tuple(t.shape)) for _, t in pspec]
+    if need_bwd and want_wgrad:
+        P.grad_flat = torch.zeros(sum(t.numel() for _, t in pspec), dtype=torch.float32, device=dev)
+        ptr, off = {}, 0
+        for name, t in pspec:
+            ptr[name] = P.grad_flat.data_ptr() + 4 * off
+            off += t.numel()
+        for name in ptr:
+            base = name.rsplit('.', 1)[0]
+            if base not in params_grad:
+                params_grad[base] = (ptr.get(base + '.weight'), ptr.get(base + '.bias'))
+
+    # ---------------------------------------------------------------- forward
+    cin0 = spec[0]['cin']
+    xin = _g32(P, B, cin0, H, W, dtype, dev)
+    P.in_op = _layout(f, dt_e, 1, B, cin0, xin, affine=input_affine)
+    nbn = sum(1 for s in spec if s.get('bn'))
+    maxc = max([s['cout'] for s in spec if 'conv' in s] + [1])
+    P.sums_f = torch.zeros(max(nbn, 1) * 2 * maxc, dtype=torch.float64, device=dev)
+    P.sums_b = torch.zeros(max(nbn, 1) * 2 * maxc, dtype=torch.float64, device=dev)
+    stats = torch.zeros(max(nbn, 1) * 2 * maxc, dtype=torch.float32, device=dev)   # mean | invstd
+    P.keep += [stats]
+    cur, ch, h, w = xin, cin0, H, W
+    recs = []          # per layer record for the backward
+    ibn = 0
+    for s in spec:
+        if 'pool' in s:
+            y = _g32(P, B, ch, h // 2, w // 2, dtype, dev)
+            pl = L.esr_pool()
+            pl.dtype, pl.mode, pl.B, pl.C, pl.H, pl.W = dt_e, 0, B, ch, h // 2, w // 2
+            pl.x, pl.y = cur.view(0, ch), y.view(0, ch)
+            f.add(L.OP_POOL, 'pool', pl)
+            recs.append(dict(kind='pool', x=cur, y=y, ch=ch, h=h // 2, w=w // 2))
+            cur, h, w = y, h // 2, w // 2
+            continue
+        key, cout, ks, st = s['conv'], s['cout'], s['ks'], s['stride']
+        pad = (ks - 1) // 2
+        ho, wo = (h + 2 * pad - ks) // st + 1, (w + 2 * pad - ks) // st + 1
+        bn = s.get('bn')
+        cpad = ((cout + 31) // 32) * 32
+        yb = _g32(P, B, cpad, ho, wo, dtype, dev)
+        if bn is None:
+            c = E._conv(dt_e, B, ho, wo, cur.view(0), ch, yb.view(0), e[key], s['act'], stride=st)
+            f.add_conv(c)
+            recs.append(dict(kind='conv', key=key, x=cur, cin=ch, y=yb, c=None, cout=cout, ks=ks, st=st,
+                             act=s['act'], h=ho, w=wo, hin=h, win=w, bn=None))
+        else:
+            cb = _g32(P, B, cpad, ho, wo, dtype, dev)
+            f.add_conv(E._conv(dt_e, B, ho, wo, cur.view(0), ch, cb.view(0), e[key], L.ACT_NONE, stride=st))
+            base = ibn * 2 * maxc
+            mk = dict(sums_f=P.sums_f.data_ptr() + 8 * base, sums_b=P.sums_b.data_ptr() + 8 * base,
+                      mean=stats.data_ptr() + 4 * base, invstd=stats.data_ptr() + 4 * (base + maxc))
+
+            def bnop(mode, x=cb, y=yb, g=None, gx=None, sums=mk['sums_f'], act=s['act'], bn=bn, mk=mk,
+                     cout=cout, ho=ho, wo=wo):
+                o = L.esr_bn()
+                o.dtype, o.mode, o.B, o.C, o.H, o.W = dt_e, mode, B, cout, ho, wo
+                o.training, o.act, o.momentum, o.eps = int(training), act, BN_MOMENTUM, BN_EPS
+                o.x, o.y = x.view(0, cout), y.view(0, cout)
+                if g is not None:
+                    o.g = g.view(0, cout)
+                if gx is not None:
+                    o.gx = gx.view(0, cout)
+                o.sums, o.mean, o.invstd = sums, mk['mean'], mk['invstd']
+                o.gamma, o.beta = bn['weight'].data_ptr(), bn['bias'].data_ptr()
+                o.running_mean, o.running_var = bn['rm'].data_ptr(), bn['rv'].data_ptr()
+                return o
+            if training:
+                f.add(L.OP_BN, 'bn', bnop(L.BN_STATS))
+            f.add(L.OP_BN, 'bn', bnop(L.BN_FINALIZE))
+            f.add(L.OP_BN, 'bn', bnop(L.BN_APPLY))
+            recs.append(dict(kind='conv', key=key, x=cur, cin=ch, y=yb, c=cb, cout=cout, ks=ks, st=st,
+                             act=s['act'], h=ho, w=wo, hin=h, win=w, bn=bn, bnop=bnop, mk=mk, ibn=ibn))
+            P.bn_layers.append(bn)
+            ibn += 1
+        cur, ch, h, w = yb, cout, ho, wo
+    if head is None:
+        P.out_tensor = torch.empty(B, ch, h, w, dtype=torch.float32, device=dev)
+        _layout(f, dt_e, 0, B, ch, cur, nchw_ptr=P.out_tensor.data_ptr())
+    else:
+        F_ = torch.empty(B, ch * h * w, dtype=torch.float32, device=dev)
+        H1 = torch.empty(B, head['w1'].shape[0], dtype=torch.float32, device=dev)
+        P.out_tensor = torch.empty(B, head['w2'].shape[0], dtype=torch.float32, device=dev)
+        P.keep += [F_, H1]
+        _layout(f, dt_e, 0, B, ch, cur, nchw_ptr=F_.data_ptr())
+        lin = _lin
+        I1, O1, O2 = ch * h * w, head['w1'].shape[0], head['w2'].shape[0]
+        f.add(L.OP_LINEAR, 'linear', lin(0, B, I1, O1, L.ACT_LRELU, x=F_.data_ptr(), w=head['w1'].data_ptr(),
+                                         b=head['b1'].data_ptr(), y=H1.data_ptr()))
+        f.add(L.OP_LINEAR, 'linear', lin(0, B, O1, O2, L.ACT_NONE, x=H1.data_ptr(), w=head['w2'].data_ptr(),
+                                         b=head['b2'].data_ptr(), y=P.out_tensor.data_ptr()))
+    if not need_bwd:
+        return P
+
+    # ---------------------------------------------------------------- backward
+    de = dp.entries
+    gcur = None      # G32 gradient w.r.t. the current layer's OUTPUT (post-activation)
+    if head is None:
+        P.gy_tensor = torch.empty(B, ch, h, w, dtype=torch.float32, device=dev)
+        gcur = _g32(P, B, ch, h, w, dtype, dev)
+        _layout(bk, dt_e, 1, B, ch, gcur, nchw_ptr=P.gy_tensor.data_ptr())
+    else:
+        P.gy_tensor = torch.empty(B, O2, dtype=torch.float32, device=dev)
+        gH1 = torch.empty(B, O1, dtype=torch.float32, device=dev)
+        gF = torch.empty(B, I1, dtype=torch.float32, device=dev)
+        P.keep += [gH1, gF]
+        lin = _lin
+        g2 = params_grad.get('head2')
+        g1 = params_grad.get('head1')
+        if g2 is not None:
+            bk.add(L.OP_LINEAR, 'linear', lin(2, B, O1, O2, L.ACT_NONE, x=H1.data_ptr(), g=P.gy_tensor.data_ptr(),
+                                              dw=g2[0], db=g2[1], w=head['w2'].data_ptr()))
+        bk.add(L.OP_LINEAR, 'linear', lin(1, B, O1, O2, L.ACT_NONE, g=P.gy_tensor.data_ptr(),
+                                          w=head['w2'].data_ptr(), gx=gH1.data_ptr()))
+        if g1 is not None:
+            bk.add(L.OP_LINEAR, 'linear', lin(2, B, I1, O1, L.ACT_LRELU, x=F_.data_ptr(), g=gH1.data_ptr(),
+                                              ysaved=H1.data_ptr(), dw=g1[0], db=g1[1], w=head['w1'].data_ptr()))
+        bk.add(L.OP_LINEAR, 'linear', lin(1, B, I1, O1, L.ACT_LRELU, g=gH1.data_ptr(), ysaved=H1.data_ptr(),
+                                          w=head['w1'].data_ptr(), gx=gF.data_ptr()))
+        gcur = _g32(P, B, ch, h, w, dtype, dev)
+        _layout(bk, dt_e, 1, B, ch, gcur, nchw_ptr=gF.data_ptr())
+
+    # gcur_masked: True when gcur already is the gradient w.r.t. the producing conv's pre-activation
+    masked = False
+    for li in range(len(recs) - 1, -1, -1):
+        r = recs[li]
+        if r['kind'] == 'pool':
+            gx = _g32(P, B, r['ch'], r['h'] * 2, r['w'] * 2, dtype, dev)
+            pl = L.esr_pool()
+            pl.dtype, pl.mode, pl.B, pl.C, pl.H, pl.W = dt_e, 1, B, r['ch'], r['h'], r['w']
+            pl.x, pl.y, pl.g, pl.gx = r['x'].view(0, r['ch']), r['y'].view(0, r['ch']), gcur.view(0, r['ch']), gx.view(0, r['ch'])
+            prev = recs[li - 1] if li > 0 else None
+            pl.relu_mask = 1 if (prev and prev['kind'] == 'conv' and prev['act'] == L.ACT_RELU and prev['bn'] is None) else 0
+            bk.add(L.OP_POOL, 'pool', pl)
+            gcur, masked = gx, bool(pl.relu_mask)
+            continue
+        cout, cin_ = r['cout'], r['cin']
+        if r['bn'] is not None:
+            gconv = _g32(P, B, ((cout + 31) // 32) * 32, r['h'], r['w'], dtype, dev)
+            bnop = r['bnop']
+            bk.add(L.OP_BN, 'bn', bnop(L.BN_BWD_REDUCE, g=gcur, sums=r['mk']['sums_b']))
+            gbn = params_grad.get('bn%d' % r['ibn'])
+            if gbn is not None:
+                o = bnop(L.BN_BWD_FINAL, sums=r['mk']['sums_b'])
+                o.dgamma, o.dbeta = gbn
+                bk.add(L.OP_BN, 'bn', o)
+            bk.add(L.OP_BN, 'bn', bnop(L.BN_BWD_APPLY, g=gcur, gx=gconv, sums=r['mk']['sums_b']))
+            gpre = gconv
+        else:
+            if r['act'] != L.ACT_NONE and not masked:
+                raise RuntimeError('internal: activation mask of %s not applied' % r['key'])
+            gpre = gcur
+        # weight gradient
+        gw = params_grad.get(r['key'])
+        if gw is not None:
+            wg = L.esr_wgrad()
+            wg.dtype, wg.ks, wg.stride, wg.upsample = dt_e, r['ks'], r['st'], 0
+            wg.B, wg.H, wg.W, wg.cout, wg.cin = B, r['h'], r['w'], cout, cin_
+            wg.g, wg.in_ = gpre.view(0, cout), r['x'].view(0, cin_)
+            wg.dw, wg.dbias, wg.scale = gw[0], gw[1], 1.0
+            bk.add(L.OP_WGRAD, 'wgrad', wg)
+        # input gradient
+        prev = recs[li - 1] if li > 0 else None
+        gx = _g32(P, B, ((cin_ + cpg - 1) // cpg) * cpg, r['hin'], r['win'], dtype, dev)
+        if r['st'] == 1:
+            c = E._conv(dt_e, B, r['hin'], r['win'], gpre.view(0), cout, None, de[r['key']], L.ACT_NONE)
+        else:
+            c = E._conv(dt_e, B, r['hin'], r['win'], gpre.view(0), cout, None, de[r['key']], L.ACT_NONE,
+                        ks=4, stride=1, upsample=2)
+        c.bias = None
+        need_mask = prev is not None and prev['kind'] == 'conv' and prev['bn'] is None and prev['act'] != L.ACT_NONE
+        if need_mask:
+            c.mask, c.out2, c.mask_cb_begin = prev['y'].view(0, cin_), gx.view(0, cin_), 0
+            c.mask_act = prev['act']
+        else:
+            c.out = gx.view(0, cin_)
+        bk.add_conv(c)
+        gcur, masked = gx, need_mask
+    P.gx_tensor = torch.empty(B, cin0, H, W, dtype=torch.float32, device=dev)
+    aff = None
+    if input_affine is not None:
+        aff = (input_affine[0], input_affine[1])
+    _layout(bk, dt_e, 0, B, cin0, gcur, nchw_ptr=P.gx_tensor.data_ptr(), affine=aff)
+    return P
+
+
+class SeqNetFn(torch.autograd.Function):
+    """One autograd node for a whole feed-forward plan."""
+
+    @staticmethod
+    def forward(ctx, x, mod, *params):
+        out, lease = mod._run_forward(x, need_bwd=True)
+        ctx.mod, ctx.lease, ctx.n = mod, lease, len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        P = ctx.lease.plan
+        if P is None:
+            raise RuntimeError('backward called twice on the same forward (retain_graph unsupported)')
+        mod = ctx.mod
+        st = E.current_stream()
+        P.gy_tensor.copy_(gy.detach().reshape(P.gy_tensor.shape))
+        P.sums_b.zero_()
+        if P.grad_flat is not None:
+            P.grad_flat.zero_()
+        P.bwd.run(st)
+        gx = P.gx_tensor.clone() if ctx.needs_input_grad[0] else None
+        grads = [None] * ctx.n
+        if P.grad_flat is not None:
+            flat = P.grad_flat.clone()
+            off = 0
+            for i, (numel, shape) in enumerate(P.grad_views):
+                if ctx.needs_input_grad[2 + i]:
+                    grads[i] = flat[off:off + numel].view(shape)
+                off += numel
+        ctx.lease.release()
+        return (gx, None) + tuple(grads)

@@ -44,6 +44,9 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       case ESR_OP_LAYOUT: rc = esr_convert_layout(&ops[i].u.layout, stream); break;
       case ESR_OP_NOISE_FILL: rc = esr_fill_noise(&ops[i].u.noise_fill, stream); break;
       case ESR_OP_WGRAD: rc = esr_conv_wgrad(&ops[i].u.wgrad, stream); break;
+      case ESR_OP_BN: rc = esr_batchnorm(&ops[i].u.bn, stream); break;
+      case ESR_OP_POOL: rc = esr_maxpool2(&ops[i].u.pool, stream); break;
+      case ESR_OP_LINEAR: rc = esr_linear_op(&ops[i].u.linear, stream); break;
       default: esr_set_error("esr_run_ops: op %d has unknown kind %d", i, ops[i].kind); return ESR_ERR_INVALID;
     }
     if (rc != ESR_OK) {

@@ -33,7 +33,8 @@ __global__ void pack_kernel(const esr_pack p, int nchunks, int64_t total) {
       // `ci` over its output channels (p.cout); src is the forward OIHW [p.cout][p.cin][3|ks][..].
       if (co < p.cin && ci < p.cout) {
         if (!p.ups_dgrad) {
-          const int fk = p.ks - 1 - kh, fw = p.ks - 1 - kw;        // taps rotated 180 degrees
+          // taps rotated 180 degrees (mode 1) or kept (mode 2: transposed stride-2 operand)
+          const int fk = p.transpose_flip == 2 ? kh : p.ks - 1 - kh, fw = p.transpose_flip == 2 ? kw : p.ks - 1 - kw;
           x = p.src[(((int64_t)ci * p.cin + co) * p.ks + fk) * p.ks + fw];
           if (p.sum_count > 0 && co >= p.sum_dst && co < p.sum_dst + p.sum_count)
             x += p.src[(((int64_t)ci * p.cin + (co - p.sum_dst + p.sum_src)) * p.ks + fk) * p.ks + fw];
@@ -94,7 +95,11 @@ __global__ void from_g32_kernel(const esr_layout p) {
 #pragma unroll
   for (int e = 0; e < CPG; ++e) {
     const int c = g * CPG + e;
-    if (c < p.C) p.nchw[(((int64_t)b * p.C + c) * p.H + y) * p.W + x] = (float)v[e];
+    if (c < p.C) {
+      float f = (float)v[e];
+      if (p.use_affine && c < 4) f *= p.inv_std_c[c];   // adjoint of (x - mean) * inv_std
+      p.nchw[(((int64_t)b * p.C + c) * p.H + y) * p.W + x] = f;
+    }
   }
 }
 

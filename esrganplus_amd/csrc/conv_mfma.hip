@@ -289,7 +289,7 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
 // Every wave issues exactly NDMA LDS-DMA instructions per K step (tail rounds re-copy an earlier
 // window), so a counted `s_waitcnt vmcnt(NDMA)` retires exactly one stage.
 // ------------------------------------------------------------------------------------------------
-template <int KS, int S, bool UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
+template <int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
 struct Geo {
   static constexpr int R = 4;
   static constexpr int NW = WR * WC * NCG;                               // waves per workgroup
@@ -317,7 +317,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int KS, int S, bool UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
+template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
 __global__ __launch_bounds__(512, 2) void conv_kernel(const esr_conv p) {
   using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>;
   constexpr int R = G::R;
@@ -368,7 +368,11 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const esr_conv p) {
   int colofs[KS];
 #pragma unroll
   for (int kw = 0; kw < KS; ++kw) {
-    const int col = UPS ? (((wc * 32 + j + kw - 1) >> 1) + 1) : ((wc * 32 + j) * S + kw);
+    // UPS==1: nearest-x2 gather; UPS==2 (transposed stride-2): this wave owns the 32 output columns
+    // of parity wc, tap kw contributes iff (wc+1-kw) is even and then reads g column j+(wc+1-kw)/2
+    const int col = UPS == 1 ? (((wc * 32 + j + kw - 1) >> 1) + 1)
+                  : UPS == 2 ? (j + ((wc + 1 - kw) >> 1) + 1)
+                             : ((wc * 32 + j) * S + kw);
     colofs[kw] = col * 32 + ((h ^ ((col >> 3) & 1)) << 4) + (UPS ? wr * (R / 2) : wr * R * S) * G::IW * 32;
   }
 
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const esr_conv p) {
           constexpr int ir = decltype(IR)::value;
           sfor<KS>([&](auto KH) __attribute__((always_inline)) {
             constexpr int kh = decltype(KH)::value;
-            if constexpr (UPS) {
+            if constexpr (UPS == 1) {
               sfor<R>([&](auto RR) __attribute__((always_inline)) {
                 constexpr int r = decltype(RR)::value;
                 if constexpr ((((r + kh - 1) >> 1) + 1) == ir) {
@@ -505,6 +509,17 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const esr_conv p) {
                   });
                 }
               });
+            } else if constexpr (UPS == 2) {
+              // adjoint of the 4x4/s2/p1 conv: output row r takes tap kh from g row (r+1-kh)/2
+              constexpr int r = 2 * (ir - 1) + kh - 1;
+              if constexpr (r >= 0 && r < R) {
+                if (((wc + 1 - kw) & 1) == 0) {
+                  sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
+                    constexpr int cw = decltype(CW)::value;
+                    mma<T>(accsel<r * NCW + cw>(acc), af[cur][kh * NCW + cw], bf[cur][ir]);
+                  });
+                }
+              }
             } else {
               constexpr int tt = ir - kh;
               if constexpr (tt >= 0 && tt % S == 0 && tt / S < R) {
@@ -535,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const esr_conv p) {
   }
 
   // ---------------------------------------------------------------- epilogue
-  const int ox = ox0 + wc * 32 + j;
+  const int ox = UPS == 2 ? ox0 + 2 * j + wc : ox0 + wc * 32 + j;
   if (ox >= p.W || (dbg & 1)) return;
   const int oyb = oy0 + wr * R;
   sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
@@ -546,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const esr_conv p) {
   });
 }
 
-template <typename T, int KS, int S, bool UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
+template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
 int launch(const esr_conv& p, hipStream_t st) {
   using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>;
   const int tiles = ((p.W + G::TW - 1) / G::TW) * ((p.H + G::TH - 1) / G::TH) * p.B;
@@ -563,20 +578,24 @@ int dispatch(const esr_conv& p, hipStream_t st) {
   if (p.ks == 3 && p.stride == 1 && !p.upsample) {
     if (has1) {
       if (cbk != 1) { esr_set_error("conv: fused 1x1 needs cout_blocks==1"); return ESR_ERR_UNSUPPORTED; }
-      return narrow ? launch<T, 3, 1, false, 8, 1, 1, 1, true, true>(p, st) : launch<T, 3, 1, false, 4, 2, 1, 1, true, true>(p, st);
+      return narrow ? launch<T, 3, 1, 0, 8, 1, 1, 1, true, true>(p, st) : launch<T, 3, 1, 0, 4, 2, 1, 1, true, true>(p, st);
     }
-    if (cbk == 1) return narrow ? launch<T, 3, 1, false, 8, 1, 1, 1, true, false>(p, st) : launch<T, 3, 1, false, 4, 2, 1, 1, true, false>(p, st);
-    if (cbk <= 3) return narrow ? launch<T, 3, 1, false, 8, 1, 1, 2, true, false>(p, st) : launch<T, 3, 1, false, 4, 2, 1, 2, true, false>(p, st);
-    return launch<T, 3, 1, false, 2, 1, 4, 1, false, false>(p, st);     // wide convs (D / VGG)
+    if (cbk == 1) return narrow ? launch<T, 3, 1, 0, 8, 1, 1, 1, true, false>(p, st) : launch<T, 3, 1, 0, 4, 2, 1, 1, true, false>(p, st);
+    if (cbk <= 3) return narrow ? launch<T, 3, 1, 0, 8, 1, 1, 2, true, false>(p, st) : launch<T, 3, 1, 0, 4, 2, 1, 2, true, false>(p, st);
+    return launch<T, 3, 1, 0, 2, 1, 4, 1, false, false>(p, st);     // wide convs (D / VGG)
   }
   if (has1) { esr_set_error("conv: fused 1x1 only with 3x3/s1"); return ESR_ERR_UNSUPPORTED; }
-  if (p.ks == 3 && p.stride == 1 && p.upsample) {
-    if ((p.H | p.W) & 1) { esr_set_error("conv: upsample needs even output size"); return ESR_ERR_INVALID; }
-    return cbk == 1 ? launch<T, 3, 1, true, 4, 2, 1, 1, true, false>(p, st) : launch<T, 3, 1, true, 4, 2, 1, 2, true, false>(p, st);
+  if (p.ks == 4 && p.stride == 1 && p.upsample == 2) {
+    if ((p.H | p.W) & 1) { esr_set_error("conv: transposed stride-2 needs even output size"); return ESR_ERR_INVALID; }
+    return cbk == 1 ? launch<T, 4, 1, 2, 4, 2, 1, 1, true, false>(p, st) : launch<T, 4, 1, 2, 4, 2, 1, 2, true, false>(p, st);
   }
-  if (p.ks == 4 && p.stride == 2 && !p.upsample) return launch<T, 4, 2, false, 2, 1, 4, 1, false, false>(p, st);
+  if (p.ks == 3 && p.stride == 1 && p.upsample == 1) {
+    if ((p.H | p.W) & 1) { esr_set_error("conv: upsample needs even output size"); return ESR_ERR_INVALID; }
+    return cbk == 1 ? launch<T, 3, 1, 1, 4, 2, 1, 1, true, false>(p, st) : launch<T, 3, 1, 1, 4, 2, 1, 2, true, false>(p, st);
+  }
+  if (p.ks == 4 && p.stride == 2 && !p.upsample) return launch<T, 4, 2, 0, 2, 1, 4, 1, false, false>(p, st);
   if (p.ks == 1 && p.stride == 1 && !p.upsample) {
-    return cbk == 1 ? launch<T, 1, 1, false, 4, 2, 1, 1, true, false>(p, st) : launch<T, 1, 1, false, 4, 2, 1, 2, true, false>(p, st);
+    return cbk == 1 ? launch<T, 1, 1, 0, 4, 2, 1, 1, true, false>(p, st) : launch<T, 1, 1, 0, 4, 2, 1, 2, true, false>(p, st);
   }
   esr_set_error("conv: unsupported ks=%d stride=%d upsample=%d", p.ks, p.stride, p.upsample);
   return ESR_ERR_UNSUPPORTED;

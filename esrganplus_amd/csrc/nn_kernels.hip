@@ -1,0 +1,276 @@
+// nn_kernels.hip — the non-conv layers of Discriminator_VGG_128 (architecture.py:87-129) and
+// VGG19 features (architecture.py:279-307): BatchNorm2d, MaxPool2d(2,2), Linear.  All HBM-bound,
+// one pass per phase over G32 tensors (row-major fp32 for the classifier).
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ void ld16(const char* p, float v[DT<T>::CPG]);
+template <> __device__ __forceinline__ void ld16<_Float16>(const char* p, float v[16]) {
+  const half8 a = __builtin_bit_cast(half8, *(const u32x4*)p), b = __builtin_bit_cast(half8, *(const u32x4*)(p + 16));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] = (float)a[i]; v[8 + i] = (float)b[i]; }
+}
+template <> __device__ __forceinline__ void ld16<float>(const char* p, float v[8]) {
+  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 16);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+template <typename T> __device__ __forceinline__ void st16(char* p, const float v[DT<T>::CPG]);
+template <> __device__ __forceinline__ void st16<_Float16>(char* p, const float v[16]) {
+  half8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)v[i]; b[i] = (_Float16)v[8 + i]; }
+  *(u32x4*)p = __builtin_bit_cast(u32x4, a);
+  *(u32x4*)(p + 16) = __builtin_bit_cast(u32x4, b);
+}
+template <> __device__ __forceinline__ void st16<float>(char* p, const float v[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+  *(f32x4*)p = a;
+  *(f32x4*)(p + 16) = b;
+}
+
+__device__ __forceinline__ int64_t pix_off(const esr_g32& t, int b, int g, int y, int x) {
+  return b * t.batch_stride + (int64_t)g * t.group_stride + ((int64_t)(y + 1) * t.wp + x + 1) * 32;
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == ESR_ACT_LRELU) return v > 0.f ? v : v * ESR_LRELU_SLOPE;
+  if (act == ESR_ACT_RELU) return v > 0.f ? v : 0.f;
+  return v;
+}
+__device__ __forceinline__ float act_bwd(float y, int act) {   // derivative selected by saved OUTPUT
+  if (act == ESR_ACT_LRELU) return y > 0.f ? 1.f : ESR_LRELU_SLOPE;
+  if (act == ESR_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+// grid: (ceil(H*W/256), groups, B); block 256.  Per-channel reductions: wave shuffle + LDS + fp64 atomics.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_pass_kernel(const esr_bn p) {
+  constexpr int CPG = DT<T>::CPG;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y, b = blockIdx.z;
+  const bool ok = pix < p.H * p.W;
+  const int y = ok ? pix / p.W : 0, x = ok ? pix % p.W : 0;
+  float xv[CPG], yv[CPG], gv[CPG];
+  float s0[CPG], s1[CPG];
+#pragma unroll
+  for (int e = 0; e < CPG; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+  const double N = (double)p.B * p.H * p.W;
+  if (ok) {
+    ld16<T>((const char*)p.x.ptr + pix_off(p.x, b, g, y, x), xv);
+    if (MODE == ESR_BN_STATS) {
+#pragma unroll
+      for (int e = 0; e < CPG; ++e) { s0[e] = xv[e]; s1[e] = xv[e] * xv[e]; }
+    } else if (MODE == ESR_BN_APPLY) {
+#pragma unroll
+      for (int e = 0; e < CPG; ++e) {
+        const int c = g * CPG + e;
+        float v = 0.f;
+        if (c < p.C) v = act_fwd((xv[e] - p.mean[c]) * p.invstd[c] * p.gamma[c] + p.beta[c], p.act);
+        yv[e] = v;
+      }
+      st16<T>((char*)p.y.ptr + pix_off(p.y, b, g, y, x), yv);
+    } else {   // BWD_REDUCE / BWD_APPLY
+      ld16<T>((const char*)p.y.ptr + pix_off(p.y, b, g, y, x), yv);
+      ld16<T>((const char*)p.g.ptr + pix_off(p.g, b, g, y, x), gv);
+#pragma unroll
+      for (int e = 0; e < CPG; ++e) {
+        const int c = g * CPG + e;
+        if (c >= p.C) { gv[e] = 0.f; continue; }
+        const float gp = gv[e] * act_bwd(yv[e], p.act);
+        const float xh = (xv[e] - p.mean[c]) * p.invstd[c];
+        if (MODE == ESR_BN_BWD_REDUCE) { s0[e] = gp; s1[e] = gp * xh; }
+        else {
+          float r = gp;
+          if (p.training) r = gp - (float)(p.sums[c] / N) - xh * (float)(p.sums[p.C + c] / N);
+          gv[e] = r * p.gamma[c] * p.invstd[c];
+        }
+      }
+      if (MODE == ESR_BN_BWD_APPLY) st16<T>((char*)p.gx.ptr + pix_off(p.gx, b, g, y, x), gv);
+    }
+  }
+  if (MODE == ESR_BN_STATS || MODE == ESR_BN_BWD_REDUCE) {
+    __shared__ float red[4][2][CPG];
+#pragma unroll
+    for (int e = 0; e < CPG; ++e) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { s0[e] += __shfl_xor(s0[e], o); s1[e] += __shfl_xor(s1[e], o); }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < CPG; ++e) { red[wave][0][e] = s0[e]; red[wave][1][e] = s1[e]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * CPG) {
+      const int k = threadIdx.x / CPG, e = threadIdx.x % CPG, c = g * CPG + e;
+      if (c < p.C) {
+        const double v = (double)red[0][k][e] + red[1][k][e] + red[2][k][e] + red[3][k][e];
+        atomicAdd(p.sums + k * p.C + c, v);
+      }
+    }
+  }
+}
+
+__global__ void bn_small_kernel(const esr_bn p) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.C) return;
+  const double N = (double)p.B * p.H * p.W;
+  if (p.mode == ESR_BN_FINALIZE) {
+    if (p.training) {
+      const double m = p.sums[c] / N;
+      double var = p.sums[p.C + c] / N - m * m;
+      if (var < 0) var = 0;
+      p.mean[c] = (float)m;
+      p.invstd[c] = (float)(1.0 / sqrt(var + (double)p.eps));
+      if (p.running_mean) {
+        p.running_mean[c] = (float)((1.0 - p.momentum) * p.running_mean[c] + p.momentum * m);
+        p.running_var[c] = (float)((1.0 - p.momentum) * p.running_var[c] + p.momentum * var * (N / (N - 1.0)));
+      }
+    } else {
+      p.mean[c] = p.running_mean[c];
+      p.invstd[c] = 1.0f / sqrtf(p.running_var[c] + p.eps);
+    }
+  } else {   // BWD_FINAL
+    if (p.dgamma) p.dgamma[c] += (float)p.sums[p.C + c];
+    if (p.dbeta) p.dbeta[c] += (float)p.sums[c];
+  }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void pool_kernel(const esr_pool p) {
+  constexpr int CPG = DT<T>::CPG;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y, b = blockIdx.z;
+  if (pix >= p.H * p.W) return;
+  const int y = pix / p.W, x = pix % p.W;
+  float v[4][CPG], m[CPG];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ld16<T>((const char*)p.x.ptr + pix_off(p.x, b, g, 2 * y + (q >> 1), 2 * x + (q & 1)), v[q]);
+  int am[CPG];
+#pragma unroll
+  for (int e = 0; e < CPG; ++e) {
+    m[e] = v[0][e]; am[e] = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) if (v[q][e] > m[e]) { m[e] = v[q][e]; am[e] = q; }   // first max wins
+  }
+  if (MODE == 0) {
+    st16<T>((char*)p.y.ptr + pix_off(p.y, b, g, y, x), m);
+  } else {
+    float gv[CPG], o[CPG];
+    ld16<T>((const char*)p.g.ptr + pix_off(p.g, b, g, y, x), gv);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int e = 0; e < CPG; ++e) o[e] = (am[e] == q && (!p.relu_mask || v[q][e] > 0.f)) ? gv[e] : 0.f;
+      st16<T>((char*)p.gx.ptr + pix_off(p.gx, b, g, 2 * y + (q >> 1), 2 * x + (q & 1)), o);
+    }
+  }
+}
+
+// y[b][o] = act(sum_i x[b][i] w[o][i] + bias[o]) — one block per (o, b)
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const esr_linear p) {
+  const int o = blockIdx.x, b = blockIdx.y;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < p.I; i += 256) s += p.x[(int64_t)b * p.I + i] * p.w[(int64_t)o * p.I + i];
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = red[0] + red[1] + red[2] + red[3] + (p.b ? p.b[o] : 0.f);
+    p.y[(int64_t)b * p.O + o] = act_fwd(v, p.act);
+  }
+}
+// gx[b][i] = sum_o (g[b][o] * act'(ysaved[b][o])) w[o][i]
+__global__ __launch_bounds__(256) void linear_bwdx_kernel(const esr_linear p) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= p.I) return;
+  float s = 0.f;
+  for (int o = 0; o < p.O; ++o) {
+    float gg = p.g[(int64_t)b * p.O + o];
+    if (p.ysaved) gg *= act_bwd(p.ysaved[(int64_t)b * p.O + o], p.act);
+    s += gg * p.w[(int64_t)o * p.I + i];
+  }
+  p.gx[(int64_t)b * p.I + i] = s;
+}
+// dw[o][i] += sum_b g'[b][o] x[b][i];  db[o] += sum_b g'[b][o]
+__global__ __launch_bounds__(256) void linear_bwdw_kernel(const esr_linear p) {
+  const int i = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
+  if (i >= p.I) return;
+  float s = 0.f, sb = 0.f;
+  for (int b = 0; b < p.B; ++b) {
+    float gg = p.g[(int64_t)b * p.O + o];
+    if (p.ysaved) gg *= act_bwd(p.ysaved[(int64_t)b * p.O + o], p.act);
+    s += gg * p.x[(int64_t)b * p.I + i];
+    sb += gg;
+  }
+  p.dw[(int64_t)o * p.I + i] += s;
+  if (i == 0 && p.db) p.db[o] += sb;
+}
+
+template <typename T>
+int bn_dispatch(const esr_bn& p, hipStream_t st) {
+  constexpr int CPG = DT<T>::CPG;
+  dim3 grid((p.H * p.W + 255) / 256, (p.C + CPG - 1) / CPG, p.B), block(256);
+  switch (p.mode) {
+    case ESR_BN_STATS: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_STATS>), grid, block, 0, st, p); break;
+    case ESR_BN_APPLY: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_APPLY>), grid, block, 0, st, p); break;
+    case ESR_BN_BWD_REDUCE: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_BWD_REDUCE>), grid, block, 0, st, p); break;
+    case ESR_BN_BWD_APPLY: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_BWD_APPLY>), grid, block, 0, st, p); break;
+    case ESR_BN_FINALIZE:
+    case ESR_BN_BWD_FINAL: hipLaunchKernelGGL(bn_small_kernel, dim3((p.C + 63) / 64), dim3(64), 0, st, p); break;
+    default: esr_set_error("esr_batchnorm: bad mode %d", p.mode); return ESR_ERR_INVALID;
+  }
+  return esr_check_launch("bn_kernel");
+}
+
+}  // namespace
+
+extern "C" int esr_batchnorm(const esr_bn* p, esr_stream_t stream) {
+  if (!p || p->B <= 0 || p->C <= 0 || p->H <= 0 || p->W <= 0 || !p->mean || !p->invstd) {
+    esr_set_error("esr_batchnorm: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (p->dtype == ESR_F16) return bn_dispatch<_Float16>(*p, st);
+  if (p->dtype == ESR_F32) return bn_dispatch<float>(*p, st);
+  esr_set_error("esr_batchnorm: bad dtype");
+  return ESR_ERR_INVALID;
+}
+
+extern "C" int esr_maxpool2(const esr_pool* p, esr_stream_t stream) {
+  if (!p || p->B <= 0 || p->C <= 0 || p->H <= 0 || p->W <= 0 || !p->x.ptr) {
+    esr_set_error("esr_maxpool2: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int cpg = p->dtype == ESR_F16 ? 16 : 8;
+  dim3 grid((p->H * p->W + 255) / 256, (p->C + cpg - 1) / cpg, p->B), block(256);
+  if (p->dtype == ESR_F16) {
+    if (p->mode == 0) hipLaunchKernelGGL((pool_kernel<_Float16, 0>), grid, block, 0, st, *p);
+    else hipLaunchKernelGGL((pool_kernel<_Float16, 1>), grid, block, 0, st, *p);
+  } else if (p->dtype == ESR_F32) {
+    if (p->mode == 0) hipLaunchKernelGGL((pool_kernel<float, 0>), grid, block, 0, st, *p);
+    else hipLaunchKernelGGL((pool_kernel<float, 1>), grid, block, 0, st, *p);
+  } else { esr_set_error("esr_maxpool2: bad dtype"); return ESR_ERR_INVALID; }
+  return esr_check_launch("pool_kernel");
+}
+
+extern "C" int esr_linear_op(const esr_linear* p, esr_stream_t stream) {
+  if (!p || p->B <= 0 || p->I <= 0 || p->O <= 0 || !p->w) {
+    esr_set_error("esr_linear_op: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (p->mode == 0) hipLaunchKernelGGL(linear_fwd_kernel, dim3(p->O, p->B), dim3(256), 0, st, *p);
+  else if (p->mode == 1) hipLaunchKernelGGL(linear_bwdx_kernel, dim3((p->I + 255) / 256, p->B), dim3(256), 0, st, *p);
+  else if (p->mode == 2) hipLaunchKernelGGL(linear_bwdw_kernel, dim3((p->I + 255) / 256, p->O), dim3(256), 0, st, *p);
+  else { esr_set_error("esr_linear_op: bad mode"); return ESR_ERR_INVALID; }
+  return esr_check_launch("linear_kernel");
+}

@@ -427,7 +427,7 @@ class DgradPack:
                 pk.cout, pk.cin = w.shape[0], w.shape[1]
                 pk.ks = e.ks
                 pk.dtype = self.esr_dtype
-                pk.transpose_flip = 1
+                pk.transpose_flip = 2 if sp.get('ts2') else 1
                 if 'sum' in sp:
                     pk.sum_dst, pk.sum_src, pk.sum_count = sp['sum']
                 pk.ups_dgrad = 1 if sp.get('ups') else 0

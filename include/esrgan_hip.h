@@ -64,7 +64,9 @@ typedef struct esr_conv {
   int32_t dtype;       /* esr_dtype: storage type of every G32 tensor here (accumulate fp32) */
   int32_t ks;          /* 1, 3 or 4 */
   int32_t stride;      /* 1, or 2 (ks==4) */
-  int32_t upsample;    /* 1: input is nearest-x2 upsampled on load (ks==3 only) */
+  int32_t upsample;    /* 1: input is nearest-x2 upsampled on load (ks==3 only);
+                          2: TRANSPOSED 4x4/stride-2 conv (adjoint of ks==4,stride==2): the input is at
+                             half the output resolution; weights packed with transpose_flip=2 */
   int32_t B, H, W;     /* OUTPUT logical size */
   int32_t cin_groups;  /* K loop length: input channel groups read from `in` */
   int32_t cout_blocks; /* ceil(Cout/32) */
@@ -106,7 +108,9 @@ typedef struct esr_pack {
   void* dst;
   int32_t cout, cin, ks;
   int32_t dtype;
-  int32_t transpose_flip; /* 1: dgrad operand; `cout`/`cin` below are still the FORWARD conv's */
+  int32_t transpose_flip; /* 1: dgrad operand (Cin<->Cout, taps rotated 180 deg); 2: Cin<->Cout only
+                             (operand of the transposed stride-2 conv, upsample==2);
+                             `cout`/`cin` below are still the FORWARD conv's */
   int32_t sum_dst;     /* transpose_flip only: dgrad output channels [sum_dst, sum_dst+sum_count) */
   int32_t sum_src;     /*   additionally receive the weights of forward input channels             */
   int32_t sum_count;   /*   [sum_src, sum_src+sum_count) (x4 = lrelu(a4) + x2, block.py:266)      */
@@ -150,8 +154,52 @@ typedef struct esr_wgrad {
   int32_t _pad;
 } esr_wgrad;
 
+/* BatchNorm2d(affine) over a G32 tensor (block.py:28-32; Discriminator_VGG_128,
+ * architecture.py:93-118), split in phases so each is one memory pass:
+ *   STATS      sums[c] += sum x, sums[C+c] += sum x^2            (fp64 atomics; caller zeroes sums)
+ *   FINALIZE   mean/invstd from sums (training: biased var; running stats updated with momentum and
+ *              the UNBIASED var) or from running stats (eval)
+ *   APPLY      y = act((x-mean)*invstd*gamma + beta)
+ *   BWD_REDUCE g' = g*act'(y);  sums[c] += sum g',  sums[C+c] += sum g'*xhat
+ *   BWD_FINAL  dgamma += sums[C+c]; dbeta += sums[c]
+ *   BWD_APPLY  gx = gamma*invstd*(g' - sum g'/N - xhat*sum(g' xhat)/N)   (eval: gamma*invstd*g') */
+enum esr_bn_mode { ESR_BN_STATS = 0, ESR_BN_FINALIZE = 1, ESR_BN_APPLY = 2, ESR_BN_BWD_REDUCE = 3,
+                   ESR_BN_BWD_FINAL = 4, ESR_BN_BWD_APPLY = 5 };
+typedef struct esr_bn {
+  int32_t dtype, mode;
+  int32_t B, C, H, W;
+  int32_t training, act;
+  float momentum, eps;
+  esr_g32 x, y, g, gx;
+  double* sums;                 /* [2*C] */
+  float* mean; float* invstd;   /* [C] batch statistics kept for backward */
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var;
+  float* dgamma; float* dbeta;
+} esr_bn;
+
+/* MaxPool2d(2,2) (torchvision VGG19 cfg 'E', architecture.py:287-298).  mode 0: y = pool(x);
+ * mode 1: gx = route g to the FIRST maximum of each 2x2 window (torch semantics). */
+typedef struct esr_pool {
+  int32_t dtype, mode;
+  int32_t B, C, H, W;           /* OUTPUT (pooled) size */
+  int32_t relu_mask;            /* mode 1: also apply ReLU' of the pooled tensor's producer (x > 0) */
+  int32_t _pad;
+  esr_g32 x, y, g, gx;
+} esr_pool;
+
+/* nn.Linear on row-major fp32 (Discriminator classifier, architecture.py:121-123).
+ * mode 0: y = act(x W^T + b);  mode 1: gx = (g * act'(y_saved)) W ... see fields;  mode 2: dw, db. */
+typedef struct esr_linear {
+  int32_t mode, B, I, O, act, _pad;
+  const float* x; const float* w; const float* b; float* y;
+  const float* g;               /* dL/dy (already multiplied by act' by the caller kernel: see gmask) */
+  const float* ysaved;          /* bwd: saved activation output of THIS layer for act' (may be NULL) */
+  float* gx; float* dw; float* db;
+} esr_linear;
+
 enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_NOISE_FILL = 4,
-                   ESR_OP_WGRAD = 5 };
+                   ESR_OP_WGRAD = 5, ESR_OP_BN = 6, ESR_OP_POOL = 7, ESR_OP_LINEAR = 8 };
 
 typedef struct esr_op {
   int32_t kind;
@@ -162,6 +210,9 @@ typedef struct esr_op {
     esr_layout layout;
     esr_noise_fill noise_fill;
     esr_wgrad wgrad;
+    esr_bn bn;
+    esr_pool pool;
+    esr_linear linear;
   } u;
 } esr_op;
 
@@ -174,6 +225,9 @@ int esr_pack_conv_weights(const esr_pack* p, esr_stream_t stream);
 int esr_convert_layout(const esr_layout* p, esr_stream_t stream);
 int esr_fill_noise(const esr_noise_fill* p, esr_stream_t stream);
 int esr_conv_wgrad(const esr_wgrad* p, esr_stream_t stream);
+int esr_batchnorm(const esr_bn* p, esr_stream_t stream);
+int esr_maxpool2(const esr_pool* p, esr_stream_t stream);
+int esr_linear_op(const esr_linear* p, esr_stream_t stream);
 
 /* Run a recorded list of ops back to back on `stream` (one host call per network pass; this is
  * what RRDBNet.forward — architecture.py:76-78 — becomes). */
