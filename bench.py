@@ -111,6 +111,56 @@ def cpu_baseline(seconds_budget=25.0):
             'gflops': round(2 * MAC_PER_LR_PIXEL * size * size / med / 1e9, 1)}
 
 
+def train_bench(args, world, rank, dev, dist):
+    """BASELINE configs[2]/[3]: full ESRGAN+ train step (RRDBNet + Discriminator_VGG_128 + VGG19
+    feature loss, Adam x2; train_ESRGANplus.json), per-GPU batch 16 of 32x32 LR -> 128x128 HR, data
+    parallel over RCCL with the gradient exchange overlapped on the other network's pass."""
+    from esrganplus_amd import architecture as arch, synth, train, dp as DP
+    prec = args.precision
+    netG = arch.RRDBNet(3, 3, 64, NB).to(dev).train().set_precision(prec)
+    netD = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision(prec)
+    netF = arch.VGGFeatureExtractor(34, False, True, dev).to(dev).eval().set_precision(prec)
+    netG.load_state_dict(synth.rrdbnet_state_dict(NB, 0, gain=0.5))
+    netD.load_state_dict(synth.discriminator_state_dict(0))
+    netF.load_state_dict(synth.vgg19_state_dict(0, 34), strict=False)
+    for n in (netG, netD):
+        DP.broadcast_parameters(n)
+    st = train.ESRGANPlusStep(netG, netD, netF, loss_scale=1024.0 if prec == 'fp16' else 1.0)
+    lr = synth.image_batch(200 + rank, 16, 3, 32, 32, name='bench.lr').to(dev)
+    hr = synth.image_batch(300 + rank, 16, 3, 128, 128, name='bench.hr').to(dev)
+    for _ in range(max(args.warmup, 1)):
+        st.step(lr, hr, sync_log=False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        log = st.step(lr, hr, sync_log=False)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert all(torch.isfinite(v).all() for v in log.values())
+    if rank == 0:
+        step_flops = 2.0 * 1.515e12          # SURVEY.md §8a: ~1.515 TMAC per batch-16 step
+        res = {'metric': 'HR megapixels/sec (x4 SR) full ESRGAN+ train step', 'unit': 'HR-Mpix/s',
+               'value': round(world * 16 * 128 * 128 / 1e6 / (elapsed / args.steps), 3), 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f16' if prec == 'fp16' else 'f32', 'data': 'synthetic',
+               'config': {'workload': 'ESRGAN+ train step (RRDBNet nb=23 + Discriminator_VGG_128 + VGG19[:35] '
+                                      'feature loss, Adam x2), batch 16 of 32x32 LR per GPU (BASELINE configs[2]/[3])',
+                          'global_batch': world * 16, 'parallelism': 'dp%d, RCCL grad all-reduce overlapped' % world},
+               'tflops_per_gpu': round(step_flops / (elapsed / args.steps) / 1e12, 1)}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -119,6 +169,10 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--lr', type=int, default=LR)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', choices=['forward', 'train'], default='forward',
+                    help="'forward' = BASELINE configs[1] (the headline metric); 'train' = configs[2]/[3]: "
+                         'full ESRGAN+ step, batch 16 of 32x32 LR per GPU, DP over RCCL')
+    ap.add_argument('--precision', choices=['fp16', 'fp32'], default='fp16')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -140,6 +194,8 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     from esrganplus_amd import architecture as arch, synth, engine as E
+    if args.mode == 'train':
+        return train_bench(args, world, rank, dev, dist)
     net = arch.RRDBNet(3, 3, 64, NB).to(dev).eval().set_precision('fp16')
     net.load_state_dict(synth.rrdbnet_state_dict(NB, 0), strict=True)
     x = synth.image_batch(100 + rank, args.batch, 3, args.lr, args.lr, name='bench.x').to(dev)

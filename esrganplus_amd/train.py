@@ -1,0 +1,91 @@
+"""ESRGAN+ training step on the HIP path — the call pattern of
+``SRRaGANModel.optimize_parameters`` (codes/models/SRRaGAN_model.py:113-186) with the
+hyper-parameters of codes/options/train/train_ESRGANplus.json:55-77: L1 pixel x0.01, L1 VGG-feature
+x1, relativistic-average GAN (BCE-with-logits) x0.005, Adam(1e-4, betas (0.9, 0.999)) for G and D.
+
+The three networks are the drop-in HIP modules; the losses are a handful of tiny reductions.  With
+``torch.distributed`` initialised (one process per GPU) the step is data-parallel: gradient
+exchanges are started right after each backward and waited for right before the matching
+``optimizer.step()``, so the G exchange overlaps the whole D forward/backward (the D step only uses
+``fake_H.detach()`` computed before the G update, exactly as in the reference).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import dp as DP
+
+
+def bce_logits(x, target_is_real):
+    """GANLoss('vanilla', 1.0, 0.0) — codes/models/modules/loss.py:6-38."""
+    t = torch.ones_like(x) if target_is_real else torch.zeros_like(x)
+    return F.binary_cross_entropy_with_logits(x, t)
+
+
+class ESRGANPlusStep:
+    def __init__(self, netG, netD, netF, lr_G=1e-4, lr_D=1e-4, beta1_G=0.9, beta1_D=0.9,
+                 pixel_weight=1e-2, feature_weight=1.0, gan_weight=5e-3, loss_scale=1.0):
+        self.netG, self.netD, self.netF = netG, netD, netF
+        self.l_pix_w, self.l_fea_w, self.l_gan_w = pixel_weight, feature_weight, gan_weight
+        self.loss_scale = loss_scale          # static loss scale for the fp16 path (1.0 for fp32)
+        self.optimizer_G = torch.optim.Adam([p for p in netG.parameters() if p.requires_grad],
+                                            lr=lr_G, betas=(beta1_G, 0.999))
+        self.optimizer_D = torch.optim.Adam(netD.parameters(), lr=lr_D, betas=(beta1_D, 0.999))
+        self.exG, self.exD = DP.GradExchange(netG), DP.GradExchange(netD)
+        self.log = {}
+        self.fake_H = None
+
+    def _unscale(self, params):
+        if self.loss_scale != 1.0:
+            inv = 1.0 / self.loss_scale
+            for p in params:
+                if p.grad is not None:
+                    p.grad.mul_(inv)
+
+    def step(self, var_L, var_H, var_ref=None, z=None, sync_log=True):
+        """One optimisation step (SRRaGAN_model.py:113-168)."""
+        netG, netD, netF = self.netG, self.netD, self.netF
+        var_ref = var_H if var_ref is None else var_ref
+        mean = DP.global_mean
+        # ---------------- G ----------------
+        for p in netD.parameters():
+            p.requires_grad = False
+        self.optimizer_G.zero_grad(set_to_none=True)
+        fake_H = netG(var_L, z=z) if z is not None else netG(var_L)
+        self.fake_H = fake_H
+        l_g_pix = self.l_pix_w * F.l1_loss(fake_H, var_H)
+        with torch.no_grad():
+            real_fea = netF(var_H)
+        fake_fea = netF(fake_H)
+        l_g_fea = self.l_fea_w * F.l1_loss(fake_fea, real_fea)
+        pred_g_fake = netD(fake_H)
+        with torch.no_grad():
+            pred_d_real = netD(var_ref)
+        l_g_gan = self.l_gan_w * (bce_logits(pred_d_real - mean(pred_g_fake), False) +
+                                  bce_logits(pred_g_fake - mean(pred_d_real), True)) / 2
+        l_g_total = l_g_pix + l_g_fea + l_g_gan
+        (l_g_total * self.loss_scale).backward()
+        self.exG.start()                      # RCCL all-reduce of G grads overlaps the D pass below
+        # ---------------- D ----------------
+        for p in netD.parameters():
+            p.requires_grad = True
+        self.optimizer_D.zero_grad(set_to_none=True)
+        pred_d_real = netD(var_ref)
+        pred_d_fake = netD(fake_H.detach())
+        l_d_real = bce_logits(pred_d_real - mean(pred_d_fake), True)
+        l_d_fake = bce_logits(pred_d_fake - mean(pred_d_real), False)
+        l_d_total = (l_d_real + l_d_fake) / 2
+        (l_d_total * self.loss_scale).backward()
+        self.exD.start()
+        self.exG.wait()
+        self._unscale(self.netG.parameters())
+        self.optimizer_G.step()
+        self.exD.wait()
+        self._unscale(self.netD.parameters())
+        self.optimizer_D.step()
+        logs = dict(l_g_pix=l_g_pix, l_g_fea=l_g_fea, l_g_gan=l_g_gan, l_d_real=l_d_real,
+                    l_d_fake=l_d_fake, D_real=pred_d_real.detach().mean(), D_fake=pred_d_fake.detach().mean())
+        if sync_log:      # the reference calls .item() on every loss each step (SRRaGAN_model.py:171-186)
+            self.log = {k: float(v.detach()) for k, v in logs.items()}
+        else:
+            self.log = {k: v.detach() for k, v in logs.items()}
+        return self.log

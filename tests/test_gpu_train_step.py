@@ -1,0 +1,47 @@
+"""One full ESRGAN+ optimisation step on the HIP path vs the golden captured from the reference's
+``SRRaGANModel.optimize_parameters`` (nb=2, batch 4; oracle/gen_golden.py: gen_train_step)."""
+import numpy as np
+import pytest
+import torch
+
+from esrganplus_amd import synth
+from tests.conftest import checks
+
+pytestmark = pytest.mark.gpu
+
+
+def test_optimize_parameters_step_matches_reference():
+    assert torch.cuda.is_available()
+    dev = torch.device('cuda:0')
+    from esrganplus_amd import architecture as arch, train
+    from oracle import ref_torch as RT
+    g = dict(np.load('tests/golden/train_step.npz'))
+    sdG, sdD = synth.rrdbnet_state_dict(nb=2, seed=30), synth.discriminator_state_dict(seed=31)
+    netG = arch.RRDBNet(3, 3, 64, 2).to(dev).train()
+    netD = arch.Discriminator_VGG_128(3, 64).to(dev).train()
+    netF = arch.VGGFeatureExtractor(34, False, True, dev).to(dev).eval()
+    netG.load_state_dict(sdG, strict=True)
+    netD.load_state_dict(sdD, strict=True)
+    netF.load_state_dict(synth.vgg19_state_dict(6, 34), strict=False)
+    lr = synth.image_batch(30, 4, 3, 32, 32, name='step.lr').to(dev)
+    hr = synth.image_batch(30, 4, 3, 128, 128, name='step.hr').to(dev)
+    z = [synth.normal_like(9, 'step.z.%d' % i, s).to(dev) for i, s in enumerate(RT.noise_shapes(lr.shape, 2, 'codes'))]
+    st = train.ESRGANPlusStep(netG, netD, netF)
+    log = st.step(lr, hr, z=z)
+    for k in ('l_g_pix', 'l_g_fea', 'l_g_gan', 'l_d_real', 'l_d_fake', 'D_real', 'D_fake'):
+        ref = float(g['log_' + k])
+        print('%-9s hip %.6e  ref %.6e' % (k, log[k], ref))
+        assert abs(log[k] - ref) <= 2e-4 * max(1.0, abs(ref)), k
+    assert np.abs(st.fake_H.detach().cpu().numpy()[:, :, ::4, ::4] - g['fake_H_sub4']).max() <= 1e-4
+    # Adam's first step moves every weight by ~lr*sign(grad): compare the updated weights
+    pg = dict(netG.named_parameters())
+    chk = np.stack([checks(pg[k]) for k in sdG.keys()])
+    assert np.abs(chk - g['G_new_chk']).max() <= 2e-3 * np.abs(g['G_new_chk']).max()
+    d = (pg['model.0.weight'].detach().cpu() - sdG['model.0.weight']).numpy()
+    ref = g['G_delta_model.0.weight']
+    agree = np.mean(np.sign(d) == np.sign(ref))
+    print('sign agreement of the first Adam update on model.0.weight: %.4f' % agree)
+    assert agree >= 0.97 and np.abs(d - ref).mean() <= 0.1 * np.abs(ref).mean()
+    pd = dict(netD.named_parameters())
+    dd = (pd['classifier.2.weight'].detach().cpu() - sdD['classifier.2.weight']).numpy()
+    assert np.mean(np.sign(dd) == np.sign(g['D_delta_classifier.2.weight'])) >= 0.97
