@@ -140,7 +140,7 @@ def train_bench(args, world, rank, dev, dist):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert all(torch.isfinite(v).all() for v in log.values())
@@ -186,12 +186,19 @@ def main():
                                    '--master-port', os.environ.get('MASTER_PORT', '29533'),
                                    os.path.abspath(__file__)] + sys.argv[1:])
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        backend = os.environ.get('ESR_BENCH_BACKEND', 'nccl')     # 'gloo' only for single-GPU dry runs
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from esrganplus_amd import architecture as arch, synth, engine as E
     if args.mode == 'train':
@@ -216,7 +223,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         assert torch.isfinite(y).all()
