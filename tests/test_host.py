@@ -100,3 +100,14 @@ def test_no_cpu_fallback():
     net = arch.RRDBNet(3, 3, 64, 1).eval()
     with torch.no_grad(), pytest.raises(_lib.HipExtensionError):
         net(torch.rand(1, 3, 8, 8))
+
+
+def test_metrics_match_reference_goldens(golden):
+    """esrganplus_amd.metrics (tensor2img / PSNR harness code) against the reference's util.py."""
+    import numpy as np
+    from esrganplus_amd import metrics
+    g = golden('psnr')
+    for i in range(3):
+        a, b = torch.from_numpy(g['a%d' % i]), torch.from_numpy(g['b%d' % i])
+        assert np.array_equal(metrics.tensor2img(a), g['img_a%d' % i])
+        assert abs(metrics.validation_psnr(a, b, 4) - float(g['psnr%d' % i])) < 1e-9
