@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, 'libesrgan_hip.so')
 ESR_F16, ESR_F32 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 NOISE_OFF, NOISE_PHILOX, NOISE_EXPLICIT = 0, 1, 2
-OP_CONV, OP_PACK, OP_LAYOUT, OP_NOISE_FILL, OP_WGRAD, OP_BN, OP_POOL, OP_LINEAR = 1, 2, 3, 4, 5, 6, 7, 8
+OP_CONV, OP_PACK, OP_LAYOUT, OP_NOISE_FILL, OP_WGRAD, OP_BN, OP_POOL, OP_LINEAR, OP_UNPERMUTE = 1, 2, 3, 4, 5, 6, 7, 8, 9
 BN_STATS, BN_FINALIZE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_FINAL, BN_BWD_APPLY = 0, 1, 2, 3, 4, 5
 NO_LAYER = 0xFFFFFFFF
 
@@ -58,7 +58,7 @@ class esr_wgrad(C.Structure):
     _fields_ = [('dtype', C.c_int32), ('ks', C.c_int32), ('stride', C.c_int32),
                 ('upsample', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
                 ('cout', C.c_int32), ('cin', C.c_int32), ('g', esr_g32), ('in_', esr_g32),
-                ('dw', C.c_void_p), ('dbias', C.c_void_p), ('scale', C.c_float), ('_pad', C.c_int32)]
+                ('dw', C.c_void_p), ('dbias', C.c_void_p), ('scale', C.c_float), ('tap_major', C.c_int32)]
 
 
 class esr_layout(C.Structure):
@@ -96,10 +96,20 @@ class esr_linear(C.Structure):
                 ('db', C.c_void_p)]
 
 
+class esr_unperm_entry(C.Structure):
+    _fields_ = [('src_off', C.c_int64), ('dst_off', C.c_int64), ('elem_begin', C.c_int64),
+                ('cout', C.c_int32), ('cin', C.c_int32), ('ntap', C.c_int32), ('_pad', C.c_int32)]
+
+
+class esr_unpermute(C.Structure):
+    _fields_ = [('table', C.c_void_p), ('n', C.c_int32), ('_pad', C.c_int32), ('total', C.c_int64),
+                ('src', C.c_void_p), ('dst', C.c_void_p)]
+
+
 class _op_union(C.Union):
     _fields_ = [('conv', esr_conv), ('pack', esr_pack), ('layout', esr_layout),
                 ('noise_fill', esr_noise_fill), ('wgrad', esr_wgrad), ('bn', esr_bn),
-                ('pool', esr_pool), ('linear', esr_linear)]
+                ('pool', esr_pool), ('linear', esr_linear), ('unpermute', esr_unpermute)]
 
 
 class esr_op(C.Structure):
@@ -109,7 +119,7 @@ class esr_op(C.Structure):
 # every symbol include/esrgan_hip.h declares (tests check the .so exports all of them)
 EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_pack_conv_weights',
            'esr_convert_layout', 'esr_fill_noise', 'esr_conv_wgrad', 'esr_batchnorm', 'esr_maxpool2',
-           'esr_linear_op', 'esr_run_ops', 'esr_run_ops_timed', 'esr_last_error',
+           'esr_linear_op', 'esr_grad_unpermute', 'esr_run_ops', 'esr_run_ops_timed', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op']
 
 _lib = None
@@ -147,7 +157,8 @@ def lib():
         for name, st in (('esr_conv_forward', esr_conv), ('esr_pack_conv_weights', esr_pack),
                          ('esr_convert_layout', esr_layout), ('esr_fill_noise', esr_noise_fill),
                          ('esr_conv_wgrad', esr_wgrad), ('esr_batchnorm', esr_bn),
-                         ('esr_maxpool2', esr_pool), ('esr_linear_op', esr_linear)):
+                         ('esr_maxpool2', esr_pool), ('esr_linear_op', esr_linear),
+                         ('esr_grad_unpermute', esr_unpermute)):
             getattr(L, name).argtypes = [C.POINTER(st), C.c_void_p]
         if L.esr_sizeof_op() != C.sizeof(esr_op):
             raise HipExtensionError('ABI mismatch: sizeof(esr_op) C=%d ctypes=%d'

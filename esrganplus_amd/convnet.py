@@ -87,13 +87,17 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
     P = SeqPlan()
     f, bk = P.fwd, P.bwd
     e = wp.entries
-    params_grad = {}
+    params_grad, poff = {}, {}
+    P.tapmajor = None
     P.grad_views = [(t.numel(), tuple(t.shape)) for _, t in pspec]
     if need_bwd and want_wgrad:
         P.grad_flat = torch.zeros(sum(t.numel() for _, t in pspec), dtype=torch.float32, device=dev)
+        if dt_e == L.ESR_F16:
+            P.tapmajor = E.TapMajorGrads(P.grad_flat)
         ptr, off = {}, 0
         for name, t in pspec:
             ptr[name] = P.grad_flat.data_ptr() + 4 * off
+            poff[name] = off
             off += t.numel()
         for name in ptr:
             base = name.rsplit('.', 1)[0]
@@ -248,6 +252,8 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
             wg.B, wg.H, wg.W, wg.cout, wg.cin = B, r['h'], r['w'], cout, cin_
             wg.g, wg.in_ = gpre.view(0, cout), r['x'].view(0, cin_)
             wg.dw, wg.dbias, wg.scale = gw[0], gw[1], 1.0
+            if P.tapmajor is not None and r['ks'] == 3 and r['st'] == 1:
+                wg.dw, wg.tap_major = P.tapmajor.slot(poff[r['key'] + '.weight'], cout, cin_), 1
             bk.add(L.OP_WGRAD, 'wgrad', wg)
         # input gradient
         prev = recs[li - 1] if li > 0 else None
@@ -266,6 +272,10 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
             c.out = gx.view(0, cin_)
         bk.add_conv(c)
         gcur, masked = gx, need_mask
+    if P.tapmajor is not None:
+        up = P.tapmajor.op()
+        if up is not None:
+            bk.add(L.OP_UNPERMUTE, 'unpermute', up)
     P.gx_tensor = torch.empty(B, cin0, H, W, dtype=torch.float32, device=dev)
     aff = None
     if input_affine is not None:
@@ -294,6 +304,8 @@ class SeqNetFn(torch.autograd.Function):
         P.sums_b.zero_()
         if P.grad_flat is not None:
             P.grad_flat.zero_()
+            if P.tapmajor is not None:
+                P.tapmajor.tm.zero_()
         P.bwd.run(st)
         gx = P.gx_tensor.clone() if ctx.needs_input_grad[0] else None
         grads = [None] * ctx.n

@@ -134,6 +134,166 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const esr_wgrad p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp16 path: the contraction over pixels runs on v_mfma_f32_32x32x16_f16.  Both operands need 8
+// consecutive PIXELS of one channel per lane, while LDS holds [pixel][16 channels] (G32 order), so
+// the fragments are fetched with the gfx950 transposing LDS read ds_read_b64_tr_b16: in a 16-lane
+// group lane i supplies the address of 4 consecutive channels of pixel (i>>2) (quarter i&3 of that
+// pixel's 32 bytes) and receives channel i of those 4 pixels.  Two reads = one 8-pixel fragment.
+// Workgroup = 8 waves = NCO cout blocks x (8/NCO) blocks of 32 input channels; a wave keeps the 9
+// (or 1) per-tap 32x32 accumulators of its (cout block, cin block) plus one bias accumulator, so a
+// g fragment read feeds up to 10 MFMAs.
+// ------------------------------------------------------------------------------------------------
+typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+__device__ __forceinline__ u32x4 tr_frag(const char* lds_base, int off0, int off1) {
+  // off0/off1: per-lane byte offsets of the two 4-pixel reads
+  const s4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(lds_base + off0));
+  const s4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(lds_base + off1));
+  u32x4 r;
+  r[0] = ((const uint32_t*)&a)[0]; r[1] = ((const uint32_t*)&a)[1];
+  r[2] = ((const uint32_t*)&b)[0]; r[3] = ((const uint32_t*)&b)[1];
+  return r;
+}
+
+struct Acc10 { f32x16 a[10]; };
+
+template <int KS, bool UPS, int NCO>
+__global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int rows_per_wg) {
+  constexpr int TR = 4, TC = 32, NTAP = KS * KS, PAD = (KS - 1) / 2;
+  constexpr int NCI = 8 / NCO;                        // cin blocks (of 32 channels) per workgroup
+  constexpr int IH = UPS ? TR / 2 + 2 : TR + KS - 1, IW = UPS ? TC / 2 + 2 : TC + KS - 1;
+  constexpr int G_BYTES = NCO * 2 * TR * TC * 32;     // [cout group][row][col][32 B]
+  constexpr int IN_GROUP = IH * IW * 32;
+  __shared__ __attribute__((aligned(16))) char smem[G_BYTES + NCI * 2 * IN_GROUP];
+  char* const lg = smem;
+  char* const li = smem + G_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave % NCO, wci = wave / NCO;       // this wave's cout block / cin block in the WG
+  const int strips = (p.W + TC - 1) / TC;
+  const int rchunks = (p.H + rows_per_wg - 1) / rows_per_wg;
+  const int sx = blockIdx.x % strips, rc = (blockIdx.x / strips) % rchunks, b = blockIdx.x / (strips * rchunks);
+  const int ox0 = sx * TC;
+  const int cb = blockIdx.z * NCO + wco;              // 32-cout block
+  const int cib = blockIdx.y * NCI + wci;             // 32-cin block  (= G32 groups 2*cib, 2*cib+1)
+  const int ngin = p.in.ngroups;
+  const bool active = cb * 32 < p.cout && 2 * cib < ngin;
+
+  // per-lane transposed-read geometry: lane -> (pixel-in-run, 8-byte quarter, group half)
+  const int i16 = lane & 15, jrow = i16 >> 2, q = i16 & 3, ghalf = (lane >> 4) & 1, kg = lane >> 5;
+  const int pk = 8 * kg + jrow;                       // pixel of the 16-pixel run for read 0 (+4 for read 1)
+
+  Acc10 acc;
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc.a[t][e] = 0.f;
+  // all-ones B fragment: column sums of g = bias gradient
+  const u32x4 ones = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+
+  const char* gbase = (const char*)p.g.ptr + b * p.g.batch_stride;
+  const char* ibase = (const char*)p.in.ptr + b * p.in.batch_stride;
+  const int y_begin = rc * rows_per_wg, y_end = min(p.H, y_begin + rows_per_wg);
+
+  for (int oy0 = y_begin; oy0 < y_end; oy0 += TR) {
+    __syncthreads();
+    // ---- stage g: NCO*2 groups x TR x TC pixels (zero outside the image)
+    for (int s = tid; s < NCO * 2 * TR * TC * 2; s += 512) {
+      const int half = s & 1, px = (s >> 1) % (TR * TC), g = (s >> 1) / (TR * TC);
+      const int r = px / TC, c = px % TC;
+      const int gg = (blockIdx.z * NCO) * 2 + g;
+      u32x4 v = {0, 0, 0, 0};
+      if (oy0 + r < y_end && ox0 + c < p.W && gg < p.g.ngroups)
+        v = *(const u32x4*)(gbase + (int64_t)gg * p.g.group_stride + ((int64_t)(oy0 + r + 1) * p.g.wp + ox0 + c + 1) * 32 + half * 16);
+      *(u32x4*)(lg + (g * TR * TC + px) * 32 + half * 16) = v;
+    }
+    // ---- stage the input tile of NCI*2 groups with its halo
+    const int iy0 = UPS ? oy0 / 2 : oy0 + 1 - PAD, ix0 = UPS ? ox0 / 2 : ox0 + 1 - PAD;
+    for (int s = tid; s < NCI * 2 * IH * IW * 2; s += 512) {
+      const int half = s & 1, px = (s >> 1) % (IH * IW), g = (s >> 1) / (IH * IW);
+      const int r = px / IW, c = px % IW;
+      const int gg = blockIdx.y * NCI * 2 + g;
+      u32x4 v = {0, 0, 0, 0};
+      if (gg < ngin)
+        v = *(const u32x4*)(ibase + (int64_t)gg * p.in.group_stride + ((int64_t)(iy0 + r) * p.in.wp + ix0 + c) * 32 + half * 16);
+      *(u32x4*)(li + g * IN_GROUP + px * 32 + half * 16) = v;
+    }
+    __syncthreads();
+    if (!active) continue;
+    const char* lgw = lg + (wco * 2 + ghalf) * TR * TC * 32 + q * 8;
+    const char* liw = li + (wci * 2 + ghalf) * IN_GROUP + q * 8;
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int c0 = 16 * hf + pk;                    // column of this lane's first pixel (read 0)
+        const u32x4 af = tr_frag(lgw, (r * TC + c0) * 32, (r * TC + c0 + 4) * 32);
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) {
+            int o0, o1;
+            if (UPS) {
+              const int rr = ((r + kh - 1) >> 1) + 1;
+              o0 = (rr * IW + ((c0 + kw - 1) >> 1) + 1) * 32;
+              o1 = (rr * IW + ((c0 + 4 + kw - 1) >> 1) + 1) * 32;
+            } else {
+              o0 = ((r + kh) * IW + c0 + kw) * 32;
+              o1 = o0 + 4 * 32;
+            }
+            const u32x4 bf = tr_frag(liw, o0, o1);
+            acc.a[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, af), __builtin_bit_cast(half8, bf), acc.a[kh * KS + kw], 0, 0, 0);
+          }
+        if (cib == 0 && p.dbias)
+          acc.a[9] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, af), __builtin_bit_cast(half8, ones), acc.a[9], 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+  // ---- fp32 atomics into dW[co][ci][kh][kw] / dbias[co]
+  const int n = lane & 31, ci = cib * 32 + n;
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+      if (co < p.cout && ci < p.cin) {
+        float* d = p.tap_major ? p.dw + ((int64_t)t * p.cout + co) * p.cin + ci
+                               : p.dw + ((int64_t)co * p.cin + ci) * NTAP + t;
+        atomicAdd(d, acc.a[t][e] * p.scale);
+      }
+    }
+  }
+  if (cib == 0 && p.dbias && n == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+      if (co < p.cout) atomicAdd(p.dbias + co, acc.a[9][e] * p.scale);
+    }
+  }
+}
+
+template <int KS, bool UPS>
+int launch_wgrad16(const esr_wgrad& p, hipStream_t st) {
+  const int strips = (p.W + 31) / 32;
+  const int coblocks = (p.cout + 31) / 32;
+  const int ciblocks = (p.in.ngroups + 1) / 2;
+  // rows per workgroup: keep >= ~512 workgroups in flight, but amortise the atomics over many rows
+  const int nco = coblocks >= 2 ? 2 : 1, nci = 8 / nco;
+  const int gy = (ciblocks + nci - 1) / nci, gz = (coblocks + nco - 1) / nco;
+  // Every workgroup ends with 8 waves x 9 taps x 1024 fp32 atomics, so use as FEW spatial splits as
+  // still give ~64 workgroups: start from whole column strips and halve only while the grid is tiny.
+  int rows = ((p.H + 3) / 4) * 4;
+  while (rows > 8 && (int64_t)p.B * strips * ((p.H + rows - 1) / rows) * gy * gz < 64) rows = ((rows / 2 + 3) / 4) * 4;
+  const int rchunks = (p.H + rows - 1) / rows;
+  dim3 grid(p.B * strips * rchunks, gy, gz);
+  if (nco == 2) hipLaunchKernelGGL((wgrad16_kernel<KS, UPS, 2>), grid, dim3(512), 0, st, p, rows);
+  else hipLaunchKernelGGL((wgrad16_kernel<KS, UPS, 1>), grid, dim3(512), 0, st, p, rows);
+  return esr_check_launch("wgrad16_kernel");
+}
+
 template <typename T, int KS, int S, bool UPS>
 int launch_wgrad(const esr_wgrad& p, hipStream_t st) {
   const int strips = (p.W + 31) / 32;
@@ -154,13 +314,49 @@ int dispatch_wgrad(const esr_wgrad& p, hipStream_t st) {
 
 }  // namespace
 
+namespace {
+__global__ void unpermute_kernel(const esr_unpermute p) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.total) return;
+  int lo = 0, hi = p.n - 1;                      // last entry with elem_begin <= idx
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (p.table[mid].elem_begin <= idx) lo = mid; else hi = mid - 1;
+  }
+  const esr_unperm_entry e = p.table[lo];
+  const int64_t k = idx - e.elem_begin;          // OIHW-linear index inside this conv
+  const int t = (int)(k % e.ntap);
+  const int64_t r = k / e.ntap;
+  const int ci = (int)(r % e.cin), co = (int)(r / e.cin);
+  p.dst[e.dst_off + k] = p.src[e.src_off + ((int64_t)t * e.cout + co) * e.cin + ci];
+}
+}  // namespace
+
+extern "C" int esr_grad_unpermute(const esr_unpermute* p, esr_stream_t stream) {
+  if (!p || !p->table || p->n <= 0 || p->total <= 0 || !p->src || !p->dst) {
+    esr_set_error("esr_grad_unpermute: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(unpermute_kernel, dim3((unsigned)((p->total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
+  return esr_check_launch("unpermute_kernel");
+}
+
 extern "C" int esr_conv_wgrad(const esr_wgrad* p, esr_stream_t stream) {
   if (!p || !p->g.ptr || !p->in.ptr || !p->dw || p->B <= 0 || p->H <= 0 || p->W <= 0 || p->cout <= 0 || p->cin <= 0) {
     esr_set_error("esr_conv_wgrad: invalid arguments");
     return ESR_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (p->dtype == ESR_F16) return dispatch_wgrad<_Float16>(*p, st);
+  if (p->tap_major && !(p->dtype == ESR_F16 && p->stride == 1 && (p->ks == 3 || p->ks == 1))) {
+    esr_set_error("esr_conv_wgrad: tap_major only with the fp16 3x3/1x1 kernel");
+    return ESR_ERR_INVALID;
+  }
+  if (p->dtype == ESR_F16) {
+    if (p->ks == 3 && p->stride == 1 && !p->upsample) return launch_wgrad16<3, false>(*p, st);
+    if (p->ks == 3 && p->stride == 1 && p->upsample) return launch_wgrad16<3, true>(*p, st);
+    if (p->ks == 1 && p->stride == 1 && !p->upsample) return launch_wgrad16<1, false>(*p, st);
+    return dispatch_wgrad<_Float16>(*p, st);        // 4x4/s2 (discriminator): round-1 fp32-MFMA kernel
+  }
   if (p->dtype == ESR_F32) return dispatch_wgrad<float>(*p, st);
   esr_set_error("esr_conv_wgrad: bad dtype %d", p->dtype);
   return ESR_ERR_INVALID;

@@ -440,6 +440,38 @@ class DgradPack:
         self.ops.run(stream)      # weights change every optimizer step: always re-pack
 
 
+class TapMajorGrads:
+    """fp16 wgrad accumulates 3x3 weight gradients tap-major ([tap][cout][cin]: atomics of one wave
+    instruction land in 2 cache lines instead of ~36); one esr_grad_unpermute launch at the end of the
+    backward pass rewrites all of them into the OIHW slots of the flat gradient buffer."""
+
+    def __init__(self, grad_flat):
+        self.flat = grad_flat
+        self.tm = torch.zeros_like(grad_flat)
+        self.rows = []
+        self.total = 0
+        self.table = None
+
+    def slot(self, off_elems, cout, cin, ntap=9):
+        self.rows.append((off_elems, off_elems, self.total, cout, cin, ntap))
+        self.total += cout * cin * ntap
+        return self.tm.data_ptr() + 4 * off_elems
+
+    def op(self):
+        if not self.rows:
+            return None
+        arr = (L.esr_unperm_entry * len(self.rows))()
+        for i, r in enumerate(self.rows):
+            arr[i].src_off, arr[i].dst_off, arr[i].elem_begin = r[0], r[1], r[2]
+            arr[i].cout, arr[i].cin, arr[i].ntap = r[3], r[4], r[5]
+        raw = bytes(arr)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.flat.device)
+        up = L.esr_unpermute()
+        up.table, up.n, up.total = self.table.data_ptr(), len(self.rows), self.total
+        up.src, up.dst = self.tm.data_ptr(), self.flat.data_ptr()
+        return up
+
+
 class TrainPlan:
     """Forward (all activations kept) + backward launch lists of RRDBNet for one input shape."""
 
@@ -452,6 +484,7 @@ class TrainPlan:
         self.bwd_noise_ops = []      # backward conv ops that need (noise_mode, seed)
         self.grad_flat = None        # fp32 flat gradient buffer; views per parameter
         self.grad_views = None
+        self.tapmajor = None
 
 
 def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, device, noise, variant,
@@ -551,9 +584,11 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         if b_ is not None:
             sizes.append(b_.numel())
     TP.grad_flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
-    views, off, gptr = [], 0, {}
+    views, off, gptr, goff = [], 0, {}, {}
+    TP.tapmajor = TapMajorGrads(TP.grad_flat) if dt_e == L.ESR_F16 else None
     for k, w, b_ in plist:
         gw = TP.grad_flat[off:off + w.numel()].view_as(w)
+        goff[k] = off
         off += w.numel()
         gb = None
         if b_ is not None:
@@ -585,6 +620,8 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         wg.cout, wg.cin = cout, cin
         wg.g, wg.in_ = g, gin
         wg.dw, wg.dbias = gptr[key]
+        if TP.tapmajor is not None and ks == 3:
+            wg.dw, wg.tap_major = TP.tapmajor.slot(goff[key], cout, cin), 1
         wg.scale = scale
         Bk.add(L.OP_WGRAD, 'wgrad', wg)
 
@@ -689,4 +726,8 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             add_b(c, noisy=True)
     # fea_conv (model.0): weight gradient only (the LR input image needs no gradient)
     wgrad('model.0', GF.view(0, 64), xin.view(0, in_nc), H, W, 64, in_nc)
+    if TP.tapmajor is not None:
+        up = TP.tapmajor.op()
+        if up is not None:
+            Bk.add(L.OP_UNPERMUTE, 'unpermute', up)
     return TP

@@ -126,6 +126,8 @@ class _RRDBNetFn(torch.autograd.Function):
         gy = gy.detach().contiguous().float()
         st = E.current_stream()
         tp.grad_flat.zero_()
+        if tp.tapmajor is not None:
+            tp.tapmajor.tm.zero_()
         arr = tp.bwd.array()
         arr[tp.gy_op].u.layout.nchw = gy.data_ptr()
         mode = L.NOISE_OFF

@@ -151,8 +151,24 @@ typedef struct esr_wgrad {
   float* dw;
   float* dbias;        /* may be NULL */
   float scale;
-  int32_t _pad;
+  int32_t tap_major;   /* 1: dw is laid out [tap][cout][cin] (lane-contiguous atomics: 2 cache lines per
+                          wave instruction instead of ~36); esr_grad_unpermute restores OIHW */
 } esr_wgrad;
+
+/* One launch that rewrites every tap-major gradient block into its OIHW slot.  `table` is a DEVICE
+ * array of n entries {src_off, dst_off, elem_begin, cout, cin, ntap} (int64 x3, int32 x3, pad);
+ * src/dst are fp32 arenas. */
+typedef struct esr_unperm_entry {
+  int64_t src_off, dst_off, elem_begin;
+  int32_t cout, cin, ntap, _pad;
+} esr_unperm_entry;
+typedef struct esr_unpermute {
+  const esr_unperm_entry* table;
+  int32_t n, _pad;
+  int64_t total;
+  const float* src;
+  float* dst;
+} esr_unpermute;
 
 /* BatchNorm2d(affine) over a G32 tensor (block.py:28-32; Discriminator_VGG_128,
  * architecture.py:93-118), split in phases so each is one memory pass:
@@ -199,7 +215,8 @@ typedef struct esr_linear {
 } esr_linear;
 
 enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_NOISE_FILL = 4,
-                   ESR_OP_WGRAD = 5, ESR_OP_BN = 6, ESR_OP_POOL = 7, ESR_OP_LINEAR = 8 };
+                   ESR_OP_WGRAD = 5, ESR_OP_BN = 6, ESR_OP_POOL = 7, ESR_OP_LINEAR = 8,
+                   ESR_OP_UNPERMUTE = 9 };
 
 typedef struct esr_op {
   int32_t kind;
@@ -213,6 +230,7 @@ typedef struct esr_op {
     esr_bn bn;
     esr_pool pool;
     esr_linear linear;
+    esr_unpermute unpermute;
   } u;
 } esr_op;
 
@@ -228,6 +246,7 @@ int esr_conv_wgrad(const esr_wgrad* p, esr_stream_t stream);
 int esr_batchnorm(const esr_bn* p, esr_stream_t stream);
 int esr_maxpool2(const esr_pool* p, esr_stream_t stream);
 int esr_linear_op(const esr_linear* p, esr_stream_t stream);
+int esr_grad_unpermute(const esr_unpermute* p, esr_stream_t stream);
 
 /* Run a recorded list of ops back to back on `stream` (one host call per network pass; this is
  * what RRDBNet.forward — architecture.py:76-78 — becomes). */
