@@ -252,8 +252,8 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
             wg.B, wg.H, wg.W, wg.cout, wg.cin = B, r['h'], r['w'], cout, cin_
             wg.g, wg.in_ = gpre.view(0, cout), r['x'].view(0, cin_)
             wg.dw, wg.dbias, wg.scale = gw[0], gw[1], 1.0
-            if P.tapmajor is not None and r['ks'] == 3 and r['st'] == 1:
-                wg.dw, wg.tap_major = P.tapmajor.slot(poff[r['key'] + '.weight'], cout, cin_), 1
+            if P.tapmajor is not None and r['ks'] in (3, 4):
+                wg.dw, wg.tap_major = P.tapmajor.slot(poff[r['key'] + '.weight'], cout, cin_, r['ks'] ** 2), 1
             bk.add(L.OP_WGRAD, 'wgrad', wg)
         # input gradient
         prev = recs[li - 1] if li > 0 else None

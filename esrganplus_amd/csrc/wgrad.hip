@@ -158,11 +158,14 @@ __device__ __forceinline__ u32x4 tr_frag(const char* lds_base, int off0, int off
 
 struct Acc10 { f32x16 a[10]; };
 
-template <int KS, bool UPS, int NCO>
+template <int KS, int S, bool UPS, int NCO, int T0, int NT>
 __global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int rows_per_wg) {
-  constexpr int TR = 4, TC = 32, NTAP = KS * KS, PAD = (KS - 1) / 2;
+  // taps [T0, T0+NT) of the KSxKS kernel are accumulated by this launch (4x4 kernels: two launches
+  // of 8 taps, keeping the accumulators within the register file)
+  constexpr int TR = S == 2 ? 2 : 4, TC = 32, NTAP = KS * KS, PAD = (KS - 1) / 2;
   constexpr int NCI = 8 / NCO;                        // cin blocks (of 32 channels) per workgroup
-  constexpr int IH = UPS ? TR / 2 + 2 : TR + KS - 1, IW = UPS ? TC / 2 + 2 : TC + KS - 1;
+  constexpr int IH = UPS ? TR / 2 + 2 : (TR - 1) * S + KS, IW = UPS ? TC / 2 + 2 : (TC - 1) * S + KS;
+  static_assert(NT <= 9 && T0 + NT <= NTAP, "tap range");
   constexpr int G_BYTES = NCO * 2 * TR * TC * 32;     // [cout group][row][col][32 B]
   constexpr int IN_GROUP = IH * IW * 32;
   __shared__ __attribute__((aligned(16))) char smem[G_BYTES + NCI * 2 * IN_GROUP];
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int row
       *(u32x4*)(lg + (g * TR * TC + px) * 32 + half * 16) = v;
     }
     // ---- stage the input tile of NCI*2 groups with its halo
-    const int iy0 = UPS ? oy0 / 2 : oy0 + 1 - PAD, ix0 = UPS ? ox0 / 2 : ox0 + 1 - PAD;
+    const int iy0 = UPS ? oy0 / 2 : oy0 * S + 1 - PAD, ix0 = UPS ? ox0 / 2 : ox0 * S + 1 - PAD;
     for (int s = tid; s < NCI * 2 * IH * IW * 2; s += 512) {
       const int half = s & 1, px = (s >> 1) % (IH * IW), g = (s >> 1) / (IH * IW);
       const int r = px / IW, c = px % IW;
@@ -231,22 +234,21 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int row
         const int c0 = 16 * hf + pk;                    // column of this lane's first pixel (read 0)
         const u32x4 af = tr_frag(lgw, (r * TC + c0) * 32, (r * TC + c0 + 4) * 32);
 #pragma unroll
-        for (int kh = 0; kh < KS; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < KS; ++kw) {
-            int o0, o1;
-            if (UPS) {
-              const int rr = ((r + kh - 1) >> 1) + 1;
-              o0 = (rr * IW + ((c0 + kw - 1) >> 1) + 1) * 32;
-              o1 = (rr * IW + ((c0 + 4 + kw - 1) >> 1) + 1) * 32;
-            } else {
-              o0 = ((r + kh) * IW + c0 + kw) * 32;
-              o1 = o0 + 4 * 32;
-            }
-            const u32x4 bf = tr_frag(liw, o0, o1);
-            acc.a[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, af), __builtin_bit_cast(half8, bf), acc.a[kh * KS + kw], 0, 0, 0);
+        for (int tt = 0; tt < NT; ++tt) {
+          const int kh = (T0 + tt) / KS, kw = (T0 + tt) % KS;
+          int o0, o1;
+          if (UPS) {
+            const int rr = ((r + kh - 1) >> 1) + 1;
+            o0 = (rr * IW + ((c0 + kw - 1) >> 1) + 1) * 32;
+            o1 = (rr * IW + ((c0 + 4 + kw - 1) >> 1) + 1) * 32;
+          } else {
+            o0 = ((r * S + kh) * IW + c0 * S + kw) * 32;
+            o1 = o0 + 4 * S * 32;
           }
-        if (cib == 0 && p.dbias)
+          const u32x4 bf = tr_frag(liw, o0, o1);
+          acc.a[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, af), __builtin_bit_cast(half8, bf), acc.a[tt], 0, 0, 0);
+        }
+        if (T0 == 0 && cib == 0 && p.dbias)
           acc.a[9] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, af), __builtin_bit_cast(half8, ones), acc.a[9], 0, 0, 0);
       }
     }
@@ -255,18 +257,19 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int row
   // ---- fp32 atomics into dW[co][ci][kh][kw] / dbias[co]
   const int n = lane & 31, ci = cib * 32 + n;
 #pragma unroll
-  for (int t = 0; t < NTAP; ++t) {
+  for (int tt = 0; tt < NT; ++tt) {
+    const int t = T0 + tt;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
       if (co < p.cout && ci < p.cin) {
         float* d = p.tap_major ? p.dw + ((int64_t)t * p.cout + co) * p.cin + ci
                                : p.dw + ((int64_t)co * p.cin + ci) * NTAP + t;
-        atomicAdd(d, acc.a[t][e] * p.scale);
+        atomicAdd(d, acc.a[tt][e] * p.scale);
       }
     }
   }
-  if (cib == 0 && p.dbias && n == 0) {
+  if (T0 == 0 && cib == 0 && p.dbias && n == 0) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
@@ -275,22 +278,28 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int row
   }
 }
 
-template <int KS, bool UPS>
+template <int KS, int S, bool UPS, int T0, int NT>
 int launch_wgrad16(const esr_wgrad& p, hipStream_t st) {
   const int strips = (p.W + 31) / 32;
   const int coblocks = (p.cout + 31) / 32;
   const int ciblocks = (p.in.ngroups + 1) / 2;
   // rows per workgroup: keep >= ~512 workgroups in flight, but amortise the atomics over many rows
-  const int nco = coblocks >= 2 ? 2 : 1, nci = 8 / nco;
+  const int nco = (coblocks >= 2 || S == 2) ? 2 : 1, nci = 8 / nco;   // stride 2: LDS only fits NCO=2
   const int gy = (ciblocks + nci - 1) / nci, gz = (coblocks + nco - 1) / nco;
   // Every workgroup ends with 8 waves x 9 taps x 1024 fp32 atomics, so use as FEW spatial splits as
   // still give ~64 workgroups: start from whole column strips and halve only while the grid is tiny.
+  constexpr int TRq = S == 2 ? 2 : 4;
   int rows = ((p.H + 3) / 4) * 4;
+  (void)TRq;
   while (rows > 8 && (int64_t)p.B * strips * ((p.H + rows - 1) / rows) * gy * gz < 64) rows = ((rows / 2 + 3) / 4) * 4;
   const int rchunks = (p.H + rows - 1) / rows;
   dim3 grid(p.B * strips * rchunks, gy, gz);
-  if (nco == 2) hipLaunchKernelGGL((wgrad16_kernel<KS, UPS, 2>), grid, dim3(512), 0, st, p, rows);
-  else hipLaunchKernelGGL((wgrad16_kernel<KS, UPS, 1>), grid, dim3(512), 0, st, p, rows);
+  if constexpr (S == 2) {
+    hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(512), 0, st, p, rows);
+  } else {
+    if (nco == 2) hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(512), 0, st, p, rows);
+    else hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 1, T0, NT>), grid, dim3(512), 0, st, p, rows);
+  }
   return esr_check_launch("wgrad16_kernel");
 }
 
@@ -347,15 +356,19 @@ extern "C" int esr_conv_wgrad(const esr_wgrad* p, esr_stream_t stream) {
     return ESR_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (p->tap_major && !(p->dtype == ESR_F16 && p->stride == 1 && (p->ks == 3 || p->ks == 1))) {
-    esr_set_error("esr_conv_wgrad: tap_major only with the fp16 3x3/1x1 kernel");
+  if (p->tap_major && p->dtype != ESR_F16) {
+    esr_set_error("esr_conv_wgrad: tap_major only with the fp16 kernels");
     return ESR_ERR_INVALID;
   }
   if (p->dtype == ESR_F16) {
-    if (p->ks == 3 && p->stride == 1 && !p->upsample) return launch_wgrad16<3, false>(*p, st);
-    if (p->ks == 3 && p->stride == 1 && p->upsample) return launch_wgrad16<3, true>(*p, st);
-    if (p->ks == 1 && p->stride == 1 && !p->upsample) return launch_wgrad16<1, false>(*p, st);
-    return dispatch_wgrad<_Float16>(*p, st);        // 4x4/s2 (discriminator): round-1 fp32-MFMA kernel
+    if (p->ks == 3 && p->stride == 1 && !p->upsample) return launch_wgrad16<3, 1, false, 0, 9>(*p, st);
+    if (p->ks == 3 && p->stride == 1 && p->upsample) return launch_wgrad16<3, 1, true, 0, 9>(*p, st);
+    if (p->ks == 1 && p->stride == 1 && !p->upsample) return launch_wgrad16<1, 1, false, 0, 1>(*p, st);
+    if (p->ks == 4 && p->stride == 2 && !p->upsample) {   // discriminator: two launches of 8 taps
+      const int rc = launch_wgrad16<4, 2, false, 0, 8>(*p, st);
+      return rc ? rc : launch_wgrad16<4, 2, false, 8, 8>(*p, st);
+    }
+    return dispatch_wgrad<_Float16>(*p, st);
   }
   if (p->dtype == ESR_F32) return dispatch_wgrad<float>(*p, st);
   esr_set_error("esr_conv_wgrad: bad dtype %d", p->dtype);

@@ -136,3 +136,37 @@ def test_vgg_golden(dev, golden):
     with torch.no_grad():
         y16 = netF.set_precision('fp16')(x)
     assert ((y16 - y.detach()).norm() / y.detach().norm()).item() <= 2e-2
+
+
+def test_discriminator_fp16_grads_track_fp32(dev):
+    """fp16 path (incl. the fp16 4x4/s2 and wide 3x3 wgrad kernels with tap-major accumulation)."""
+    from esrganplus_amd import architecture as arch
+    sd = synth.discriminator_state_dict(seed=7)
+    x = synth.image_batch(7, 4, 3, 128, 128, name='d16.x').to(dev)
+    gy = synth.normal_like(7, 'd16.gy', (4, 1)).to(dev)
+    grads, gxs = {}, {}
+    for prec in ('fp32', 'fp16'):
+        net = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision(prec)
+        net.load_state_dict(sd)
+        xr = x.clone().requires_grad_(True)
+        scale = 1024.0 if prec == 'fp16' else 1.0        # static loss scaling, as train.py does
+        (net(xr) * gy * scale).sum().backward()
+        grads[prec] = {k: p.grad.clone() / scale for k, p in net.named_parameters()}
+        gxs[prec] = xr.grad.clone() / scale
+    # fp16 activations flip a few LeakyReLU signs (9 BatchNorms re-normalise the rounding noise), which
+    # alone moves gradients by ~10-15 % in norm — even classifier.0, which is computed in fp32 from
+    # the exported features.  So gate on direction (cosine) and a loose norm bound: an indexing bug in
+    # the fp16 wgrad kernels (taps, transposed reads, tap-major scatter) gives cosines far below 0.9.
+    worst = {}
+    bn_fed = {'features.%d.bias' % i for i in (2, 5, 8, 11, 14, 17, 20, 23, 26)}
+    for k in grads['fp32']:
+        if k in bn_fed:      # a bias in front of train-mode BN has an exactly-zero gradient: pure round-off
+            continue
+        a, b = grads['fp32'][k].flatten(), grads['fp16'][k].flatten()
+        cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+        worst[k] = (round(cos, 4), round(((a - b).norm() / a.norm().clamp_min(1e-6)).item(), 4))
+    print(worst)
+    bad = {k: v for k, v in worst.items() if v[0] < 0.97 or v[1] > 0.3}
+    assert not bad, bad
+    a, b = gxs['fp32'].flatten(), gxs['fp16'].flatten()
+    assert torch.nn.functional.cosine_similarity(a, b, dim=0).item() >= 0.97
