@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, 'libesrgan_hip.so')
 ESR_F16, ESR_F32 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 NOISE_OFF, NOISE_PHILOX, NOISE_EXPLICIT = 0, 1, 2
-OP_CONV, OP_PACK, OP_LAYOUT, OP_NOISE_FILL, OP_WGRAD, OP_BN, OP_POOL, OP_LINEAR, OP_UNPERMUTE = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OP_CONV, OP_PACK, OP_LAYOUT, OP_NOISE_FILL, OP_WGRAD, OP_BN, OP_POOL, OP_LINEAR, OP_UNPERMUTE, OP_PACK_BATCH = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 BN_STATS, BN_FINALIZE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_FINAL, BN_BWD_APPLY = 0, 1, 2, 3, 4, 5
 NO_LAYER = 0xFFFFFFFF
 
@@ -106,10 +106,16 @@ class esr_unpermute(C.Structure):
                 ('src', C.c_void_p), ('dst', C.c_void_p)]
 
 
+class esr_pack_batch(C.Structure):
+    _fields_ = [('table', C.c_void_p), ('piece_begin', C.c_void_p), ('n', C.c_int32), ('_pad', C.c_int32),
+                ('total_pieces', C.c_int64)]
+
+
 class _op_union(C.Union):
     _fields_ = [('conv', esr_conv), ('pack', esr_pack), ('layout', esr_layout),
                 ('noise_fill', esr_noise_fill), ('wgrad', esr_wgrad), ('bn', esr_bn),
-                ('pool', esr_pool), ('linear', esr_linear), ('unpermute', esr_unpermute)]
+                ('pool', esr_pool), ('linear', esr_linear), ('unpermute', esr_unpermute),
+                ('pack_batch', esr_pack_batch)]
 
 
 class esr_op(C.Structure):
@@ -119,7 +125,8 @@ class esr_op(C.Structure):
 # every symbol include/esrgan_hip.h declares (tests check the .so exports all of them)
 EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_pack_conv_weights',
            'esr_convert_layout', 'esr_fill_noise', 'esr_conv_wgrad', 'esr_batchnorm', 'esr_maxpool2',
-           'esr_linear_op', 'esr_grad_unpermute', 'esr_run_ops', 'esr_run_ops_timed', 'esr_last_error',
+           'esr_linear_op', 'esr_grad_unpermute', 'esr_pack_conv_weights_batch', 'esr_pack_pieces',
+           'esr_run_ops', 'esr_run_ops_timed', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op']
 
 _lib = None
@@ -148,6 +155,8 @@ def lib():
                 raise HipExtensionError('libesrgan_hip.so lacks symbol ' + name)
         L.esr_last_error.restype = C.c_char_p
         L.esr_sizeof_op.restype = C.c_size_t
+        L.esr_pack_pieces.restype = C.c_int64
+        L.esr_pack_pieces.argtypes = [C.POINTER(esr_pack)]
         L.esr_packed_weight_bytes.restype = C.c_size_t
         L.esr_packed_weight_bytes.argtypes = [C.c_int32] * 4
         L.esr_g32_dims.restype = None
@@ -158,7 +167,8 @@ def lib():
                          ('esr_convert_layout', esr_layout), ('esr_fill_noise', esr_noise_fill),
                          ('esr_conv_wgrad', esr_wgrad), ('esr_batchnorm', esr_bn),
                          ('esr_maxpool2', esr_pool), ('esr_linear_op', esr_linear),
-                         ('esr_grad_unpermute', esr_unpermute)):
+                         ('esr_grad_unpermute', esr_unpermute),
+                         ('esr_pack_conv_weights_batch', esr_pack_batch)):
             getattr(L, name).argtypes = [C.POINTER(st), C.c_void_p]
         if L.esr_sizeof_op() != C.sizeof(esr_op):
             raise HipExtensionError('ABI mismatch: sizeof(esr_op) C=%d ctypes=%d'
@@ -226,3 +236,19 @@ class OpList:
         arr = self.array()
         check(lib().esr_run_ops(C.cast(arr, C.c_void_p), len(self.ops), C.c_void_p(stream)),
               'esr_run_ops')
+
+
+def batch_pack_op(packs, device):
+    """One OP_PACK_BATCH replacing a list of esr_pack ops; returns (esr_pack_batch, keepalive)."""
+    n = len(packs)
+    arr = (esr_pack * n)(*packs)
+    begins, tot = [], 0
+    for pk in packs:
+        begins.append(tot)
+        tot += lib().esr_pack_pieces(C.byref(pk))
+    begins.append(tot)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    pb = torch.tensor(begins, dtype=torch.int64, device=device)
+    b = esr_pack_batch()
+    b.table, b.piece_begin, b.n, b.total_pieces = table.data_ptr(), pb.data_ptr(), n, tot
+    return b, (table, pb)

@@ -48,6 +48,7 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       case ESR_OP_POOL: rc = esr_maxpool2(&ops[i].u.pool, stream); break;
       case ESR_OP_LINEAR: rc = esr_linear_op(&ops[i].u.linear, stream); break;
       case ESR_OP_UNPERMUTE: rc = esr_grad_unpermute(&ops[i].u.unpermute, stream); break;
+      case ESR_OP_PACK_BATCH: rc = esr_pack_conv_weights_batch(&ops[i].u.pack_batch, stream); break;
       default: esr_set_error("esr_run_ops: op %d has unknown kind %d", i, ops[i].kind); return ESR_ERR_INVALID;
     }
     if (rc != ESR_OK) {

@@ -5,11 +5,11 @@ namespace {
 
 // One thread per 16-byte fragment piece: [cb][chunk][kh][kw][lane] -> 8 halves / 4 floats.
 template <typename T>
-__global__ void pack_kernel(const esr_pack p, int nchunks, int64_t total) {
+__device__ __forceinline__ void pack_piece(const esr_pack& p, int64_t idx) {
   constexpr int CPG = DT<T>::CPG;
   constexpr int EPL = CPG / 2;   // elements per lane (8 halves / 4 floats)
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
+  const int kdim = p.transpose_flip ? p.cout : p.cin;
+  const int nchunks = (kdim + CPG - 1) / CPG;
   const int lane = idx & 63;
   int64_t rest = idx >> 6;
   const int taps = p.ks * p.ks;
@@ -53,6 +53,25 @@ __global__ void pack_kernel(const esr_pack p, int nchunks, int64_t total) {
   T* dst = (T*)p.dst + idx * EPL;
 #pragma unroll
   for (int e = 0; e < EPL; ++e) dst[e] = v[e];
+}
+
+template <typename T>
+__global__ void pack_kernel(const esr_pack p, int nchunks, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < total) pack_piece<T>(p, idx);
+}
+
+__global__ void pack_batch_kernel(const esr_pack_batch pb) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= pb.total_pieces) return;
+  int lo = 0, hi = pb.n - 1;                      // last entry with piece_begin <= idx
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (pb.piece_begin[mid] <= idx) lo = mid; else hi = mid - 1;
+  }
+  const esr_pack p = pb.table[lo];
+  if (p.dtype == ESR_F16) pack_piece<_Float16>(p, idx - pb.piece_begin[lo]);
+  else pack_piece<float>(p, idx - pb.piece_begin[lo]);
 }
 
 template <typename T>
@@ -143,6 +162,22 @@ extern "C" int esr_pack_conv_weights(const esr_pack* p, esr_stream_t stream) {
   else if (p->dtype == ESR_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, *p, nchunks, total);
   else { esr_set_error("esr_pack_conv_weights: bad dtype"); return ESR_ERR_INVALID; }
   return esr_check_launch("pack_kernel");
+}
+
+extern "C" int64_t esr_pack_pieces(const esr_pack* p) {
+  const int cpg = p->dtype == ESR_F16 ? 16 : 8;
+  const int rows = p->transpose_flip ? p->cin : p->cout;
+  const int kdim = p->transpose_flip ? p->cout : p->cin;
+  return (int64_t)((rows + 31) / 32) * ((kdim + cpg - 1) / cpg) * p->ks * p->ks * 64;
+}
+
+extern "C" int esr_pack_conv_weights_batch(const esr_pack_batch* p, esr_stream_t stream) {
+  if (!p || !p->table || !p->piece_begin || p->n <= 0 || p->total_pieces <= 0) {
+    esr_set_error("esr_pack_conv_weights_batch: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)((p->total_pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
+  return esr_check_launch("pack_batch_kernel");
 }
 
 extern "C" int esr_convert_layout(const esr_layout* p, esr_stream_t stream) {

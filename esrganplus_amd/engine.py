@@ -122,7 +122,7 @@ class WeightPack:
 
     def _rebuild(self):
         self._check_params()
-        ops = L.OpList()
+        packs = []
         for key, w, b in self.convs:
             e = self.entries[key]
             pk = L.esr_pack()
@@ -131,9 +131,12 @@ class WeightPack:
             pk.cout, pk.cin, pk.ks = e.cout, e.cin, e.ks
             pk.dtype = self.esr_dtype
             pk.transpose_flip = 0
-            ops.add(L.OP_PACK, 'pack', pk)
+            packs.append(pk)
             if b is not None and e.cout % 32 == 0:
                 e.bias_ptr = b.data_ptr()
+        ops = L.OpList()                      # ONE launch re-packs every conv of the network
+        bp, self._pack_keep = L.batch_pack_op(packs, self.device)
+        ops.add(L.OP_PACK_BATCH, 'pack_batch', bp)
         self.ops = ops
         self.generation += 1
 
@@ -422,7 +425,7 @@ class DgradPack:
     def ensure(self, stream):
         ptrs = tuple(w.data_ptr() for _, w in self.convs)
         if ptrs != self._ptrs:
-            ops = L.OpList()
+            packs = []
             for key, w in self.convs:
                 e = self.entries[key]
                 sp = self.special.get(key, {})
@@ -435,7 +438,10 @@ class DgradPack:
                 if 'sum' in sp:
                     pk.sum_dst, pk.sum_src, pk.sum_count = sp['sum']
                 pk.ups_dgrad = 1 if sp.get('ups') else 0
-                ops.add(L.OP_PACK, 'pack', pk)
+                packs.append(pk)
+            ops = L.OpList()
+            bp, self._pack_keep = L.batch_pack_op(packs, self.arena.device)
+            ops.add(L.OP_PACK_BATCH, 'pack_batch', bp)
             self.ops, self._ptrs = ops, ptrs
         self.ops.run(stream)      # weights change every optimizer step: always re-pack
 

@@ -118,6 +118,16 @@ typedef struct esr_pack {
                           exact adjoint of nearest-x2-upsample + 3x3 conv (block.py:315-322)       */
 } esr_pack;
 
+/* All weight packs of a network in ONE launch: `table` is a DEVICE array of n esr_pack entries,
+ * `piece_begin` a DEVICE int64[n+1] prefix sum of their 16-byte piece counts. */
+typedef struct esr_pack_batch {
+  const esr_pack* table;
+  const int64_t* piece_begin;
+  int32_t n, _pad;
+  int64_t total_pieces;
+} esr_pack_batch;
+int64_t esr_pack_pieces(const esr_pack* p);   /* host helper: 16-byte pieces one entry produces */
+
 size_t esr_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ks, int32_t dtype);
 
 /* NCHW fp32 <-> G32 (the tensors crossing the nn.Module boundary are NCHW fp32:
@@ -216,7 +226,7 @@ typedef struct esr_linear {
 
 enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_NOISE_FILL = 4,
                    ESR_OP_WGRAD = 5, ESR_OP_BN = 6, ESR_OP_POOL = 7, ESR_OP_LINEAR = 8,
-                   ESR_OP_UNPERMUTE = 9 };
+                   ESR_OP_UNPERMUTE = 9, ESR_OP_PACK_BATCH = 10 };
 
 typedef struct esr_op {
   int32_t kind;
@@ -231,6 +241,7 @@ typedef struct esr_op {
     esr_pool pool;
     esr_linear linear;
     esr_unpermute unpermute;
+    esr_pack_batch pack_batch;
   } u;
 } esr_op;
 
@@ -247,6 +258,7 @@ int esr_batchnorm(const esr_bn* p, esr_stream_t stream);
 int esr_maxpool2(const esr_pool* p, esr_stream_t stream);
 int esr_linear_op(const esr_linear* p, esr_stream_t stream);
 int esr_grad_unpermute(const esr_unpermute* p, esr_stream_t stream);
+int esr_pack_conv_weights_batch(const esr_pack_batch* p, esr_stream_t stream);
 
 /* Run a recorded list of ops back to back on `stream` (one host call per network pass; this is
  * what RRDBNet.forward — architecture.py:76-78 — becomes). */
