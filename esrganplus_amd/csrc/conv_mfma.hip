@@ -320,11 +320,14 @@ struct Geo {
   static constexpr int WLD = (WWIN + NW - 1) / NW;                        // weight DMA rounds
   static constexpr int NDMA = NLD + WLD;
   static constexpr int STAGE = ACT + WWIN * 1024;
-  static constexpr int NST = (3 * STAGE <= 160 * 1024) ? 3 : 2;          // ring depth
+  // 8-wave workgroups own the CU's LDS; 4-wave workgroups are sized so TWO fit a CU (their barrier
+  // and DMA-wait phases then interleave instead of idling the matrix pipe)
+  static constexpr int LDS_BUDGET = (NW == 8 ? 160 : 80) * 1024;
+  static constexpr int NST = (3 * STAGE <= LDS_BUDGET) ? 3 : 2;          // ring depth
   static constexpr int PAD = (KS - 1) / 2;
-  static_assert(NW == 8, "8 waves per workgroup");
+  static_assert(NW == 8 || NW == 4, "4 or 8 waves per workgroup");
   static_assert(R * NCW <= 8, "accumulator budget");
-  static_assert(2 * STAGE <= 160 * 1024, "LDS budget");
+  static_assert(2 * STAGE <= LDS_BUDGET, "LDS budget");
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -332,7 +335,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD>
-__global__ __launch_bounds__(512, 2) void conv_kernel(const esr_conv p) {
+__global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_conv p) {
   using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>;
   constexpr int R = G::R;
   constexpr int NST = G::NST;
@@ -595,15 +598,18 @@ template <typename T>
 int dispatch(const esr_conv& p, hipStream_t st) {
   const bool has1 = p.w1x1 != nullptr;
   const int cbk = p.cout_blocks;
-  const bool narrow = p.W <= 32;
+  // Tile shapes.  Up to 96 couts: 4-wave workgroups on a 16x32 tile, TWO resident per CU so their
+  // barrier / DMA-wait phases interleave (measured +3.6 % over one 8-wave 16x64 workgroup, and twice
+  // the workgroup count on small images).  Wider convs (discriminator, VGG): 8 waves = 2 spatial x 4
+  // cout groups with register-resident weights.
   if (p.ks == 3 && p.stride == 1 && !p.upsample) {
     if (has1) {
       if (cbk != 1) { esr_set_error("conv: fused 1x1 needs cout_blocks==1"); return ESR_ERR_UNSUPPORTED; }
-      return narrow ? launch<T, 3, 1, 0, 8, 1, 1, 1, true, true>(p, st) : launch<T, 3, 1, 0, 4, 2, 1, 1, true, true>(p, st);
+      return launch<T, 3, 1, 0, 4, 1, 1, 1, true, true>(p, st);
     }
-    if (cbk == 1) return narrow ? launch<T, 3, 1, 0, 8, 1, 1, 1, true, false>(p, st) : launch<T, 3, 1, 0, 4, 2, 1, 1, true, false>(p, st);
-    if (cbk <= 3) return narrow ? launch<T, 3, 1, 0, 8, 1, 1, 2, true, false>(p, st) : launch<T, 3, 1, 0, 4, 2, 1, 2, true, false>(p, st);
-    return launch<T, 3, 1, 0, 2, 1, 4, 1, false, false>(p, st);     // wide convs (D / VGG)
+    if (cbk == 1) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false>(p, st);
+    if (cbk <= 3) return launch<T, 3, 1, 0, 4, 1, 1, 2, true, false>(p, st);
+    return launch<T, 3, 1, 0, 2, 1, 4, 1, false, false>(p, st);
   }
   if (has1) { esr_set_error("conv: fused 1x1 only with 3x3/s1"); return ESR_ERR_UNSUPPORTED; }
   if (p.ks == 4 && p.stride == 1 && p.upsample == 2) {
@@ -612,11 +618,11 @@ int dispatch(const esr_conv& p, hipStream_t st) {
   }
   if (p.ks == 3 && p.stride == 1 && p.upsample == 1) {
     if ((p.H | p.W) & 1) { esr_set_error("conv: upsample needs even output size"); return ESR_ERR_INVALID; }
-    return cbk == 1 ? launch<T, 3, 1, 1, 4, 2, 1, 1, true, false>(p, st) : launch<T, 3, 1, 1, 4, 2, 1, 2, true, false>(p, st);
+    return cbk == 1 ? launch<T, 3, 1, 1, 4, 1, 1, 1, true, false>(p, st) : launch<T, 3, 1, 1, 4, 1, 1, 2, true, false>(p, st);
   }
   if (p.ks == 4 && p.stride == 2 && !p.upsample) return launch<T, 4, 2, 0, 2, 1, 4, 1, false, false>(p, st);
   if (p.ks == 1 && p.stride == 1 && !p.upsample) {
-    return cbk == 1 ? launch<T, 1, 1, 0, 4, 2, 1, 1, true, false>(p, st) : launch<T, 1, 1, 0, 4, 2, 1, 2, true, false>(p, st);
+    return cbk == 1 ? launch<T, 1, 1, 0, 4, 1, 1, 1, true, false>(p, st) : launch<T, 1, 1, 0, 4, 1, 1, 2, true, false>(p, st);
   }
   esr_set_error("conv: unsupported ks=%d stride=%d upsample=%d", p.ks, p.stride, p.upsample);
   return ESR_ERR_UNSUPPORTED;
