@@ -264,8 +264,15 @@ def main():
         tot_ms = sum(a[0] for a in agg.values()) / reps
         t_ms, fl, n = agg[dom]
         ach = fl / (t_ms * 1e-3) / 1e12
+        traffic = None
+        try:      # PMC-measured HBM-side bytes per launch (separate rocprofv3 --pmc passes, committed)
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')))
+            if dom in tj and args.batch == BATCH and args.lr == LR:
+                traffic = tj[dom]['read_bytes'] + tj[dom]['write_bytes']
+        except (OSError, ValueError, KeyError):
+            pass
         res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_F16_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4), 'traffic': None,
+                           'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
                            'launches_per_step': n // reps, 'avg_launch_us': round(t_ms / n * 1e3, 2),
                            'share_of_step_time': round(t_ms / reps / tot_ms, 3)}
         res['kernels'] = {k: {'launches': a[2] // reps, 'ms_per_step': round(a[0] / reps, 3),

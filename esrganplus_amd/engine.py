@@ -180,7 +180,7 @@ def _conv(dtype_e, B, H, W, src, src_ch, dst, cw, act=L.ACT_NONE, ks=None, strid
     c.layer3 = L.NO_LAYER
     c.gamma = 1.0
     c.mask_act = L.ACT_LRELU
-    c.debug_flags = _STORE_FLAVOUR << 3
+    c.debug_flags = (_STORE_FLAVOUR << 3) | (int(_os.environ.get('ESR_DBG', '0')) & ~7)
     return c
 
 

@@ -9,11 +9,14 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r'conv_kernelI(DF16_|f)Li(\d)ELi(\d)ELb(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)', name)
+    """conv_kernel<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, BWD> from its mangled name."""
+    m = re.search(r'conv_kernelI(DF16_|f)((?:L[ib]\d+E)+)', name)
     if m:
-        t, ks, s, ups, wr, wc, ncg, ncw, wlds, h1 = m.groups()
-        return 'conv<%s,k%s,s%s,ups%s,%sx%sx%s,ncw%s,wlds%s,1x1=%s>' % ('f16' if t != 'f' else 'f32', ks, s, ups, wr, wc, ncg, ncw, wlds, h1)
-    return name[:60]
+        a = re.findall(r'L[ib](\d+)E', m.group(2))
+        keys = ['k', 's', 'ups', 'wr', 'wc', 'ncg', 'ncw', 'wlds', '1x1', 'bwd']
+        return 'conv<%s,%s>' % ('f16' if m.group(1) != 'f' else 'f32', ','.join('%s%s' % kv for kv in zip(keys, a)))
+    m = re.search(r'(wgrad16_kernel<[^>]*>|wgrad_kernel\w*|pack_batch_kernel|unpermute_kernel|bn_\w+|pool_kernel\w*|linear_\w+)', name)
+    return m.group(1)[:70] if m else name[:70]
 
 
 def main(root):
@@ -37,7 +40,8 @@ def main(root):
             wk = c['WRITE_SIZE'][0] / c['WRITE_SIZE'][1] if 'WRITE_SIZE' in c else float('nan')
             print('    => HBM-side read ~ %.1f MB (2x-corrected FETCH_SIZE), write ~ %.1f MB per dispatch' % (2 * fk / 1024, wk / 1024))
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and 'GRBM_GUI_ACTIVE' in c:
-            print('    => MFMA busy / (GUI_ACTIVE * 1024 SIMDs) = %.3f' % (c['SQ_VALU_MFMA_BUSY_CYCLES'][0] / (c['GRBM_GUI_ACTIVE'][0] * 1024)))
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
+            print('    => MfmaUtil = MFMA busy / (GUI_ACTIVE/8 * 1024 SIMDs) = %.3f' % (c['SQ_VALU_MFMA_BUSY_CYCLES'][0] / (c['GRBM_GUI_ACTIVE'][0] / 8 * 1024)))
         if 'TCC_HIT_sum' in c:
             h, m = c['TCC_HIT_sum'][0], c['TCC_MISS_sum'][0]
             print('    => L2 hit rate %.3f' % (h / max(h + m, 1)))

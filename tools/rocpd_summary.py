@@ -7,11 +7,14 @@ import sys
 
 
 def short(name):
-    m = re.search(r'conv_kernelI(DF16_|f)Li(\d)ELi(\d)ELb(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)', name)
+    """conv_kernel<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, BWD> from its mangled name."""
+    m = re.search(r'conv_kernelI(DF16_|f)((?:L[ib]\d+E)+)', name)
     if m:
-        t, ks, s, ups, wr, wc, ncg, h1 = m.groups()
-        return 'conv_kernel<%s,ks%s,s%s,ups%s,%sx%sx%s,1x1=%s>' % ('f16' if t != 'f' else 'f32', ks, s, ups, wr, wc, ncg, h1)
-    return name[:90]
+        a = re.findall(r'L[ib](\d+)E', m.group(2))
+        keys = ['k', 's', 'ups', 'wr', 'wc', 'ncg', 'ncw', 'wlds', '1x1', 'bwd']
+        return 'conv<%s,%s>' % ('f16' if m.group(1) != 'f' else 'f32', ','.join('%s%s' % kv for kv in zip(keys, a)))
+    m = re.search(r'(wgrad16_kernel<[^>]*>|wgrad_kernel\w*|pack_batch_kernel|unpermute_kernel|bn_\w+|pool_kernel\w*|linear_\w+)', name)
+    return m.group(1)[:70] if m else name[:70]
 
 
 def main(path):
