@@ -13,7 +13,7 @@ import threading
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libesrgan_hip.so')
+LIB_PATH = os.environ.get('ESR_LIB_PATH', os.path.join(_HERE, 'libesrgan_hip.so'))   # override: A/B builds
 
 ESR_F16, ESR_F32 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
@@ -126,7 +126,7 @@ class esr_op(C.Structure):
 EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_pack_conv_weights',
            'esr_convert_layout', 'esr_fill_noise', 'esr_conv_wgrad', 'esr_batchnorm', 'esr_maxpool2',
            'esr_linear_op', 'esr_grad_unpermute', 'esr_pack_conv_weights_batch', 'esr_pack_pieces',
-           'esr_run_ops', 'esr_run_ops_timed', 'esr_last_error',
+           'esr_rdb_nosync_probe', 'esr_run_ops', 'esr_run_ops_timed', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op']
 
 _lib = None

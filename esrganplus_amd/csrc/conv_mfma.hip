@@ -20,6 +20,10 @@
 
 #include "common.h"
 
+#ifndef ESR_NSA_MAX
+#define ESR_NSA_MAX 2   // activation ring depth cap. A/B (profiles/r01_experiments.md): 3 (two K steps ahead) is 1.5 % SLOWER
+#endif
+
 namespace {
 
 template <typename T> __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b);
@@ -298,10 +302,11 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
 // ------------------------------------------------------------------------------------------------
 // Tile geometry.  A workgroup = 8 waves = WR x WC spatial waves x NCG cout-groups; every wave owns
 // R=4 output rows x 32 output pixels x NCW blocks of 32 couts (R*NCW <= 8 MFMA accumulators).
-// LDS holds an NST-deep ring of K-step stages; one stage = the activation halo tile of ONE 32-byte
-// channel group [+ the A fragments (weights) of that K step for every cout block of the workgroup].
-// Every wave issues exactly NDMA LDS-DMA instructions per K step (tail rounds re-copy an earlier
-// window), so a counted `s_waitcnt vmcnt(NDMA)` retires exactly one stage.
+// LDS holds a ring of activation stages (the halo tile of ONE 32-byte channel group per K step) and
+// a 2-deep ring of weight stages (the A fragments of that K step for every cout block of the
+// workgroup).  Every wave issues exactly NLD activation DMAs and WLD weight DMAs per K step (tail
+// rounds re-copy an earlier window), weights before activations, so a counted
+// `s_waitcnt vmcnt(NLD)` leaves exactly the newest activation stage in flight.
 // ------------------------------------------------------------------------------------------------
 template <int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
 struct Geo {
@@ -318,16 +323,20 @@ struct Geo {
   static constexpr int NTAP = KS * KS;
   static constexpr int WWIN = WLDS ? NCG * NCW * NTAP + (HAS1X1 ? 1 : 0) : 0;   // 1 KB weight windows
   static constexpr int WLD = (WWIN + NW - 1) / NW;                        // weight DMA rounds
-  static constexpr int NDMA = NLD + WLD;
-  static constexpr int STAGE = ACT + WWIN * 1024;
+  static constexpr int WBYTES = WWIN * 1024;                              // weight stage
   // 8-wave workgroups own the CU's LDS; 4-wave workgroups are sized so TWO fit a CU (their barrier
   // and DMA-wait phases then interleave instead of idling the matrix pipe)
   static constexpr int LDS_BUDGET = (NW == 8 ? 160 : 80) * 1024;
-  static constexpr int NST = (3 * STAGE <= LDS_BUDGET) ? 3 : 2;          // ring depth
+  // Two rings: activations (the bulk, MALL/HBM latency ~2-3 us under load) are prefetched TWO K
+  // steps ahead when three stages fit; weights (L2-resident) one step ahead in a 2-deep ring.
+  static constexpr int NSW = WLDS ? 2 : 0;
+  static constexpr int NSA = (ESR_NSA_MAX >= 3 && 3 * ACT + NSW * WBYTES <= LDS_BUDGET) ? 3 : 2;
+  static constexpr int WOFF = NSA * ACT;                                  // weight ring base
+  static constexpr int LDS_BYTES = NSA * ACT + NSW * WBYTES;
   static constexpr int PAD = (KS - 1) / 2;
   static_assert(NW == 8 || NW == 4, "4 or 8 waves per workgroup");
   static_assert(R * NCW <= 8, "accumulator budget");
-  static_assert(2 * STAGE <= LDS_BUDGET, "LDS budget");
+  static_assert(LDS_BYTES <= LDS_BUDGET, "LDS budget");
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -335,12 +344,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD>
-__global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_conv p) {
+__device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, const int block_x, const int grid_x,
+                                          const int block_y) {
   using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>;
   constexpr int R = G::R;
-  constexpr int NST = G::NST;
+  constexpr int NSA = G::NSA;
   static_assert(!HAS1X1 || (NCW == 1 && NCG == 1 && KS == 3 && S == 1 && !UPS && WLDS), "fused 1x1 only on the N=32 3x3 conv");
-  __shared__ __attribute__((aligned(16))) char smem[NST * G::STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -355,11 +364,11 @@ __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_c
   const int tiles_x = (p.W + G::TW - 1) / G::TW, tiles_y = (p.H + G::TH - 1) / G::TH;
   int t;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int nwg = grid_x, bid = block_x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
-  const int cb0 = (blockIdx.y * NCG + cg) * NCW;     // first 32-cout block of this wave
+  const int cb0 = (block_y * NCG + cg) * NCW;     // first 32-cout block of this wave
   const int oy0 = ty * G::TH, ox0 = tx * G::TW;      // output tile origin (logical)
 
   // ---- activation staging map: LDS slot s = tid + NT*i (16 bytes) <- input tile, by LDS-DMA.
@@ -406,13 +415,13 @@ __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_c
 #pragma unroll
     for (int i = 0; i < G::WLD; ++i) {
       const int q = (wave + G::NW * i) % G::WWIN;
-      wdst[i] = G::ACT + q * 1024;
+      wdst[i] = q * 1024;
       if (HAS1X1 && q == G::WWIN - 1) {              // the fused 1x1's A fragment: [cb][chunk][lane]
         wsrc[i] = (const char*)p.w1x1 + ((int64_t)cb0 * n1x1 * 64 + lane) * 16;
         wstep[i] = 1024;
       } else {
         const int blk = q / G::NTAP;                  // cout block within the workgroup
-        int cb = blockIdx.y * NCG * NCW + blk;
+        int cb = block_y * NCG * NCW + blk;
         if (cb >= p.cout_blocks) cb = 0;
         wsrc[i] = wbase + cb * w_cb_stride + ((q - blk * G::NTAP) * 64 + lane) * 16;
         wstep[i] = (int64_t)G::NTAP * 1024;
@@ -434,25 +443,28 @@ __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_c
 
   u32x4 wf[WLDS ? 1 : NCW * G::NTAP], wn[WLDS ? 1 : NCW * G::NTAP];
 
-  auto stage_in = [&](int chunk, int st) __attribute__((always_inline)) {
+  auto stage_acts = [&](int chunk, int sa) __attribute__((always_inline)) {
     const char* src = in_b + (int64_t)chunk * in_gs;
-    char* dst = lds_wv + st * G::STAGE;
+    char* dst = lds_wv + sa * G::ACT;
     if (!(dbg & 4)) {
 #pragma unroll
       for (int i = 0; i < G::NLD; ++i) dma16(src + goff[i], dst + G::NT * 16 * i);
     }
+  };
+  auto stage_wts = [&](int chunk, int sw) __attribute__((always_inline)) {
     if constexpr (WLDS) {
 #pragma unroll
       for (int i = 0; i < G::WLD; ++i) {
         const int cc = (HAS1X1 && wstep[i] == 1024 && chunk >= n1x1) ? 0 : chunk;   // 1x1 has fewer K steps
-        dma16(wsrc[i] + cc * wstep[i], smem + st * G::STAGE + wdst[i]);
+        dma16(wsrc[i] + cc * wstep[i], smem + G::WOFF + sw * G::WBYTES + wdst[i]);
       }
     }
   };
 
-  // prologue: fill NST-1 stages
-  stage_in(0, 0);
-  if constexpr (NST == 3) { if (nchunks > 1) stage_in(1, 1); }
+  // prologue: weights of step 0, activations of steps 0 .. NSA-2
+  stage_wts(0, 0);
+  stage_acts(0, 0);
+  if constexpr (NSA == 3) { if (nchunks > 1) stage_acts(1, 1); }
   if constexpr (!WLDS) {
 #pragma unroll
     for (int cw = 0; cw < NCW; ++cw)
@@ -460,20 +472,22 @@ __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_c
       for (int tp = 0; tp < G::NTAP; ++tp) wf[cw * G::NTAP + tp] = *(const u32x4*)(wreg[cw] + tp * 1024);
   }
 
-  int st = 0;   // ring slot of K step c
+  int st = 0;   // activation ring slot of K step c
   for (int c = 0; c < nchunks; ++c) {
-    // ---- retire K step c: its DMAs were issued before those of step c+1 (in-order return)
+    // ---- retire K step c.  In-order return: everything older than the NLD activation DMAs of
+    // step c+1 (issued last) has landed once vmcnt <= NLD.
     if constexpr (WLDS) {
-      if (NST == 3 && c + 1 < nchunks) wait_vmcnt<G::NDMA>(); else wait_vmcnt<0>();
+      if (NSA == 3 && c + 1 < nchunks) wait_vmcnt<G::NLD>(); else wait_vmcnt<0>();
     } else {
       wait_vmcnt<0>();   // mixed VGPR loads + DMA: plain drain
     }
-    __builtin_amdgcn_s_barrier();   // step c visible to all waves; all waves done reading slot (c-1)
-    // ---- refill the slot that step c-1 just vacated with step c+NST-1
-    const int cn = c + NST - 1;
+    __builtin_amdgcn_s_barrier();   // step c visible to all waves; all waves done reading step c-1
+    // ---- refill: weights of step c+1 first, then activations of step c+NSA-1
+    if (c + 1 < nchunks) stage_wts(c + 1, (c + 1) & 1);
+    const int cn = c + NSA - 1;
     if (cn < nchunks) {
-      int sn = st + NST - 1; if (sn >= NST) sn -= NST;
-      stage_in(cn, sn);
+      int sn = st + NSA - 1; if (sn >= NSA) sn -= NSA;
+      stage_acts(cn, sn);
     }
     if constexpr (!WLDS) {
       if (c + 1 < nchunks) {
@@ -485,8 +499,9 @@ __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_c
       }
     }
 
-    const char* lds = smem + st * G::STAGE;
-    const char* ldw = lds + G::ACT + ((cg * NCW) * G::NTAP * 64 + lane) * 16;   // this wave's A fragments
+    const char* lds = smem + st * G::ACT;
+    const char* ldwb = smem + G::WOFF + (c & 1) * G::WBYTES;
+    const char* ldw = ldwb + ((cg * NCW) * G::NTAP * 64 + lane) * 16;   // this wave's A fragments
     const bool do1x1 = HAS1X1 && c < n1x1;
 
     // kw-major: the KS*NCW A fragments of column tap kw stay in registers while the wave walks its
@@ -507,7 +522,7 @@ __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_c
     };
     if (!(dbg & 2)) {
       read_step(std::integral_constant<int, 0>{}, af[0], bf[0]);
-      if constexpr (HAS1X1) a1f = *(const u32x4*)(lds + G::ACT + ((G::WWIN - 1) * 64 + lane) * 16);
+      if constexpr (HAS1X1) a1f = *(const u32x4*)(ldwb + ((G::WWIN - 1) * 64 + lane) * 16);
       sfor<KS>([&](auto KW) __attribute__((always_inline)) {
         constexpr int kw = decltype(KW)::value;
         constexpr int cur = kw & 1;
@@ -563,7 +578,7 @@ __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_c
         for (int tp = 0; tp < NCW * G::NTAP; ++tp) wf[tp] = wn[tp];
       }
     }
-    if (++st == NST) st = 0;
+    if (++st == NSA) st = 0;
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -576,6 +591,38 @@ __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_c
     if (cb >= p.cout_blocks) return;
     epilogue_block<T, R, NCW, cw, HAS1X1, BWD>(p, acc, acc1, b, cb, h, oyb, ox);
   });
+}
+
+template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD>
+__global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_conv p) {
+  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>;
+  __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
+  conv_body<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, BWD>(p, smem, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// EXPERIMENT (measurement only): the five convs of one ResidualDenseBlock_5C in ONE launch, every
+// workgroup walking conv1..conv5 for its own 16x32 tile with only workgroup-local barriers.  The
+// halo pixels owned by neighbouring workgroups are NOT synchronised, so results are wrong — the
+// timing is the upper bound of what an image-synchronised persistent RDB kernel could gain.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void rdb_nosync_kernel(const esr_conv* convs) {
+  using G1 = Geo<3, 1, 0, 4, 1, 1, 1, true, true>;
+  using G2 = Geo<3, 1, 0, 4, 1, 1, 2, true, false>;
+  constexpr int LDS = G1::LDS_BYTES > G2::LDS_BYTES ? G1::LDS_BYTES : G2::LDS_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[LDS];
+  conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, false, false>(convs[0], smem, blockIdx.x, gridDim.x, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, true, false>(convs[1], smem, blockIdx.x, gridDim.x, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, false, false>(convs[2], smem, blockIdx.x, gridDim.x, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, false, false>(convs[3], smem, blockIdx.x, gridDim.x, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  conv_body<T, 3, 1, 0, 4, 1, 1, 2, true, false, false>(convs[4], smem, blockIdx.x, gridDim.x, 0);
 }
 
 template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
@@ -629,6 +676,11 @@ int dispatch(const esr_conv& p, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int esr_rdb_nosync_probe(const esr_conv* dev_convs, int32_t tiles, esr_stream_t stream) {
+  hipLaunchKernelGGL(rdb_nosync_kernel<_Float16>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, dev_convs);
+  return esr_check_launch("rdb_nosync_kernel");
+}
 
 extern "C" int esr_conv_forward(const esr_conv* p, esr_stream_t stream) {
   if (!p || !p->in.ptr || !p->w || p->cin_groups <= 0 || p->cout_blocks <= 0 || p->B <= 0 || p->H <= 0 || p->W <= 0) {

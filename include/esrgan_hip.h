@@ -269,6 +269,9 @@ int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream);
  * creates events and synchronises; never call it under graph capture. */
 int esr_run_ops_timed(const esr_op* ops, int32_t n, esr_stream_t stream, float* ms_out);
 
+/* Measurement-only probe (results are NOT valid): see conv_mfma.hip rdb_nosync_kernel. */
+int esr_rdb_nosync_probe(const esr_conv* dev_convs, int32_t tiles, esr_stream_t stream);
+
 const char* esr_last_error(void);
 int esr_abi_version(void);
 size_t esr_sizeof_op(void);
