@@ -41,8 +41,9 @@ def probe(cin, cout, res, flags, prec='fp16', ups=0, ks=3):
     return best
 
 
-print('cin cout res | full   noEpi  noMMA  noDMA  noMMA+noDMA  onlyLaunch(all off)  nt-store  wt-store [us per launch, back-to-back]')
-for cin, cout, res in ((16, 32, 0), (64, 32, 0), (128, 32, 0), (160, 32, 1), (192, 64, 1), (64, 64, 0)):
-    r = [probe(cin, cout, res, f) for f in (0, 1, 2, 4, 6, 7, 8, 16)]
-    mac = B * H * W * cin * cout * 9
-    print('%3d %3d %d | %s   | %.0f TF/s full' % (cin, cout, res, '  '.join('%5.1f' % v for v in r), 2 * mac / r[0] / 1e6))
+if __name__ == '__main__':
+    print('cin cout res | full   noEpi  noMMA  noDMA  noMMA+noDMA  onlyLaunch(all off)  nt-store  wt-store [us per launch, back-to-back]')
+    for cin, cout, res in ((16, 32, 0), (64, 32, 0), (128, 32, 0), (160, 32, 1), (192, 64, 1), (64, 64, 0)):
+        r = [probe(cin, cout, res, f) for f in (0, 1, 2, 4, 6, 7, 8, 16)]
+        mac = B * H * W * cin * cout * 9
+        print('%3d %3d %d | %s   | %.0f TF/s full' % (cin, cout, res, '  '.join('%5.1f' % v for v in r), 2 * mac / r[0] / 1e6))
