@@ -124,7 +124,7 @@ class esr_op(C.Structure):
 
 # every symbol include/esrgan_hip.h declares (tests check the .so exports all of them)
 EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_pack_conv_weights',
-           'esr_convert_layout', 'esr_fill_noise', 'esr_conv_wgrad', 'esr_batchnorm', 'esr_maxpool2',
+           'esr_convert_layout', 'esr_fill_noise', 'esr_conv_wgrad', 'esr_conv_wgrad_multi', 'esr_batchnorm', 'esr_maxpool2',
            'esr_linear_op', 'esr_grad_unpermute', 'esr_pack_conv_weights_batch', 'esr_pack_pieces',
            'esr_rdb_nosync_probe', 'esr_run_ops', 'esr_run_ops_timed', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op']
@@ -163,6 +163,7 @@ def lib():
         L.esr_g32_dims.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.esr_run_ops.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.esr_run_ops_timed.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.esr_conv_wgrad_multi.argtypes = [C.POINTER(esr_wgrad), C.c_int32, C.c_void_p]
         for name, st in (('esr_conv_forward', esr_conv), ('esr_pack_conv_weights', esr_pack),
                          ('esr_convert_layout', esr_layout), ('esr_fill_noise', esr_noise_fill),
                          ('esr_conv_wgrad', esr_wgrad), ('esr_batchnorm', esr_bn),

@@ -43,7 +43,18 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       case ESR_OP_PACK: rc = esr_pack_conv_weights(&ops[i].u.pack, stream); break;
       case ESR_OP_LAYOUT: rc = esr_convert_layout(&ops[i].u.layout, stream); break;
       case ESR_OP_NOISE_FILL: rc = esr_fill_noise(&ops[i].u.noise_fill, stream); break;
-      case ESR_OP_WGRAD: rc = esr_conv_wgrad(&ops[i].u.wgrad, stream); break;
+      case ESR_OP_WGRAD: {
+        // consecutive weight-gradient ops are independent by construction (disjoint dW blocks, read
+        // only g / saved inputs): hand the run to the batched launcher
+        int m = 1;
+        while (i + m < n && m < 16 && ops[i + m].kind == ESR_OP_WGRAD) ++m;
+        if (m == 1) { rc = esr_conv_wgrad(&ops[i].u.wgrad, stream); break; }
+        esr_wgrad run[16];
+        for (int k = 0; k < m; ++k) run[k] = ops[i + k].u.wgrad;
+        rc = esr_conv_wgrad_multi(run, m, stream);
+        if (rc == ESR_OK) i += m - 1;
+        break;
+      }
       case ESR_OP_BN: rc = esr_batchnorm(&ops[i].u.bn, stream); break;
       case ESR_OP_POOL: rc = esr_maxpool2(&ops[i].u.pool, stream); break;
       case ESR_OP_LINEAR: rc = esr_linear_op(&ops[i].u.linear, stream); break;

@@ -158,8 +158,21 @@ __device__ __forceinline__ u32x4 tr_frag(const char* lds_base, int off0, int off
 
 struct Acc10 { f32x16 a[10]; };
 
+template <int KS, int S, bool UPS, int NCO>
+struct Wg16Geo {
+  static constexpr int TR = S == 2 ? 2 : 4, TC = 32;
+  static constexpr int NCI = 8 / NCO;
+  static constexpr int IH = UPS ? TR / 2 + 2 : (TR - 1) * S + KS, IW = UPS ? TC / 2 + 2 : (TC - 1) * S + KS;
+  static constexpr int G_BYTES = NCO * 2 * TR * TC * 32;
+  static constexpr int IN_GROUP = IH * IW * 32;
+  static constexpr int LDS_BYTES = G_BYTES + NCI * 2 * IN_GROUP;
+};
+
+// (bx, by, bz) = the workgroup's coordinates in THIS conv's grid (the batched launch packs the grids
+// of several convs into one 1-D grid)
 template <int KS, int S, bool UPS, int NCO, int T0, int NT>
-__global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int rows_per_wg) {
+__device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_per_wg, char* const smem,
+                                             const int bx, const int by, const int bz) {
   // taps [T0, T0+NT) of the KSxKS kernel are accumulated by this launch (4x4 kernels: two launches
   // of 8 taps, keeping the accumulators within the register file)
   constexpr int TR = S == 2 ? 2 : 4, TC = 32, NTAP = KS * KS, PAD = (KS - 1) / 2;
@@ -168,7 +181,6 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int row
   static_assert(NT <= 9 && T0 + NT <= NTAP, "tap range");
   constexpr int G_BYTES = NCO * 2 * TR * TC * 32;     // [cout group][row][col][32 B]
   constexpr int IN_GROUP = IH * IW * 32;
-  __shared__ __attribute__((aligned(16))) char smem[G_BYTES + NCI * 2 * IN_GROUP];
   char* const lg = smem;
   char* const li = smem + G_BYTES;
 
@@ -177,10 +189,10 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int row
   const int wco = wave % NCO, wci = wave / NCO;       // this wave's cout block / cin block in the WG
   const int strips = (p.W + TC - 1) / TC;
   const int rchunks = (p.H + rows_per_wg - 1) / rows_per_wg;
-  const int sx = blockIdx.x % strips, rc = (blockIdx.x / strips) % rchunks, b = blockIdx.x / (strips * rchunks);
+  const int sx = bx % strips, rc = (bx / strips) % rchunks, b = bx / (strips * rchunks);
   const int ox0 = sx * TC;
-  const int cb = blockIdx.z * NCO + wco;              // 32-cout block
-  const int cib = blockIdx.y * NCI + wci;             // 32-cin block  (= G32 groups 2*cib, 2*cib+1)
+  const int cb = bz * NCO + wco;              // 32-cout block
+  const int cib = by * NCI + wci;             // 32-cin block  (= G32 groups 2*cib, 2*cib+1)
   const int ngin = p.in.ngroups;
   const bool active = cb * 32 < p.cout && 2 * cib < ngin;
 
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int row
     for (int s = tid; s < NCO * 2 * TR * TC * 2; s += 512) {
       const int half = s & 1, px = (s >> 1) % (TR * TC), g = (s >> 1) / (TR * TC);
       const int r = px / TC, c = px % TC;
-      const int gg = (blockIdx.z * NCO) * 2 + g;
+      const int gg = (bz * NCO) * 2 + g;
       u32x4 v = {0, 0, 0, 0};
       if (oy0 + r < y_end && ox0 + c < p.W && gg < p.g.ngroups)
         v = *(const u32x4*)(gbase + (int64_t)gg * p.g.group_stride + ((int64_t)(oy0 + r + 1) * p.g.wp + ox0 + c + 1) * 32 + half * 16);
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int row
     for (int s = tid; s < NCI * 2 * IH * IW * 2; s += 512) {
       const int half = s & 1, px = (s >> 1) % (IH * IW), g = (s >> 1) / (IH * IW);
       const int r = px / IW, c = px % IW;
-      const int gg = blockIdx.y * NCI * 2 + g;
+      const int gg = by * NCI * 2 + g;
       u32x4 v = {0, 0, 0, 0};
       if (gg < ngin)
         v = *(const u32x4*)(ibase + (int64_t)gg * p.in.group_stride + ((int64_t)(iy0 + r) * p.in.wp + ix0 + c) * 32 + half * 16);
@@ -278,27 +290,74 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int row
   }
 }
 
-template <int KS, int S, bool UPS, int T0, int NT>
-int launch_wgrad16(const esr_wgrad& p, hipStream_t st) {
+
+template <int KS, int S, bool UPS, int NCO, int T0, int NT>
+__global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int rows_per_wg) {
+  __shared__ __attribute__((aligned(16))) char smem[Wg16Geo<KS, S, UPS, NCO>::LDS_BYTES];
+  wgrad16_body<KS, S, UPS, NCO, T0, NT>(p, rows_per_wg, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- several independent 3x3/s1 and 1x1 wgrads in ONE launch.  At training sizes (16 x 32x32) one
+// conv's wgrad is ~64 workgroups of mostly idle waves and ~25 us of pure latency; the six convs of a
+// residual dense block (same saved input, six gradient slices) fill the chip together.
+constexpr int WG_BATCH_MAX = 8;
+struct WgradBatch {
+  int32_t n;
+  int32_t start[WG_BATCH_MAX + 1];   // first linear workgroup of entry i
+  int32_t gx[WG_BATCH_MAX], gy[WG_BATCH_MAX];
+  int32_t rows[WG_BATCH_MAX];
+  int32_t kind[WG_BATCH_MAX];        // 0: 3x3 NCO=1   1: 3x3 NCO=2   2: 1x1 NCO=1   3: 1x1 NCO=2
+  esr_wgrad w[WG_BATCH_MAX];
+};
+
+__global__ __launch_bounds__(512) void wgrad16_batch_kernel(const WgradBatch pb) {
+  constexpr int L0 = Wg16Geo<3, 1, false, 1>::LDS_BYTES, L1 = Wg16Geo<3, 1, false, 2>::LDS_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[L0 > L1 ? L0 : L1];
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < WG_BATCH_MAX; ++k)
+    if (k < pb.n && (int)blockIdx.x >= pb.start[k]) i = k;
+  const int l = blockIdx.x - pb.start[i];
+  const int bx = l % pb.gx[i], by = (l / pb.gx[i]) % pb.gy[i], bz = l / (pb.gx[i] * pb.gy[i]);
+  const esr_wgrad& p = pb.w[i];
+  switch (pb.kind[i]) {
+    case 0: wgrad16_body<3, 1, false, 1, 0, 9>(p, pb.rows[i], smem, bx, by, bz); break;
+    case 1: wgrad16_body<3, 1, false, 2, 0, 9>(p, pb.rows[i], smem, bx, by, bz); break;
+    case 2: wgrad16_body<1, 1, false, 1, 0, 1>(p, pb.rows[i], smem, bx, by, bz); break;
+    default: wgrad16_body<1, 1, false, 2, 0, 1>(p, pb.rows[i], smem, bx, by, bz); break;
+  }
+}
+
+// grid shape of one conv's fp16 wgrad (shared by the single and the batched launch)
+struct Wg16Grid { int nco, gx, gy, gz, rows; };
+template <int S>
+Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs) {
   const int strips = (p.W + 31) / 32;
   const int coblocks = (p.cout + 31) / 32;
   const int ciblocks = (p.in.ngroups + 1) / 2;
-  // rows per workgroup: keep >= ~512 workgroups in flight, but amortise the atomics over many rows
-  const int nco = (coblocks >= 2 || S == 2) ? 2 : 1, nci = 8 / nco;   // stride 2: LDS only fits NCO=2
-  const int gy = (ciblocks + nci - 1) / nci, gz = (coblocks + nco - 1) / nco;
+  Wg16Grid g;
+  g.nco = (coblocks >= 2 || S == 2) ? 2 : 1;           // stride 2: LDS only fits NCO=2
+  const int nci = 8 / g.nco;
+  g.gy = (ciblocks + nci - 1) / nci;
+  g.gz = (coblocks + g.nco - 1) / g.nco;
   // Every workgroup ends with 8 waves x 9 taps x 1024 fp32 atomics, so use as FEW spatial splits as
-  // still give ~64 workgroups: start from whole column strips and halve only while the grid is tiny.
-  constexpr int TRq = S == 2 ? 2 : 4;
+  // still give ~min_wgs workgroups: start from whole column strips and halve only while the grid is tiny.
   int rows = ((p.H + 3) / 4) * 4;
-  (void)TRq;
-  while (rows > 8 && (int64_t)p.B * strips * ((p.H + rows - 1) / rows) * gy * gz < 64) rows = ((rows / 2 + 3) / 4) * 4;
-  const int rchunks = (p.H + rows - 1) / rows;
-  dim3 grid(p.B * strips * rchunks, gy, gz);
+  while (rows > 8 && (int64_t)p.B * strips * ((p.H + rows - 1) / rows) * g.gy * g.gz < min_wgs) rows = ((rows / 2 + 3) / 4) * 4;
+  g.rows = rows;
+  g.gx = p.B * strips * ((p.H + rows - 1) / rows);
+  return g;
+}
+
+template <int KS, int S, bool UPS, int T0, int NT>
+int launch_wgrad16(const esr_wgrad& p, hipStream_t st) {
+  const Wg16Grid g = wgrad16_grid<S>(p, 64);
+  dim3 grid(g.gx, g.gy, g.gz);
   if constexpr (S == 2) {
-    hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(512), 0, st, p, rows);
+    hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(512), 0, st, p, g.rows);
   } else {
-    if (nco == 2) hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(512), 0, st, p, rows);
-    else hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 1, T0, NT>), grid, dim3(512), 0, st, p, rows);
+    if (g.nco == 2) hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(512), 0, st, p, g.rows);
+    else hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 1, T0, NT>), grid, dim3(512), 0, st, p, g.rows);
   }
   return esr_check_launch("wgrad16_kernel");
 }
@@ -373,4 +432,50 @@ extern "C" int esr_conv_wgrad(const esr_wgrad* p, esr_stream_t stream) {
   if (p->dtype == ESR_F32) return dispatch_wgrad<float>(*p, st);
   esr_set_error("esr_conv_wgrad: bad dtype %d", p->dtype);
   return ESR_ERR_INVALID;
+}
+
+static bool wgrad_batchable(const esr_wgrad& p) {
+  return p.dtype == ESR_F16 && p.stride == 1 && !p.upsample && (p.ks == 3 || p.ks == 1) && p.g.ptr && p.in.ptr &&
+         p.dw && p.B > 0 && p.H > 0 && p.W > 0 && p.cout > 0 && p.cin > 0;
+}
+
+extern "C" int esr_conv_wgrad_multi(const esr_wgrad* items, int32_t n, esr_stream_t stream) {
+  if (!items || n <= 0) { esr_set_error("esr_conv_wgrad_multi: invalid arguments"); return ESR_ERR_INVALID; }
+  int i = 0;
+  while (i < n) {
+    // greedily pack consecutive batchable entries; anything else goes through the single launch
+    if (!wgrad_batchable(items[i])) {
+      const int rc = esr_conv_wgrad(&items[i], stream);
+      if (rc) return rc;
+      ++i;
+      continue;
+    }
+    int m = 0;
+    while (i + m < n && m < WG_BATCH_MAX && wgrad_batchable(items[i + m])) ++m;
+    if (m == 1) {
+      const int rc = esr_conv_wgrad(&items[i], stream);
+      if (rc) return rc;
+      ++i;
+      continue;
+    }
+    WgradBatch pb;
+    pb.n = m;
+    int total = 0;
+    for (int k = 0; k < m; ++k) {
+      const esr_wgrad& p = items[i + k];
+      const Wg16Grid g = wgrad16_grid<1>(p, 64);
+      pb.start[k] = total;
+      pb.gx[k] = g.gx; pb.gy[k] = g.gy; pb.rows[k] = g.rows;
+      pb.kind[k] = (p.ks == 3 ? 0 : 2) + (g.nco == 2 ? 1 : 0);
+      pb.w[k] = p;
+      total += g.gx * g.gy * g.gz;
+    }
+    for (int k = m; k <= WG_BATCH_MAX; ++k) pb.start[k] = total;
+    for (int k = m; k < WG_BATCH_MAX; ++k) { pb.gx[k] = pb.gy[k] = 1; pb.rows[k] = 8; pb.kind[k] = 0; pb.w[k] = items[i]; }
+    hipLaunchKernelGGL(wgrad16_batch_kernel, dim3(total), dim3(512), 0, (hipStream_t)stream, pb);
+    const int rc = esr_check_launch("wgrad16_batch_kernel");
+    if (rc) return rc;
+    i += m;
+  }
+  return ESR_OK;
 }

@@ -56,6 +56,27 @@ def broadcast_parameters(module, src=0):
             dist.broadcast(t, src)
 
 
+def flat_grad_spans(params):
+    """Gradients grouped by storage: for every group of ``.grad`` tensors that are views tiling one
+    contiguous span of a flat buffer (what the fused backward nodes emit) return that span as ONE 1-D
+    tensor; all other grads are returned individually.  -> (spans, loose)"""
+    groups = {}
+    for p in params:
+        if p.grad is not None:
+            groups.setdefault(p.grad.untyped_storage().data_ptr(), []).append(p.grad)
+    spans, loose = [], []
+    for gs in groups.values():
+        if len(gs) > 1 and all(g.is_contiguous() for g in gs):
+            lo = min(g.storage_offset() for g in gs)
+            hi = max(g.storage_offset() + g.numel() for g in gs)
+            if sum(g.numel() for g in gs) == hi - lo:
+                spans.append(torch.empty(0, dtype=gs[0].dtype, device=gs[0].device).set_(
+                    gs[0].untyped_storage(), lo, (hi - lo,)))
+                continue
+        loose.extend(gs)
+    return spans, loose
+
+
 class GradExchange:
     """Mean all-reduce of a module's gradients, bucketed, asynchronous."""
 

@@ -619,6 +619,8 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             TP.bwd_noise_ops.append(k)
         return k
 
+    deferred = None
+
     def wgrad(key, g, gin, Hh, Ww, cout, cin, ks=3, ups=0, scale=1.0):
         wg = L.esr_wgrad()
         wg.dtype, wg.ks, wg.stride, wg.upsample = dt_e, ks, 1, ups
@@ -629,7 +631,10 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         if TP.tapmajor is not None and ks == 3:
             wg.dw, wg.tap_major = TP.tapmajor.slot(goff[key], cout, cin), 1
         wg.scale = scale
-        Bk.add(L.OP_WGRAD, 'wgrad', wg)
+        if deferred is not None:
+            deferred.append(wg)      # emitted as one run at the end of the block (one batched launch)
+        else:
+            Bk.add(L.OP_WGRAD, 'wgrad', wg)
 
     GY = buf(out_nc, 4 * H, 4 * W)
     TP.gy_op = imp(Bk, GY, out_nc)
@@ -677,6 +682,9 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             bf, ax = S[i][j], AUX[i][j]
             p = 'model.1.sub.%d.RDB%d' % (i, j + 1)
             gt = gT[ct]
+            # the block's six weight gradients read g_t, GA[0:128], G[96:128] and the saved input, all
+            # intact until the next block starts -> emit them together after the dgrad chain
+            deferred = []
             # conv5: g_x5 = 0.2 g_t ; G = conv5^T(g_x5) (+ g_t on the x channels: d(0.2x5+x)/dx)
             wgrad(p + '.conv5.0', gt.view(0, 64), bf.view(0, 192), H, W, 64, 192, scale=0.2)
             c = dconv(H, W, gt.view(0), 64, G.view(0, 192), p + '.conv5.0')
@@ -730,6 +738,9 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
                 else:
                     c.out = GF.view(0, 64)
             add_b(c, noisy=True)
+            for wg in deferred:
+                Bk.add(L.OP_WGRAD, 'wgrad', wg)
+            deferred = None
     # fea_conv (model.0): weight gradient only (the LR input image needs no gradient)
     wgrad('model.0', GF.view(0, 64), xin.view(0, in_nc), H, W, 64, in_nc)
     if TP.tapmajor is not None:

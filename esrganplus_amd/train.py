@@ -37,9 +37,12 @@ class ESRGANPlusStep:
     def _unscale(self, params):
         if self.loss_scale != 1.0:
             inv = 1.0 / self.loss_scale
-            for p in params:
-                if p.grad is not None:
-                    p.grad.mul_(inv)
+            # one launch per flat gradient buffer instead of one per parameter (~800 launches/step)
+            spans, loose = DP.flat_grad_spans(params)
+            for t in spans:
+                t.mul_(inv)
+            if loose:
+                torch._foreach_mul_(loose, inv)
 
     def step(self, var_L, var_H, var_ref=None, z=None, sync_log=True):
         """One optimisation step (SRRaGAN_model.py:113-168)."""

@@ -254,6 +254,11 @@ int esr_pack_conv_weights(const esr_pack* p, esr_stream_t stream);
 int esr_convert_layout(const esr_layout* p, esr_stream_t stream);
 int esr_fill_noise(const esr_noise_fill* p, esr_stream_t stream);
 int esr_conv_wgrad(const esr_wgrad* p, esr_stream_t stream);
+/* n independent weight-gradient problems (disjoint dw/dbias blocks).  fp16 3x3/s1 and 1x1 entries are
+ * packed, up to 8 at a time, into ONE launch (at training sizes a single conv's wgrad is ~64
+ * mostly-idle workgroups); anything else falls back to esr_conv_wgrad.  esr_run_ops routes every run
+ * of consecutive ESR_OP_WGRAD ops through this entry. */
+int esr_conv_wgrad_multi(const esr_wgrad* items, int32_t n, esr_stream_t stream);
 int esr_batchnorm(const esr_bn* p, esr_stream_t stream);
 int esr_maxpool2(const esr_pool* p, esr_stream_t stream);
 int esr_linear_op(const esr_linear* p, esr_stream_t stream);

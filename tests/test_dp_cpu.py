@@ -80,3 +80,23 @@ def test_dp_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+
+
+def test_flat_grad_spans_groups_views_of_one_buffer():
+    import torch
+    from esrganplus_amd import dp as DP
+    flat = torch.arange(10, dtype=torch.float32)
+    a, b, c = (torch.nn.Parameter(torch.zeros(n)) for n in (4, 6, 3))
+    a.grad, b.grad = flat[:4], flat[4:]          # views tiling one buffer -> one span
+    c.grad = torch.ones(3)                        # separate storage -> loose
+    spans, loose = DP.flat_grad_spans([a, b, c])
+    assert len(spans) == 1 and spans[0].numel() == 10 and len(loose) == 1
+    spans[0].mul_(0.5)
+    assert torch.equal(a.grad, torch.arange(4, dtype=torch.float32) * 0.5)
+    assert torch.equal(b.grad, torch.arange(4, 10, dtype=torch.float32) * 0.5)
+    # a gap in the tiling must not be treated as one span
+    d, e = torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(2))
+    buf = torch.zeros(8)
+    d.grad, e.grad = buf[:2], buf[4:6]
+    spans, loose = DP.flat_grad_spans([d, e])
+    assert not spans and len(loose) == 2

@@ -10,7 +10,8 @@ from esrganplus_amd import architecture as arch, synth, engine as E, _lib as L
 dev = torch.device('cuda:0')
 net = arch.RRDBNet(3, 3, 64, 1).to(dev).eval().set_precision('fp16')
 net.load_state_dict(synth.rrdbnet_state_dict(1, 0))
-x = synth.image_batch(1, 16, 3, 128, 128).to(dev)
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+x = synth.image_batch(1, BATCH, 3, 128, 128).to(dev)
 with torch.no_grad():
     net(x)
 plan = next(iter(net._plans.values()))
@@ -21,7 +22,7 @@ dbuf = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
 st = E.current_stream()
 lib = L.lib()
 lib.esr_rdb_nosync_probe.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
-tiles = 16 * (128 // 16) * (128 // 32)
+tiles = BATCH * (128 // 16) * (128 // 32)
 five = L.OpList()
 for _ in range(20):
     for c in convs:
@@ -41,6 +42,7 @@ def timed(fn, reps):
 one = L.OpList()
 for c in convs:
     one.add_conv(c)
+print('batch', BATCH)
 for _ in range(2):
     print('5 launches              %.1f us per RDB' % timed(lambda: one.run(st), 200))
     print('1 launch (no halo sync) %.1f us per RDB' % timed(lambda: L.check(lib.esr_rdb_nosync_probe(dbuf.data_ptr(), tiles, st)), 200))
