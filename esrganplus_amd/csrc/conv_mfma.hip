@@ -661,7 +661,13 @@ int dispatch(const esr_conv& p, hipStream_t st) {
       return launch<T, 3, 1, 0, 4, 1, 1, 1, true, true>(p, st);
     }
     if (cbk == 1) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false>(p, st);
-    if (cbk <= 3) return launch<T, 3, 1, 0, 4, 1, 1, 2, true, false>(p, st);
+    if (cbk <= 3) {
+      // small grids (training tiles): one 32-cout block per workgroup doubles the workgroup count and
+      // halves each one's MFMA chain; large grids keep two blocks per wave (each B fragment feeds 2 MFMAs)
+      const int64_t tiles = (int64_t)((p.W + 31) / 32) * ((p.H + 15) / 16) * p.B;
+      if (tiles * ((cbk + 1) / 2) < 256) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false>(p, st);
+      return launch<T, 3, 1, 0, 4, 1, 1, 2, true, false>(p, st);
+    }
     return launch<T, 3, 1, 0, 2, 1, 4, 1, false, false>(p, st);
   }
   if (has1) { esr_set_error("conv: fused 1x1 only with 3x3/s1"); return ESR_ERR_UNSUPPORTED; }

@@ -11,6 +11,7 @@
 // gradient — the layout torch.optim.Adam consumes directly (SRRaGAN_model.py:82-89).
 // Round-1 version: correctness first (plain staging, scalar LDS operand reads); the fp16
 // transposed-read (ds_read_b64_tr_b16) MFMA-f16 version is the planned upgrade.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -434,6 +435,13 @@ extern "C" int esr_conv_wgrad(const esr_wgrad* p, esr_stream_t stream) {
   return ESR_ERR_INVALID;
 }
 
+// spatial splits per conv inside a batched launch: every split costs a full set of dW atomics, and the
+// batch as a whole (not each conv) has to fill the chip
+static int batch_min_wgs() {
+  static const int v = [] { const char* e = getenv("ESR_WGRAD_MIN_WGS"); return e ? atoi(e) : 16; }();
+  return v;
+}
+
 static bool wgrad_batchable(const esr_wgrad& p) {
   return p.dtype == ESR_F16 && p.stride == 1 && !p.upsample && (p.ks == 3 || p.ks == 1) && p.g.ptr && p.in.ptr &&
          p.dw && p.B > 0 && p.H > 0 && p.W > 0 && p.cout > 0 && p.cin > 0;
@@ -463,7 +471,7 @@ extern "C" int esr_conv_wgrad_multi(const esr_wgrad* items, int32_t n, esr_strea
     int total = 0;
     for (int k = 0; k < m; ++k) {
       const esr_wgrad& p = items[i + k];
-      const Wg16Grid g = wgrad16_grid<1>(p, 64);
+      const Wg16Grid g = wgrad16_grid<1>(p, batch_min_wgs());
       pb.start[k] = total;
       pb.gx[k] = g.gx; pb.gy[k] = g.gy; pb.rows[k] = g.rows;
       pb.kind[k] = (p.ks == 3 ? 0 : 2) + (g.nco == 2 ? 1 : 0);
