@@ -119,7 +119,7 @@ class _op_union(C.Union):
 
 
 class esr_op(C.Structure):
-    _fields_ = [('kind', C.c_int32), ('_pad', C.c_int32), ('u', _op_union)]
+    _fields_ = [('kind', C.c_int32), ('flags', C.c_int32), ('u', _op_union)]
 
 
 # every symbol include/esrgan_hip.h declares (tests check the .so exports all of them)
@@ -194,6 +194,9 @@ def packed_weight_bytes(cout, cin, ks, dtype):
     return lib().esr_packed_weight_bytes(cout, cin, ks, dtype)
 
 
+OPF_SIDE = 1   # esr_op.flags: run of wgrad ops on the library's side stream (include/esrgan_hip.h)
+
+
 class OpList:
     """A recorded launch sequence: a contiguous array of esr_op replayed by ONE C call."""
 
@@ -210,9 +213,10 @@ class OpList:
         self._arr = None
         return len(self.ops) - 1
 
-    def add(self, kind, field, st):
+    def add(self, kind, field, st, flags=0):
         o = esr_op()
         o.kind = kind
+        o.flags = flags
         setattr(o.u, field, st)
         self.ops.append(o)
         self._arr = None

@@ -1,6 +1,7 @@
 // api.hip — error plumbing, geometry helper and the op-list runner of libesrgan_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <mutex>
 
 #include "common.h"
 
@@ -34,8 +35,33 @@ extern "C" void esr_g32_dims(int32_t H, int32_t W, int32_t* Hp, int32_t* Wp) {
   if (Wp) *Wp = ((W + 31) / 32) * 32 + 2;
 }
 
+// Side stream for ESR_OPF_SIDE runs: one non-blocking stream + two fork/join event pairs per device,
+// created on first use (the only resources the library ever owns).
+namespace {
+struct SideState { hipStream_t stream; hipEvent_t fork[2], join[2]; };
+SideState* side_state() {
+  static std::mutex mu;
+  static SideState* per_dev[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { esr_set_error("side stream: bad device"); return nullptr; }
+  std::lock_guard<std::mutex> lk(mu);
+  if (!per_dev[dev]) {
+    SideState* s = new SideState();
+    bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2 && ok; ++k)
+      ok = hipEventCreateWithFlags(&s->fork[k], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&s->join[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { esr_set_error("side stream: creation failed"); delete s; return nullptr; }
+    per_dev[dev] = s;
+  }
+  return per_dev[dev];
+}
+}  // namespace
+
 extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
   if (!ops || n < 0) { esr_set_error("esr_run_ops: invalid arguments"); return ESR_ERR_INVALID; }
+  int nside = 0;        // side runs launched by this call
+  bool joined = true;   // main stream already waits for the last side run
   for (int i = 0; i < n; ++i) {
     int rc;
     switch (ops[i].kind) {
@@ -46,19 +72,37 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       case ESR_OP_WGRAD: {
         // consecutive weight-gradient ops are independent by construction (disjoint dW blocks, read
         // only g / saved inputs): hand the run to the batched launcher
+        const int side = ops[i].flags & ESR_OPF_SIDE;
         int m = 1;
-        while (i + m < n && m < 16 && ops[i + m].kind == ESR_OP_WGRAD) ++m;
-        if (m == 1) { rc = esr_conv_wgrad(&ops[i].u.wgrad, stream); break; }
+        while (i + m < n && m < 16 && ops[i + m].kind == ESR_OP_WGRAD && (ops[i + m].flags & ESR_OPF_SIDE) == side) ++m;
         esr_wgrad run[16];
         for (int k = 0; k < m; ++k) run[k] = ops[i + k].u.wgrad;
-        rc = esr_conv_wgrad_multi(run, m, stream);
+        if (!side) {
+          rc = m == 1 ? esr_conv_wgrad(&run[0], stream) : esr_conv_wgrad_multi(run, m, stream);
+        } else {
+          // fork: side stream waits for everything enqueued so far; the previous side run must be done
+          // before anything after this point (its inputs may be overwritten from here on)
+          SideState* ss = side_state();
+          if (!ss) return ESR_ERR_LAUNCH;
+          hipStream_t main_st = (hipStream_t)stream;
+          if (nside > 0) hipStreamWaitEvent(main_st, ss->join[(nside - 1) & 1], 0);
+          hipEventRecord(ss->fork[nside & 1], main_st);
+          hipStreamWaitEvent(ss->stream, ss->fork[nside & 1], 0);
+          rc = esr_conv_wgrad_multi(run, m, (esr_stream_t)ss->stream);
+          hipEventRecord(ss->join[nside & 1], ss->stream);
+          ++nside;
+          joined = false;
+        }
         if (rc == ESR_OK) i += m - 1;
         break;
       }
       case ESR_OP_BN: rc = esr_batchnorm(&ops[i].u.bn, stream); break;
       case ESR_OP_POOL: rc = esr_maxpool2(&ops[i].u.pool, stream); break;
       case ESR_OP_LINEAR: rc = esr_linear_op(&ops[i].u.linear, stream); break;
-      case ESR_OP_UNPERMUTE: rc = esr_grad_unpermute(&ops[i].u.unpermute, stream); break;
+      case ESR_OP_UNPERMUTE:
+        if (nside > 0 && !joined) { hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0); joined = true; }
+        rc = esr_grad_unpermute(&ops[i].u.unpermute, stream);
+        break;
       case ESR_OP_PACK_BATCH: rc = esr_pack_conv_weights_batch(&ops[i].u.pack_batch, stream); break;
       default: esr_set_error("esr_run_ops: op %d has unknown kind %d", i, ops[i].kind); return ESR_ERR_INVALID;
     }
@@ -66,9 +110,11 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       char tmp[400];
       snprintf(tmp, sizeof(tmp), "%s", esr_last_error());
       esr_set_error("op %d (kind %d): %s", i, ops[i].kind, tmp);
+      if (nside > 0 && !joined) hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0);
       return rc;
     }
   }
+  if (nside > 0 && !joined) hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0);
   return ESR_OK;
 }
 

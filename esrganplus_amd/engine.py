@@ -642,8 +642,13 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
     GA3 = buf(64, 2 * H, 2 * W)
     GTt = buf(64)                                   # dL/dT (trunk output)
     gA = [buf(64), buf(64)]                         # RRDB skip gradient A(i), ping-pong
-    gT = [buf(64), buf(64)]                         # g_t of the current RDB, ping-pong
-    G, GA = buf(192), buf(128)
+    # The six weight gradients of a block run on the side stream, concurrently with the NEXT block's
+    # dgrad chain (both are latency-bound, ~64-workgroup launches at training sizes), and are joined
+    # before the block after that starts: what they read (g_t, GA, G[96:128]) rotates so that the
+    # chain running next to them writes other buffers — g_t through 3, G/GA through 2.
+    gT = [buf(64), buf(64), buf(64)]
+    Gs, GAs = [buf(192), buf(192)], [buf(128), buf(128)]
+    rdb_no = 0
     GF = buf(64)                                    # dL/dfea
 
     # HR_conv1 (model.10): u3 -> y
@@ -682,6 +687,8 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             bf, ax = S[i][j], AUX[i][j]
             p = 'model.1.sub.%d.RDB%d' % (i, j + 1)
             gt = gT[ct]
+            G, GA = Gs[rdb_no & 1], GAs[rdb_no & 1]
+            rdb_no += 1
             # the block's six weight gradients read g_t, GA[0:128], G[96:128] and the saved input, all
             # intact until the next block starts -> emit them together after the dgrad chain
             deferred = []
@@ -722,24 +729,24 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             c.res1 = G.view(0, 64)
             if j > 0:
                 # g_x = g_y of RDB j (previous in forward order) -> its g_t = g_y * n
-                c.out = gT[ct ^ 1].view(0, 64)
+                c.out = gT[(ct + 1) % 3].view(0, 64)
                 set_noise(c, 2, per * i + j - 1)
-                ct ^= 1
+                ct = (ct + 1) % 3
             else:
                 c.res2, c.beta = gA[ca].view(0, 64), 1.0
                 if i > 0:
                     c.out = gA[ca ^ 1].view(0, 64)
                     if variant == 'test_image':
                         set_noise(c, 2, per * (i - 1) + 3)
-                    c.out3, c.gamma = gT[ct ^ 1].view(0, 64), 0.2
+                    c.out3, c.gamma = gT[(ct + 1) % 3].view(0, 64), 0.2
                     set_noise(c, 3, per * (i - 1) + 2)
                     ca ^= 1
-                    ct ^= 1
+                    ct = (ct + 1) % 3
                 else:
                     c.out = GF.view(0, 64)
             add_b(c, noisy=True)
             for wg in deferred:
-                Bk.add(L.OP_WGRAD, 'wgrad', wg)
+                Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE)
             deferred = None
     # fea_conv (model.0): weight gradient only (the LR input image needs no gradient)
     wgrad('model.0', GF.view(0, 64), xin.view(0, in_nc), H, W, 64, in_nc)

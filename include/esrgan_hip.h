@@ -228,9 +228,17 @@ enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_N
                    ESR_OP_WGRAD = 5, ESR_OP_BN = 6, ESR_OP_POOL = 7, ESR_OP_LINEAR = 8,
                    ESR_OP_UNPERMUTE = 9, ESR_OP_PACK_BATCH = 10 };
 
+/* esr_op.flags */
+#define ESR_OPF_SIDE 1   /* on a run of consecutive ESR_OP_WGRAD ops: launch the run on the library's side
+                            stream, ordered after every earlier op.  It is complete (a) before any op that
+                            follows the NEXT side run, (b) before any ESR_OP_UNPERMUTE op, (c) when the work
+                            esr_run_ops enqueued on `stream` completes.  The caller guarantees that nothing
+                            up to the end of the next side run writes the run's inputs or reads its outputs
+                            (the train plan double-buffers the gradient slices it reads). */
+
 typedef struct esr_op {
   int32_t kind;
-  int32_t _pad;
+  int32_t flags;
   union {
     esr_conv conv;
     esr_pack pack;
