@@ -254,7 +254,9 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
             wg.dw, wg.dbias, wg.scale = gw[0], gw[1], 1.0
             if P.tapmajor is not None and r['ks'] in (3, 4):
                 wg.dw, wg.tap_major = P.tapmajor.slot(poff[r['key'] + '.weight'], cout, cin_, r['ks'] ** 2), 1
-            bk.add(L.OP_WGRAD, 'wgrad', wg)
+            # every layer owns its gradient buffers, so the weight gradient can run on the side stream
+            # next to the dgrad chain (joined before the unpermute / at the end of the plan)
+            bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE)
         # input gradient
         prev = recs[li - 1] if li > 0 else None
         gx = _g32(P, B, ((cin_ + cpg - 1) // cpg) * cpg, r['hin'], r['win'], dtype, dev)
