@@ -161,6 +161,77 @@ def train_bench(args, world, rank, dev, dist):
         dist.destroy_process_group()
 
 
+def gtrain_bench(args, world, rank, dev, dist):
+    """BASELINE configs[4]: the noise-injection generator in TRAIN mode (noise
+    on), forward + backward + Adam with an L1 pixel loss, on mixed LR tiles bucketed by size
+    (128/192/256 -> HR 512/768/1024).  The reference's discriminators only accept HR 96/128/192
+    crops, so at these sizes there is no GAN step to reproduce: generator-only, as SURVEY.md reads it.
+    One bench "step" = one optimizer iteration per bucket (4x128^2, 2x192^2, 1x256^2 LR per GPU)."""
+    import torch.nn.functional as F
+    from esrganplus_amd import architecture as arch, synth, dp as DP
+    prec = args.precision
+    netG = arch.RRDBNet(3, 3, 64, NB).to(dev).train().set_precision(prec)
+    netG.load_state_dict(synth.rrdbnet_state_dict(NB, 0, gain=0.5))
+    DP.broadcast_parameters(netG)
+    opt = torch.optim.Adam(netG.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    ex = DP.GradExchange(netG)
+    scale = 1024.0 if prec == 'fp16' else 1.0
+    buckets = []
+    for k, (n, sz) in enumerate(((4, 128), (2, 192), (1, 256))):
+        lr = synth.image_batch(400 + 10 * rank + k, n, 3, sz, sz, name='bench.glr').to(dev)
+        hr = synth.image_batch(500 + 10 * rank + k, n, 3, 4 * sz, 4 * sz, name='bench.ghr').to(dev)
+        buckets.append((lr, hr))
+    lr_pix = sum(l.shape[0] * l.shape[2] * l.shape[3] for l, _ in buckets)
+
+    def step():
+        for lr, hr in buckets:
+            opt.zero_grad(set_to_none=True)
+            loss = F.l1_loss(netG(lr), hr)
+            (loss * scale).backward()
+            ex.start()
+            ex.wait()
+            if scale != 1.0:
+                spans, loose = DP.flat_grad_spans(netG.parameters())
+                for t in spans:
+                    t.mul_(1.0 / scale)
+                if loose:
+                    torch._foreach_mul_(loose, 1.0 / scale)
+            opt.step()
+        return loss
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(loss).all()
+    if rank == 0:
+        step_flops = 3.0 * 2.0 * MAC_PER_LR_PIXEL * lr_pix      # fwd + dgrad + wgrad (first-layer dgrad omitted: <0.1 %)
+        res = {'metric': 'HR megapixels/sec (x4 SR) generator train step (noise on, L1)', 'unit': 'HR-Mpix/s',
+               'value': round(world * 16 * lr_pix / 1e6 / (elapsed / args.steps), 3), 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f16' if prec == 'fp16' else 'f32', 'data': 'synthetic',
+               'config': {'workload': 'nESRGAN+ generator (RRDBNet nb=23, GaussianNoise on) fwd+bwd+Adam, L1 loss, mixed LR '
+                                      'tiles bucketed by size: 4x128^2 + 2x192^2 + 1x256^2 per GPU per step (BASELINE configs[4])',
+                          'lr_pixels_per_gpu_step': lr_pix, 'parallelism': 'dp%d, RCCL grad all-reduce per bucket' % world},
+               'tflops_per_gpu': round(step_flops / (elapsed / args.steps) / 1e12, 1)}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -169,9 +240,10 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--lr', type=int, default=LR)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--mode', choices=['forward', 'train'], default='forward',
+    ap.add_argument('--mode', choices=['forward', 'train', 'gtrain'], default='forward',
                     help="'forward' = BASELINE configs[1] (the headline metric); 'train' = configs[2]/[3]: "
-                         'full ESRGAN+ step, batch 16 of 32x32 LR per GPU, DP over RCCL')
+                         'full ESRGAN+ step, batch 16 of 32x32 LR per GPU, DP over RCCL; '
+                         "'gtrain' = configs[4]: noise-on generator fwd+bwd+Adam on mixed 128/192/256 LR tiles")
     ap.add_argument('--precision', choices=['fp16', 'fp32'], default='fp16')
     args = ap.parse_args()
 
@@ -203,6 +275,8 @@ def main():
     from esrganplus_amd import architecture as arch, synth, engine as E
     if args.mode == 'train':
         return train_bench(args, world, rank, dev, dist)
+    if args.mode == 'gtrain':
+        return gtrain_bench(args, world, rank, dev, dist)
     net = arch.RRDBNet(3, 3, 64, NB).to(dev).eval().set_precision('fp16')
     net.load_state_dict(synth.rrdbnet_state_dict(NB, 0), strict=True)
     x = synth.image_batch(100 + rank, args.batch, 3, args.lr, args.lr, name='bench.x').to(dev)
