@@ -166,7 +166,7 @@ def gtrain_bench(args, world, rank, dev, dist):
     on), forward + backward + Adam with an L1 pixel loss, on mixed LR tiles bucketed by size
     (128/192/256 -> HR 512/768/1024).  The reference's discriminators only accept HR 96/128/192
     crops, so at these sizes there is no GAN step to reproduce: generator-only, as SURVEY.md reads it.
-    One bench "step" = one optimizer iteration per bucket (4x128^2, 2x192^2, 1x256^2 LR per GPU)."""
+    One bench "step" = one optimizer iteration per bucket (16x128^2, 8x192^2, 4x256^2 LR per GPU: ~45 GB of saved activations, sized for 288 GB HBM)."""
     import torch.nn.functional as F
     from esrganplus_amd import architecture as arch, synth, dp as DP
     prec = args.precision
@@ -177,7 +177,7 @@ def gtrain_bench(args, world, rank, dev, dist):
     ex = DP.GradExchange(netG)
     scale = 1024.0 if prec == 'fp16' else 1.0
     buckets = []
-    for k, (n, sz) in enumerate(((4, 128), (2, 192), (1, 256))):
+    for k, (n, sz) in enumerate(((16, 128), (8, 192), (4, 256))):
         lr = synth.image_batch(400 + 10 * rank + k, n, 3, sz, sz, name='bench.glr').to(dev)
         hr = synth.image_batch(500 + 10 * rank + k, n, 3, 4 * sz, 4 * sz, name='bench.ghr').to(dev)
         buckets.append((lr, hr))
@@ -223,7 +223,7 @@ def gtrain_bench(args, world, rank, dev, dist):
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f16' if prec == 'fp16' else 'f32', 'data': 'synthetic',
                'config': {'workload': 'nESRGAN+ generator (RRDBNet nb=23, GaussianNoise on) fwd+bwd+Adam, L1 loss, mixed LR '
-                                      'tiles bucketed by size: 4x128^2 + 2x192^2 + 1x256^2 per GPU per step (BASELINE configs[4])',
+                                      'tiles bucketed by size: 16x128^2 + 8x192^2 + 4x256^2 per GPU per step (BASELINE configs[4])',
                           'lr_pixels_per_gpu_step': lr_pix, 'parallelism': 'dp%d, RCCL grad all-reduce per bucket' % world},
                'tflops_per_gpu': round(step_flops / (elapsed / args.steps) / 1e12, 1)}
         print(json.dumps(res), flush=True)

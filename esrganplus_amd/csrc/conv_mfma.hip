@@ -18,6 +18,7 @@
 #include <type_traits>
 #include <utility>
 
+#include <cstdlib>
 #include "common.h"
 
 #ifndef ESR_PROBES
@@ -661,14 +662,13 @@ int dispatch(const esr_conv& p, hipStream_t st) {
       return launch<T, 3, 1, 0, 4, 1, 1, 1, true, true>(p, st);
     }
     if (cbk == 1) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false>(p, st);
-    if (cbk <= 3) {
-      // small grids (training tiles): one 32-cout block per workgroup doubles the workgroup count and
-      // halves each one's MFMA chain; large grids keep two blocks per wave (each B fragment feeds 2 MFMAs)
-      const int64_t tiles = (int64_t)((p.W + 31) / 32) * ((p.H + 15) / 16) * p.B;
-      if (tiles * ((cbk + 1) / 2) < 256) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false>(p, st);
-      return launch<T, 3, 1, 0, 4, 1, 1, 2, true, false>(p, st);
-    }
-    return launch<T, 3, 1, 0, 2, 1, 4, 1, false, false>(p, st);
+    // Several cout blocks: grid.y walks them, ONE per workgroup on small grids (training tiles: twice
+    // the workgroups, half the MFMA chain each), TWO per wave otherwise (each B fragment feeds two
+    // MFMAs).  The 8-wave 2x4 register-weight kernel this used to switch to at >= 4 blocks lost on
+    // every shape measured (tools/wide_probe.py: 32->128 ... 256->256: 426-928 vs 474-1192 TF/s).
+    const int64_t tiles = (int64_t)((p.W + 31) / 32) * ((p.H + 15) / 16) * p.B;
+    if (tiles * ((cbk + 1) / 2) < 256) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false>(p, st);
+    return launch<T, 3, 1, 0, 4, 1, 1, 2, true, false>(p, st);
   }
   if (has1) { esr_set_error("conv: fused 1x1 only with 3x3/s1"); return ESR_ERR_UNSUPPORTED; }
   if (p.ks == 4 && p.stride == 1 && p.upsample == 2) {

@@ -213,30 +213,59 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
   const char* ibase = (const char*)p.in.ptr + b * p.in.batch_stride;
   const int y_begin = rc * rows_per_wg, y_end = min(p.H, y_begin + rows_per_wg);
 
-  for (int oy0 = y_begin; oy0 < y_end; oy0 += TR) {
-    __syncthreads();
-    // ---- stage g: NCO*2 groups x TR x TC pixels (zero outside the image)
-    for (int s = tid; s < NCO * 2 * TR * TC * 2; s += 512) {
+  // Software-pipelined staging: the NEXT row tile's g / input slots are fetched into registers while
+  // the MFMAs of the current tile run (the loop used to be load -> LDS -> barrier -> MFMA, ~3.7 us per
+  // tile of which 1.1 us is MFMA).  Input groups past the tensor's last one are never read by an
+  // active wave, so they are neither fetched nor zero-filled.
+  constexpr int GS = NCO * 2 * TR * TC * 2;                 // 16-byte slots of the g tile
+  constexpr int NG = (GS + 511) / 512;
+  const int in_groups = min(NCI * 2, ngin - (int)by * NCI * 2);
+  const int IS = in_groups > 0 ? in_groups * IH * IW * 2 : 0;
+  constexpr int NI = (NCI * 2 * IH * IW * 2 + 511) / 512;
+  u32x4 rg[NG], ri[NI];
+  auto fetch = [&](int oy0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int s = tid + 512 * k;
       const int half = s & 1, px = (s >> 1) % (TR * TC), g = (s >> 1) / (TR * TC);
       const int r = px / TC, c = px % TC;
       const int gg = (bz * NCO) * 2 + g;
       u32x4 v = {0, 0, 0, 0};
-      if (oy0 + r < y_end && ox0 + c < p.W && gg < p.g.ngroups)
+      if (s < GS && oy0 + r < y_end && ox0 + c < p.W && gg < p.g.ngroups)
         v = *(const u32x4*)(gbase + (int64_t)gg * p.g.group_stride + ((int64_t)(oy0 + r + 1) * p.g.wp + ox0 + c + 1) * 32 + half * 16);
-      *(u32x4*)(lg + (g * TR * TC + px) * 32 + half * 16) = v;
+      rg[k] = v;
     }
-    // ---- stage the input tile of NCI*2 groups with its halo
     const int iy0 = UPS ? oy0 / 2 : oy0 * S + 1 - PAD, ix0 = UPS ? ox0 / 2 : ox0 * S + 1 - PAD;
-    for (int s = tid; s < NCI * 2 * IH * IW * 2; s += 512) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int s = tid + 512 * k;
       const int half = s & 1, px = (s >> 1) % (IH * IW), g = (s >> 1) / (IH * IW);
       const int r = px / IW, c = px % IW;
       const int gg = by * NCI * 2 + g;
       u32x4 v = {0, 0, 0, 0};
-      if (gg < ngin)
+      if (s < IS)
         v = *(const u32x4*)(ibase + (int64_t)gg * p.in.group_stride + ((int64_t)(iy0 + r) * p.in.wp + ix0 + c) * 32 + half * 16);
-      *(u32x4*)(li + g * IN_GROUP + px * 32 + half * 16) = v;
+      ri[k] = v;
     }
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int s = tid + 512 * k;
+      if (s < GS) *(u32x4*)(lg + s * 16) = rg[k];           // [g][px][half] is slot-linear
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int s = tid + 512 * k;
+      if (s < IS) *(u32x4*)(li + s * 16) = ri[k];           // [g][px][half]: IN_GROUP = IH*IW*32 bytes per group
+    }
+  };
+  fetch(y_begin);
+  for (int oy0 = y_begin; oy0 < y_end; oy0 += TR) {
+    __syncthreads();                 // every wave is done reading the previous tile
+    stash();
     __syncthreads();
+    if (oy0 + TR < y_end) fetch(oy0 + TR);
     if (!active) continue;
     const char* lgw = lg + (wco * 2 + ghalf) * TR * TC * 32 + q * 8;
     const char* liw = li + (wci * 2 + ghalf) * IN_GROUP + q * 8;
@@ -330,6 +359,10 @@ __global__ __launch_bounds__(512) void wgrad16_batch_kernel(const WgradBatch pb)
 }
 
 // grid shape of one conv's fp16 wgrad (shared by the single and the batched launch)
+static int max_rows() {
+  static const int v = [] { const char* e = getenv("ESR_WGRAD_MAX_ROWS"); return e ? atoi(e) : 32; }();
+  return v;
+}
 struct Wg16Grid { int nco, gx, gy, gz, rows; };
 template <int S>
 Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs) {
@@ -344,6 +377,7 @@ Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs) {
   // Every workgroup ends with 8 waves x 9 taps x 1024 fp32 atomics, so use as FEW spatial splits as
   // still give ~min_wgs workgroups: start from whole column strips and halve only while the grid is tiny.
   int rows = ((p.H + 3) / 4) * 4;
+  if (rows > max_rows()) rows = max_rows();   // bound the serial load->LDS->MFMA iterations of one workgroup
   while (rows > 8 && (int64_t)p.B * strips * ((p.H + rows - 1) / rows) * g.gy * g.gz < min_wgs) rows = ((rows / 2 + 3) / 4) * 4;
   g.rows = rows;
   g.gx = p.B * strips * ((p.H + rows - 1) / rows);

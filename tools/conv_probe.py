@@ -18,9 +18,9 @@ def probe(cin, cout, res, flags, prec='fp16', ups=0, ks=3):
     wp = E.WeightPack([('c', w, b)], prec, dev)
     st = E.current_stream()
     wp.ensure(st, force=True)
-    src = E.G32(B, 192, H // (2 if ups else 1), W // (2 if ups else 1), prec, dev)
+    src = E.G32(B, max(192, cin), H // (2 if ups else 1), W // (2 if ups else 1), prec, dev)
     src.t.normal_()
-    dst = E.G32(B, 192, H, W, prec, dev)
+    dst = E.G32(B, max(192, cout), H, W, prec, dev)
     c = E._conv(wp.esr_dtype, B, H, W, src.view(0), cin, dst.view(0, cout), wp.entries['c'], L.ACT_LRELU, upsample=ups)
     if res:
         c.res1, c.alpha = dst.view(64, cout), 0.2
