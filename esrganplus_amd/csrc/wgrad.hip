@@ -365,7 +365,7 @@ static int max_rows() {
 }
 struct Wg16Grid { int nco, gx, gy, gz, rows; };
 template <int S>
-Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs) {
+Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs, int min_rows, int cap_rows) {
   const int strips = (p.W + 31) / 32;
   const int coblocks = (p.cout + 31) / 32;
   const int ciblocks = (p.in.ngroups + 1) / 2;
@@ -377,8 +377,8 @@ Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs) {
   // Every workgroup ends with 8 waves x 9 taps x 1024 fp32 atomics, so use as FEW spatial splits as
   // still give ~min_wgs workgroups: start from whole column strips and halve only while the grid is tiny.
   int rows = ((p.H + 3) / 4) * 4;
-  if (rows > max_rows()) rows = max_rows();   // bound the serial load->LDS->MFMA iterations of one workgroup
-  while (rows > 8 && (int64_t)p.B * strips * ((p.H + rows - 1) / rows) * g.gy * g.gz < min_wgs) rows = ((rows / 2 + 3) / 4) * 4;
+  if (rows > cap_rows) rows = cap_rows;       // bound the serial load->LDS->MFMA iterations of one workgroup
+  while (rows > min_rows && (int64_t)p.B * strips * ((p.H + rows - 1) / rows) * g.gy * g.gz < min_wgs) rows = ((rows / 2 + 3) / 4) * 4;
   g.rows = rows;
   g.gx = p.B * strips * ((p.H + rows - 1) / rows);
   return g;
@@ -386,7 +386,7 @@ Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs) {
 
 template <int KS, int S, bool UPS, int T0, int NT>
 int launch_wgrad16(const esr_wgrad& p, hipStream_t st) {
-  const Wg16Grid g = wgrad16_grid<S>(p, 64);
+  const Wg16Grid g = wgrad16_grid<S>(p, 64, 8, max_rows());
   dim3 grid(g.gx, g.gy, g.gz);
   if constexpr (S == 2) {
     hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(512), 0, st, p, g.rows);
@@ -472,7 +472,7 @@ extern "C" int esr_conv_wgrad(const esr_wgrad* p, esr_stream_t stream) {
 // spatial splits per conv inside a batched launch: every split costs a full set of dW atomics, and the
 // batch as a whole (not each conv) has to fill the chip
 static int batch_min_wgs() {
-  static const int v = [] { const char* e = getenv("ESR_WGRAD_MIN_WGS"); return e ? atoi(e) : 16; }();
+  static const int v = [] { const char* e = getenv("ESR_WGRAD_MIN_WGS"); return e ? atoi(e) : 64; }();
   return v;
 }
 
@@ -505,7 +505,10 @@ extern "C" int esr_conv_wgrad_multi(const esr_wgrad* items, int32_t n, esr_strea
     int total = 0;
     for (int k = 0; k < m; ++k) {
       const esr_wgrad& p = items[i + k];
-      const Wg16Grid g = wgrad16_grid<1>(p, batch_min_wgs());
+      // batched launch: every spatial split costs a full set of dW atomics (~5 us per million), so take
+      // the LARGEST row chunk that still gives each conv ~64 workgroups (6 convs fill the chip once),
+      // and never less than 32 rows
+      const Wg16Grid g = wgrad16_grid<1>(p, batch_min_wgs(), 32, 1 << 30);
       pb.start[k] = total;
       pb.gx[k] = g.gx; pb.gy[k] = g.gy; pb.rows[k] = g.rows;
       pb.kind[k] = (p.ks == 3 ? 0 : 2) + (g.nco == 2 ? 1 : 0);
