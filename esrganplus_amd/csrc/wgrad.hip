@@ -157,7 +157,7 @@ __device__ __forceinline__ u32x4 tr_frag(const char* lds_base, int off0, int off
   return r;
 }
 
-struct Acc10 { f32x16 a[10]; };
+struct Acc9 { f32x16 a[9]; };
 
 template <int KS, int S, bool UPS, int NCO>
 struct Wg16Geo {
@@ -201,13 +201,12 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
   const int i16 = lane & 15, jrow = i16 >> 2, q = i16 & 3, ghalf = (lane >> 4) & 1, kg = lane >> 5;
   const int pk = 8 * kg + jrow;                       // pixel of the 16-pixel run for read 0 (+4 for read 1)
 
-  Acc10 acc;
+  Acc9 acc;
+  float bsum = 0.f;     // bias gradient: this lane's share of sum_px g[co = cb*32 + lane%32][px]
 #pragma unroll
-  for (int t = 0; t < 10; ++t)
+  for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc.a[t][e] = 0.f;
-  // all-ones B fragment: column sums of g = bias gradient
-  const u32x4 ones = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
 
   const char* gbase = (const char*)p.g.ptr + b * p.g.batch_stride;
   const char* ibase = (const char*)p.in.ptr + b * p.in.batch_stride;
@@ -291,7 +290,13 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
           acc.a[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, af), __builtin_bit_cast(half8, bf), acc.a[tt], 0, 0, 0);
         }
         if (T0 == 0 && cib == 0 && p.dbias)
-          acc.a[9] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, af), __builtin_bit_cast(half8, ones), acc.a[9], 0, 0, 0);
+        {
+          // A-fragment layout: lane holds 8 consecutive pixels (k) of cout row lane%32 — summing them on
+          // the VALU costs one register instead of a 16-register all-ones-column accumulator
+          const half8 hv = __builtin_bit_cast(half8, af);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum += (float)hv[e];
+        }
       }
     }
   }
@@ -311,12 +316,9 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
       }
     }
   }
-  if (T0 == 0 && cib == 0 && p.dbias && n == 0) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
-      if (co < p.cout) atomicAdd(p.dbias + co, acc.a[9][e] * p.scale);
-    }
+  if (T0 == 0 && cib == 0 && p.dbias) {
+    const int co = cb * 32 + (lane & 31);          // lanes l and l+32 hold the two k halves of row l%32
+    if (co < p.cout) atomicAdd(p.dbias + co, bsum * p.scale);
   }
 }
 
