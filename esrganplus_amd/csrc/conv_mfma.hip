@@ -612,24 +612,40 @@ __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_c
 // halo pixels owned by neighbouring workgroups are NOT synchronised, so results are wrong — the
 // timing is the upper bound of what an image-synchronised persistent RDB kernel could gain.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void rdb_nosync_kernel(const esr_conv* convs) {
+__global__ __launch_bounds__(256, 2) void rdb_nosync_kernel(const esr_conv* convs, const int delay_ticks, const int nrep) {
   using G1 = Geo<3, 1, 0, 4, 1, 1, 1, true, true>;
   using G2 = Geo<3, 1, 0, 4, 1, 1, 2, true, false>;
   constexpr int LDS = G1::LDS_BYTES > G2::LDS_BYTES ? G1::LDS_BYTES : G2::LDS_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[LDS];
-  conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, false, false>(convs[0], smem, blockIdx.x, gridDim.x, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, true, false>(convs[1], smem, blockIdx.x, gridDim.x, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, false, false>(convs[2], smem, blockIdx.x, gridDim.x, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, false, false>(convs[3], smem, blockIdx.x, gridDim.x, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  conv_body<T, 3, 1, 0, 4, 1, 1, 2, true, false, false>(convs[4], smem, blockIdx.x, gridDim.x, 0);
+  // staggering probe: workgroups of odd images start `delay_ticks` (10 ns) late, so the two
+  // workgroups sharing a CU run their K loops / epilogues out of phase for the rest of the launch
+  if (delay_ticks > 0) {
+    const int tiles_per_img = ((convs[0].W + 31) / 32) * ((convs[0].H + 15) / 16);
+    int t;
+    { const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3); }
+    if ((t / tiles_per_img) & 1) {
+      const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+      while ((int64_t)(__builtin_amdgcn_s_memrealtime() - t0) < delay_ticks) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  for (int rep = 0; rep < nrep; ++rep) {
+    conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, false, false>(convs[0], smem, blockIdx.x, gridDim.x, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, true, false>(convs[1], smem, blockIdx.x, gridDim.x, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, false, false>(convs[2], smem, blockIdx.x, gridDim.x, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, false, false>(convs[3], smem, blockIdx.x, gridDim.x, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_body<T, 3, 1, 0, 4, 1, 1, 2, true, false, false>(convs[4], smem, blockIdx.x, gridDim.x, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 }
 
 template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
@@ -690,7 +706,11 @@ int dispatch(const esr_conv& p, hipStream_t st) {
 }  // namespace
 
 extern "C" int esr_rdb_nosync_probe(const esr_conv* dev_convs, int32_t tiles, esr_stream_t stream) {
-  hipLaunchKernelGGL(rdb_nosync_kernel<_Float16>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, dev_convs);
+  // measurement-only knobs: ESR_PROBE_DELAY (10 ns ticks, odd images start late), ESR_PROBE_NREP (RDBs per launch)
+  const char* e = getenv("ESR_PROBE_DELAY");
+  const char* r = getenv("ESR_PROBE_NREP");
+  hipLaunchKernelGGL(rdb_nosync_kernel<_Float16>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, dev_convs,
+                     e ? atoi(e) : 0, r ? atoi(r) : 1);
   return esr_check_launch("rdb_nosync_kernel");
 }
 

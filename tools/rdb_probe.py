@@ -45,4 +45,5 @@ for c in convs:
 print('batch', BATCH)
 for _ in range(2):
     print('5 launches              %.1f us per RDB' % timed(lambda: one.run(st), 200))
-    print('1 launch (no halo sync) %.1f us per RDB' % timed(lambda: L.check(lib.esr_rdb_nosync_probe(dbuf.data_ptr(), tiles, st)), 200))
+    nrep = int(os.environ.get('ESR_PROBE_NREP', '1'))
+    print('1 launch (no halo sync, %d RDBs per launch, delay %s ticks) %.1f us per RDB' % (nrep, os.environ.get('ESR_PROBE_DELAY', '0'), timed(lambda: L.check(lib.esr_rdb_nosync_probe(dbuf.data_ptr(), tiles, st)), 100) / nrep))
