@@ -175,11 +175,24 @@ class _PlannedModule(nn.Module):
     def _dgrad_special(self):
         return {}
 
+    def _dgrad_extra(self, device):
+        """Constant operands of the backward plan that are not parameters."""
+        return []
+
+    def _eye_operand(self, device):
+        # 1x1 identity kernel: carries the incoming gradient of a stand-alone block through the conv
+        # epilogue's noise / scale stages (engine.build_rrdbnet_train_plan, kind 'rdb' / 'rrdb')
+        eye = getattr(self, '_eye64', None)
+        if eye is None or eye.device != torch.device(device):
+            eye = torch.eye(64, device=device).view(64, 64, 1, 1).contiguous()
+            self._eye64 = eye
+        return [('__eye', eye)]
+
     def _dgrad_weights(self, device):
         key = ('dgrad', self.precision, str(device))
         dp = self._wp.get(key)
         if dp is None:
-            convs = [(k, w) for k, w, _ in self._conv_list()]
+            convs = [(k, w) for k, w, _ in self._conv_list()] + self._dgrad_extra(device)
             dp = E.DgradPack(convs, self.precision, device, self._dgrad_special())
             self._wp[key] = dp
         return dp
@@ -229,6 +242,12 @@ class ResidualDenseBlock_5C(_PlannedModule):
     def _conv_list(self):
         return _rdb_convs('rdb', self)
 
+    def _dgrad_special(self):
+        return {'rdb.conv5.0': dict(sum=(96, 160, 32))}
+
+    def _dgrad_extra(self, device):
+        return self._eye_operand(device)
+
     def forward(self, x, z=None):
         from .functional import run_block
         return run_block(self, 'rdb', x, z)
@@ -253,6 +272,12 @@ class RRDB(_PlannedModule):
         for j in (1, 2, 3):
             out += _rdb_convs('rrdb.RDB%d' % j, getattr(self, 'RDB%d' % j))
         return out
+
+    def _dgrad_special(self):
+        return {'rrdb.RDB%d.conv5.0' % j: dict(sum=(96, 160, 32)) for j in (1, 2, 3)}
+
+    def _dgrad_extra(self, device):
+        return self._eye_operand(device)
 
     def forward(self, x, z=None):
         from .functional import run_block

@@ -491,22 +491,34 @@ class TrainPlan:
         self.grad_flat = None        # fp32 flat gradient buffer; views per parameter
         self.grad_views = None
         self.tapmajor = None
+        self.gx_op = None            # stand-alone blocks: layout op exporting dL/dx (NCHW fp32)
 
 
 def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, device, noise, variant,
-                             explicit_z):
+                             explicit_z, kind='net'):
     """RRDBNet forward keeping every RDB concat buffer (+ pre-residual activations of conv2/conv4,
     whose signs are the LeakyReLU masks) and the backward pass:
       * input gradients = the same fused conv kernel over transposed/rotated weights, with the
         LeakyReLU-mask / noise / residual-scale backward applied in its epilogue;
-      * weight/bias gradients = esr_conv_wgrad."""
+      * weight/bias gradients = esr_conv_wgrad.
+    kind 'net' = the whole generator; 'rrdb' / 'rdb' = a stand-alone RRDB / ResidualDenseBlock_5C
+    (64-channel NCHW in and out, gradient w.r.t. the input returned): same block code, no head/tail."""
     dt_e, tdtype, cpg = _dt(dtype)
+    block = kind != 'net'
+    nj = 1 if kind == 'rdb' else 3                 # dense blocks per RRDB
+    if block:
+        nb = 1
+
+    def pkey(i, j):
+        if kind == 'rdb':
+            return 'rdb'
+        return ('rrdb.RDB%d' % (j + 1)) if kind == 'rrdb' else 'model.1.sub.%d.RDB%d' % (i, j + 1)
     TP = TrainPlan()
     P = TP.fwd
     e = wp.entries
     d = dt_e
     per = 4 if variant == 'test_image' else 3
-    n_noise = per * nb if noise else 0
+    n_noise = ((1 if kind == 'rdb' else per * nb) if noise else 0)
 
     def buf(C_, h=H, w=W):
         b = G32(B, C_, h, w, dtype, device)
@@ -536,19 +548,22 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             setattr(c, 'z%d' % slot, zb[lid].view(0, 64))
 
     # ------------------------------------------------------------------ forward
-    xin, fea = buf(in_nc), buf(64)
-    S = [[buf(192) for _ in range(3)] for _ in range(nb)]
-    AUX = [[buf(64) for _ in range(3)] for _ in range(nb)]
+    S = [[buf(192) for _ in range(nj)] for _ in range(nb)]
+    AUX = [[buf(64) for _ in range(nj)] for _ in range(nb)]
     XF = buf(64)                                   # output of the last RRDB
-    P.in_op = imp(P.ops, xin, in_nc)
-    c = _conv(d, B, H, W, xin.view(0), in_nc, (S[0][0] if nb else XF).view(0, 64), e['model.0'])
-    c.aux_out = fea.view(0, 64)
-    P.ops.add_conv(c)
+    if block:
+        P.in_op = imp(P.ops, S[0][0], 64)          # x straight into the concat buffer's first slice
+    else:
+        xin, fea = buf(in_nc), buf(64)
+        P.in_op = imp(P.ops, xin, in_nc)
+        c = _conv(d, B, H, W, xin.view(0), in_nc, (S[0][0] if nb else XF).view(0, 64), e['model.0'])
+        c.aux_out = fea.view(0, 64)
+        P.ops.add_conv(c)
     for i in range(nb):
-        for j in range(3):
+        for j in range(nj):
             bf, ax = S[i][j], AUX[i][j]
-            bn = S[i][j + 1] if j < 2 else (S[i + 1][0] if i + 1 < nb else XF)
-            p = 'model.1.sub.%d.RDB%d' % (i, j + 1)
+            bn = S[i][j + 1] if j < nj - 1 else (S[i + 1][0] if i + 1 < nb else XF)
+            p = pkey(i, j)
             P.ops.add_conv(_conv(d, B, H, W, bf.view(0), 64, bf.view(64, 32), e[p + '.conv1.0'], L.ACT_LRELU))
             c = _conv(d, B, H, W, bf.view(0), 96, bf.view(96, 32), e[p + '.conv2.0'], L.ACT_LRELU)
             c.w1x1, c.n1x1_groups = e[p + '.conv1x1'].w_ptr, 64 // cpg
@@ -562,25 +577,33 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             c = _conv(d, B, H, W, bf.view(0), 192, bn.view(0, 64), e[p + '.conv5.0'], L.ACT_NONE)
             c.res1, c.alpha = bf.view(0, 64), 0.2
             set_noise(c, 1, per * i + j)
-            if j == 2:
+            if j == 2 and kind != 'rdb':
                 c.res2, c.beta = S[i][0].view(0, 64), 0.2
                 if variant == 'test_image':
                     set_noise(c, 2, per * i + 3)
             k = P.ops.add_conv(c)
             if noise:
                 P.noise_ops.append(k)
-    T_ = buf(64)
-    c = _conv(d, B, H, W, XF.view(0), 64, T_.view(0, 64), e['model.1.sub.%d' % nb])
-    c.res1, c.alpha = fea.view(0, 64), 1.0
-    P.ops.add_conv(c)
-    U1, U2, U3 = buf(64, 2 * H, 2 * W), buf(64, 4 * H, 4 * W), buf(64, 4 * H, 4 * W)
-    P.ops.add_conv(_conv(d, B, 2 * H, 2 * W, T_.view(0), 64, U1.view(0, 64), e['model.3'], L.ACT_LRELU, upsample=1))
-    P.ops.add_conv(_conv(d, B, 4 * H, 4 * W, U1.view(0), 64, U2.view(0, 64), e['model.6'], L.ACT_LRELU, upsample=1))
-    P.ops.add_conv(_conv(d, B, 4 * H, 4 * W, U2.view(0), 64, U3.view(0, 64), e['model.8'], L.ACT_LRELU))
-    c = _conv(d, B, 4 * H, 4 * W, U3.view(0), 64, None, e['model.10'])
-    c.nchw_out_c = out_nc
-    P.out_op = P.ops.add_conv(c)
-    P.out_shape = (B, out_nc, 4 * H, 4 * W)
+    if block:
+        lo = L.esr_layout()
+        lo.dtype, lo.to_g32 = dt_e, 0
+        lo.B, lo.C, lo.H, lo.W = B, 64, H, W
+        lo.g32 = XF.view(0, 64)
+        P.out_op = P.ops.add(L.OP_LAYOUT, 'layout', lo)
+        P.out_shape = (B, 64, H, W)
+    T_ = buf(64) if not block else None
+    if not block:
+        c = _conv(d, B, H, W, XF.view(0), 64, T_.view(0, 64), e['model.1.sub.%d' % nb])
+        c.res1, c.alpha = fea.view(0, 64), 1.0
+        P.ops.add_conv(c)
+        U1, U2, U3 = buf(64, 2 * H, 2 * W), buf(64, 4 * H, 4 * W), buf(64, 4 * H, 4 * W)
+        P.ops.add_conv(_conv(d, B, 2 * H, 2 * W, T_.view(0), 64, U1.view(0, 64), e['model.3'], L.ACT_LRELU, upsample=1))
+        P.ops.add_conv(_conv(d, B, 4 * H, 4 * W, U1.view(0), 64, U2.view(0, 64), e['model.6'], L.ACT_LRELU, upsample=1))
+        P.ops.add_conv(_conv(d, B, 4 * H, 4 * W, U2.view(0), 64, U3.view(0, 64), e['model.8'], L.ACT_LRELU))
+        c = _conv(d, B, 4 * H, 4 * W, U3.view(0), 64, None, e['model.10'])
+        c.nchw_out_c = out_nc
+        P.out_op = P.ops.add_conv(c)
+        P.out_shape = (B, out_nc, 4 * H, 4 * W)
 
     # ------------------------------------------------------------------ gradient storage
     plist = [(k, w, b_) for k, w, b_ in net._conv_list()]
@@ -636,11 +659,16 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         else:
             Bk.add(L.OP_WGRAD, 'wgrad', wg)
 
-    GY = buf(out_nc, 4 * H, 4 * W)
-    TP.gy_op = imp(Bk, GY, out_nc)
-    GA8, GA6 = buf(64, 4 * H, 4 * W), buf(64, 4 * H, 4 * W)
-    GA3 = buf(64, 2 * H, 2 * W)
-    GTt = buf(64)                                   # dL/dT (trunk output)
+    if block:
+        GY = buf(64)
+        TP.gy_op = imp(Bk, GY, 64)
+        GTt = None
+    else:
+        GY = buf(out_nc, 4 * H, 4 * W)
+        TP.gy_op = imp(Bk, GY, out_nc)
+        GA8, GA6 = buf(64, 4 * H, 4 * W), buf(64, 4 * H, 4 * W)
+        GA3 = buf(64, 2 * H, 2 * W)
+        GTt = buf(64)                               # dL/dT (trunk output)
     gA = [buf(64), buf(64)]                         # RRDB skip gradient A(i), ping-pong
     # The six weight gradients of a block run on the side stream, concurrently with the NEXT block's
     # dgrad chain (both are latency-bound, ~64-workgroup launches at training sizes), and are joined
@@ -651,41 +679,59 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
     rdb_no = 0
     GF = buf(64)                                    # dL/dfea
 
-    # HR_conv1 (model.10): u3 -> y
-    wgrad('model.10', GY.view(0, out_nc), U3.view(0, 64), 4 * H, 4 * W, out_nc, 64)
-    c = dconv(4 * H, 4 * W, GY.view(0), out_nc, None, 'model.10')
-    c.mask, c.out2, c.mask_cb_begin = U3.view(0, 64), GA8.view(0, 64), 0
-    add_b(c)
-    # HR_conv0 (model.8): u2 -> u3 (lrelu)
-    wgrad('model.8', GA8.view(0, 64), U2.view(0, 64), 4 * H, 4 * W, 64, 64)
-    c = dconv(4 * H, 4 * W, GA8.view(0), 64, None, 'model.8')
-    c.mask, c.out2 = U2.view(0, 64), GA6.view(0, 64)
-    add_b(c)
-    # upconv 2 (model.6): up(u1) -> u2 ; adjoint = 4x4/s2 conv
-    wgrad('model.6', GA6.view(0, 64), U1.view(0, 64), 4 * H, 4 * W, 64, 64, ups=1)
-    c = dconv(2 * H, 2 * W, GA6.view(0), 64, None, 'model.6', ks=4, stride=2)
-    c.mask, c.out2 = U1.view(0, 64), GA3.view(0, 64)
-    add_b(c)
-    # upconv 1 (model.3): up(T) -> u1
-    wgrad('model.3', GA3.view(0, 64), T_.view(0, 64), 2 * H, 2 * W, 64, 64, ups=1)
-    add_b(dconv(H, W, GA3.view(0), 64, GTt.view(0, 64), 'model.3', ks=4, stride=2))
-    # LR_conv (model.1.sub.nb): XF -> T - fea
-    lrk = 'model.1.sub.%d' % nb
-    wgrad(lrk, GTt.view(0, 64), XF.view(0, 64), H, W, 64, 64)
-    c = dconv(H, W, GTt.view(0), 64, gA[0].view(0, 64) if nb else GF.view(0, 64), lrk)
-    if nb:
-        if variant == 'test_image':
-            set_noise(c, 2, per * (nb - 1) + 3)
-        c.out3, c.gamma = gT[0].view(0, 64), 0.2
-        set_noise(c, 3, per * (nb - 1) + 2)
+    if block:
+        # Entry of the chain: the incoming gradient through the block's own tail.
+        #   rdb : y = (0.2 x5 + x) n            -> g_t = g_y n
+        #   rrdb: y = ((t3 n2) 0.2 + x) [n3']   -> skip gradient A = g_y [n3'],  g_t3 = 0.2 A n2
+        # = a 1x1 identity "conv" (key '__eye') whose epilogue applies the noise / scale stages.
+        c = dconv(H, W, GY.view(0), 64, None, '__eye')
+        if kind == 'rdb':
+            c.out = gT[0].view(0, 64)
+            set_noise(c, 2, 0)
+        else:
+            c.out = gA[0].view(0, 64)
+            if variant == 'test_image':
+                set_noise(c, 2, 3)
+            c.out3, c.gamma = gT[0].view(0, 64), 0.2
+            set_noise(c, 3, 2)
+        add_b(c, noisy=True)
     else:
-        c.res1 = GTt.view(0, 64)                    # fea feeds both the trunk and the shortcut
-    add_b(c, noisy=bool(nb))
+        # HR_conv1 (model.10): u3 -> y
+        wgrad('model.10', GY.view(0, out_nc), U3.view(0, 64), 4 * H, 4 * W, out_nc, 64)
+        c = dconv(4 * H, 4 * W, GY.view(0), out_nc, None, 'model.10')
+        c.mask, c.out2, c.mask_cb_begin = U3.view(0, 64), GA8.view(0, 64), 0
+        add_b(c)
+        # HR_conv0 (model.8): u2 -> u3 (lrelu)
+        wgrad('model.8', GA8.view(0, 64), U2.view(0, 64), 4 * H, 4 * W, 64, 64)
+        c = dconv(4 * H, 4 * W, GA8.view(0), 64, None, 'model.8')
+        c.mask, c.out2 = U2.view(0, 64), GA6.view(0, 64)
+        add_b(c)
+        # upconv 2 (model.6): up(u1) -> u2 ; adjoint = 4x4/s2 conv
+        wgrad('model.6', GA6.view(0, 64), U1.view(0, 64), 4 * H, 4 * W, 64, 64, ups=1)
+        c = dconv(2 * H, 2 * W, GA6.view(0), 64, None, 'model.6', ks=4, stride=2)
+        c.mask, c.out2 = U1.view(0, 64), GA3.view(0, 64)
+        add_b(c)
+        # upconv 1 (model.3): up(T) -> u1
+        wgrad('model.3', GA3.view(0, 64), T_.view(0, 64), 2 * H, 2 * W, 64, 64, ups=1)
+        add_b(dconv(H, W, GA3.view(0), 64, GTt.view(0, 64), 'model.3', ks=4, stride=2))
+        # LR_conv (model.1.sub.nb): XF -> T - fea
+        lrk = 'model.1.sub.%d' % nb
+        wgrad(lrk, GTt.view(0, 64), XF.view(0, 64), H, W, 64, 64)
+        c = dconv(H, W, GTt.view(0), 64, gA[0].view(0, 64) if nb else GF.view(0, 64), lrk)
+        if nb:
+            if variant == 'test_image':
+                set_noise(c, 2, per * (nb - 1) + 3)
+            c.out3, c.gamma = gT[0].view(0, 64), 0.2
+            set_noise(c, 3, per * (nb - 1) + 2)
+        else:
+            c.res1 = GTt.view(0, 64)                    # fea feeds both the trunk and the shortcut
+        add_b(c, noisy=bool(nb))
     ca, ct = 0, 0
+    GX = buf(64) if block else None                 # dL/dx of a stand-alone block
     for i in range(nb - 1, -1, -1):
-        for j in (2, 1, 0):
+        for j in range(nj - 1, -1, -1):
             bf, ax = S[i][j], AUX[i][j]
-            p = 'model.1.sub.%d.RDB%d' % (i, j + 1)
+            p = pkey(i, j)
             gt = gT[ct]
             G, GA = Gs[rdb_no & 1], GAs[rdb_no & 1]
             rdb_no += 1
@@ -720,7 +766,7 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             wgrad(p + '.conv1x1', G.view(96, 32), bf.view(0, 64), H, W, 32, 64, ks=1)
             c = dconv(H, W, G.view(96), 32, G.view(0, 64), p + '.conv1x1')
             c.res1 = G.view(0, 64)
-            if i == 0 and j == 0:
+            if i == 0 and j == 0 and not block:
                 c.res2, c.beta = GTt.view(0, 64), 1.0    # trunk shortcut: fea also feeds T directly
             add_b(c)
             # conv1: closes the block: g_x = conv1^T(g_a1) + G[x]  (+ RRDB skip for RDB1)
@@ -732,9 +778,13 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
                 c.out = gT[(ct + 1) % 3].view(0, 64)
                 set_noise(c, 2, per * i + j - 1)
                 ct = (ct + 1) % 3
+            elif kind == 'rdb':
+                c.out = GX.view(0, 64)
             else:
                 c.res2, c.beta = gA[ca].view(0, 64), 1.0
-                if i > 0:
+                if block:
+                    c.out = GX.view(0, 64)
+                elif i > 0:
                     c.out = gA[ca ^ 1].view(0, 64)
                     if variant == 'test_image':
                         set_noise(c, 2, per * (i - 1) + 3)
@@ -748,10 +798,20 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             for wg in deferred:
                 Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE)
             deferred = None
-    # fea_conv (model.0): weight gradient only (the LR input image needs no gradient)
-    wgrad('model.0', GF.view(0, 64), xin.view(0, in_nc), H, W, 64, in_nc)
+    if block:
+        lo = L.esr_layout()
+        lo.dtype, lo.to_g32 = dt_e, 0
+        lo.B, lo.C, lo.H, lo.W = B, 64, H, W
+        lo.g32 = GX.view(0, 64)
+        TP.gx_op = None                             # bound after the unpermute op is appended
+        gx_layout = lo
+    else:
+        # fea_conv (model.0): weight gradient only (the LR input image needs no gradient)
+        wgrad('model.0', GF.view(0, 64), xin.view(0, in_nc), H, W, 64, in_nc)
     if TP.tapmajor is not None:
         up = TP.tapmajor.op()
         if up is not None:
             Bk.add(L.OP_UNPERMUTE, 'unpermute', up)
+    if block:
+        TP.gx_op = Bk.add(L.OP_LAYOUT, 'layout', gx_layout)
     return TP

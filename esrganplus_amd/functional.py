@@ -41,8 +41,20 @@ def _zs_list(z, n, shape, device):
 def run_block(mod, kind, x, z=None):
     """ResidualDenseBlock_5C / RRDB forward (block.py:260-268, 287-291) on the HIP path."""
     if _needs_grad(mod, x):
-        raise NotImplementedError('autograd through a stand-alone %s is not wired yet; use '
-                                  'torch.no_grad() or the full RRDBNet' % kind)
+        E.require_cuda(x, 'input')
+        B, C_, H, W = x.shape
+        if C_ != 64:
+            raise ValueError('expected 64 input channels, got %d' % C_)
+        has_noise = getattr(mod, 'noise', None) is not None if kind == 'rdb' else True
+        noise = bool(mod.training and has_noise)
+        n_noise = 0 if not noise else (1 if kind == 'rdb' else (4 if mod.variant == 'test_image' else 3))
+        zs = _zs_list(z, n_noise, (B, 64, H, W), x.device) if noise else None
+        params = []
+        for _, w, b in mod._conv_list():
+            params.append(w)
+            if b is not None:
+                params.append(b)
+        return _BlockFn.apply(x, mod, kind, noise, zs, *params)
     xin = _prep_input(x, 'input')
     B, C_, H, W = xin.shape
     if C_ != 64:
@@ -149,6 +161,75 @@ class _RRDBNetFn(torch.autograd.Function):
         assert len(grads) == ctx.n_params
         grads = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:])]
         return (None, None, None) + tuple(grads)
+
+
+def _block_train_plan(mod, kind, wp, dp, B, H, W, dev, noise, explicit):
+    key = ('train', kind, B, H, W, mod.precision, noise, explicit, wp.generation, str(dev))
+    pool = mod._plans.setdefault(key, [])
+    for tp in pool:
+        if not tp.busy:
+            return tp
+    tp = E.build_rrdbnet_train_plan(mod, wp, dp, 1, 64, 64, B, H, W, mod.precision, dev, noise,
+                                    mod.variant, explicit, kind=kind)
+    pool.append(tp)
+    return tp
+
+
+class _BlockFn(torch.autograd.Function):
+    """Stand-alone ResidualDenseBlock_5C / RRDB (block.py:260-268, 287-291) forward + backward as one
+    autograd node; unlike the whole generator it also returns the gradient w.r.t. its input."""
+
+    @staticmethod
+    def forward(ctx, x, mod, kind, noise, zs, *params):
+        xin = _prep_input(x, 'input')
+        B, _, H, W = xin.shape
+        dev = xin.device
+        st = E.current_stream()
+        wp = mod._weights(dev)
+        dp = mod._dgrad_weights(dev)
+        dp.ensure(st)
+        tp = _block_train_plan(mod, kind, wp, dp, B, H, W, dev, noise, zs is not None)
+        ctx.lease = _PlanLease(tp)
+        ctx.seed = _draw_seed() if (noise and zs is None) else 0
+        ctx.explicit, ctx.noise, ctx.n_params = zs is not None, noise, len(params)
+        out = torch.empty(tp.fwd.out_shape, dtype=torch.float32, device=dev)
+        tp.fwd.run(xin, out, st, ctx.seed, zs)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        tp = ctx.lease.tp
+        if tp is None:
+            raise RuntimeError('backward called twice (retain_graph is not supported: the saved '
+                               'activations live in a reusable launch plan)')
+        gy = gy.detach().contiguous().float()
+        st = E.current_stream()
+        tp.grad_flat.zero_()
+        if tp.tapmajor is not None:
+            tp.tapmajor.tm.zero_()
+        gx = torch.empty_like(gy)
+        arr = tp.bwd.array()
+        arr[tp.gy_op].u.layout.nchw = gy.data_ptr()
+        arr[tp.gx_op].u.layout.nchw = gx.data_ptr()
+        mode = L.NOISE_OFF
+        if ctx.noise:
+            mode = L.NOISE_EXPLICIT if ctx.explicit else L.NOISE_PHILOX
+        for i in tp.bwd_noise_ops:
+            arr[i].u.conv.noise_mode = mode
+            arr[i].u.conv.seed = ctx.seed
+        tp.bwd.run(st)
+        flat = tp.grad_flat.clone()
+        ctx.lease.release()
+        grads, off = [], 0
+        for gw, gb in tp.grad_views:
+            grads.append(flat[off:off + gw.numel()].view_as(gw))
+            off += gw.numel()
+            if gb is not None:
+                grads.append(flat[off:off + gb.numel()].view_as(gb))
+                off += gb.numel()
+        assert len(grads) == ctx.n_params
+        grads = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[5:])]
+        return (gx if ctx.needs_input_grad[0] else None, None, None, None, None) + tuple(grads)
 
 
 def run_rrdbnet(net, x, z=None):
