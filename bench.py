@@ -173,7 +173,8 @@ def gtrain_bench(args, world, rank, dev, dist):
     netG = arch.RRDBNet(3, 3, 64, NB).to(dev).train().set_precision(prec)
     netG.load_state_dict(synth.rrdbnet_state_dict(NB, 0, gain=0.5))
     DP.broadcast_parameters(netG)
-    opt = torch.optim.Adam(netG.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    from esrganplus_amd.optim import FusedAdam
+    opt = FusedAdam(netG.parameters(), lr=1e-4, betas=(0.9, 0.999))
     ex = DP.GradExchange(netG)
     scale = 1024.0 if prec == 'fp16' else 1.0
     buckets = []
@@ -190,13 +191,7 @@ def gtrain_bench(args, world, rank, dev, dist):
             (loss * scale).backward()
             ex.start()
             ex.wait()
-            if scale != 1.0:
-                spans, loose = DP.flat_grad_spans(netG.parameters())
-                for t in spans:
-                    t.mul_(1.0 / scale)
-                if loose:
-                    torch._foreach_mul_(loose, 1.0 / scale)
-            opt.step()
+            opt.step(grad_scale=1.0 / scale)
         return loss
 
     for _ in range(max(args.warmup, 1)):

@@ -1,0 +1,112 @@
+"""Fused multi-tensor Adam for the ESRGAN+ train step.
+
+The reference builds two ``torch.optim.Adam`` instances over ~770 (G) and 42 (D) parameter tensors
+(SRRaGAN_model.py:77-91) and steps them every iteration; on a GPU that is ~8 ``foreach`` launches per
+optimizer plus a per-parameter gradient un-scaling pass under loss scaling.  ``FusedAdam`` is a
+drop-in ``torch.optim.Optimizer`` (so ``lr_scheduler.MultiStepLR`` and ``state_dict`` plumbing keep
+working, train.py:102 / base_model.py:35-40) whose ``step`` is ONE HIP launch (``esr_adam_step``):
+moments live in two flat fp32 buffers laid out like the flat gradient buffer the fused backward nodes
+emit, the loss-scale division is folded in (``grad_scale``), parameters stay ordinary leaf tensors.
+Same arithmetic as torch.optim.Adam (amsgrad off, L2 weight decay)."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import dp as DP
+from . import engine as E
+
+
+def adam_tables(sizes):
+    """Host-side launch tables: (goff per tensor, blocks [(entry, first_elem)]).  Every element of
+    every tensor is covered by exactly one block of at most ADAM_BLOCK_ELEMS elements."""
+    goff, blocks, off = [], [], 0
+    for e, n in enumerate(sizes):
+        goff.append(off)
+        off += n
+        for first in range(0, n, L.ADAM_BLOCK_ELEMS):
+            blocks.append((e, first))
+    return goff, blocks, off
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._g = {}          # per param group: device tables + flat moment buffers
+
+    def _group_state(self, gi, params):
+        st = self._g.get(gi)
+        sig = tuple((p.data_ptr(), p.numel()) for p in params)
+        if st is not None and st['sig'] == sig:
+            return st
+        dev = params[0].device
+        E.require_cuda(params[0], 'FusedAdam parameter')
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+                raise L.HipExtensionError('FusedAdam needs contiguous fp32 parameters on one device')
+        sizes = [p.numel() for p in params]
+        goff, blocks, total = adam_tables(sizes)
+        ent = np.zeros((len(params), 3), dtype=np.int64)
+        for i, p in enumerate(params):
+            ent[i] = (p.data_ptr(), goff[i], sizes[i])
+        blk = np.asarray(blocks, dtype=np.int32).reshape(-1, 2)
+        old = st or {}
+        st = dict(sig=sig, total=total, goff=goff, sizes=sizes,
+                  entries=torch.from_numpy(ent).to(dev), blocks=torch.from_numpy(blk).to(dev),
+                  nblocks=len(blocks),
+                  exp_avg=old.get('exp_avg') if old.get('total') == total else torch.zeros(total, device=dev),
+                  exp_avg_sq=old.get('exp_avg_sq') if old.get('total') == total else torch.zeros(total, device=dev),
+                  step=old.get('step', 0) if old.get('total') == total else 0, stage=None)
+        self._g[gi] = st
+        return st
+
+    def _flat_grad(self, st, params):
+        """The gradients as one flat fp32 tensor in parameter order: zero-copy when they already are
+        views tiling one buffer in that order (what the fused backward nodes emit), else staged."""
+        g0 = params[0].grad
+        base = g0.storage_offset()
+        ok = g0.dtype == torch.float32
+        if ok:
+            sp = g0.untyped_storage().data_ptr()
+            for p, off in zip(params, st['goff']):
+                g = p.grad
+                if (g is None or g.dtype != torch.float32 or not g.is_contiguous()
+                        or g.untyped_storage().data_ptr() != sp or g.storage_offset() != base + off):
+                    ok = False
+                    break
+        if ok:
+            return torch.empty(0, dtype=torch.float32, device=g0.device).set_(
+                g0.untyped_storage(), base, (st['total'],))
+        if st['stage'] is None:
+            st['stage'] = torch.zeros(st['total'], device=params[0].device)
+        views = [st['stage'][o:o + n].view_as(p) for p, o, n in zip(params, st['goff'], st['sizes'])]
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+        torch._foreach_copy_(views, [g.to(torch.float32) for g in grads])
+        return st['stage']
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        """``grad_scale`` multiplies every gradient on the fly (1/loss_scale under loss scaling)."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        stream = E.current_stream()
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group['params'] if p.requires_grad]
+            if not params or all(p.grad is None for p in params):
+                continue
+            st = self._group_state(gi, params)
+            flat = self._flat_grad(st, params)
+            st['step'] += 1
+            b1, b2 = group['betas']
+            a = L.esr_adam()
+            a.entries, a.blocks, a.nblocks = st['entries'].data_ptr(), st['blocks'].data_ptr(), st['nblocks']
+            a.grad, a.exp_avg, a.exp_avg_sq = flat.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
+            a.lr, a.beta1, a.beta2, a.eps = group['lr'], b1, b2, group['eps']
+            a.bc1, a.bc2 = 1.0 - math.pow(b1, st['step']), 1.0 - math.pow(b2, st['step'])
+            a.grad_scale, a.weight_decay = grad_scale, group['weight_decay']
+            L.check(L.lib().esr_adam_step(C.byref(a), C.c_void_p(stream)), 'esr_adam_step')
+        return loss

@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from . import dp as DP
+from .optim import FusedAdam
 
 
 def bce_logits(x, target_is_real):
@@ -27,22 +28,14 @@ class ESRGANPlusStep:
         self.netG, self.netD, self.netF = netG, netD, netF
         self.l_pix_w, self.l_fea_w, self.l_gan_w = pixel_weight, feature_weight, gan_weight
         self.loss_scale = loss_scale          # static loss scale for the fp16 path (1.0 for fp32)
-        self.optimizer_G = torch.optim.Adam([p for p in netG.parameters() if p.requires_grad],
-                                            lr=lr_G, betas=(beta1_G, 0.999))
-        self.optimizer_D = torch.optim.Adam(netD.parameters(), lr=lr_D, betas=(beta1_D, 0.999))
+        # one fused launch per optimizer (optim.FusedAdam == torch.optim.Adam arithmetic; it stays a
+        # torch.optim.Optimizer, so the reference's MultiStepLR schedulers attach unchanged)
+        self.optimizer_G = FusedAdam([p for p in netG.parameters() if p.requires_grad],
+                                     lr=lr_G, betas=(beta1_G, 0.999))
+        self.optimizer_D = FusedAdam(netD.parameters(), lr=lr_D, betas=(beta1_D, 0.999))
         self.exG, self.exD = DP.GradExchange(netG), DP.GradExchange(netD)
         self.log = {}
         self.fake_H = None
-
-    def _unscale(self, params):
-        if self.loss_scale != 1.0:
-            inv = 1.0 / self.loss_scale
-            # one launch per flat gradient buffer instead of one per parameter (~800 launches/step)
-            spans, loose = DP.flat_grad_spans(params)
-            for t in spans:
-                t.mul_(inv)
-            if loose:
-                torch._foreach_mul_(loose, inv)
 
     def step(self, var_L, var_H, var_ref=None, z=None, sync_log=True):
         """One optimisation step (SRRaGAN_model.py:113-168)."""
@@ -79,12 +72,11 @@ class ESRGANPlusStep:
         l_d_total = (l_d_real + l_d_fake) / 2
         (l_d_total * self.loss_scale).backward()
         self.exD.start()
+        inv = 1.0 / self.loss_scale          # the loss-scale division rides inside the Adam kernel
         self.exG.wait()
-        self._unscale(self.netG.parameters())
-        self.optimizer_G.step()
+        self.optimizer_G.step(grad_scale=inv)
         self.exD.wait()
-        self._unscale(self.netD.parameters())
-        self.optimizer_D.step()
+        self.optimizer_D.step(grad_scale=inv)
         logs = dict(l_g_pix=l_g_pix, l_g_fea=l_g_fea, l_g_gan=l_g_gan, l_d_real=l_d_real,
                     l_d_fake=l_d_fake, D_real=pred_d_real.detach().mean(), D_fake=pred_d_fake.detach().mean())
         if sync_log:      # the reference calls .item() on every loss each step (SRRaGAN_model.py:171-186)

@@ -224,6 +224,26 @@ typedef struct esr_linear {
   float* gx; float* dw; float* db;
 } esr_linear;
 
+/* Adam over a whole network in ONE launch (torch.optim.Adam semantics, SRRaGAN_model.py:77-91:
+ * amsgrad off; the reference steps ~770 parameter tensors per optimizer).  `entries` / `blocks` are
+ * DEVICE tables built once per parameter set: entry e = {param pointer, offset of its gradient /
+ * moments in the flat fp32 buffers, element count}; block b = {entry, first element}: each
+ * workgroup updates up to ESR_ADAM_BLOCK_ELEMS consecutive elements of one tensor.
+ *   g = grad[goff+i]*grad_scale (+ weight_decay*p);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ *   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)          bc1 = 1-b1^t, bc2 = 1-b2^t (host). */
+#define ESR_ADAM_BLOCK_ELEMS 4096
+typedef struct esr_adam_entry { float* p; int64_t goff; int64_t n; } esr_adam_entry;
+typedef struct esr_adam_block { int32_t entry; int32_t first; } esr_adam_block;
+typedef struct esr_adam {
+  const esr_adam_entry* entries;
+  const esr_adam_block* blocks;
+  int32_t nblocks, _pad;
+  const float* grad;      /* flat gradients (loss-scaled; see grad_scale) */
+  float* exp_avg;         /* flat first / second moments, same offsets as grad */
+  float* exp_avg_sq;
+  float lr, beta1, beta2, eps, bc1, bc2, grad_scale, weight_decay;
+} esr_adam;
+
 enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_NOISE_FILL = 4,
                    ESR_OP_WGRAD = 5, ESR_OP_BN = 6, ESR_OP_POOL = 7, ESR_OP_LINEAR = 8,
                    ESR_OP_UNPERMUTE = 9, ESR_OP_PACK_BATCH = 10 };
@@ -271,6 +291,7 @@ int esr_batchnorm(const esr_bn* p, esr_stream_t stream);
 int esr_maxpool2(const esr_pool* p, esr_stream_t stream);
 int esr_linear_op(const esr_linear* p, esr_stream_t stream);
 int esr_grad_unpermute(const esr_unpermute* p, esr_stream_t stream);
+int esr_adam_step(const esr_adam* p, esr_stream_t stream);
 int esr_pack_conv_weights_batch(const esr_pack_batch* p, esr_stream_t stream);
 
 /* Run a recorded list of ops back to back on `stream` (one host call per network pass; this is

@@ -111,3 +111,15 @@ def test_metrics_match_reference_goldens(golden):
         a, b = torch.from_numpy(g['a%d' % i]), torch.from_numpy(g['b%d' % i])
         assert np.array_equal(metrics.tensor2img(a), g['img_a%d' % i])
         assert abs(metrics.validation_psnr(a, b, 4) - float(g['psnr%d' % i])) < 1e-9
+
+
+def test_adam_tables_cover_every_element_once():
+    from esrganplus_amd import optim, _lib as L
+    sizes = [1, 31, L.ADAM_BLOCK_ELEMS, L.ADAM_BLOCK_ELEMS + 1, 3 * L.ADAM_BLOCK_ELEMS + 17, 64]
+    goff, blocks, total = optim.adam_tables(sizes)
+    assert total == sum(sizes) and goff == [sum(sizes[:i]) for i in range(len(sizes))]
+    seen = [0] * len(sizes)
+    for e, first in blocks:
+        assert first % L.ADAM_BLOCK_ELEMS == 0 and first < sizes[e]
+        seen[e] += min(L.ADAM_BLOCK_ELEMS, sizes[e] - first)
+    assert seen == sizes
