@@ -44,7 +44,7 @@ class esr_conv(C.Structure):
                 ('nchw_out_c', C.c_int32), ('nchw_out', C.c_void_p),
                 ('debug_flags', C.c_int32), ('mask_cb_begin', C.c_int32), ('gamma', C.c_float),
                 ('layer3', C.c_uint32), ('z3', esr_g32), ('out3', esr_g32),
-                ('mask_act', C.c_int32), ('_pad2', C.c_int32)]
+                ('mask_act', C.c_int32), ('_pad2', C.c_int32), ('seed_dev', C.c_void_p)]
 
 
 class esr_pack(C.Structure):
@@ -136,7 +136,7 @@ class esr_op(C.Structure):
 EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_pack_conv_weights',
            'esr_convert_layout', 'esr_fill_noise', 'esr_conv_wgrad', 'esr_conv_wgrad_multi', 'esr_batchnorm', 'esr_maxpool2',
            'esr_linear_op', 'esr_grad_unpermute', 'esr_adam_step', 'esr_pack_conv_weights_batch', 'esr_pack_pieces',
-           'esr_rdb_nosync_probe', 'esr_run_ops', 'esr_run_ops_timed', 'esr_last_error',
+           'esr_rdb_nosync_probe', 'esr_run_ops', 'esr_run_ops_timed', 'esr_graph_create', 'esr_graph_launch', 'esr_graph_destroy', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op']
 
 _lib = None
@@ -173,6 +173,9 @@ def lib():
         L.esr_g32_dims.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.esr_run_ops.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.esr_run_ops_timed.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.esr_graph_create.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+        L.esr_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
+        L.esr_graph_destroy.argtypes = [C.c_void_p]
         L.esr_conv_wgrad_multi.argtypes = [C.POINTER(esr_wgrad), C.c_int32, C.c_void_p]
         for name, st in (('esr_conv_forward', esr_conv), ('esr_pack_conv_weights', esr_pack),
                          ('esr_convert_layout', esr_layout), ('esr_fill_noise', esr_noise_fill),
@@ -221,6 +224,7 @@ class OpList:
         o.u.conv = conv
         self.ops.append(o)
         self._arr = None
+        self.drop_graph()
         return len(self.ops) - 1
 
     def add(self, kind, field, st, flags=0):
@@ -251,6 +255,31 @@ class OpList:
         arr = self.array()
         check(lib().esr_run_ops(C.cast(arr, C.c_void_p), len(self.ops), C.c_void_p(stream)),
               'esr_run_ops')
+
+    def graph_launch(self, stream):
+        """Replay the list as a captured hipGraph (one host call).  The graph is captured on first use
+        from the CURRENT contents of the op array: every pointer / scalar is baked in, so callers must
+        have bound their I/O to fixed buffers before the first launch."""
+        if not self.ops:
+            return
+        g = self.__dict__.get('_graph')
+        if g is None:
+            g = C.c_void_p()
+            check(lib().esr_graph_create(C.cast(self.array(), C.c_void_p), len(self.ops), C.byref(g)),
+                  'esr_graph_create')
+            self._graph = g
+        check(lib().esr_graph_launch(g, C.c_void_p(stream)), 'esr_graph_launch')
+
+    def drop_graph(self):
+        g = self.__dict__.pop('_graph', None)
+        if g is not None and _lib is not None:
+            _lib.esr_graph_destroy(g)
+
+    def __del__(self):
+        try:
+            self.drop_graph()
+        except Exception:
+            pass
 
 
 def batch_pack_op(packs, device):

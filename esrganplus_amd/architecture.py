@@ -139,13 +139,22 @@ class _SeqNet(B._PlannedModule):
         if plan is None:
             plan = CN.build_seq_plan(self._spec(), wp, dp, self._pspec(), want_w, Bn, H, W, self.precision,
                                      dev, training, need_bwd, self._input_affine(), self._head())
+            if E.use_graphs():
+                # hipGraph replay: the input lands in a fixed staging tensor (everything else these
+                # plans touch — outputs, upstream gradients, BN sums — already lives in fixed buffers)
+                plan.x_static = torch.empty_like(xin)
+                plan.fwd.array()[plan.in_op].u.layout.nchw = plan.x_static.data_ptr()
+                plan.graph = True
             pool.append(plan)
         lease = CN._Lease(plan) if need_bwd else None
-        arr = plan.fwd.array()
-        arr[plan.in_op].u.layout.nchw = xin.data_ptr()
         if training:
             plan.sums_f.zero_()
-        plan.fwd.run(st)
+        if getattr(plan, 'graph', False):
+            plan.x_static.copy_(xin)
+            plan.fwd.graph_launch(st)
+        else:
+            plan.fwd.array()[plan.in_op].u.layout.nchw = xin.data_ptr()
+            plan.fwd.run(st)
         if training:
             with torch.no_grad():
                 for m in self.modules():

@@ -163,7 +163,23 @@ class _PlannedModule(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._force_repack = True
+        self.__dict__['_conv_cache'] = None
         return super()._apply(fn, *a, **k)
+
+    def _convs(self):
+        """Cached (key, weight, bias) list + the flat parameter list autograd sees (rebuilding them
+        walks ~350 modules: 1.8 ms of host time per training step)."""
+        c = self.__dict__.get('_conv_cache')
+        if c is None:
+            lst = self._conv_list()
+            flat = []
+            for _, w, b in lst:
+                flat.append(w)
+                if b is not None:
+                    flat.append(b)
+            c = (lst, flat)
+            self.__dict__['_conv_cache'] = c
+        return c
 
     def load_state_dict(self, *a, **k):
         self._force_repack = True

@@ -308,7 +308,10 @@ class SeqNetFn(torch.autograd.Function):
             P.grad_flat.zero_()
             if P.tapmajor is not None:
                 P.tapmajor.tm.zero_()
-        P.bwd.run(st)
+        if getattr(P, 'graph', False):
+            P.bwd.graph_launch(st)
+        else:
+            P.bwd.run(st)
         gx = P.gx_tensor.clone() if ctx.needs_input_grad[0] else None
         grads = [None] * ctx.n
         if P.grad_flat is not None:

@@ -118,6 +118,65 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
   return ESR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// hipGraph replay
+// ------------------------------------------------------------------------------------------------
+struct esr_graph_s { hipGraph_t graph; hipGraphExec_t exec; };
+
+namespace {
+hipStream_t capture_stream() {
+  static std::mutex mu;
+  static hipStream_t per_dev[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!per_dev[dev] && hipStreamCreateWithFlags(&per_dev[dev], hipStreamNonBlocking) != hipSuccess) return nullptr;
+  return per_dev[dev];
+}
+}  // namespace
+
+extern "C" int esr_graph_create(const esr_op* ops, int32_t n, esr_graph_t* out) {
+  if (!ops || n <= 0 || !out) { esr_set_error("esr_graph_create: invalid arguments"); return ESR_ERR_INVALID; }
+  hipStream_t cs = capture_stream();
+  if (!cs) { esr_set_error("esr_graph_create: no capture stream"); return ESR_ERR_LAUNCH; }
+  static std::mutex cap_mu;                    // one capture at a time on the shared capture stream
+  std::lock_guard<std::mutex> lk(cap_mu);
+  hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
+  if (e != hipSuccess) { esr_set_error("esr_graph_create: begin capture: %s", hipGetErrorString(e)); return ESR_ERR_LAUNCH; }
+  const int rc = esr_run_ops(ops, n, (esr_stream_t)cs);
+  hipGraph_t g = nullptr;
+  e = hipStreamEndCapture(cs, &g);
+  if (rc != ESR_OK) { if (g) hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess || !g) { esr_set_error("esr_graph_create: end capture: %s", hipGetErrorString(e)); return ESR_ERR_LAUNCH; }
+  hipGraphExec_t x = nullptr;
+  e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    hipGraphDestroy(g);
+    esr_set_error("esr_graph_create: instantiate: %s", hipGetErrorString(e));
+    return ESR_ERR_LAUNCH;
+  }
+  esr_graph_s* h = new esr_graph_s();
+  h->graph = g;
+  h->exec = x;
+  *out = h;
+  return ESR_OK;
+}
+
+extern "C" int esr_graph_launch(esr_graph_t g, esr_stream_t stream) {
+  if (!g || !g->exec) { esr_set_error("esr_graph_launch: invalid graph"); return ESR_ERR_INVALID; }
+  const hipError_t e = hipGraphLaunch(g->exec, (hipStream_t)stream);
+  if (e != hipSuccess) { esr_set_error("esr_graph_launch: %s", hipGetErrorString(e)); return ESR_ERR_LAUNCH; }
+  return ESR_OK;
+}
+
+extern "C" int esr_graph_destroy(esr_graph_t g) {
+  if (!g) return ESR_OK;
+  if (g->exec) hipGraphExecDestroy(g->exec);
+  if (g->graph) hipGraphDestroy(g->graph);
+  delete g;
+  return ESR_OK;
+}
+
 extern "C" int esr_run_ops_timed(const esr_op* ops, int32_t n, esr_stream_t stream, float* ms_out) {
   if (!ops || n <= 0 || !ms_out) { esr_set_error("esr_run_ops_timed: invalid arguments"); return ESR_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;

@@ -110,6 +110,11 @@ __device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Philox seed: by value, or through device memory so a captured graph replays with a fresh seed
+__device__ __forceinline__ uint64_t noise_seed(const esr_conv& p) {
+  return p.seed_dev ? __builtin_nontemporal_load(p.seed_dev) : p.seed;
+}
+
 // Accumulators are 8 NAMED vector members (never an indexable array): every access is resolved at
 // compile time, so the register allocator keeps them in AGPRs for the whole kernel.  (An
 // `f32x16 acc[8]` that is indexed by a not-fully-unrolled loop anywhere — e.g. the epilogue — is
@@ -249,7 +254,7 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
       if (xz) Px16<T>::load(p.z1, b, cb, h, (int64_t)(oy + 1) * p.z1.wp + ox + 1, tmp);
       else {
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer1, p.seed, &tmp[4 * q]);
+        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer1, noise_seed(p), &tmp[4 * q]);
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);   // block.py:119-121
@@ -263,7 +268,7 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
       if (xz) Px16<T>::load(p.z2, b, cb, h, (int64_t)(oy + 1) * p.z2.wp + ox + 1, tmp);
       else {
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer2, p.seed, &tmp[4 * q]);
+        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer2, noise_seed(p), &tmp[4 * q]);
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
@@ -285,7 +290,7 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
         if (xz) Px16<T>::load(p.z3, b, cb, h, (int64_t)(oy + 1) * p.z3.wp + ox + 1, tmp);
         else {
 #pragma unroll 1
-          for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer3, p.seed, &tmp[4 * q]);
+          for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer3, noise_seed(p), &tmp[4 * q]);
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);

@@ -153,7 +153,8 @@ class GradExchange:
 class _GlobalMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        s = torch.stack([x.sum(), x.new_tensor(float(x.numel()))])
+        # torch.full, not new_tensor(scalar): the latter is a synchronous host->device copy (2 ms stall)
+        s = torch.stack([x.sum(), torch.full((), float(x.numel()), dtype=x.dtype, device=x.device)])
         if world_size() > 1:
             dist.all_reduce(s)
         ctx.save_for_backward(s[1:2])

@@ -9,6 +9,8 @@ torch is used here for device memory (buffers are torch tensors) and the stream 
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -360,6 +362,13 @@ class Builder:
         return P
 
 
+def use_graphs():
+    """hipGraph replay of the training plans (ESR_GRAPH=1).  Off by default: on ROCm 7.2 a graph launch
+    of ~1 000 kernel nodes costs the host about as much as the individual launches (train step 25.6 ms
+    with graphs vs 25.2 ms without, profiles/r01_experiments.md), so it buys nothing yet."""
+    return os.environ.get('ESR_GRAPH', '0') == '1'
+
+
 def current_stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -492,6 +501,39 @@ class TrainPlan:
         self.grad_views = None
         self.tapmajor = None
         self.gx_op = None            # stand-alone blocks: layout op exporting dL/dx (NCHW fp32)
+        self.graph = False           # hipGraph replay with I/O bound to the static tensors below
+
+    def enable_graph(self, in_shape, device):
+        """Bind every per-step pointer / scalar of both launch lists to fixed device buffers so the
+        lists can be captured once and replayed as hipGraphs (the train step is host-launch-bound):
+        input / output / upstream-gradient tensors become static staging buffers, the Philox seed is
+        read from `seed_t` on the device."""
+        P = self.fwd
+        assert not P.z_ops, 'graph replay is for the fused-Philox path (explicit z tensors re-bind pointers)'
+        f32 = dict(dtype=torch.float32, device=device)
+        self.x_static = torch.empty(in_shape, **f32)
+        self.out_static = torch.empty(P.out_shape, **f32)
+        self.gy_static = torch.empty(P.out_shape, **f32)
+        self.gx_static = torch.empty(in_shape, **f32) if self.gx_op is not None else None
+        self.seed_t = torch.zeros(1, dtype=torch.int64, device=device)
+        arr = P.ops.array()
+        arr[P.in_op].u.layout.nchw = self.x_static.data_ptr()
+        o = arr[P.out_op]
+        if o.kind == L.OP_CONV:
+            o.u.conv.nchw_out = self.out_static.data_ptr()
+        else:
+            o.u.layout.nchw = self.out_static.data_ptr()
+        for i in P.noise_ops:
+            arr[i].u.conv.noise_mode = L.NOISE_PHILOX
+            arr[i].u.conv.seed_dev = self.seed_t.data_ptr()
+        barr = self.bwd.array()
+        barr[self.gy_op].u.layout.nchw = self.gy_static.data_ptr()
+        if self.gx_op is not None:
+            barr[self.gx_op].u.layout.nchw = self.gx_static.data_ptr()
+        for i in self.bwd_noise_ops:
+            barr[i].u.conv.noise_mode = L.NOISE_PHILOX
+            barr[i].u.conv.seed_dev = self.seed_t.data_ptr()
+        self.graph = True
 
 
 def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, device, noise, variant,

@@ -49,12 +49,7 @@ def run_block(mod, kind, x, z=None):
         noise = bool(mod.training and has_noise)
         n_noise = 0 if not noise else (1 if kind == 'rdb' else (4 if mod.variant == 'test_image' else 3))
         zs = _zs_list(z, n_noise, (B, 64, H, W), x.device) if noise else None
-        params = []
-        for _, w, b in mod._conv_list():
-            params.append(w)
-            if b is not None:
-                params.append(b)
-        return _BlockFn.apply(x, mod, kind, noise, zs, *params)
+        return _BlockFn.apply(x, mod, kind, noise, zs, *mod._convs()[1])
     xin = _prep_input(x, 'input')
     B, C_, H, W = xin.shape
     if C_ != 64:
@@ -73,6 +68,43 @@ def run_block(mod, kind, x, z=None):
     out = torch.empty(plan.out_shape, dtype=torch.float32, device=xin.device)
     plan.run(xin, out, E.current_stream(), _draw_seed() if (noise and zs is None) else 0, zs)
     return out
+
+
+def _train_forward(tp, xin, st, seed, zs):
+    if tp.graph:
+        tp.x_static.copy_(xin)
+        tp.seed_t.fill_(seed)
+        tp.fwd.ops.graph_launch(st)
+        return tp.out_static.clone()
+    out = torch.empty(tp.fwd.out_shape, dtype=torch.float32, device=xin.device)
+    tp.fwd.run(xin, out, st, seed, zs)
+    return out
+
+
+def _train_backward(tp, gy, st, noise, explicit, seed, want_gx):
+    """Runs the backward launch list; returns dL/dx (stand-alone blocks) or None."""
+    tp.grad_flat.zero_()
+    if tp.tapmajor is not None:
+        tp.tapmajor.tm.zero_()
+    if tp.graph:
+        tp.gy_static.copy_(gy)
+        tp.bwd.graph_launch(st)                 # seed_t still holds this step's seed
+        return tp.gx_static.clone() if (want_gx and tp.gx_op is not None) else None
+    arr = tp.bwd.array()
+    arr[tp.gy_op].u.layout.nchw = gy.data_ptr()
+    gx = None
+    if tp.gx_op is not None:
+        lo = arr[tp.gx_op].u.layout
+        gx = torch.empty((lo.B, lo.C, lo.H, lo.W), dtype=torch.float32, device=gy.device)
+        arr[tp.gx_op].u.layout.nchw = gx.data_ptr()
+    mode = L.NOISE_OFF
+    if noise:
+        mode = L.NOISE_EXPLICIT if explicit else L.NOISE_PHILOX
+    for i in tp.bwd_noise_ops:
+        arr[i].u.conv.noise_mode = mode
+        arr[i].u.conv.seed = seed
+    tp.bwd.run(st)
+    return gx
 
 
 class _PlanLease:
@@ -99,6 +131,8 @@ def _train_plan(net, wp, dp, B, H, W, dev, noise, explicit):
             return tp
     tp = E.build_rrdbnet_train_plan(net, wp, dp, net.nb, net.in_nc, net.out_nc, B, H, W,
                                     net.precision, dev, noise, net.variant, explicit)
+    if not explicit and E.use_graphs():
+        tp.enable_graph((B, net.in_nc, H, W), dev)
     pool.append(tp)
     return tp
 
@@ -123,9 +157,7 @@ class _RRDBNetFn(torch.autograd.Function):
         ctx.explicit = zs is not None
         ctx.noise = noise
         ctx.n_params = len(params)
-        out = torch.empty(tp.fwd.out_shape, dtype=torch.float32, device=dev)
-        tp.fwd.run(xin, out, st, ctx.seed, zs)
-        return out
+        return _train_forward(tp, xin, st, ctx.seed, zs)
 
     @staticmethod
     def backward(ctx, gy):
@@ -136,19 +168,7 @@ class _RRDBNetFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise NotImplementedError('gradient w.r.t. the LR input image is not provided')
         gy = gy.detach().contiguous().float()
-        st = E.current_stream()
-        tp.grad_flat.zero_()
-        if tp.tapmajor is not None:
-            tp.tapmajor.tm.zero_()
-        arr = tp.bwd.array()
-        arr[tp.gy_op].u.layout.nchw = gy.data_ptr()
-        mode = L.NOISE_OFF
-        if ctx.noise:
-            mode = L.NOISE_EXPLICIT if ctx.explicit else L.NOISE_PHILOX
-        for i in tp.bwd_noise_ops:
-            arr[i].u.conv.noise_mode = mode
-            arr[i].u.conv.seed = ctx.seed
-        tp.bwd.run(st)
+        _train_backward(tp, gy, E.current_stream(), ctx.noise, ctx.explicit, ctx.seed, False)
         flat = tp.grad_flat.clone()
         ctx.lease.release()
         grads, off = [], 0
@@ -171,6 +191,8 @@ def _block_train_plan(mod, kind, wp, dp, B, H, W, dev, noise, explicit):
             return tp
     tp = E.build_rrdbnet_train_plan(mod, wp, dp, 1, 64, 64, B, H, W, mod.precision, dev, noise,
                                     mod.variant, explicit, kind=kind)
+    if not explicit and E.use_graphs():
+        tp.enable_graph((B, 64, H, W), dev)
     pool.append(tp)
     return tp
 
@@ -192,9 +214,7 @@ class _BlockFn(torch.autograd.Function):
         ctx.lease = _PlanLease(tp)
         ctx.seed = _draw_seed() if (noise and zs is None) else 0
         ctx.explicit, ctx.noise, ctx.n_params = zs is not None, noise, len(params)
-        out = torch.empty(tp.fwd.out_shape, dtype=torch.float32, device=dev)
-        tp.fwd.run(xin, out, st, ctx.seed, zs)
-        return out
+        return _train_forward(tp, xin, st, ctx.seed, zs)
 
     @staticmethod
     def backward(ctx, gy):
@@ -203,21 +223,7 @@ class _BlockFn(torch.autograd.Function):
             raise RuntimeError('backward called twice (retain_graph is not supported: the saved '
                                'activations live in a reusable launch plan)')
         gy = gy.detach().contiguous().float()
-        st = E.current_stream()
-        tp.grad_flat.zero_()
-        if tp.tapmajor is not None:
-            tp.tapmajor.tm.zero_()
-        gx = torch.empty_like(gy)
-        arr = tp.bwd.array()
-        arr[tp.gy_op].u.layout.nchw = gy.data_ptr()
-        arr[tp.gx_op].u.layout.nchw = gx.data_ptr()
-        mode = L.NOISE_OFF
-        if ctx.noise:
-            mode = L.NOISE_EXPLICIT if ctx.explicit else L.NOISE_PHILOX
-        for i in tp.bwd_noise_ops:
-            arr[i].u.conv.noise_mode = mode
-            arr[i].u.conv.seed = ctx.seed
-        tp.bwd.run(st)
+        gx = _train_backward(tp, gy, E.current_stream(), ctx.noise, ctx.explicit, ctx.seed, True)
         flat = tp.grad_flat.clone()
         ctx.lease.release()
         grads, off = [], 0
@@ -241,12 +247,7 @@ def run_rrdbnet(net, x, z=None):
             raise ValueError('expected %d input channels, got %d' % (net.in_nc, C_))
         per = 4 if net.variant == 'test_image' else 3
         zs = _zs_list(z, per * net.nb, (B, 64, H, W), x.device) if net.training else None
-        params = []
-        for _, w, b in net._conv_list():
-            params.append(w)
-            if b is not None:
-                params.append(b)
-        return _RRDBNetFn.apply(x, net, zs, *params)
+        return _RRDBNetFn.apply(x, net, zs, *net._convs()[1])
     xin = _prep_input(x, 'input')
     B, C_, H, W = xin.shape
     if C_ != net.in_nc:

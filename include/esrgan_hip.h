@@ -97,6 +97,8 @@ typedef struct esr_conv {
   esr_g32 out3;         /* ptr NULL = off */
   int32_t mask_act;     /* esr_act whose derivative the mask selects (LRELU: 1 / 0.2, RELU: 1 / 0) */
   int32_t _pad2;
+  const uint64_t* seed_dev; /* non-NULL: the Philox seed is read from DEVICE memory at run time (so a
+                               captured graph can be replayed with a fresh seed); overrides `seed` */
 } esr_conv;
 
 /* Weight packing: OIHW fp32 master (the nn.Parameter the reference keeps, e.g. state-dict key
@@ -297,6 +299,17 @@ int esr_pack_conv_weights_batch(const esr_pack_batch* p, esr_stream_t stream);
 /* Run a recorded list of ops back to back on `stream` (one host call per network pass; this is
  * what RRDBNet.forward — architecture.py:76-78 — becomes). */
 int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream);
+
+/* hipGraph replay of an op list (training plans are ~1 000 launches of 10-100 us: per-launch host cost
+ * is what bounds the step).  esr_graph_create captures `esr_run_ops(ops, n)` — including its
+ * ESR_OPF_SIDE fork/joins — on a library-owned capture stream and instantiates it; every pointer and
+ * scalar inside the ops is baked in, so callers keep their I/O in fixed buffers and pass per-step
+ * scalars through device memory (esr_conv.seed_dev).  esr_graph_launch enqueues the whole list on
+ * `stream` with one host call. */
+typedef struct esr_graph_s* esr_graph_t;
+int esr_graph_create(const esr_op* ops, int32_t n, esr_graph_t* out);
+int esr_graph_launch(esr_graph_t g, esr_stream_t stream);
+int esr_graph_destroy(esr_graph_t g);
 
 /* Measurement-only variant (bench.py): brackets every op with hipEvents on `stream`, waits for the
  * stream, and writes each op's elapsed milliseconds to ms_out[n].  This is the one entry point that
