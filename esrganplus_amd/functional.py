@@ -20,6 +20,9 @@ def _prep_input(x, what):
     E.require_cuda(x, what)
     if x.dim() != 4:
         raise ValueError('%s must be NCHW, got shape %s' % (what, tuple(x.shape)))
+    if x.shape[2] == 0 or x.shape[3] == 0:
+        # torch's Conv2d rejects these too ("Kernel size can't be greater than actual input size")
+        raise ValueError('%s has an empty spatial extent: shape %s' % (what, tuple(x.shape)))
     return x.detach().contiguous().float()
 
 
@@ -40,6 +43,9 @@ def _zs_list(z, n, shape, device):
 
 def run_block(mod, kind, x, z=None):
     """ResidualDenseBlock_5C / RRDB forward (block.py:260-268, 287-291) on the HIP path."""
+    if x.dim() == 4 and x.shape[0] == 0:
+        E.require_cuda(x, 'input')
+        return x.new_zeros(tuple(x.shape), dtype=torch.float32)
     if _needs_grad(mod, x):
         E.require_cuda(x, 'input')
         B, C_, H, W = x.shape
@@ -240,6 +246,9 @@ class _BlockFn(torch.autograd.Function):
 
 def run_rrdbnet(net, x, z=None):
     """RRDBNet.forward (architecture.py:76-78) on the HIP path."""
+    if x.dim() == 4 and x.shape[0] == 0:          # empty batch: torch returns an empty result
+        E.require_cuda(x, 'input')
+        return x.new_zeros((0, net.out_nc, 4 * x.shape[2], 4 * x.shape[3]), dtype=torch.float32)
     if _needs_grad(net, x):
         E.require_cuda(x, 'input')
         B, C_, H, W = x.shape

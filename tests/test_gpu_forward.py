@@ -178,3 +178,33 @@ def test_cpu_input_fails_loudly(dev):
     with pytest.raises(_lib.HipExtensionError):
         with torch.no_grad():
             net(torch.rand(1, 3, 8, 8))
+
+
+@pytest.mark.parametrize('shape', [(1, 3, 1, 1), (1, 3, 2, 3), (3, 3, 7, 5), (1, 3, 33, 31), (2, 3, 1, 40),
+                                   (1, 3, 64, 1)])
+def test_rrdbnet_ragged_and_tiny_shapes(dev, shape):
+    """Sizes far below / not a multiple of the 16x32 workgroup tile (single pixels, 1-pixel-wide
+    strips, odd sizes): fp32 path must still match the oracle to 1e-4."""
+    from esrganplus_amd import architecture as arch
+    from oracle import ref_torch as RT
+    sd = synth.rrdbnet_state_dict(nb=1, seed=2)
+    net = arch.RRDBNet(3, 3, 64, 1).to(dev).eval()
+    net.load_state_dict(sd)
+    x = synth.image_batch(5, *shape, name='edge.x')
+    with torch.no_grad():
+        ref = RT.rrdbnet_forward(x, sd, 1)
+        y = net(x.to(dev)).cpu()
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max().item() <= 1e-4
+
+
+def test_rrdbnet_empty_inputs(dev):
+    from esrganplus_amd import architecture as arch
+    net = arch.RRDBNet(3, 3, 64, 1).to(dev).eval()
+    with torch.no_grad():
+        y = net(torch.zeros(0, 3, 8, 8, device=dev))          # empty batch -> empty result, as torch
+        assert tuple(y.shape) == (0, 3, 32, 32)
+        with pytest.raises(ValueError):                        # torch's Conv2d rejects 0-sized images too
+            net(torch.zeros(1, 3, 0, 8, device=dev))
+    with pytest.raises(Exception):                             # CPU tensors: the product path has no fallback
+        net(torch.zeros(1, 3, 8, 8))
