@@ -110,3 +110,43 @@ class FusedAdam(torch.optim.Optimizer):
             a.grad_scale, a.weight_decay = grad_scale, group['weight_decay']
             L.check(L.lib().esr_adam_step(C.byref(a), C.c_void_p(stream)), 'esr_adam_step')
         return loss
+
+    # ---- checkpoint plumbing: the reference stores `optimizer.state_dict()` of torch.optim.Adam in its
+    # `.state` files and feeds them back through `load_state_dict` (base_model.py:66-85).  The moments
+    # live in flat buffers here, so both directions translate to / from Adam's per-parameter layout.
+    def state_dict(self):
+        sd = super().state_dict()                       # param_groups with index lists; state = {}
+        state, idx = {}, 0
+        for gi, group in enumerate(self.param_groups):
+            st = self._g.get(gi)
+            live = [p for p in group['params'] if p.requires_grad]
+            pos = {id(p): k for k, p in enumerate(live)}
+            for p in group['params']:
+                if st is not None and id(p) in pos and st['step'] > 0:
+                    k = pos[id(p)]
+                    o, n = st['goff'][k], st['sizes'][k]
+                    state[idx] = {'step': torch.tensor(float(st['step'])),
+                                  'exp_avg': st['exp_avg'][o:o + n].view_as(p).clone(),
+                                  'exp_avg_sq': st['exp_avg_sq'][o:o + n].view_as(p).clone()}
+                idx += 1
+        sd['state'] = state
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state = state_dict.get('state', {})
+        super().load_state_dict({'state': {}, 'param_groups': state_dict['param_groups']})
+        idx = 0
+        for gi, group in enumerate(self.param_groups):
+            live = [p for p in group['params'] if p.requires_grad]
+            pos = {id(p): k for k, p in enumerate(live)}
+            st = self._group_state(gi, live) if live else None
+            for p in group['params']:
+                ent = state.get(idx, state.get(str(idx)))
+                if ent is not None and st is not None and id(p) in pos:
+                    k = pos[id(p)]
+                    o, n = st['goff'][k], st['sizes'][k]
+                    st['exp_avg'][o:o + n].copy_(ent['exp_avg'].reshape(-1).to(st['exp_avg'].device, torch.float32))
+                    st['exp_avg_sq'][o:o + n].copy_(ent['exp_avg_sq'].reshape(-1).to(st['exp_avg'].device, torch.float32))
+                    st['step'] = int(float(ent['step']))
+                idx += 1
+

@@ -117,3 +117,46 @@ def test_graph_replay_matches_per_op_launches(dev, monkeypatch):
         assert torch.equal(ta[0], tb[0])                  # generator forward: deterministic, bit-exact
         for u, v in zip(ta[1:], tb[1:]):                  # BN sums / weight gradients use float atomics
             assert (u.float() - v.float()).abs().max().item() <= 2e-3 * max(1e-6, v.float().abs().max().item())
+
+
+def test_fused_adam_state_dict_interchanges_with_torch_adam(dev, tmp_path):
+    """`.state` resume files (base_model.py:66-85): FusedAdam -> state_dict -> torch.optim.Adam and back
+    must continue the very same trajectory."""
+    from esrganplus_amd.optim import FusedAdam
+    from esrganplus_amd import checkpoint as ck
+    torch.manual_seed(1)
+    shapes = [(16, 3, 3, 3), (16,), (700,)]
+    init = [torch.randn(s, device=dev) for s in shapes]
+    grads = [[torch.randn(s, device=dev) for s in shapes] for _ in range(4)]
+
+    def mk(cls):
+        ps = [torch.nn.Parameter(t.clone()) for t in init]
+        return ps, cls(ps, lr=1e-3, betas=(0.9, 0.999))
+
+    def step(ps, opt, gs):
+        for p, g in zip(ps, gs):
+            p.grad = g.clone()
+        opt.step()
+
+    pf, of = mk(FusedAdam)
+    sched = torch.optim.lr_scheduler.MultiStepLR(of, [1, 3], 0.5)
+    for k in range(2):
+        step(pf, of, grads[k])
+        sched.step()
+    ck.save_training_state(str(tmp_path / 's.state'), 0, 2, [of], [sched])
+    rs = torch.load(str(tmp_path / 's.state'), weights_only=False)
+    # resume into torch's Adam and into a fresh FusedAdam: both must match continuing the original
+    pt, ot = mk(torch.optim.Adam)
+    pn, on = mk(FusedAdam)
+    for ps in (pt, pn):
+        for p, q in zip(ps, pf):
+            p.data.copy_(q.data)
+    st, sn = torch.optim.lr_scheduler.MultiStepLR(ot, [1, 3], 0.5), torch.optim.lr_scheduler.MultiStepLR(on, [1, 3], 0.5)
+    ck.resume_training(rs, [ot], [st])
+    ck.resume_training(rs, [on], [sn])
+    for k in range(2, 4):
+        for ps, o, s in ((pf, of, sched), (pt, ot, st), (pn, on, sn)):
+            step(ps, o, grads[k])
+            s.step()
+    for a, b, c in zip(pf, pt, pn):
+        assert (a - b).abs().max().item() <= 2e-6 and (a - c).abs().max().item() <= 1e-7

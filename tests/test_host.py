@@ -123,3 +123,18 @@ def test_adam_tables_cover_every_element_once():
         assert first % L.ADAM_BLOCK_ELEMS == 0 and first < sizes[e]
         seen[e] += min(L.ADAM_BLOCK_ELEMS, sizes[e] - first)
     assert seen == sizes
+
+
+def test_net_interp_and_network_roundtrip(tmp_path):
+    import torch
+    from esrganplus_amd import architecture as arch, checkpoint as ck, synth
+    a, b = synth.rrdbnet_state_dict(nb=1, seed=1), synth.rrdbnet_state_dict(nb=1, seed=2)
+    mid = ck.interpolate(a, b, 0.8)
+    k = 'model.1.sub.0.RDB2.conv3.0.weight'
+    assert torch.allclose(mid[k], 0.2 * a[k] + 0.8 * b[k])
+    net = arch.RRDBNet(3, 3, 64, 1)
+    net.load_state_dict(mid, strict=True)
+    ck.save_network(torch.nn.DataParallel(net), str(tmp_path / 'n.pth'))
+    net2 = arch.RRDBNet(3, 3, 64, 1)
+    ck.load_network(str(tmp_path / 'n.pth'), net2)
+    assert all(torch.equal(v, net2.state_dict()[kk]) for kk, v in net.state_dict().items())
