@@ -116,6 +116,12 @@ class esr_adam(C.Structure):
                 ('bc1', C.c_float), ('bc2', C.c_float), ('grad_scale', C.c_float), ('weight_decay', C.c_float)]
 
 
+class esr_resample(C.Structure):
+    _fields_ = [('in_', C.c_void_p), ('out', C.c_void_p), ('planes', C.c_int32), ('in_h', C.c_int32),
+                ('in_w', C.c_int32), ('out_len', C.c_int32), ('axis', C.c_int32), ('taps', C.c_int32),
+                ('w', C.c_void_p), ('idx', C.c_void_p)]
+
+
 class esr_pack_batch(C.Structure):
     _fields_ = [('table', C.c_void_p), ('piece_begin', C.c_void_p), ('n', C.c_int32), ('_pad', C.c_int32),
                 ('total_pieces', C.c_int64)]
@@ -135,7 +141,7 @@ class esr_op(C.Structure):
 # every symbol include/esrgan_hip.h declares (tests check the .so exports all of them)
 EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_pack_conv_weights',
            'esr_convert_layout', 'esr_fill_noise', 'esr_conv_wgrad', 'esr_conv_wgrad_multi', 'esr_batchnorm', 'esr_maxpool2',
-           'esr_linear_op', 'esr_grad_unpermute', 'esr_adam_step', 'esr_pack_conv_weights_batch', 'esr_pack_pieces',
+           'esr_linear_op', 'esr_grad_unpermute', 'esr_adam_step', 'esr_resample_axis', 'esr_pack_conv_weights_batch', 'esr_pack_pieces',
            'esr_rdb_nosync_probe', 'esr_run_ops', 'esr_run_ops_timed', 'esr_graph_create', 'esr_graph_launch', 'esr_graph_destroy', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op']
 
@@ -181,7 +187,7 @@ def lib():
                          ('esr_convert_layout', esr_layout), ('esr_fill_noise', esr_noise_fill),
                          ('esr_conv_wgrad', esr_wgrad), ('esr_batchnorm', esr_bn),
                          ('esr_maxpool2', esr_pool), ('esr_linear_op', esr_linear),
-                         ('esr_grad_unpermute', esr_unpermute), ('esr_adam_step', esr_adam),
+                         ('esr_grad_unpermute', esr_unpermute), ('esr_adam_step', esr_adam), ('esr_resample_axis', esr_resample),
                          ('esr_pack_conv_weights_batch', esr_pack_batch)):
             getattr(L, name).argtypes = [C.POINTER(st), C.c_void_p]
         if L.esr_sizeof_op() != C.sizeof(esr_op):

@@ -308,3 +308,40 @@ extern "C" int esr_adam_step(const esr_adam* p, esr_stream_t stream) {
   return esr_check_launch("adam_kernel");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Separable resampling (data path: MATLAB-style bicubic imresize).  HBM-bound gather of <= ~18 taps.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void resample_kernel(const esr_resample a) {
+  const int oh = a.axis == 0 ? a.out_len : a.in_h, ow = a.axis == 0 ? a.in_w : a.out_len;
+  const int64_t n = (int64_t)a.planes * oh * ow;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int x = (int)(e % ow), y = (int)((e / ow) % oh);
+  const int64_t pl = e / ((int64_t)ow * oh);
+  const float* src = a.in + pl * a.in_h * a.in_w;
+  const int o = a.axis == 0 ? y : x;
+  const float* w = a.w + (int64_t)o * a.taps;
+  const int32_t* ix = a.idx + (int64_t)o * a.taps;
+  float acc = 0.f;
+  if (a.axis == 0) {
+    for (int t = 0; t < a.taps; ++t) acc += w[t] * src[(int64_t)ix[t] * a.in_w + x];
+  } else {
+    for (int t = 0; t < a.taps; ++t) acc += w[t] * src[(int64_t)y * a.in_w + ix[t]];
+  }
+  a.out[e] = acc;
+}
+}  // namespace
+
+extern "C" int esr_resample_axis(const esr_resample* p, esr_stream_t stream) {
+  if (!p || !p->in || !p->out || !p->w || !p->idx || p->planes <= 0 || p->in_h <= 0 || p->in_w <= 0 ||
+      p->out_len <= 0 || p->taps <= 0 || (p->axis != 0 && p->axis != 1)) {
+    esr_set_error("esr_resample_axis: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  const int oh = p->axis == 0 ? p->out_len : p->in_h, ow = p->axis == 0 ? p->in_w : p->out_len;
+  const int64_t n = (int64_t)p->planes * oh * ow;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
+  return esr_check_launch("resample_kernel");
+}
+

@@ -226,6 +226,17 @@ typedef struct esr_linear {
   float* gx; float* dw; float* db;
 } esr_linear;
 
+/* One axis of a separable resampling on fp32 planes (MATLAB-style bicubic `imresize`,
+ * codes/data/util.py:221-343: the H pass then the W pass).  out[p][i][j] = sum_t w[o][t] * in[p][..]
+ * where o is the output coordinate along `axis` (0 = rows/H, 1 = columns/W) and idx[o][t] the source
+ * coordinate of tap t with the symmetric border padding already resolved.  Tables are DEVICE arrays. */
+typedef struct esr_resample {
+  const float* in; float* out;
+  int32_t planes, in_h, in_w, out_len, axis, taps;
+  const float* w;        /* [out_len][taps] */
+  const int32_t* idx;    /* [out_len][taps] */
+} esr_resample;
+
 /* Adam over a whole network in ONE launch (torch.optim.Adam semantics, SRRaGAN_model.py:77-91:
  * amsgrad off; the reference steps ~770 parameter tensors per optimizer).  `entries` / `blocks` are
  * DEVICE tables built once per parameter set: entry e = {param pointer, offset of its gradient /
@@ -294,6 +305,7 @@ int esr_maxpool2(const esr_pool* p, esr_stream_t stream);
 int esr_linear_op(const esr_linear* p, esr_stream_t stream);
 int esr_grad_unpermute(const esr_unpermute* p, esr_stream_t stream);
 int esr_adam_step(const esr_adam* p, esr_stream_t stream);
+int esr_resample_axis(const esr_resample* p, esr_stream_t stream);
 int esr_pack_conv_weights_batch(const esr_pack_batch* p, esr_stream_t stream);
 
 /* Run a recorded list of ops back to back on `stream` (one host call per network pass; this is

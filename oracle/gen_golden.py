@@ -375,12 +375,44 @@ def gen_psnr():
     np.savez_compressed(os.path.join(OUT, 'psnr.npz'), **res)
 
 
+def gen_imresize():
+    """MATLAB-style bicubic imresize (codes/data/util.py:276-412) and augment (94-106): outputs of
+    the imported reference on seeded inputs."""
+    import random
+    U = RI.data_util()
+    res = {}
+    cases = ((0, 37, 45, 0.25), (1, 64, 48, 0.25), (2, 33, 20, 0.5), (3, 9, 12, 2), (4, 7, 5, 4),
+             (5, 31, 50, 1.0 / 3), (6, 40, 40, 0.7))
+    for i, h, w, sc in cases:
+        x = synth.image_batch(60 + i, 1, 3, h, w, name='imresize.x')[0]
+        y = U.imresize(x.clone(), sc, True)
+        ynp = U.imresize_np(x.permute(1, 2, 0).contiguous().numpy().copy(), sc, True)
+        assert np.abs(ynp - y.permute(1, 2, 0).numpy()).max() < 1e-6
+        res['scale%d' % i] = np.array(sc)
+        res['shape%d' % i] = np.array([h, w])
+        res['y%d' % i] = npy(y)
+    x = synth.image_batch(70, 1, 3, 6, 8, name='imresize.x')[0]
+    res['y_noaa'] = npy(U.imresize(x.clone(), 0.5, False))
+    # augment: the 8 outcomes of (hflip, vflip, rot90) as the reference draws them from `random`
+    a = np.arange(2 * 3 * 4, dtype=np.float32).reshape(3, 4, 2)       # HWC
+    outs, draws = [], []
+    for seed in range(12):
+        random.seed(seed)
+        o = U.augment([a.copy()], True, True)[0]
+        random.seed(seed)
+        draws.append([random.random() < 0.5 for _ in range(3)])
+        outs.append(np.ascontiguousarray(o).reshape(-1))
+    res['aug_out'] = np.stack(outs)
+    res['aug_draws'] = np.array(draws)
+    np.savez_compressed(os.path.join(OUT, 'imresize.npz'), **res)
+
+
 if __name__ == '__main__':
     assert RI.available(), 'reference tree not found — fixtures can only be generated in the build container'
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['rdb', 'rrdbnet_small', 'rrdbnet_full', 'disc', 'vgg', 'train_step',
-                             'psnr']
+                             'psnr', 'imresize']
     for w in which:
         print('[gen_golden]', w)
         globals()['gen_' + w]()

@@ -99,3 +99,15 @@ def build_discriminator():
     arch, _ = codes_arch()
     return arch.Discriminator_VGG_128(in_nc=3, base_nf=64, norm_type='batch',
                                       mode='CNA', act_type='leakyrelu')
+
+
+def data_util():
+    """codes/data/util.py (imresize / augment).  It imports lmdb and cv2 at module level (absent here,
+    unused by the functions we pin) -> empty stub modules; loaded by file path under a private name."""
+    for m in ('lmdb', 'cv2'):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    spec = importlib.util.spec_from_file_location('ref_data_util', os.path.join(REF, 'codes', 'data', 'util.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
