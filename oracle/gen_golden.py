@@ -375,6 +375,23 @@ def gen_psnr():
     np.savez_compressed(os.path.join(OUT, 'psnr.npz'), **res)
 
 
+def gen_metrics():
+    """Y-channel conversion (codes/data/util.py:123-168) from the imported reference.  SSIM
+    (codes/utils/util.py:117-158) needs cv2, absent here: it is pinned in tests/test_metrics.py
+    against a scipy restatement of cv2.filter2D's valid region instead ("parity unpinned by the
+    reference" for SSIM)."""
+    U = RI.data_util()
+    rng = np.random.RandomState(7)
+    u8 = rng.randint(0, 256, (12, 10, 3)).astype(np.uint8)
+    fl = rng.rand(12, 10, 3).astype(np.float32)
+    res = {'u8': u8, 'fl': fl}
+    for name, fn in (('bgr', U.bgr2ycbcr), ('rgb', U.rgb2ycbcr)):
+        for only_y in (True, False):
+            res['%s_u8_%d' % (name, only_y)] = fn(u8.copy(), only_y)
+            res['%s_fl_%d' % (name, only_y)] = fn(fl.copy(), only_y)
+    np.savez_compressed(os.path.join(OUT, 'metrics.npz'), **res)
+
+
 def gen_imresize():
     """MATLAB-style bicubic imresize (codes/data/util.py:276-412) and augment (94-106): outputs of
     the imported reference on seeded inputs."""
@@ -412,7 +429,7 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['rdb', 'rrdbnet_small', 'rrdbnet_full', 'disc', 'vgg', 'train_step',
-                             'psnr', 'imresize']
+                             'psnr', 'imresize', 'metrics']
     for w in which:
         print('[gen_golden]', w)
         globals()['gen_' + w]()

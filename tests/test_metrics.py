@@ -1,0 +1,51 @@
+"""Evaluation metrics: Y-channel conversion against the imported reference's outputs
+(tests/golden/metrics.npz), SSIM against a scipy restatement of `cv2.filter2D(...)[5:-5, 5:-5]`
+(cv2 is not installed, so the reference's own SSIM cannot run here: SSIM parity is unpinned by the
+reference)."""
+import numpy as np
+import pytest
+
+from esrganplus_amd import metrics as M
+
+
+def test_ycbcr_matches_reference():
+    g = dict(np.load('tests/golden/metrics.npz'))
+    for name, fn in (('bgr', M.bgr2ycbcr), ('rgb', M.rgb2ycbcr)):
+        for only_y in (True, False):
+            assert np.array_equal(fn(g['u8'], only_y), g['%s_u8_%d' % (name, only_y)])
+            assert np.abs(fn(g['fl'], only_y) - g['%s_fl_%d' % (name, only_y)]).max() <= 1e-6
+    before = g['fl'].copy()
+    M.bgr2ycbcr(g['fl'])
+    assert np.array_equal(before, g['fl'])            # no in-place scaling of the caller's array
+
+
+def _ssim_scipy(a, b):
+    from scipy.ndimage import correlate
+    w = M.gaussian_window()
+
+    def f(x):
+        return correlate(x, w, mode='mirror')[5:-5, 5:-5]
+    c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    mu1, mu2 = f(a), f(b)
+    s1, s2, s12 = f(a * a) - mu1 ** 2, f(b * b) - mu2 ** 2, f(a * b) - mu1 * mu2
+    return (((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 ** 2 + mu2 ** 2 + c1) * (s1 + s2 + c2))).mean()
+
+
+def test_ssim_matches_filter2d_restatement():
+    rng = np.random.RandomState(3)
+    a = rng.rand(40, 33) * 255
+    b = np.clip(a + rng.randn(40, 33) * 12, 0, 255)
+    assert abs(M.calculate_ssim(a, b) - _ssim_scipy(a, b)) < 1e-12
+    assert abs(M.calculate_ssim(a, a) - 1.0) < 1e-12
+    a3, b3 = np.stack([a, a * 0.5, 255 - a], -1), np.stack([b, b * 0.5, 255 - b], -1)
+    want = np.mean([_ssim_scipy(a3[..., c], b3[..., c]) for c in range(3)])
+    assert abs(M.calculate_ssim(a3, b3) - want) < 1e-12
+    with pytest.raises(ValueError):
+        M.calculate_ssim(a, a[:-1])
+
+
+def test_gaussian_window_is_cv2_formula():
+    w = M.gaussian_window()
+    assert w.shape == (11, 11) and abs(w.sum() - 1.0) < 1e-15
+    k = w.sum(0)
+    assert abs(k[5] / k[4] - np.exp(1.0 / (2 * 1.5 ** 2))) < 1e-12
