@@ -69,6 +69,12 @@ template <> struct Px16<_Float16> {
     if (flavour == 1) {          // non-temporal (measured +1 % on the forward bench, profiles/)
       __builtin_nontemporal_store(a, (u32x4*)p);
       __builtin_nontemporal_store(c, (u32x4*)(p + 16));
+    } else if (flavour == 3) {   // measurement-only (WRONG layout): each store instruction of a half-wave
+                                 // covers 512 contiguous bytes instead of every other 16 bytes of 1 KB
+      const int j = __lane_id() & 31;
+      char* row = p - j * 32;
+      *(u32x4*)(row + j * 16) = a;
+      *(u32x4*)(row + 512 + j * 16) = c;
     } else {
       *(u32x4*)p = a;
       *(u32x4*)(p + 16) = c;
