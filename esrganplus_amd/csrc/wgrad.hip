@@ -159,10 +159,24 @@ __device__ __forceinline__ u32x4 tr_frag(const char* lds_base, int off0, int off
 
 struct Acc9 { f32x16 a[9]; };
 
+// async global -> LDS copy of 16 bytes per lane (LDS-DMA): wave-uniform LDS base + lane*16
+__device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Plain 3x3/s1 and 1x1 problems (the generator's, batched per dense block) run as 4-wave workgroups
+// staged by LDS-DMA, two resident per CU; the upsample-on-load and stride-2 variants keep the 8-wave
+// register-staged form (their source addresses are not slot-linear / need the zero fill).
+template <int S, bool UPS> struct Wg16Mode {
+  static constexpr bool DMA = S == 1 && !UPS;
+  static constexpr int NWV = DMA ? 4 : 8;              // waves per workgroup
+};
+
 template <int KS, int S, bool UPS, int NCO>
 struct Wg16Geo {
   static constexpr int TR = S == 2 ? 2 : 4, TC = 32;
-  static constexpr int NCI = 8 / NCO;
+  static constexpr int NCI = Wg16Mode<S, UPS>::NWV / NCO;
   static constexpr int IH = UPS ? TR / 2 + 2 : (TR - 1) * S + KS, IW = UPS ? TC / 2 + 2 : (TC - 1) * S + KS;
   static constexpr int G_BYTES = NCO * 2 * TR * TC * 32;
   static constexpr int IN_GROUP = IH * IW * 32;
@@ -177,7 +191,9 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
   // taps [T0, T0+NT) of the KSxKS kernel are accumulated by this launch (4x4 kernels: two launches
   // of 8 taps, keeping the accumulators within the register file)
   constexpr int TR = S == 2 ? 2 : 4, TC = 32, NTAP = KS * KS, PAD = (KS - 1) / 2;
-  constexpr int NCI = 8 / NCO;                        // cin blocks (of 32 channels) per workgroup
+  constexpr bool DMA = Wg16Mode<S, UPS>::DMA;
+  constexpr int NWV = Wg16Mode<S, UPS>::NWV, NTH = NWV * 64;
+  constexpr int NCI = NWV / NCO;                      // cin blocks (of 32 channels) per workgroup
   constexpr int IH = UPS ? TR / 2 + 2 : (TR - 1) * S + KS, IW = UPS ? TC / 2 + 2 : (TC - 1) * S + KS;
   static_assert(NT <= 9 && T0 + NT <= NTAP, "tap range");
   constexpr int G_BYTES = NCO * 2 * TR * TC * 32;     // [cout group][row][col][32 B]
@@ -217,15 +233,15 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
   // tile of which 1.1 us is MFMA).  Input groups past the tensor's last one are never read by an
   // active wave, so they are neither fetched nor zero-filled.
   constexpr int GS = NCO * 2 * TR * TC * 2;                 // 16-byte slots of the g tile
-  constexpr int NG = (GS + 511) / 512;
+  constexpr int NG = (GS + NTH - 1) / NTH;
   const int in_groups = min(NCI * 2, ngin - (int)by * NCI * 2);
   const int IS = in_groups > 0 ? in_groups * IH * IW * 2 : 0;
-  constexpr int NI = (NCI * 2 * IH * IW * 2 + 511) / 512;
+  constexpr int NI = (NCI * 2 * IH * IW * 2 + NTH - 1) / NTH;
   u32x4 rg[NG], ri[NI];
   auto fetch = [&](int oy0) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
-      const int s = tid + 512 * k;
+      const int s = tid + NTH * k;
       const int half = s & 1, px = (s >> 1) % (TR * TC), g = (s >> 1) / (TR * TC);
       const int r = px / TC, c = px % TC;
       const int gg = (bz * NCO) * 2 + g;
@@ -237,7 +253,7 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
     const int iy0 = UPS ? oy0 / 2 : oy0 * S + 1 - PAD, ix0 = UPS ? ox0 / 2 : ox0 * S + 1 - PAD;
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
-      const int s = tid + 512 * k;
+      const int s = tid + NTH * k;
       const int half = s & 1, px = (s >> 1) % (IH * IW), g = (s >> 1) / (IH * IW);
       const int r = px / IW, c = px % IW;
       const int gg = by * NCI * 2 + g;
@@ -250,21 +266,49 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
   auto stash = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
-      const int s = tid + 512 * k;
+      const int s = tid + NTH * k;
       if (s < GS) *(u32x4*)(lg + s * 16) = rg[k];           // [g][px][half] is slot-linear
     }
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
-      const int s = tid + 512 * k;
+      const int s = tid + NTH * k;
       if (s < IS) *(u32x4*)(li + s * 16) = ri[k];           // [g][px][half]: IN_GROUP = IH*IW*32 bytes per group
     }
   };
-  fetch(y_begin);
+  // LDS-DMA staging: slot s (16 bytes) of the linear [g tile | input tile] image comes straight from
+  // global memory; no bounds tests — the G32 invariant (zero ring, nothing ever written outside the
+  // image) supplies the padding, lanes past the last existing group are masked off.
+  constexpr int NP = (GS + NCI * 2 * IH * IW * 2 + NTH - 1) / NTH;
+  auto dma_tile = [&](int oy0) __attribute__((always_inline)) {
+    const int iy0 = oy0 * S + 1 - PAD, ix0 = ox0 * S + 1 - PAD;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int s = tid + NTH * k;
+      char* const dst = smem + (wave * 64 + NTH * k) * 16;         // wave-uniform; lane*16 is implicit
+      if (s < GS) {
+        const int half = s & 1, px = (s >> 1) % (TR * TC), g = (s >> 1) / (TR * TC);
+        const int gg = (bz * NCO) * 2 + g;
+        if (gg < p.g.ngroups)
+          dma16(gbase + (int64_t)gg * p.g.group_stride + ((int64_t)(oy0 + px / TC + 1) * p.g.wp + ox0 + px % TC + 1) * 32 + half * 16, dst);
+      } else if (s - GS < IS) {
+        const int t = s - GS;
+        const int half = t & 1, px = (t >> 1) % (IH * IW), g = (t >> 1) / (IH * IW);
+        const int gg = by * NCI * 2 + g;
+        dma16(ibase + (int64_t)gg * p.in.group_stride + ((int64_t)(iy0 + px / IW) * p.in.wp + ix0 + px % IW) * 32 + half * 16, dst);
+      }
+    }
+  };
+  if constexpr (!DMA) fetch(y_begin);
   for (int oy0 = y_begin; oy0 < y_end; oy0 += TR) {
     __syncthreads();                 // every wave is done reading the previous tile
-    stash();
+    if constexpr (DMA) {
+      dma_tile(oy0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      stash();
+    }
     __syncthreads();
-    if (oy0 + TR < y_end) fetch(oy0 + TR);
+    if constexpr (!DMA) { if (oy0 + TR < y_end) fetch(oy0 + TR); }
     if (!active) continue;
     const char* lgw = lg + (wco * 2 + ghalf) * TR * TC * 32 + q * 8;
     const char* liw = li + (wci * 2 + ghalf) * IN_GROUP + q * 8;
@@ -324,7 +368,7 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
 
 
 template <int KS, int S, bool UPS, int NCO, int T0, int NT>
-__global__ __launch_bounds__(512) void wgrad16_kernel(const esr_wgrad p, int rows_per_wg) {
+__global__ __launch_bounds__((Wg16Mode<S, UPS>::NWV * 64), (Wg16Mode<S, UPS>::DMA ? 2 : 1)) void wgrad16_kernel(const esr_wgrad p, int rows_per_wg) {
   __shared__ __attribute__((aligned(16))) char smem[Wg16Geo<KS, S, UPS, NCO>::LDS_BYTES];
   wgrad16_body<KS, S, UPS, NCO, T0, NT>(p, rows_per_wg, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
@@ -342,7 +386,7 @@ struct WgradBatch {
   esr_wgrad w[WG_BATCH_MAX];
 };
 
-__global__ __launch_bounds__(512) void wgrad16_batch_kernel(const WgradBatch pb) {
+__global__ __launch_bounds__(256, 2) void wgrad16_batch_kernel(const WgradBatch pb) {
   constexpr int L0 = Wg16Geo<3, 1, false, 1>::LDS_BYTES, L1 = Wg16Geo<3, 1, false, 2>::LDS_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[L0 > L1 ? L0 : L1];
   int i = 0;
@@ -366,14 +410,14 @@ static int max_rows() {
   return v;
 }
 struct Wg16Grid { int nco, gx, gy, gz, rows; };
-template <int S>
+template <int S, bool UPS>
 Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs, int min_rows, int cap_rows) {
   const int strips = (p.W + 31) / 32;
   const int coblocks = (p.cout + 31) / 32;
   const int ciblocks = (p.in.ngroups + 1) / 2;
   Wg16Grid g;
   g.nco = (coblocks >= 2 || S == 2) ? 2 : 1;           // stride 2: LDS only fits NCO=2
-  const int nci = 8 / g.nco;
+  const int nci = Wg16Mode<S, UPS>::NWV / g.nco;
   g.gy = (ciblocks + nci - 1) / nci;
   g.gz = (coblocks + g.nco - 1) / g.nco;
   // Every workgroup ends with 8 waves x 9 taps x 1024 fp32 atomics, so use as FEW spatial splits as
@@ -388,13 +432,13 @@ Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs, int min_rows, int cap
 
 template <int KS, int S, bool UPS, int T0, int NT>
 int launch_wgrad16(const esr_wgrad& p, hipStream_t st) {
-  const Wg16Grid g = wgrad16_grid<S>(p, 64, 8, max_rows());
+  const Wg16Grid g = wgrad16_grid<S, UPS>(p, 64, 8, max_rows());
   dim3 grid(g.gx, g.gy, g.gz);
   if constexpr (S == 2) {
-    hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(512), 0, st, p, g.rows);
+    hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(Wg16Mode<S, UPS>::NWV * 64), 0, st, p, g.rows);
   } else {
-    if (g.nco == 2) hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(512), 0, st, p, g.rows);
-    else hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 1, T0, NT>), grid, dim3(512), 0, st, p, g.rows);
+    if (g.nco == 2) hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(Wg16Mode<S, UPS>::NWV * 64), 0, st, p, g.rows);
+    else hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 1, T0, NT>), grid, dim3(Wg16Mode<S, UPS>::NWV * 64), 0, st, p, g.rows);
   }
   return esr_check_launch("wgrad16_kernel");
 }
@@ -510,7 +554,7 @@ extern "C" int esr_conv_wgrad_multi(const esr_wgrad* items, int32_t n, esr_strea
       // batched launch: every spatial split costs a full set of dW atomics (~5 us per million), so take
       // the LARGEST row chunk that still gives each conv ~64 workgroups (6 convs fill the chip once),
       // and never less than 32 rows
-      const Wg16Grid g = wgrad16_grid<1>(p, batch_min_wgs(), 32, 1 << 30);
+      const Wg16Grid g = wgrad16_grid<1, false>(p, batch_min_wgs(), 32, 1 << 30);
       pb.start[k] = total;
       pb.gx[k] = g.gx; pb.gy[k] = g.gy; pb.rows[k] = g.rows;
       pb.kind[k] = (p.ks == 3 ? 0 : 2) + (g.nco == 2 ? 1 : 0);
@@ -519,7 +563,7 @@ extern "C" int esr_conv_wgrad_multi(const esr_wgrad* items, int32_t n, esr_strea
     }
     for (int k = m; k <= WG_BATCH_MAX; ++k) pb.start[k] = total;
     for (int k = m; k < WG_BATCH_MAX; ++k) { pb.gx[k] = pb.gy[k] = 1; pb.rows[k] = 8; pb.kind[k] = 0; pb.w[k] = items[i]; }
-    hipLaunchKernelGGL(wgrad16_batch_kernel, dim3(total), dim3(512), 0, (hipStream_t)stream, pb);
+    hipLaunchKernelGGL(wgrad16_batch_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, pb);
     const int rc = esr_check_launch("wgrad16_batch_kernel");
     if (rc) return rc;
     i += m;
