@@ -51,7 +51,10 @@ class esr_pack(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('cout', C.c_int32), ('cin', C.c_int32),
                 ('ks', C.c_int32), ('dtype', C.c_int32), ('transpose_flip', C.c_int32),
                 ('sum_dst', C.c_int32), ('sum_src', C.c_int32), ('sum_count', C.c_int32),
-                ('ups_dgrad', C.c_int32)]
+                ('ups_dgrad', C.c_int32),
+                ('gather', C.c_int32), ('dst_cout', C.c_int32), ('dst_chunk0', C.c_int32),
+                ('dst_nchunks', C.c_int32), ('src_co0', C.c_int32), ('src_ks', C.c_int32),
+                ('scale', C.c_float), ('_pad', C.c_int32)]
 
 
 class esr_wgrad(C.Structure):

@@ -54,12 +54,18 @@ class _RRDBNetBase(B._PlannedModule):
         return out
 
     def _dgrad_special(self):
-        sp = {'model.3': {'ups': True}, 'model.6': {'ups': True}}
+        return {'model.3': {'ups': True}, 'model.6': {'ups': True}}
+
+    def _dgrad_extra(self, device):
+        return self._eye_operand(device)
+
+    def _dgrad_gathers(self):
+        out = []
         for i in range(self.nb):
+            rr = self.model[1].sub[i]
             for j in (1, 2, 3):
-                # x4 = lrelu(a4) + x2 (block.py:266): dL/dx2 also receives conv5's x4 slice
-                sp['model.1.sub.%d.RDB%d.conv5.0' % (i, j)] = {'sum': (96, 160, 32)}
-        return sp
+                out += B._rdb_gathers('model.1.sub.%d.RDB%d' % (i, j), getattr(rr, 'RDB%d' % j))
+        return out
 
     def forward(self, x, z=None):
         """x: NCHW float32 in [0,1] on the MI355X -> [B, out_nc, 4H, 4W] float32.

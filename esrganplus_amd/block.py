@@ -195,6 +195,9 @@ class _PlannedModule(nn.Module):
         """Constant operands of the backward plan that are not parameters."""
         return []
 
+    def _dgrad_gathers(self):
+        return []
+
     def _eye_operand(self, device):
         # 1x1 identity kernel: carries the incoming gradient of a stand-alone block through the conv
         # epilogue's noise / scale stages (engine.build_rrdbnet_train_plan, kind 'rdb' / 'rrdb')
@@ -208,8 +211,11 @@ class _PlannedModule(nn.Module):
         key = ('dgrad', self.precision, str(device))
         dp = self._wp.get(key)
         if dp is None:
-            convs = [(k, w) for k, w, _ in self._conv_list()] + self._dgrad_extra(device)
-            dp = E.DgradPack(convs, self.precision, device, self._dgrad_special())
+            # dense-block convs get gather-form operands (one per channel slice); only the other
+            # convs (head / tail of the generator) are packed as plain transposes
+            convs = [(k, w) for k, w, _ in self._conv_list()
+                     if 'RDB' not in k and not k.startswith('rdb')] + self._dgrad_extra(device)
+            dp = E.DgradPack(convs, self.precision, device, self._dgrad_special(), self._dgrad_gathers())
             self._wp[key] = dp
         return dp
 
@@ -222,6 +228,20 @@ class _PlannedModule(nn.Module):
         wp.ensure(E.current_stream(), force=self._force_repack or self.training)
         self._force_repack = False
         return wp
+
+
+def _rdb_gathers(prefix, m):
+    """Gather-form input-gradient operands of one dense block (engine.DgradPack): the gradient of
+    channel slice j (x4, x3, x2, x1, x) is ONE conv over Q = [g_t | g_a4 | g_a3 | g_a2 | g_a1 | g_x2]
+    (the pre-activation gradients of the LATER convs, in that channel order; g_t stands for g_a5 / 0.2,
+    hence the 0.2 on conv5's piece; g_x2, un-masked, feeds the transposed 1x1 at the centre tap)."""
+    w = [None] + [getattr(m, 'conv%d' % k)[0].weight for k in range(1, 6)]
+    later = lambda j: [(w[5], 0.2)] + [(w[k], 1.0) for k in range(4, j, -1)]
+    out = []
+    for j, co0 in ((4, 160), (3, 128), (2, 96), (1, 64)):
+        out.append((prefix + '.g%d' % j, 32, [(t, co0, sc) for t, sc in later(j)]))
+    out.append((prefix + '.g0', 64, [(t, 0, sc) for t, sc in later(0)] + [(m.conv1x1.weight, 0, 1.0)]))
+    return out
 
 
 def _rdb_convs(prefix, m):
@@ -258,8 +278,8 @@ class ResidualDenseBlock_5C(_PlannedModule):
     def _conv_list(self):
         return _rdb_convs('rdb', self)
 
-    def _dgrad_special(self):
-        return {'rdb.conv5.0': dict(sum=(96, 160, 32))}
+    def _dgrad_gathers(self):
+        return _rdb_gathers('rdb', self)
 
     def _dgrad_extra(self, device):
         return self._eye_operand(device)
@@ -289,8 +309,11 @@ class RRDB(_PlannedModule):
             out += _rdb_convs('rrdb.RDB%d' % j, getattr(self, 'RDB%d' % j))
         return out
 
-    def _dgrad_special(self):
-        return {'rrdb.RDB%d.conv5.0' % j: dict(sum=(96, 160, 32)) for j in (1, 2, 3)}
+    def _dgrad_gathers(self):
+        out = []
+        for j in (1, 2, 3):
+            out += _rdb_gathers('rrdb.RDB%d' % j, getattr(self, 'RDB%d' % j))
+        return out
 
     def _dgrad_extra(self, device):
         return self._eye_operand(device)

@@ -8,6 +8,34 @@ template <typename T>
 __device__ __forceinline__ void pack_piece(const esr_pack& p, int64_t idx) {
   constexpr int CPG = DT<T>::CPG;
   constexpr int EPL = CPG / 2;   // elements per lane (8 halves / 4 floats)
+  if (p.gather) {
+    // one K range of a gather-form dgrad operand (esrgan_hip.h): rows = slice channels, K = fwd couts
+    const int nchunks = (p.cout + CPG - 1) / CPG;
+    const int lane = idx & 63;
+    int64_t rest = idx >> 6;
+    const int tap = rest % 9; rest /= 9;
+    const int chunk = rest % nchunks;
+    const int cb = rest / nchunks;
+    const int kh = tap / 3, kw = tap % 3;
+    const int i = lane & 31, h = lane >> 5;
+    const int co = cb * 32 + esr_pi(i);
+    T v[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int ci = chunk * CPG + EPL * h + e;
+      float x = 0.f;
+      if (co < p.dst_cout && ci < p.cout) {
+        const int64_t base = (int64_t)ci * p.cin + p.src_co0 + co;
+        if (p.src_ks == 3) x = p.src[(base * 3 + (2 - kh)) * 3 + (2 - kw)];
+        else if (kh == 1 && kw == 1) x = p.src[base];
+      }
+      v[e] = (T)(x * p.scale);
+    }
+    T* dst = (T*)p.dst + ((((int64_t)cb * p.dst_nchunks + p.dst_chunk0 + chunk) * 9 + tap) * 64 + lane) * EPL;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) dst[e] = v[e];
+    return;
+  }
   const int kdim = p.transpose_flip ? p.cout : p.cin;
   const int nchunks = (kdim + CPG - 1) / CPG;
   const int lane = idx & 63;
@@ -166,6 +194,7 @@ extern "C" int esr_pack_conv_weights(const esr_pack* p, esr_stream_t stream) {
 
 extern "C" int64_t esr_pack_pieces(const esr_pack* p) {
   const int cpg = p->dtype == ESR_F16 ? 16 : 8;
+  if (p->gather) return (int64_t)((p->dst_cout + 31) / 32) * ((p->cout + cpg - 1) / cpg) * 9 * 64;
   const int rows = p->transpose_flip ? p->cin : p->cout;
   const int kdim = p->transpose_flip ? p->cout : p->cin;
   return (int64_t)((rows + 31) / 32) * ((kdim + cpg - 1) / cpg) * p->ks * p->ks * 64;

@@ -408,10 +408,12 @@ class DgradPack:
     degrees (esr_pack.transpose_flip); conv5 of an RDB additionally folds the x4->x2 identity path
     (block.py:266) into its x2 output slice, and the upconvs get the 4x4/stride-2 adjoint kernel."""
 
-    def __init__(self, convs, dtype, device, special):
+    def __init__(self, convs, dtype, device, special, gathers=()):
         # convs: list of (key, weight_param); special: key -> dict(sum=(dst,src,count)) / dict(ups=True)
+        # gathers: list of (key, dst_cout, [(weight_param, src_co0, scale), ...]) — gather-form operands
+        # of a dense block (include/esrgan_hip.h: esr_pack.gather): K = the pieces' forward couts, in order
         self.esr_dtype, self.tdtype, self.cpg = _dt(dtype)
-        self.convs, self.special = convs, special
+        self.convs, self.special, self.gathers = convs, special, list(gathers)
         self.entries = {}
         total, offs = 0, []
         for key, w in convs:
@@ -419,7 +421,17 @@ class DgradPack:
             ks_out = 4 if special.get(key, {}).get('ups') else ks
             offs.append(total)
             total += L.packed_weight_bytes(cin, cout, ks_out, self.esr_dtype)
+        goffs = []
+        for key, dst_cout, pieces in self.gathers:
+            k_total = sum(w.shape[0] for w, _, _ in pieces)
+            goffs.append(total)
+            total += L.packed_weight_bytes(dst_cout, k_total, 3, self.esr_dtype)
         self.arena = torch.zeros(total, dtype=torch.uint8, device=device)
+        for (key, dst_cout, pieces), off in zip(self.gathers, goffs):
+            e = ConvW()
+            e.key, e.cout, e.cin, e.ks = key, dst_cout, sum(w.shape[0] for w, _, _ in pieces), 3
+            e.w_ptr, e.bias_ptr, e.has_bias = self.arena.data_ptr() + off, None, False
+            self.entries[key] = e
         for (key, w), off in zip(convs, offs):
             e = ConvW()
             e.key = key
@@ -432,9 +444,23 @@ class DgradPack:
         self.ops = None
 
     def ensure(self, stream):
-        ptrs = tuple(w.data_ptr() for _, w in self.convs)
+        ptrs = tuple(w.data_ptr() for _, w in self.convs) + tuple(
+            w.data_ptr() for _, _, pieces in self.gathers for w, _, _ in pieces)
         if ptrs != self._ptrs:
             packs = []
+            for key, dst_cout, pieces in self.gathers:
+                e = self.entries[key]
+                nchunks, chunk0 = e.cin // self.cpg, 0
+                for w, src_co0, scale in pieces:
+                    assert w.shape[0] % self.cpg == 0 and src_co0 + dst_cout <= w.shape[1]
+                    pk = L.esr_pack()
+                    pk.src, pk.dst = w.data_ptr(), e.w_ptr
+                    pk.cout, pk.cin, pk.ks = w.shape[0], w.shape[1], 3
+                    pk.dtype, pk.transpose_flip, pk.gather = self.esr_dtype, 1, 1
+                    pk.dst_cout, pk.dst_chunk0, pk.dst_nchunks = dst_cout, chunk0, nchunks
+                    pk.src_co0, pk.src_ks, pk.scale = src_co0, w.shape[2], scale
+                    packs.append(pk)
+                    chunk0 += w.shape[0] // self.cpg
             for key, w in self.convs:
                 e = self.entries[key]
                 sp = self.special.get(key, {})
@@ -716,9 +742,15 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
     # dgrad chain (both are latency-bound, ~64-workgroup launches at training sizes), and are joined
     # before the block after that starts: what they read (g_t, GA, G[96:128]) rotates so that the
     # chain running next to them writes other buffers — g_t through 3, G/GA through 2.
-    gT = [buf(64), buf(64), buf(64)]
-    Gs, GAs = [buf(192), buf(192)], [buf(128), buf(128)]
-    rdb_no = 0
+    # Gather-form dgrad (block._rdb_gathers): per block one 224-channel gradient concat
+    #   Q = [g_t (64) | g_a4 | g_a3 | g_a2 | g_a1 | g_x2 raw]   (32 each)
+    # that the slice convs read as a growing prefix and each fills one slice of — the dense
+    # connectivity mirrored, no read-modify-write of an accumulator.  Q rotates through 3 buffers: the
+    # block's weight gradients read it on the side stream while the next block runs, and the block
+    # after that is the first to overwrite it (its predecessor already writes ITS g_t into slot 0).
+    Qs = [buf(224), buf(224), buf(224)]
+    gT = [q for q in Qs]                            # g_t of a block = channels [0,64) of its Q
+    X4 = buf(32)                                    # raw g_x4 (identity path x4 = lrelu(a4) + x2)
     GF = buf(64)                                    # dL/dfea
 
     if block:
@@ -774,47 +806,37 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         for j in range(nj - 1, -1, -1):
             bf, ax = S[i][j], AUX[i][j]
             p = pkey(i, j)
-            gt = gT[ct]
-            G, GA = Gs[rdb_no & 1], GAs[rdb_no & 1]
-            rdb_no += 1
-            # the block's six weight gradients read g_t, GA[0:128], G[96:128] and the saved input, all
-            # intact until the next block starts -> emit them together after the dgrad chain
+            Q = Qs[ct]                              # Q[0:64] already holds this block's g_t
+            # the block's six weight gradients read Q and the saved input, intact until the block after
+            # next starts -> emit them together after the dgrad chain (one batched side-stream launch)
             deferred = []
-            # conv5: g_x5 = 0.2 g_t ; G = conv5^T(g_x5) (+ g_t on the x channels: d(0.2x5+x)/dx)
-            wgrad(p + '.conv5.0', gt.view(0, 64), bf.view(0, 192), H, W, 64, 192, scale=0.2)
-            c = dconv(H, W, gt.view(0), 64, G.view(0, 192), p + '.conv5.0')
-            c.alpha, c.res1 = 0.2, gt.view(0, 64)
-            c.mask, c.out2, c.mask_cb_begin = ax.view(32, 32), GA.view(96, 32), 5
+            wgrad(p + '.conv5.0', Q.view(0, 64), bf.view(0, 192), H, W, 64, 192, scale=0.2)
+            wgrad(p + '.conv4.0', Q.view(64, 32), bf.view(0, 160), H, W, 32, 160)
+            wgrad(p + '.conv3.0', Q.view(96, 32), bf.view(0, 128), H, W, 32, 128)
+            wgrad(p + '.conv2.0', Q.view(128, 32), bf.view(0, 96), H, W, 32, 96)
+            wgrad(p + '.conv1x1', Q.view(192, 32), bf.view(0, 64), H, W, 32, 64, ks=1)
+            wgrad(p + '.conv1.0', Q.view(160, 32), bf.view(0, 64), H, W, 32, 64)
+            # slice x4: g_x4 = conv5^T[x4](0.2 g_t)  -> raw to X4, masked (lrelu'(a4)) to Q[64:96]
+            c = dconv(H, W, Q.view(0), 64, X4.view(0, 32), p + '.g4')
+            c.mask, c.out2, c.mask_cb_begin = ax.view(32, 32), Q.view(64, 32), 0
             add_b(c)
-            # conv4
-            wgrad(p + '.conv4.0', GA.view(96, 32), bf.view(0, 160), H, W, 32, 160)
-            c = dconv(H, W, GA.view(96), 32, G.view(0, 160), p + '.conv4.0')
-            c.res1 = G.view(0, 160)
-            c.mask, c.out2, c.mask_cb_begin = bf.view(128, 32), GA.view(64, 32), 4
+            # slice x3 -> g_a3 = masked into Q[96:128]
+            c = dconv(H, W, Q.view(0), 96, None, p + '.g3')
+            c.mask, c.out2, c.mask_cb_begin = bf.view(128, 32), Q.view(96, 32), 0
             add_b(c)
-            # conv3
-            wgrad(p + '.conv3.0', GA.view(64, 32), bf.view(0, 128), H, W, 32, 128)
-            c = dconv(H, W, GA.view(64), 32, G.view(0, 128), p + '.conv3.0')
-            c.res1 = G.view(0, 128)
-            c.mask, c.out2, c.mask_cb_begin = ax.view(0, 32), GA.view(32, 32), 3
+            # slice x2 (+ g_x4: x4 = lrelu(a4) + x2) -> raw to Q[192:224] (feeds the 1x1), masked to Q[128:160]
+            c = dconv(H, W, Q.view(0), 128, Q.view(192, 32), p + '.g2')
+            c.res1 = X4.view(0, 32)
+            c.mask, c.out2, c.mask_cb_begin = ax.view(0, 32), Q.view(128, 32), 0
             add_b(c)
-            # conv2
-            wgrad(p + '.conv2.0', GA.view(32, 32), bf.view(0, 96), H, W, 32, 96)
-            c = dconv(H, W, GA.view(32), 32, G.view(0, 96), p + '.conv2.0')
-            c.res1 = G.view(0, 96)
-            c.mask, c.out2, c.mask_cb_begin = bf.view(64, 32), GA.view(0, 32), 2
+            # slice x1 -> g_a1 = masked into Q[160:192]
+            c = dconv(H, W, Q.view(0), 160, None, p + '.g1')
+            c.mask, c.out2, c.mask_cb_begin = bf.view(64, 32), Q.view(160, 32), 0
             add_b(c)
-            # conv1x1 (x2 = lrelu(a2) + conv1x1(x)): raw g_x2 = G[96:128]
-            wgrad(p + '.conv1x1', G.view(96, 32), bf.view(0, 64), H, W, 32, 64, ks=1)
-            c = dconv(H, W, G.view(96), 32, G.view(0, 64), p + '.conv1x1')
-            c.res1 = G.view(0, 64)
-            if i == 0 and j == 0 and not block:
-                c.res2, c.beta = GTt.view(0, 64), 1.0    # trunk shortcut: fea also feeds T directly
-            add_b(c)
-            # conv1: closes the block: g_x = conv1^T(g_a1) + G[x]  (+ RRDB skip for RDB1)
-            wgrad(p + '.conv1.0', GA.view(0, 32), bf.view(0, 64), H, W, 32, 64)
-            c = dconv(H, W, GA.view(0), 32, None, p + '.conv1.0')
-            c.res1 = G.view(0, 64)
+            # slice x closes the block: g_x = sum_k conv_k^T[x](g_ak) + conv1x1^T(g_x2) + g_t
+            # (d(0.2 x5 + x)/dx)  (+ RRDB skip for RDB1)
+            c = dconv(H, W, Q.view(0), 224, None, p + '.g0')
+            c.res1 = Q.view(0, 64)
             if j > 0:
                 # g_x = g_y of RDB j (previous in forward order) -> its g_t = g_y * n
                 c.out = gT[(ct + 1) % 3].view(0, 64)
@@ -848,6 +870,13 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         TP.gx_op = None                             # bound after the unpermute op is appended
         gx_layout = lo
     else:
+        if nb:
+            # trunk shortcut (fea feeds T directly as well): dL/dfea = chain result + dL/dT
+            GF2 = buf(64)
+            c = dconv(H, W, GF.view(0), 64, GF2.view(0, 64), '__eye')
+            c.res1 = GTt.view(0, 64)
+            add_b(c)
+            GF = GF2
         # fea_conv (model.0): weight gradient only (the LR input image needs no gradient)
         wgrad('model.0', GF.view(0, 64), xin.view(0, in_nc), H, W, 64, in_nc)
     if TP.tapmajor is not None:

@@ -118,6 +118,17 @@ typedef struct esr_pack {
   int32_t sum_count;   /*   [sum_src, sum_src+sum_count) (x4 = lrelu(a4) + x2, block.py:266)      */
   int32_t ups_dgrad;   /* 1 (with transpose_flip, ks==3): emit the 4x4/stride-2 kernel that is the
                           exact adjoint of nearest-x2-upsample + 3x3 conv (block.py:315-322)       */
+  /* gather == 1 (with transpose_flip == 1, ks == 3): this entry fills ONE K range of a larger packed
+   * operand — the input-gradient conv of a dense-block channel slice in "gather" form:
+   *   g_slice = sum over the later convs k of  conv_k^T[slice] (g_ak)
+   * is ONE conv whose K dimension concatenates the gradients g_ak (dense connectivity mirrored), so
+   * the slice's gradient is written once instead of being accumulated conv by conv.  The piece
+   * maps packed row r -> forward input channel src_co0 + r (r < dst_cout) and packed K index c
+   * (c < cout, placed at chunks [dst_chunk0, ...) of dst_nchunks) -> forward output channel c;
+   * weights are multiplied by `scale`; src_ks == 1 embeds a 1x1 kernel as the centre tap. */
+  int32_t gather, dst_cout, dst_chunk0, dst_nchunks, src_co0, src_ks;
+  float scale;
+  int32_t _pad;
 } esr_pack;
 
 /* All weight packs of a network in ONE launch: `table` is a DEVICE array of n esr_pack entries,
