@@ -34,4 +34,4 @@ for _ in range(5):
     st.step(lr, hr, sync_log=False)
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
+pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
