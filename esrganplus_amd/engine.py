@@ -17,8 +17,7 @@ from . import _lib as L
 
 SIGMA = 0.1   # GaussianNoise sigma (block.py:111)
 
-import os as _os
-_STORE_FLAVOUR = int(_os.environ.get('ESR_STORE_FLAVOUR', '0'))   # experiment knob: 1 = nt epilogue stores
+_STORE_FLAVOUR = int(os.environ.get('ESR_STORE_FLAVOUR', '0'))   # experiment knob: 1 = nt epilogue stores
 
 
 def _dt(dtype):
@@ -182,7 +181,7 @@ def _conv(dtype_e, B, H, W, src, src_ch, dst, cw, act=L.ACT_NONE, ks=None, strid
     c.layer3 = L.NO_LAYER
     c.gamma = 1.0
     c.mask_act = L.ACT_LRELU
-    c.debug_flags = (_STORE_FLAVOUR << 3) | (int(_os.environ.get('ESR_DBG', '0')) & ~7)
+    c.debug_flags = (_STORE_FLAVOUR << 3) | (int(os.environ.get('ESR_DBG', '0')) & ~7)
     return c
 
 

@@ -15,7 +15,6 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from . import dp as DP
 from . import engine as E
 
 
