@@ -166,6 +166,16 @@ class _PlannedModule(nn.Module):
         self.__dict__['_conv_cache'] = None
         return super()._apply(fn, *a, **k)
 
+    def _replicate_for_data_parallel(self):
+        # nn.DataParallel (networks.py:105-107) shallow-copies __dict__ and then swaps in per-device
+        # parameter copies: anything derived from the ORIGINAL's parameters must not leak into the replica
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__['_conv_cache'] = None
+        replica.__dict__['_wp'] = {}
+        replica.__dict__['_plans'] = {}
+        replica.__dict__['_force_repack'] = True
+        return replica
+
     def _convs(self):
         """Cached (key, weight, bias) list + the flat parameter list autograd sees (rebuilding them
         walks ~350 modules: 1.8 ms of host time per training step)."""

@@ -138,3 +138,13 @@ def test_net_interp_and_network_roundtrip(tmp_path):
     net2 = arch.RRDBNet(3, 3, 64, 1)
     ck.load_network(str(tmp_path / 'n.pth'), net2)
     assert all(torch.equal(v, net2.state_dict()[kk]) for kk, v in net.state_dict().items())
+
+
+def test_data_parallel_replica_does_not_inherit_caches():
+    from esrganplus_amd import architecture as arch
+    net = arch.RRDBNet(3, 3, 64, 1)
+    net._convs()                                   # populate the cache on the original
+    net._plans['x'] = object()
+    rep = net._replicate_for_data_parallel()
+    assert rep.__dict__['_conv_cache'] is None and rep._plans == {} and rep._wp == {}
+    assert net.__dict__['_conv_cache'] is not None and 'x' in net._plans
