@@ -148,3 +148,23 @@ def test_data_parallel_replica_does_not_inherit_caches():
     rep = net._replicate_for_data_parallel()
     assert rep.__dict__['_conv_cache'] is None and rep._plans == {} and rep._wp == {}
     assert net.__dict__['_conv_cache'] is not None and 'x' in net._plans
+
+
+def test_header_is_plain_c_and_structs_match_ctypes(tmp_path):
+    """include/esrgan_hip.h must be consumable from C (the boundary is a C ABI) and every struct the
+    Python binding mirrors must have the size the C compiler gives it."""
+    import ctypes as C
+    import subprocess
+    from esrganplus_amd import _lib as L
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'esrgan_hip.h')
+    subprocess.check_call(['gcc', '-std=c99', '-fsyntax-only', '-x', 'c', hdr])
+    names = ['esr_g32', 'esr_conv', 'esr_pack', 'esr_pack_batch', 'esr_layout', 'esr_noise_fill', 'esr_wgrad',
+             'esr_unpermute', 'esr_bn', 'esr_pool', 'esr_linear', 'esr_adam', 'esr_resample', 'esr_op']
+    src = tmp_path / 'sz.c'
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(void){%s return 0;}\n' % (
+        hdr, ''.join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names)))
+    exe = tmp_path / 'sz'
+    subprocess.check_call(['gcc', '-std=c99', str(src), '-o', str(exe)])
+    out = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for n in names:
+        assert int(out[n]) == C.sizeof(getattr(L, n)), (n, out[n], C.sizeof(getattr(L, n)))
