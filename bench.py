@@ -126,8 +126,9 @@ def train_bench(args, world, rank, dev, dist):
     for n in (netG, netD):
         DP.broadcast_parameters(n)
     st = train.ESRGANPlusStep(netG, netD, netF, loss_scale=1024.0 if prec == 'fp16' else 1.0)
-    lr = synth.image_batch(200 + rank, 16, 3, 32, 32, name='bench.lr').to(dev)
-    hr = synth.image_batch(300 + rank, 16, 3, 128, 128, name='bench.hr').to(dev)
+    tb = args.train_batch
+    lr = synth.image_batch(200 + rank, tb, 3, 32, 32, name='bench.lr').to(dev)
+    hr = synth.image_batch(300 + rank, tb, 3, 128, 128, name='bench.hr').to(dev)
     for _ in range(max(args.warmup, 1)):
         st.step(lr, hr, sync_log=False)
     torch.cuda.synchronize()
@@ -145,15 +146,15 @@ def train_bench(args, world, rank, dev, dist):
         elapsed = float(t.item())
     assert all(torch.isfinite(v).all() for v in log.values())
     if rank == 0:
-        step_flops = 2.0 * 1.515e12          # ~1.515 TMAC per batch-16 step
+        step_flops = 2.0 * 1.515e12 * tb / 16          # ~1.515 TMAC per batch-16 step
         res = {'metric': 'HR megapixels/sec (x4 SR) full ESRGAN+ train step', 'unit': 'HR-Mpix/s',
-               'value': round(world * 16 * 128 * 128 / 1e6 / (elapsed / args.steps), 3), 'n_gpus': world,
+               'value': round(world * tb * 128 * 128 / 1e6 / (elapsed / args.steps), 3), 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f16' if prec == 'fp16' else 'f32', 'data': 'synthetic',
                'config': {'workload': 'ESRGAN+ train step (RRDBNet nb=23 + Discriminator_VGG_128 + VGG19[:35] '
-                                      'feature loss, Adam x2), batch 16 of 32x32 LR per GPU (BASELINE configs[2]/[3])',
-                          'global_batch': world * 16, 'parallelism': 'dp%d, RCCL grad all-reduce overlapped' % world},
+                                      'feature loss, Adam x2), batch %d of 32x32 LR per GPU (BASELINE configs[2]/[3])' % tb,
+                          'global_batch': world * tb, 'parallelism': 'dp%d, RCCL grad all-reduce overlapped' % world},
                'tflops_per_gpu': round(step_flops / (elapsed / args.steps) / 1e12, 1)}
         print(json.dumps(res), flush=True)
     if dist is not None:
@@ -240,6 +241,8 @@ def main():
                          'full ESRGAN+ step, batch 16 of 32x32 LR per GPU, DP over RCCL; '
                          "'gtrain' = configs[4]: noise-on generator fwd+bwd+Adam on mixed 128/192/256 LR tiles")
     ap.add_argument('--precision', choices=['fp16', 'fp32'], default='fp16')
+    ap.add_argument('--train-batch', type=int, default=16,
+                    help="--mode train: LR tiles per GPU per step (the reference's config uses 16)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
