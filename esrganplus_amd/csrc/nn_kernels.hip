@@ -48,23 +48,27 @@ __device__ __forceinline__ float act_bwd(float y, int act) {   // derivative sel
 }
 
 // grid: (ceil(H*W/256), groups, B); block 256.  Per-channel reductions: wave shuffle + LDS + fp64 atomics.
+// `ppt` = pixels per thread: the reduction modes walk several 256-pixel chunks per workgroup so the
+// fp64 atomics (2*CPG per workgroup, all workgroups of a channel group hitting the same addresses) are
+// amortised — one chunk per workgroup made the backward reduce atomic-bound (928 us on 256x64x128^2).
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void bn_pass_kernel(const esr_bn p) {
+__global__ __launch_bounds__(256) void bn_pass_kernel(const esr_bn p, const int ppt) {
   constexpr int CPG = DT<T>::CPG;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
   const int g = blockIdx.y, b = blockIdx.z;
-  const bool ok = pix < p.H * p.W;
-  const int y = ok ? pix / p.W : 0, x = ok ? pix % p.W : 0;
   float xv[CPG], yv[CPG], gv[CPG];
   float s0[CPG], s1[CPG];
 #pragma unroll
   for (int e = 0; e < CPG; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
   const double N = (double)p.B * p.H * p.W;
+  for (int k = 0; k < ppt; ++k) {
+  const int pix = (blockIdx.x * ppt + k) * 256 + threadIdx.x;
+  const bool ok = pix < p.H * p.W;
+  const int y = ok ? pix / p.W : 0, x = ok ? pix % p.W : 0;
   if (ok) {
     ld16<T>((const char*)p.x.ptr + pix_off(p.x, b, g, y, x), xv);
     if (MODE == ESR_BN_STATS) {
 #pragma unroll
-      for (int e = 0; e < CPG; ++e) { s0[e] = xv[e]; s1[e] = xv[e] * xv[e]; }
+      for (int e = 0; e < CPG; ++e) { s0[e] += xv[e]; s1[e] += xv[e] * xv[e]; }
     } else if (MODE == ESR_BN_APPLY) {
 #pragma unroll
       for (int e = 0; e < CPG; ++e) {
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256) void bn_pass_kernel(const esr_bn p) {
         if (c >= p.C) { gv[e] = 0.f; continue; }
         const float gp = gv[e] * act_bwd(yv[e], p.act);
         const float xh = (xv[e] - p.mean[c]) * p.invstd[c];
-        if (MODE == ESR_BN_BWD_REDUCE) { s0[e] = gp; s1[e] = gp * xh; }
+        if (MODE == ESR_BN_BWD_REDUCE) { s0[e] += gp; s1[e] += gp * xh; }
         else {
           float r = gp;
           if (p.training) r = gp - (float)(p.sums[c] / N) - xh * (float)(p.sums[p.C + c] / N);
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(256) void bn_pass_kernel(const esr_bn p) {
       if (MODE == ESR_BN_BWD_APPLY) st16<T>((char*)p.gx.ptr + pix_off(p.gx, b, g, y, x), gv);
     }
   }
+  }   // pixel chunks
   if (MODE == ESR_BN_STATS || MODE == ESR_BN_BWD_REDUCE) {
     __shared__ float red[4][2][CPG];
 #pragma unroll
@@ -217,12 +222,17 @@ __global__ __launch_bounds__(256) void linear_bwdw_kernel(const esr_linear p) {
 template <typename T>
 int bn_dispatch(const esr_bn& p, hipStream_t st) {
   constexpr int CPG = DT<T>::CPG;
-  dim3 grid((p.H * p.W + 255) / 256, (p.C + CPG - 1) / CPG, p.B), block(256);
+  const int chunks = (p.H * p.W + 255) / 256;
+  dim3 grid(chunks, (p.C + CPG - 1) / CPG, p.B), block(256);
+  // reductions: up to 16 chunks per workgroup, but keep >= ~1024 workgroups in flight
+  int ppt = 1;
+  while (ppt < 16 && (int64_t)((chunks + 2 * ppt - 1) / (2 * ppt)) * grid.y * grid.z >= 1024) ppt *= 2;
+  dim3 rgrid((chunks + ppt - 1) / ppt, grid.y, grid.z);
   switch (p.mode) {
-    case ESR_BN_STATS: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_STATS>), grid, block, 0, st, p); break;
-    case ESR_BN_APPLY: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_APPLY>), grid, block, 0, st, p); break;
-    case ESR_BN_BWD_REDUCE: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_BWD_REDUCE>), grid, block, 0, st, p); break;
-    case ESR_BN_BWD_APPLY: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_BWD_APPLY>), grid, block, 0, st, p); break;
+    case ESR_BN_STATS: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_STATS>), rgrid, block, 0, st, p, ppt); break;
+    case ESR_BN_APPLY: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_APPLY>), grid, block, 0, st, p, 1); break;
+    case ESR_BN_BWD_REDUCE: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_BWD_REDUCE>), rgrid, block, 0, st, p, ppt); break;
+    case ESR_BN_BWD_APPLY: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_BWD_APPLY>), grid, block, 0, st, p, 1); break;
     case ESR_BN_FINALIZE:
     case ESR_BN_BWD_FINAL: hipLaunchKernelGGL(bn_small_kernel, dim3((p.C + 63) / 64), dim3(64), 0, st, p); break;
     default: esr_set_error("esr_batchnorm: bad mode %d", p.mode); return ESR_ERR_INVALID;
