@@ -169,7 +169,7 @@ __device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
 // staged by LDS-DMA, two resident per CU; the upsample-on-load and stride-2 variants keep the 8-wave
 // register-staged form (their source addresses are not slot-linear / need the zero fill).
 template <int S, bool UPS> struct Wg16Mode {
-  static constexpr bool DMA = S == 1 && !UPS;
+  static constexpr bool DMA = true;                    // (the register-staged path is kept for reference)
   static constexpr int NWV = DMA ? 4 : 8;              // waves per workgroup
 };
 
@@ -280,7 +280,7 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
   // image) supplies the padding, lanes past the last existing group are masked off.
   constexpr int NP = (GS + NCI * 2 * IH * IW * 2 + NTH - 1) / NTH;
   auto dma_tile = [&](int oy0) __attribute__((always_inline)) {
-    const int iy0 = oy0 * S + 1 - PAD, ix0 = ox0 * S + 1 - PAD;
+    const int iy0 = UPS ? oy0 / 2 : oy0 * S + 1 - PAD, ix0 = UPS ? ox0 / 2 : ox0 * S + 1 - PAD;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const int s = tid + NTH * k;
