@@ -165,12 +165,10 @@ __device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// Plain 3x3/s1 and 1x1 problems (the generator's, batched per dense block) run as 4-wave workgroups
-// staged by LDS-DMA, two resident per CU; the upsample-on-load and stride-2 variants keep the 8-wave
-// register-staged form (their source addresses are not slot-linear / need the zero fill).
+// Every variant runs as 4-wave workgroups staged by LDS-DMA, two resident per CU (an earlier 8-wave
+// form staged through registers: 112 KB of LDS per workgroup, spills, no overlap — 2.3x slower).
 template <int S, bool UPS> struct Wg16Mode {
-  static constexpr bool DMA = true;                    // (the register-staged path is kept for reference)
-  static constexpr int NWV = DMA ? 4 : 8;              // waves per workgroup
+  static constexpr int NWV = 4;                        // waves per workgroup
 };
 
 template <int KS, int S, bool UPS, int NCO>
@@ -191,7 +189,6 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
   // taps [T0, T0+NT) of the KSxKS kernel are accumulated by this launch (4x4 kernels: two launches
   // of 8 taps, keeping the accumulators within the register file)
   constexpr int TR = S == 2 ? 2 : 4, TC = 32, NTAP = KS * KS, PAD = (KS - 1) / 2;
-  constexpr bool DMA = Wg16Mode<S, UPS>::DMA;
   constexpr int NWV = Wg16Mode<S, UPS>::NWV, NTH = NWV * 64;
   constexpr int NCI = NWV / NCO;                      // cin blocks (of 32 channels) per workgroup
   constexpr int IH = UPS ? TR / 2 + 2 : (TR - 1) * S + KS, IW = UPS ? TC / 2 + 2 : (TC - 1) * S + KS;
@@ -228,53 +225,10 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
   const char* ibase = (const char*)p.in.ptr + b * p.in.batch_stride;
   const int y_begin = rc * rows_per_wg, y_end = min(p.H, y_begin + rows_per_wg);
 
-  // Software-pipelined staging: the NEXT row tile's g / input slots are fetched into registers while
-  // the MFMAs of the current tile run (the loop used to be load -> LDS -> barrier -> MFMA, ~3.7 us per
-  // tile of which 1.1 us is MFMA).  Input groups past the tensor's last one are never read by an
-  // active wave, so they are neither fetched nor zero-filled.
   constexpr int GS = NCO * 2 * TR * TC * 2;                 // 16-byte slots of the g tile
-  constexpr int NG = (GS + NTH - 1) / NTH;
+  // input groups past the tensor's last one are never read by an active wave: not staged
   const int in_groups = min(NCI * 2, ngin - (int)by * NCI * 2);
   const int IS = in_groups > 0 ? in_groups * IH * IW * 2 : 0;
-  constexpr int NI = (NCI * 2 * IH * IW * 2 + NTH - 1) / NTH;
-  u32x4 rg[NG], ri[NI];
-  auto fetch = [&](int oy0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < NG; ++k) {
-      const int s = tid + NTH * k;
-      const int half = s & 1, px = (s >> 1) % (TR * TC), g = (s >> 1) / (TR * TC);
-      const int r = px / TC, c = px % TC;
-      const int gg = (bz * NCO) * 2 + g;
-      u32x4 v = {0, 0, 0, 0};
-      if (s < GS && oy0 + r < y_end && ox0 + c < p.W && gg < p.g.ngroups)
-        v = *(const u32x4*)(gbase + (int64_t)gg * p.g.group_stride + ((int64_t)(oy0 + r + 1) * p.g.wp + ox0 + c + 1) * 32 + half * 16);
-      rg[k] = v;
-    }
-    const int iy0 = UPS ? oy0 / 2 : oy0 * S + 1 - PAD, ix0 = UPS ? ox0 / 2 : ox0 * S + 1 - PAD;
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      const int s = tid + NTH * k;
-      const int half = s & 1, px = (s >> 1) % (IH * IW), g = (s >> 1) / (IH * IW);
-      const int r = px / IW, c = px % IW;
-      const int gg = by * NCI * 2 + g;
-      u32x4 v = {0, 0, 0, 0};
-      if (s < IS)
-        v = *(const u32x4*)(ibase + (int64_t)gg * p.in.group_stride + ((int64_t)(iy0 + r) * p.in.wp + ix0 + c) * 32 + half * 16);
-      ri[k] = v;
-    }
-  };
-  auto stash = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < NG; ++k) {
-      const int s = tid + NTH * k;
-      if (s < GS) *(u32x4*)(lg + s * 16) = rg[k];           // [g][px][half] is slot-linear
-    }
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      const int s = tid + NTH * k;
-      if (s < IS) *(u32x4*)(li + s * 16) = ri[k];           // [g][px][half]: IN_GROUP = IH*IW*32 bytes per group
-    }
-  };
   // LDS-DMA staging: slot s (16 bytes) of the linear [g tile | input tile] image comes straight from
   // global memory; no bounds tests — the G32 invariant (zero ring, nothing ever written outside the
   // image) supplies the padding, lanes past the last existing group are masked off.
@@ -298,17 +252,11 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
       }
     }
   };
-  if constexpr (!DMA) fetch(y_begin);
   for (int oy0 = y_begin; oy0 < y_end; oy0 += TR) {
     __syncthreads();                 // every wave is done reading the previous tile
-    if constexpr (DMA) {
-      dma_tile(oy0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      stash();
-    }
-    __syncthreads();
-    if constexpr (!DMA) { if (oy0 + TR < y_end) fetch(oy0 + TR); }
+    dma_tile(oy0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                 // (the CU's other workgroup computes meanwhile)
     if (!active) continue;
     const char* lgw = lg + (wco * 2 + ghalf) * TR * TC * 32 + q * 8;
     const char* liw = li + (wci * 2 + ghalf) * IN_GROUP + q * 8;
@@ -368,7 +316,7 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
 
 
 template <int KS, int S, bool UPS, int NCO, int T0, int NT>
-__global__ __launch_bounds__((Wg16Mode<S, UPS>::NWV * 64), (Wg16Mode<S, UPS>::DMA ? 2 : 1)) void wgrad16_kernel(const esr_wgrad p, int rows_per_wg) {
+__global__ __launch_bounds__((Wg16Mode<S, UPS>::NWV * 64), 2) void wgrad16_kernel(const esr_wgrad p, int rows_per_wg) {
   __shared__ __attribute__((aligned(16))) char smem[Wg16Geo<KS, S, UPS, NCO>::LDS_BYTES];
   wgrad16_body<KS, S, UPS, NCO, T0, NT>(p, rows_per_wg, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
