@@ -184,7 +184,7 @@ struct Wg16Geo {
 // (bx, by, bz) = the workgroup's coordinates in THIS conv's grid (the batched launch packs the grids
 // of several convs into one 1-D grid)
 template <int KS, int S, bool UPS, int NCO, int T0, int NT>
-__device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_per_wg, char* const smem,
+__device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_arg, char* const smem,
                                              const int bx, const int by, const int bz) {
   // taps [T0, T0+NT) of the KSxKS kernel are accumulated by this launch (4x4 kernels: two launches
   // of 8 taps, keeping the accumulators within the register file)
@@ -202,8 +202,12 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wco = wave % NCO, wci = wave / NCO;       // this wave's cout block / cin block in the WG
   const int strips = (p.W + TC - 1) / TC;
+  // rows_arg = rows per workgroup | images per workgroup << 16 (many small images: one workgroup walks
+  // several of them, so the number of dW atomic rounds stays ~64 per conv instead of one per image)
+  const int rows_per_wg = rows_arg & 0xFFFF, ipw = (rows_arg >> 16) > 0 ? (rows_arg >> 16) : 1;
   const int rchunks = (p.H + rows_per_wg - 1) / rows_per_wg;
-  const int sx = bx % strips, rc = (bx / strips) % rchunks, b = bx / (strips * rchunks);
+  const int sx = bx % strips, rc = (bx / strips) % rchunks, b0 = (bx / (strips * rchunks)) * ipw;
+  const int bend = min(p.B, b0 + ipw);
   const int ox0 = sx * TC;
   const int cb = bz * NCO + wco;              // 32-cout block
   const int cib = by * NCI + wci;             // 32-cin block  (= G32 groups 2*cib, 2*cib+1)
@@ -221,8 +225,8 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc.a[t][e] = 0.f;
 
-  const char* gbase = (const char*)p.g.ptr + b * p.g.batch_stride;
-  const char* ibase = (const char*)p.in.ptr + b * p.in.batch_stride;
+  const char* gbase = (const char*)p.g.ptr + b0 * p.g.batch_stride;
+  const char* ibase = (const char*)p.in.ptr + b0 * p.in.batch_stride;
   const int y_begin = rc * rows_per_wg, y_end = min(p.H, y_begin + rows_per_wg);
 
   constexpr int GS = NCO * 2 * TR * TC * 2;                 // 16-byte slots of the g tile
@@ -252,6 +256,7 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
       }
     }
   };
+  for (int b = b0; b < bend; ++b, gbase += p.g.batch_stride, ibase += p.in.batch_stride)
   for (int oy0 = y_begin; oy0 < y_end; oy0 += TR) {
     __syncthreads();                 // every wave is done reading the previous tile
     dma_tile(oy0);
@@ -357,7 +362,7 @@ static int max_rows() {
   static const int v = [] { const char* e = getenv("ESR_WGRAD_MAX_ROWS"); return e ? atoi(e) : 32; }();
   return v;
 }
-struct Wg16Grid { int nco, gx, gy, gz, rows; };
+struct Wg16Grid { int nco, gx, gy, gz, rows; };   // rows = rows per workgroup | images per workgroup << 16
 template <int S, bool UPS>
 Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs, int min_rows, int cap_rows) {
   const int strips = (p.W + 31) / 32;
@@ -373,8 +378,12 @@ Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs, int min_rows, int cap
   int rows = ((p.H + 3) / 4) * 4;
   if (rows > cap_rows) rows = cap_rows;       // bound the serial load->LDS->MFMA iterations of one workgroup
   while (rows > min_rows && (int64_t)p.B * strips * ((p.H + rows - 1) / rows) * g.gy * g.gz < min_wgs) rows = ((rows / 2 + 3) / 4) * 4;
-  g.rows = rows;
-  g.gx = p.B * strips * ((p.H + rows - 1) / rows);
+  const int rchunks = (p.H + rows - 1) / rows;
+  int ipw = 1;                                            // images per workgroup
+  while (ipw < p.B && ipw < 0x7FFF &&
+         (int64_t)((p.B + 2 * ipw - 1) / (2 * ipw)) * strips * rchunks * g.gy * g.gz >= min_wgs) ipw *= 2;
+  g.rows = rows | (ipw << 16);
+  g.gx = ((p.B + ipw - 1) / ipw) * strips * rchunks;
   return g;
 }
 
