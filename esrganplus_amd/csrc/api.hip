@@ -25,6 +25,16 @@ int esr_check_launch(const char* what) {
   return ESR_OK;
 }
 
+// HIP runtime calls on the control path: report instead of ignoring a failure
+#define ESR_HIP(call)                                                                   \
+  do {                                                                                  \
+    const hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                             \
+      esr_set_error("%s: %s", #call, hipGetErrorString(e_));                            \
+      return ESR_ERR_LAUNCH;                                                            \
+    }                                                                                   \
+  } while (0)
+
 extern "C" const char* esr_last_error(void) { return g_err; }
 extern "C" int esr_abi_version(void) { return 1; }
 extern "C" size_t esr_sizeof_op(void) { return sizeof(esr_op); }
@@ -85,11 +95,11 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
           SideState* ss = side_state();
           if (!ss) return ESR_ERR_LAUNCH;
           hipStream_t main_st = (hipStream_t)stream;
-          if (nside > 0) hipStreamWaitEvent(main_st, ss->join[(nside - 1) & 1], 0);
-          hipEventRecord(ss->fork[nside & 1], main_st);
-          hipStreamWaitEvent(ss->stream, ss->fork[nside & 1], 0);
+          if (nside > 0) ESR_HIP(hipStreamWaitEvent(main_st, ss->join[(nside - 1) & 1], 0));
+          ESR_HIP(hipEventRecord(ss->fork[nside & 1], main_st));
+          ESR_HIP(hipStreamWaitEvent(ss->stream, ss->fork[nside & 1], 0));
           rc = esr_conv_wgrad_multi(run, m, (esr_stream_t)ss->stream);
-          hipEventRecord(ss->join[nside & 1], ss->stream);
+          ESR_HIP(hipEventRecord(ss->join[nside & 1], ss->stream));
           ++nside;
           joined = false;
         }
@@ -100,7 +110,7 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       case ESR_OP_POOL: rc = esr_maxpool2(&ops[i].u.pool, stream); break;
       case ESR_OP_LINEAR: rc = esr_linear_op(&ops[i].u.linear, stream); break;
       case ESR_OP_UNPERMUTE:
-        if (nside > 0 && !joined) { hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0); joined = true; }
+        if (nside > 0 && !joined) { ESR_HIP(hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0)); joined = true; }
         rc = esr_grad_unpermute(&ops[i].u.unpermute, stream);
         break;
       case ESR_OP_PACK_BATCH: rc = esr_pack_conv_weights_batch(&ops[i].u.pack_batch, stream); break;
@@ -110,11 +120,11 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       char tmp[400];
       snprintf(tmp, sizeof(tmp), "%s", esr_last_error());
       esr_set_error("op %d (kind %d): %s", i, ops[i].kind, tmp);
-      if (nside > 0 && !joined) hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0);
+      if (nside > 0 && !joined) (void)hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0);
       return rc;
     }
   }
-  if (nside > 0 && !joined) hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0);
+  if (nside > 0 && !joined) ESR_HIP(hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0));
   return ESR_OK;
 }
 
@@ -146,12 +156,12 @@ extern "C" int esr_graph_create(const esr_op* ops, int32_t n, esr_graph_t* out) 
   const int rc = esr_run_ops(ops, n, (esr_stream_t)cs);
   hipGraph_t g = nullptr;
   e = hipStreamEndCapture(cs, &g);
-  if (rc != ESR_OK) { if (g) hipGraphDestroy(g); return rc; }
+  if (rc != ESR_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
   if (e != hipSuccess || !g) { esr_set_error("esr_graph_create: end capture: %s", hipGetErrorString(e)); return ESR_ERR_LAUNCH; }
   hipGraphExec_t x = nullptr;
   e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
   if (e != hipSuccess) {
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     esr_set_error("esr_graph_create: instantiate: %s", hipGetErrorString(e));
     return ESR_ERR_LAUNCH;
   }
@@ -171,8 +181,8 @@ extern "C" int esr_graph_launch(esr_graph_t g, esr_stream_t stream) {
 
 extern "C" int esr_graph_destroy(esr_graph_t g) {
   if (!g) return ESR_OK;
-  if (g->exec) hipGraphExecDestroy(g->exec);
-  if (g->graph) hipGraphDestroy(g->graph);
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
   delete g;
   return ESR_OK;
 }
@@ -181,17 +191,17 @@ extern "C" int esr_run_ops_timed(const esr_op* ops, int32_t n, esr_stream_t stre
   if (!ops || n <= 0 || !ms_out) { esr_set_error("esr_run_ops_timed: invalid arguments"); return ESR_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   hipEvent_t* ev = new hipEvent_t[n + 1];
-  for (int i = 0; i <= n; ++i) hipEventCreate(&ev[i]);
+  for (int i = 0; i <= n; ++i) (void)hipEventCreate(&ev[i]);
   int rc = ESR_OK;
-  hipEventRecord(ev[0], st);
+  (void)hipEventRecord(ev[0], st);
   for (int i = 0; i < n && rc == ESR_OK; ++i) {
     rc = esr_run_ops(&ops[i], 1, stream);
-    hipEventRecord(ev[i + 1], st);
+    (void)hipEventRecord(ev[i + 1], st);
   }
-  hipStreamSynchronize(st);
+  if (hipStreamSynchronize(st) != hipSuccess && rc == ESR_OK) { esr_set_error("esr_run_ops_timed: stream sync failed"); rc = ESR_ERR_LAUNCH; }
   if (rc == ESR_OK)
-    for (int i = 0; i < n; ++i) hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
-  for (int i = 0; i <= n; ++i) hipEventDestroy(ev[i]);
+    for (int i = 0; i < n; ++i) (void)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
+  for (int i = 0; i <= n; ++i) (void)hipEventDestroy(ev[i]);
   delete[] ev;
   return rc;
 }
