@@ -115,6 +115,13 @@ __device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+#ifndef ESR_ACT_AUX
+#define ESR_ACT_AUX 0   // cache-policy bits of the ACTIVATION DMAs (A/B knob: 2 = nt, 1 = sc0, 16 = sc1)
+#endif
+__device__ __forceinline__ void dma16_act(const char* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, ESR_ACT_AUX);
+}
 
 // Philox seed: by value, or through device memory so a captured graph replays with a fresh seed
 __device__ __forceinline__ uint64_t noise_seed(const esr_conv& p) {
@@ -463,7 +470,7 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
     char* dst = lds_wv + sa * G::ACT;
     if (!(dbg & 4)) {
 #pragma unroll
-      for (int i = 0; i < G::NLD; ++i) dma16(src + goff[i], dst + G::NT * 16 * i);
+      for (int i = 0; i < G::NLD; ++i) dma16_act(src + goff[i], dst + G::NT * 16 * i);
     }
   };
   auto stage_wts = [&](int chunk, int sw) __attribute__((always_inline)) {
