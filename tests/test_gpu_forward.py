@@ -232,3 +232,18 @@ def test_full_size_batch_independence_and_determinism(dev):
         ys = net(xs)
         a, b = ys[0, :, 4 * 64:4 * 80, 4 * 64:4 * 96], y[0, :, 4 * 48:4 * 64, 4 * 32:4 * 64]
         assert (a - b).abs().max().item() <= 5e-2
+
+
+def test_two_stream_forward_matches_single_stream(dev, monkeypatch):
+    """ESR_FWD_STREAMS=2 (two half-batches on two streams) must return exactly the single-stream result."""
+    from esrganplus_amd import architecture as arch, functional as Fn
+    net = arch.RRDBNet(3, 3, 64, 2).to(dev).eval().set_precision('fp16')
+    net.load_state_dict(synth.rrdbnet_state_dict(2, 3))
+    x = synth.image_batch(11, 6, 3, 40, 24, name='2s.x').to(dev)
+    with torch.no_grad():
+        y1 = net(x)
+        monkeypatch.setattr(Fn, '_FWD_STREAMS', 2)
+        y2 = net(x)
+        y3 = net(x)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2) and torch.equal(y1, y3)
