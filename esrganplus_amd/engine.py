@@ -724,7 +724,9 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         if deferred is not None:
             deferred.append(wg)      # emitted as one run at the end of the block (one batched launch)
         else:
-            Bk.add(L.OP_WGRAD, 'wgrad', wg)
+            # head / tail convs: their gradient and input buffers are written once per backward pass,
+            # so these launches too can run next to the main chain
+            Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE)
 
     if block:
         GY = buf(64)
