@@ -350,6 +350,23 @@ def main():
         res['kernels'] = {k: {'launches': a[2] // reps, 'ms_per_step': round(a[0] / reps, 3),
                               'tflops': round(a[1] / (a[0] * 1e-3) / 1e12, 1) if a[1] else 0.0}
                           for k, a in sorted(agg.items())}
+        if world == 1 and args.batch % 2 == 0:
+            # informational: the same forward as two half-batches on two streams (ESR_FWD_STREAMS=2).  Not
+            # the headline: with two kernels in flight the per-launch roofline above no longer applies.
+            from esrganplus_amd import functional as Fn
+            old_streams, Fn._FWD_STREAMS = Fn._FWD_STREAMS, 2
+            with torch.no_grad():
+                for _ in range(2):
+                    net(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    y2 = net(x)
+                torch.cuda.synchronize()
+                dt2 = (time.perf_counter() - t0) / args.steps
+            Fn._FWD_STREAMS = old_streams
+            res['two_stream_variant'] = {'value': round(hr_mpix_per_step / dt2, 2), 'ms_per_step': round(dt2 * 1e3, 4),
+                                         'identical_output': bool(torch.equal(y, y2))}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)
