@@ -105,10 +105,26 @@ def cpu_baseline(seconds_budget=25.0):
     timed(size)
     ts = sorted(timed(size) for _ in range(n))
     med = ts[len(ts) // 2]
+    # the single-thread figure, on a 32x32 tile so it stays within a few seconds
+    torch.set_num_threads(1)
+    timed(32)
+    t1 = timed(32)
+    torch.set_num_threads(cores)
+    model = ''
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {'value': round((4 * size) ** 2 / 1e6 / med, 4), 'unit': 'HR-Mpix/s', 'cores': cores,
             'kind': 'port',
             'sample': '%d forwards of one 1x3x%dx%d LR tile, fp32 eval, median %.3f s' % (n, size, size, med),
-            'gflops': round(2 * MAC_PER_LR_PIXEL * size * size / med / 1e9, 1)}
+            'gflops': round(2 * MAC_PER_LR_PIXEL * size * size / med / 1e9, 1),
+            'one_thread': {'value': round(128 ** 2 / 1e6 / t1, 4), 'unit': 'HR-Mpix/s',
+                           'sample': 'one forward of a 1x3x32x32 LR tile, %.3f s' % t1},
+            'cpu_model': model}
 
 
 def train_bench(args, world, rank, dev, dist):
