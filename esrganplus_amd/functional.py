@@ -1,4 +1,6 @@
 """Glue between the drop-in nn.Modules and the recorded HIP launch plans."""
+import os
+
 import torch
 
 from . import engine as E
@@ -248,8 +250,7 @@ class _BlockFn(torch.autograd.Function):
         return (gx if ctx.needs_input_grad[0] else None, None, None, None, None) + tuple(grads)
 
 
-import os as _os
-_FWD_STREAMS = int(_os.environ.get('ESR_FWD_STREAMS', '1'))   # experiment knob (profiles/r01_experiments.md)
+_FWD_STREAMS = int(os.environ.get('ESR_FWD_STREAMS', '1'))   # opt-in two-stream inference (README: knobs)
 
 
 def _forward_two_streams(net, wp, xin):
