@@ -365,6 +365,11 @@ def main():
                            'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
                            'launches_per_step': n // reps, 'avg_launch_us': round(t_ms / n * 1e3, 2),
                            'share_of_step_time': round(t_ms / reps / tot_ms, 3)}
+        if traffic:
+            # secondary bound: HBM-side bytes of that launch over its duration vs 8 TB/s
+            gbps = traffic / (t_ms / n * 1e-3) / 1e9
+            res['roofline']['hbm_achieved_GBps'] = round(gbps, 1)
+            res['roofline']['hbm_frac'] = round(gbps / 8000.0, 4)
         res['kernels'] = {k: {'launches': a[2] // reps, 'ms_per_step': round(a[0] / reps, 3),
                               'tflops': round(a[1] / (a[0] * 1e-3) / 1e12, 1) if a[1] else 0.0}
                           for k, a in sorted(agg.items())}
