@@ -330,7 +330,7 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
 // rounds re-copy an earlier window), weights before activations, so a counted
 // `s_waitcnt vmcnt(NLD)` leaves exactly the newest activation stage in flight.
 // ------------------------------------------------------------------------------------------------
-template <int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
+template <int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool PIPE_ = false>
 struct Geo {
   static constexpr int R = 4;
   static constexpr int NW = WR * WC * NCG;                               // waves per workgroup
@@ -352,7 +352,9 @@ struct Geo {
   // Two rings: activations (the bulk, MALL/HBM latency ~2-3 us under load) are prefetched TWO K
   // steps ahead when three stages fit; weights (L2-resident) one step ahead in a 2-deep ring.
   static constexpr int NSW = WLDS ? 2 : 0;
-  static constexpr int NSA = (ESR_NSA_MAX >= 3 && 3 * ACT + NSW * WBYTES <= LDS_BUDGET) ? 3 : 2;
+  // PIPE: the hand-pipelined K loop (small grids, below) prefetches activations two K steps ahead
+  static constexpr bool PIPE = PIPE_;
+  static constexpr int NSA = ((PIPE_ || ESR_NSA_MAX >= 3) && 3 * ACT + NSW * WBYTES <= LDS_BUDGET) ? 3 : 2;
   static constexpr int WOFF = NSA * ACT;                                  // weight ring base
   static constexpr int LDS_BYTES = NSA * ACT + NSW * WBYTES;
   static constexpr int PAD = (KS - 1) / 2;
@@ -361,14 +363,24 @@ struct Geo {
   static_assert(LDS_BYTES <= LDS_BUDGET, "LDS budget");
 };
 
+// s_waitcnt through the builtin: the compiler's own waitcnt pass SEES these (it does not parse inline
+// asm and would re-wait, conservatively with lgkmcnt(0), before the next use).  gfx9 encoding:
+// vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]
+template <int N> __device__ __forceinline__ void wait_vmcnt_b() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | 0x70 | 0xF00 | ((N >> 4) << 14));
+}
+__device__ __forceinline__ void wait_lgkm0_b() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD>
+template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD, bool PIPE = false>
 __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, const int block_x, const int grid_x,
                                           const int block_y) {
-  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>;
+  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, PIPE>;
+  static_assert(!PIPE || (KS == 3 && S == 1 && UPS == 0 && WLDS && NCG == 1), "pipelined K loop: 3x3/s1, LDS weights");
   constexpr int R = G::R;
   constexpr int NSA = G::NSA;
   static_assert(!HAS1X1 || (NCW == 1 && NCG == 1 && KS == 3 && S == 1 && !UPS && WLDS), "fused 1x1 only on the N=32 3x3 conv");
@@ -468,7 +480,7 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
   auto stage_acts = [&](int chunk, int sa) __attribute__((always_inline)) {
     const char* src = in_b + (int64_t)chunk * in_gs;
     char* dst = lds_wv + sa * G::ACT;
-    if (!(dbg & 4)) {
+    if (PIPE || !(dbg & 4)) {
 #pragma unroll
       for (int i = 0; i < G::NLD; ++i) dma16_act(src + goff[i], dst + G::NT * 16 * i);
     }
@@ -483,127 +495,272 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
     }
   };
 
-  // prologue: weights of step 0, activations of steps 0 .. NSA-2
-  stage_wts(0, 0);
-  stage_acts(0, 0);
-  if constexpr (NSA == 3) { if (nchunks > 1) stage_acts(1, 1); }
-  if constexpr (!WLDS) {
-#pragma unroll
-    for (int cw = 0; cw < NCW; ++cw)
-#pragma unroll
-      for (int tp = 0; tp < G::NTAP; ++tp) wf[cw * G::NTAP + tp] = *(const u32x4*)(wreg[cw] + tp * 1024);
-  }
-
-  int st = 0;   // activation ring slot of K step c
-  for (int c = 0; c < nchunks; ++c) {
-    // ---- retire K step c.  In-order return: everything older than the NLD activation DMAs of
-    // step c+1 (issued last) has landed once vmcnt <= NLD.
-    if constexpr (WLDS) {
-      if (NSA == 3 && c + 1 < nchunks) wait_vmcnt<G::NLD>(); else wait_vmcnt<0>();
-    } else {
-      wait_vmcnt<0>();   // mixed VGPR loads + DMA: plain drain
-    }
-    __builtin_amdgcn_s_barrier();   // step c visible to all waves; all waves done reading step c-1
-    // ---- refill: weights of step c+1 first, then activations of step c+NSA-1
-    if (c + 1 < nchunks) stage_wts(c + 1, (c + 1) & 1);
-    const int cn = c + NSA - 1;
-    if (cn < nchunks) {
-      int sn = st + NSA - 1; if (sn >= NSA) sn -= NSA;
-      stage_acts(cn, sn);
-    }
-    if constexpr (!WLDS) {
-      if (c + 1 < nchunks) {
-#pragma unroll
-        for (int cw = 0; cw < NCW; ++cw)
-#pragma unroll
-          for (int tp = 0; tp < G::NTAP; ++tp)
-            wn[cw * G::NTAP + tp] = *(const u32x4*)(wreg[cw] + (int64_t)(c + 1) * G::NTAP * 1024 + tp * 1024);
-      }
-    }
-
-    const char* lds = smem + st * G::ACT;
-    const char* ldwb = smem + G::WOFF + (c & 1) * G::WBYTES;
-    const char* ldw = ldwb + ((cg * NCW) * G::NTAP * 64 + lane) * 16;   // this wave's A fragments
-    const bool do1x1 = HAS1X1 && c < n1x1;
-
-    // kw-major: the KS*NCW A fragments of column tap kw stay in registers while the wave walks its
-    // WIH input rows; each B fragment read feeds up to KS*NCW MFMAs.  Fragments of tap kw+1 are
-    // read from LDS while the MFMAs of tap kw run.
+  if constexpr (PIPE) {
+    // ------------------------------------------------------------------------------------------
+    // Hand-pipelined K loop.  Measured on the compiler-scheduled loop (tools/mma_probe.py): per K
+    // step the MFMAs (0.95 us/CU), the LDS fragment reads (+0.5), the DMA issue (+0.3) and the
+    // barrier (+0.2) ADD UP — nothing overlaps, because every wave runs the phases
+    //   barrier -> issue DMAs -> read fragments -> wait -> MFMAs
+    // strictly in that order.  Here each K step c is three MFMA groups (one per column tap kw) and
+    // everything else rides BETWEEN the MFMAs of a group:
+    //   kw=0: MFMAs(0,c)  || ds_read fragments (1,c)
+    //   kw=1: MFMAs(1,c)  || ds_read fragments (2,c)
+    //   kw=2: retire step c+1 (own DMAs landed, own reads of step c done), s_barrier,
+    //         ds_read fragments (0,c+1), then MFMAs(2,c) || DMA issue of weights c+2, acts c+NSA
+    // so the matrix pipe never waits for a barrier, an LDS round trip or a DMA issue.  Fragment
+    // registers are double-buffered; with 3 groups per step the buffer parity flips every step,
+    // hence the two instantiations P=0/1.  STEADY bodies (all refills in range) are branch-free.
+    // ------------------------------------------------------------------------------------------
     u32x4 af[2][KS * NCW], bf[2][G::WIH], a1f;
-    auto read_step = [&](auto KW, u32x4 (&a)[KS * NCW], u32x4 (&bq)[G::WIH]) __attribute__((always_inline)) {
-      constexpr int kw = decltype(KW)::value;
-#if ESR_PROBES
-      if (dbg & 32) return;   // measurement-only: MFMAs on stale fragments, no LDS reads
-#endif
+    auto rd = [&](auto KW, auto BUF, const char* lds, const char* ldw) __attribute__((always_inline)) {
+      constexpr int kw = decltype(KW)::value, buf = decltype(BUF)::value;
 #pragma unroll
       for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
-        for (int cw = 0; cw < NCW; ++cw) {
-          if constexpr (WLDS) a[kh * NCW + cw] = *(const u32x4*)(ldw + (cw * G::NTAP + kh * KS + kw) * 1024);
-          else a[kh * NCW + cw] = wf[cw * G::NTAP + kh * KS + kw];
-        }
+        for (int cw = 0; cw < NCW; ++cw)
+          af[buf][kh * NCW + cw] = *(const u32x4*)(ldw + (cw * G::NTAP + kh * KS + kw) * 1024);
 #pragma unroll
-      for (int ir = 0; ir < G::WIH; ++ir) bq[ir] = *(const u32x4*)(lds + colofs[kw] + ir * G::IW * 32);
+      for (int ir = 0; ir < G::WIH; ++ir) bf[buf][ir] = *(const u32x4*)(lds + colofs[kw] + ir * G::IW * 32);
     };
-    if (!(dbg & 2)) {
-      read_step(std::integral_constant<int, 0>{}, af[0], bf[0]);
-      if constexpr (HAS1X1) a1f = *(const u32x4*)(ldwb + ((G::WWIN - 1) * 64 + lane) * 16);
+    auto mm = [&](auto KW, auto BUF) __attribute__((always_inline)) {
+      constexpr int kw = decltype(KW)::value, buf = decltype(BUF)::value;
+      sfor<G::WIH>([&](auto IR) __attribute__((always_inline)) {
+        constexpr int ir = decltype(IR)::value;
+        sfor<KS>([&](auto KH) __attribute__((always_inline)) {
+          constexpr int kh = decltype(KH)::value;
+          constexpr int r = ir - kh;
+          if constexpr (r >= 0 && r < R) {
+            sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
+              constexpr int cw = decltype(CW)::value;
+              mma<T>(accsel<r * NCW + cw>(acc), af[buf][kh * NCW + cw], bf[buf][ir]);
+            });
+          }
+        });
+        if constexpr (HAS1X1 && kw == G::PAD) {   // centre tap also feeds the fused 1x1 conv
+          constexpr int r = ir - G::PAD;          // (zero A fragment on K steps past its 64 inputs)
+          if constexpr (r >= 0 && r < R) mma<T>(accsel<r>(acc1), a1f, bf[buf][ir]);
+        }
+      });
+    };
+    constexpr int NMM = R * KS * NCW;                       // MFMAs of one kw group (per T=f16)
+    constexpr int NRD = KS * NCW + G::WIH;                  // fragment reads of one kw group
+    constexpr int NDM = G::NLD + G::WLD;                    // DMA issues of one K step
+    constexpr bool F16 = true;                              // group-interleave both dtypes
+    constexpr int MPER = sizeof(T) == 2 ? 1 : 4;            // MFMA instructions per mma<T>()
+    const char* const ldw0 = smem + G::WOFF + lane * 16;
+    auto load_a1f = [&](int c, const char* ldwb) __attribute__((always_inline)) {
+      if constexpr (HAS1X1) {
+        a1f = *(const u32x4*)(ldwb + (G::WWIN - 1) * 1024);
+        if (c >= n1x1) a1f = u32x4{0, 0, 0, 0};
+      }
+    };
+
+    // prologue: step 0 (and 1) in flight, retire step 0, refill, first fragments
+    stage_wts(0, 0);
+    stage_acts(0, 0);
+    if constexpr (NSA == 3) { if (nchunks > 1) stage_acts(1, 1); }
+    if (NSA == 3 && nchunks > 1) wait_vmcnt<G::NLD>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (nchunks > 1) stage_wts(1, 1);
+    if (NSA - 1 < nchunks) stage_acts(NSA - 1, NSA - 1);
+    rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, smem, ldw0);
+    load_a1f(0, ldw0);
+
+    auto kstep = [&](auto PAR, auto STEADY, int c, int st) __attribute__((always_inline)) {
+      constexpr int par = decltype(PAR)::value;
+      constexpr bool steady = decltype(STEADY)::value;
+      const char* lds = smem + st * G::ACT;
+      const char* ldw = ldw0 + (c & 1) * G::WBYTES;
       sfor<KS>([&](auto KW) __attribute__((always_inline)) {
         constexpr int kw = decltype(KW)::value;
-        constexpr int cur = kw & 1;
-        if constexpr (kw + 1 < KS) read_step(std::integral_constant<int, kw + 1>{}, af[cur ^ 1], bf[cur ^ 1]);
-        sfor<G::WIH>([&](auto IR) __attribute__((always_inline)) {
-          constexpr int ir = decltype(IR)::value;
-          sfor<KS>([&](auto KH) __attribute__((always_inline)) {
-            constexpr int kh = decltype(KH)::value;
-            if constexpr (UPS == 1) {
-              sfor<R>([&](auto RR) __attribute__((always_inline)) {
-                constexpr int r = decltype(RR)::value;
-                if constexpr ((((r + kh - 1) >> 1) + 1) == ir) {
-                  sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
-                    constexpr int cw = decltype(CW)::value;
-                    mma<T>(accsel<r * NCW + cw>(acc), af[cur][kh * NCW + cw], bf[cur][ir]);
-                  });
+        constexpr int buf = (kw + par) & 1;
+        using BUF = std::integral_constant<int, buf>;
+        using NBUF = std::integral_constant<int, buf ^ 1>;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kw + 1 < KS) {
+          rd(std::integral_constant<int, kw + 1>{}, NBUF{}, lds, ldw);
+          mm(KW, BUF{});
+          if constexpr (F16) {
+            constexpr int NP = NRD < NMM ? NRD : NMM;
+            sfor<NP>([&](auto) __attribute__((always_inline)) {
+              __builtin_amdgcn_sched_group_barrier(0x008, MPER, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            });
+            if constexpr (NRD > NP) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NP, 0);
+            if constexpr (NMM > NP) __builtin_amdgcn_sched_group_barrier(0x008, (NMM - NP) * MPER, 0);
+          }
+        } else {
+          int sn = st + 1; if (sn == NSA) sn = 0;               // ring slot of step c+1
+          const char* ldsn = smem + sn * G::ACT;
+          const char* ldwn = ldw0 + ((c + 1) & 1) * G::WBYTES;
+          if (steady || c + 1 < nchunks) {
+            // retire step c+1: my fragment reads of step c are done (their slots get refilled
+            // below), my DMAs of step c+1 have landed; only acts c+2 may still be in flight
+            wait_lgkm0_b();
+            if (NSA == 3 && (steady || c + 2 < nchunks)) wait_vmcnt_b<G::NLD>(); else wait_vmcnt_b<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            rd(std::integral_constant<int, 0>{}, NBUF{}, ldsn, ldwn);
+            load_a1f(c + 1, ldwn);
+            if (steady || c + 2 < nchunks) stage_wts(c + 2, c & 1);
+            if (steady || c + NSA < nchunks) stage_acts(c + NSA, st);
+          }
+          mm(KW, BUF{});
+          if constexpr (F16 && steady) {
+            __builtin_amdgcn_sched_group_barrier(0x100, NRD + (HAS1X1 ? 1 : 0), 0);
+            constexpr int NP = NDM < NMM ? NDM : NMM;
+            sfor<NP>([&](auto) __attribute__((always_inline)) {
+              __builtin_amdgcn_sched_group_barrier(0x008, MPER, 0);
+              __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            });
+            if constexpr (NDM > NP) __builtin_amdgcn_sched_group_barrier(0x010, NDM - NP, 0);
+            if constexpr (NMM > NP) __builtin_amdgcn_sched_group_barrier(0x008, (NMM - NP) * MPER, 0);
+          }
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    int c = 0, st = 0;
+    const int nsteady = nchunks - NSA;          // steps whose refills (w c+2, acts c+NSA) are all in range
+    for (; c + 1 < nsteady; c += 2) {
+      kstep(std::integral_constant<int, 0>{}, std::true_type{}, c, st);
+      if (++st == NSA) st = 0;
+      kstep(std::integral_constant<int, 1>{}, std::true_type{}, c + 1, st);
+      if (++st == NSA) st = 0;
+    }
+    for (; c < nchunks; c += 2) {
+      kstep(std::integral_constant<int, 0>{}, std::false_type{}, c, st);
+      if (++st == NSA) st = 0;
+      if (c + 1 < nchunks) {
+        kstep(std::integral_constant<int, 1>{}, std::false_type{}, c + 1, st);
+        if (++st == NSA) st = 0;
+      }
+    }
+  } else {
+  // prologue: weights of step 0, activations of steps 0 .. NSA-2
+    stage_wts(0, 0);
+    stage_acts(0, 0);
+    if constexpr (NSA == 3) { if (nchunks > 1) stage_acts(1, 1); }
+    if constexpr (!WLDS) {
+  #pragma unroll
+      for (int cw = 0; cw < NCW; ++cw)
+  #pragma unroll
+        for (int tp = 0; tp < G::NTAP; ++tp) wf[cw * G::NTAP + tp] = *(const u32x4*)(wreg[cw] + tp * 1024);
+    }
+  
+    int st = 0;   // activation ring slot of K step c
+    for (int c = 0; c < nchunks; ++c) {
+      // ---- retire K step c.  In-order return: everything older than the NLD activation DMAs of
+      // step c+1 (issued last) has landed once vmcnt <= NLD.
+      if constexpr (WLDS) {
+        if (NSA == 3 && c + 1 < nchunks) wait_vmcnt<G::NLD>(); else wait_vmcnt<0>();
+      } else {
+        wait_vmcnt<0>();   // mixed VGPR loads + DMA: plain drain
+      }
+      __builtin_amdgcn_s_barrier();   // step c visible to all waves; all waves done reading step c-1
+      // ---- refill: weights of step c+1 first, then activations of step c+NSA-1
+      if (c + 1 < nchunks) stage_wts(c + 1, (c + 1) & 1);
+      const int cn = c + NSA - 1;
+      if (cn < nchunks) {
+        int sn = st + NSA - 1; if (sn >= NSA) sn -= NSA;
+        stage_acts(cn, sn);
+      }
+      if constexpr (!WLDS) {
+        if (c + 1 < nchunks) {
+  #pragma unroll
+          for (int cw = 0; cw < NCW; ++cw)
+  #pragma unroll
+            for (int tp = 0; tp < G::NTAP; ++tp)
+              wn[cw * G::NTAP + tp] = *(const u32x4*)(wreg[cw] + (int64_t)(c + 1) * G::NTAP * 1024 + tp * 1024);
+        }
+      }
+  
+      const char* lds = smem + st * G::ACT;
+      const char* ldwb = smem + G::WOFF + (c & 1) * G::WBYTES;
+      const char* ldw = ldwb + ((cg * NCW) * G::NTAP * 64 + lane) * 16;   // this wave's A fragments
+      const bool do1x1 = HAS1X1 && c < n1x1;
+  
+      // kw-major: the KS*NCW A fragments of column tap kw stay in registers while the wave walks its
+      // WIH input rows; each B fragment read feeds up to KS*NCW MFMAs.  Fragments of tap kw+1 are
+      // read from LDS while the MFMAs of tap kw run.
+      u32x4 af[2][KS * NCW], bf[2][G::WIH], a1f;
+      auto read_step = [&](auto KW, u32x4 (&a)[KS * NCW], u32x4 (&bq)[G::WIH]) __attribute__((always_inline)) {
+        constexpr int kw = decltype(KW)::value;
+  #if ESR_PROBES
+        if (dbg & 32) return;   // measurement-only: MFMAs on stale fragments, no LDS reads
+  #endif
+  #pragma unroll
+        for (int kh = 0; kh < KS; ++kh)
+  #pragma unroll
+          for (int cw = 0; cw < NCW; ++cw) {
+            if constexpr (WLDS) a[kh * NCW + cw] = *(const u32x4*)(ldw + (cw * G::NTAP + kh * KS + kw) * 1024);
+            else a[kh * NCW + cw] = wf[cw * G::NTAP + kh * KS + kw];
+          }
+  #pragma unroll
+        for (int ir = 0; ir < G::WIH; ++ir) bq[ir] = *(const u32x4*)(lds + colofs[kw] + ir * G::IW * 32);
+      };
+      if (!(dbg & 2)) {
+        read_step(std::integral_constant<int, 0>{}, af[0], bf[0]);
+        if constexpr (HAS1X1) a1f = *(const u32x4*)(ldwb + ((G::WWIN - 1) * 64 + lane) * 16);
+        sfor<KS>([&](auto KW) __attribute__((always_inline)) {
+          constexpr int kw = decltype(KW)::value;
+          constexpr int cur = kw & 1;
+          if constexpr (kw + 1 < KS) read_step(std::integral_constant<int, kw + 1>{}, af[cur ^ 1], bf[cur ^ 1]);
+          sfor<G::WIH>([&](auto IR) __attribute__((always_inline)) {
+            constexpr int ir = decltype(IR)::value;
+            sfor<KS>([&](auto KH) __attribute__((always_inline)) {
+              constexpr int kh = decltype(KH)::value;
+              if constexpr (UPS == 1) {
+                sfor<R>([&](auto RR) __attribute__((always_inline)) {
+                  constexpr int r = decltype(RR)::value;
+                  if constexpr ((((r + kh - 1) >> 1) + 1) == ir) {
+                    sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
+                      constexpr int cw = decltype(CW)::value;
+                      mma<T>(accsel<r * NCW + cw>(acc), af[cur][kh * NCW + cw], bf[cur][ir]);
+                    });
+                  }
+                });
+              } else if constexpr (UPS == 2) {
+                // adjoint of the 4x4/s2/p1 conv: output row r takes tap kh from g row (r+1-kh)/2
+                constexpr int r = 2 * (ir - 1) + kh - 1;
+                if constexpr (r >= 0 && r < R) {
+                  if (((wc + 1 - kw) & 1) == 0) {
+                    sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
+                      constexpr int cw = decltype(CW)::value;
+                      mma<T>(accsel<r * NCW + cw>(acc), af[cur][kh * NCW + cw], bf[cur][ir]);
+                    });
+                  }
                 }
-              });
-            } else if constexpr (UPS == 2) {
-              // adjoint of the 4x4/s2/p1 conv: output row r takes tap kh from g row (r+1-kh)/2
-              constexpr int r = 2 * (ir - 1) + kh - 1;
-              if constexpr (r >= 0 && r < R) {
-                if (((wc + 1 - kw) & 1) == 0) {
+              } else {
+                constexpr int tt = ir - kh;
+                if constexpr (tt >= 0 && tt % S == 0 && tt / S < R) {
                   sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
                     constexpr int cw = decltype(CW)::value;
-                    mma<T>(accsel<r * NCW + cw>(acc), af[cur][kh * NCW + cw], bf[cur][ir]);
+                    mma<T>(accsel<(tt / S) * NCW + cw>(acc), af[cur][kh * NCW + cw], bf[cur][ir]);
                   });
                 }
               }
-            } else {
-              constexpr int tt = ir - kh;
-              if constexpr (tt >= 0 && tt % S == 0 && tt / S < R) {
-                sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
-                  constexpr int cw = decltype(CW)::value;
-                  mma<T>(accsel<(tt / S) * NCW + cw>(acc), af[cur][kh * NCW + cw], bf[cur][ir]);
-                });
+            });
+            if constexpr (HAS1X1 && kw == G::PAD) {   // centre tap also feeds the fused 1x1 conv
+              constexpr int r = ir - G::PAD;
+              if constexpr (r >= 0 && r < R) {
+                if (do1x1) mma<T>(accsel<r>(acc1), a1f, bf[cur][ir]);
               }
             }
           });
-          if constexpr (HAS1X1 && kw == G::PAD) {   // centre tap also feeds the fused 1x1 conv
-            constexpr int r = ir - G::PAD;
-            if constexpr (r >= 0 && r < R) {
-              if (do1x1) mma<T>(accsel<r>(acc1), a1f, bf[cur][ir]);
-            }
-          }
         });
-      });
-    }
-
-    if constexpr (!WLDS) {
-      if (c + 1 < nchunks) {
-#pragma unroll
-        for (int tp = 0; tp < NCW * G::NTAP; ++tp) wf[tp] = wn[tp];
       }
+  
+      if constexpr (!WLDS) {
+        if (c + 1 < nchunks) {
+  #pragma unroll
+          for (int tp = 0; tp < NCW * G::NTAP; ++tp) wf[tp] = wn[tp];
+        }
+      }
+      if (++st == NSA) st = 0;
     }
-    if (++st == NSA) st = 0;
+  
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -618,11 +775,11 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
   });
 }
 
-template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD>
+template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD, bool PIPE = false>
 __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_conv p) {
-  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>;
+  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, PIPE>;
   __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
-  conv_body<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, BWD>(p, smem, blockIdx.x, gridDim.x, blockIdx.y);
+  conv_body<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, BWD, PIPE>(p, smem, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // EXPERIMENT (measurement only): the five convs of one ResidualDenseBlock_5C in ONE launch, every
@@ -666,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void rdb_nosync_kernel(const esr_conv* conv
   }
 }
 
-template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1>
+template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool PIPE = false>
 int launch(const esr_conv& p, hipStream_t st) {
   using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>;
   const int tiles = ((p.W + G::TW - 1) / G::TW) * ((p.H + G::TH - 1) / G::TH) * p.B;
@@ -677,8 +834,8 @@ int launch(const esr_conv& p, hipStream_t st) {
   const bool bwd = p.mask.ptr || p.out3.ptr || (!p.res1.ptr && p.alpha != 1.0f) ||
                    (p.res1.ptr && p.res1.ngroups < p.cout_blocks * GPB && p.res1.ngroups < p.out.ngroups) ||
                    (p.res2.ptr && p.res2.ngroups < p.cout_blocks * GPB && p.res2.ngroups < p.out.ngroups);
-  if (bwd) hipLaunchKernelGGL((conv_kernel<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, true>), grid, dim3(G::NT), 0, st, p);
-  else hipLaunchKernelGGL((conv_kernel<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, false>), grid, dim3(G::NT), 0, st, p);
+  if (bwd) hipLaunchKernelGGL((conv_kernel<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, true, PIPE>), grid, dim3(G::NT), 0, st, p);
+  else hipLaunchKernelGGL((conv_kernel<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, false, PIPE>), grid, dim3(G::NT), 0, st, p);
   return esr_check_launch("conv_kernel");
 }
 
@@ -695,12 +852,19 @@ int dispatch(const esr_conv& p, hipStream_t st) {
       if (cbk != 1) { esr_set_error("conv: fused 1x1 needs cout_blocks==1"); return ESR_ERR_UNSUPPORTED; }
       return launch<T, 3, 1, 0, 4, 1, 1, 1, true, true>(p, st);
     }
-    if (cbk == 1) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false>(p, st);
+    const int64_t tiles = (int64_t)((p.W + 31) / 32) * ((p.H + 15) / 16) * p.B;
+    if (cbk == 1) {
+      // Few workgroups (training tiles: at most one per CU): nothing else hides a wave's barrier / LDS
+      // round trip / DMA issue, so the hand-pipelined K loop pays (0.87 -> ~0.55 us per K step);
+      // with two lock-stepped workgroups per CU streaming at the fabric limit it does not (r01_experiments.md)
+      static const int pipe_max = [] { const char* e = getenv("ESR_PIPE_MAX_TILES"); return e ? atoi(e) : 256; }();
+      if (tiles <= pipe_max) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false, true>(p, st);
+      return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false>(p, st);
+    }
     // Several cout blocks: grid.y walks them, ONE per workgroup on small grids (training tiles: twice
     // the workgroups, half the MFMA chain each), TWO per wave otherwise (each B fragment feeds two
     // MFMAs).  The 8-wave 2x4 register-weight kernel this used to switch to at >= 4 blocks lost on
     // every shape measured (tools/wide_probe.py: 32->128 ... 256->256: 426-928 vs 474-1192 TF/s).
-    const int64_t tiles = (int64_t)((p.W + 31) / 32) * ((p.H + 15) / 16) * p.B;
     if (tiles * ((cbk + 1) / 2) < 256) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false>(p, st);
     return launch<T, 3, 1, 0, 4, 1, 1, 2, true, false>(p, st);
   }
