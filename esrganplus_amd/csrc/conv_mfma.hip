@@ -354,7 +354,10 @@ struct Geo {
   static constexpr int NSW = WLDS ? 2 : 0;
   // PIPE: the hand-pipelined K loop (small grids, below) prefetches activations two K steps ahead
   static constexpr bool PIPE = PIPE_;
-  static constexpr int NSA = ((PIPE_ || ESR_NSA_MAX >= 3) && 3 * ACT + NSW * WBYTES <= LDS_BUDGET) ? 3 : 2;
+#ifndef ESR_PIPE_NSA
+#define ESR_PIPE_NSA 3   // activation ring depth of the pipelined instantiation (A/B knob)
+#endif
+  static constexpr int NSA = (((PIPE_ && ESR_PIPE_NSA >= 3) || ESR_NSA_MAX >= 3) && 3 * ACT + NSW * WBYTES <= LDS_BUDGET) ? 3 : 2;
   static constexpr int WOFF = NSA * ACT;                                  // weight ring base
   static constexpr int LDS_BYTES = NSA * ACT + NSW * WBYTES;
   static constexpr int PAD = (KS - 1) / 2;
