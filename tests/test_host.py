@@ -168,3 +168,25 @@ def test_header_is_plain_c_and_structs_match_ctypes(tmp_path):
     out = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
     for n in names:
         assert int(out[n]) == C.sizeof(getattr(L, n)), (n, out[n], C.sizeof(getattr(L, n)))
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench.json is the line `python bench.py` printed on the MI355X: every key the
+    measurement contract names must be there, with the headline workload and a roofline/cpu_baseline."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.loads(open(os.path.join(root, 'profiles', 'r01_bench.json')).read().strip().splitlines()[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+              'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['unit'] == 'HR-Mpix/s' and d['higher_is_better'] is True and d['scaling'] == 'weak'
+    assert d['vs_baseline'] is None and d['dtype'] == 'f16' and d['data'] == 'synthetic'
+    assert 'workload' in d['config'] and 'configs[1]' in d['config']['workload']
+    r = d['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and (r['traffic'] is None or r['traffic'] > 0)
+    c = d['cpu_baseline']
+    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+    # consistency of the headline itself: value = HR megapixels of one step / time of one step
+    hr_mpix = d['config']['global_batch'] * 512 * 512 / 1e6
+    assert abs(d['value'] - hr_mpix / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-3
