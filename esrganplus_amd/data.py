@@ -85,6 +85,8 @@ def imresize(img, scale, antialiasing=True):
         if t is None:
             w, idx, ol = resample_tables(length, scale, antialiasing)
             t = (w.to(dev), idx.to(dev), ol)
+            if len(_TABLES) >= 64:            # (length, scale) pairs of a dataset are few; stay bounded anyway
+                _TABLES.clear()
             _TABLES[key] = t
         tabs.append(t)
     y = _axis_pass(x, 0, tabs[0][0], tabs[0][1], tabs[0][2], st)
