@@ -19,6 +19,7 @@ ESR_F16, ESR_F32 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 NOISE_OFF, NOISE_PHILOX, NOISE_EXPLICIT = 0, 1, 2
 OP_CONV, OP_PACK, OP_LAYOUT, OP_NOISE_FILL, OP_WGRAD, OP_BN, OP_POOL, OP_LINEAR, OP_UNPERMUTE, OP_PACK_BATCH = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+OP_RDB_CHAIN, OP_FRAG_GATHER = 11, 12
 BN_STATS, BN_FINALIZE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_FINAL, BN_BWD_APPLY = 0, 1, 2, 3, 4, 5
 NO_LAYER = 0xFFFFFFFF
 
@@ -130,11 +131,27 @@ class esr_pack_batch(C.Structure):
                 ('total_pieces', C.c_int64)]
 
 
+class esr_rdb_block(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('bias', C.c_void_p * 5), ('x_in', esr_g32), ('x_out', esr_g32),
+                ('res2', esr_g32), ('layer1', C.c_uint32), ('layer2', C.c_uint32)]
+
+
+class esr_rdb_chain(C.Structure):
+    _fields_ = [('dtype', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('n_blocks', C.c_int32), ('noise_mode', C.c_int32), ('sigma', C.c_float), ('_pad', C.c_int32),
+                ('seed', C.c_uint64), ('seed_dev', C.c_void_p), ('dense', esr_g32), ('blocks', C.c_void_p),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('trace', C.c_void_p)]
+
+
+class esr_frag_gather(C.Structure):
+    _fields_ = [('src_off', C.c_void_p), ('src_base', C.c_void_p), ('dst', C.c_void_p), ('n', C.c_int64)]
+
+
 class _op_union(C.Union):
     _fields_ = [('conv', esr_conv), ('pack', esr_pack), ('layout', esr_layout),
                 ('noise_fill', esr_noise_fill), ('wgrad', esr_wgrad), ('bn', esr_bn),
                 ('pool', esr_pool), ('linear', esr_linear), ('unpermute', esr_unpermute),
-                ('pack_batch', esr_pack_batch)]
+                ('pack_batch', esr_pack_batch), ('rdb_chain', esr_rdb_chain), ('frag_gather', esr_frag_gather)]
 
 
 class esr_op(C.Structure):
@@ -145,8 +162,9 @@ class esr_op(C.Structure):
 EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_pack_conv_weights',
            'esr_convert_layout', 'esr_fill_noise', 'esr_conv_wgrad', 'esr_conv_wgrad_multi', 'esr_batchnorm', 'esr_maxpool2',
            'esr_linear_op', 'esr_grad_unpermute', 'esr_adam_step', 'esr_resample_axis', 'esr_pack_conv_weights_batch', 'esr_pack_pieces',
-           'esr_rdb_nosync_probe', 'esr_run_ops', 'esr_run_ops_timed', 'esr_graph_create', 'esr_graph_launch', 'esr_graph_destroy', 'esr_last_error',
-           'esr_abi_version', 'esr_sizeof_op']
+           'esr_run_ops', 'esr_run_ops_timed', 'esr_graph_create', 'esr_graph_launch', 'esr_graph_destroy', 'esr_last_error',
+           'esr_abi_version', 'esr_sizeof_op', 'esr_rdb_forward', 'esr_rdb_workspace_bytes', 'esr_rdb_weight_stream_bytes',
+           'esr_rdb_max_tiles_per_image', 'esr_gather_fragments']
 
 _lib = None
 _lock = threading.Lock()
@@ -186,12 +204,17 @@ def lib():
         L.esr_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
         L.esr_graph_destroy.argtypes = [C.c_void_p]
         L.esr_conv_wgrad_multi.argtypes = [C.POINTER(esr_wgrad), C.c_int32, C.c_void_p]
+        L.esr_rdb_workspace_bytes.restype = C.c_size_t
+        L.esr_rdb_workspace_bytes.argtypes = [C.c_int32] * 3
+        L.esr_rdb_weight_stream_bytes.restype = C.c_size_t
+        L.esr_rdb_weight_stream_bytes.argtypes = [C.c_int32]
         for name, st in (('esr_conv_forward', esr_conv), ('esr_pack_conv_weights', esr_pack),
                          ('esr_convert_layout', esr_layout), ('esr_fill_noise', esr_noise_fill),
                          ('esr_conv_wgrad', esr_wgrad), ('esr_batchnorm', esr_bn),
                          ('esr_maxpool2', esr_pool), ('esr_linear_op', esr_linear),
                          ('esr_grad_unpermute', esr_unpermute), ('esr_adam_step', esr_adam), ('esr_resample_axis', esr_resample),
-                         ('esr_pack_conv_weights_batch', esr_pack_batch)):
+                         ('esr_pack_conv_weights_batch', esr_pack_batch), ('esr_rdb_forward', esr_rdb_chain),
+                         ('esr_gather_fragments', esr_frag_gather)):
             getattr(L, name).argtypes = [C.POINTER(st), C.c_void_p]
         if L.esr_sizeof_op() != C.sizeof(esr_op):
             raise HipExtensionError('ABI mismatch: sizeof(esr_op) C=%d ctypes=%d'

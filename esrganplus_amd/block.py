@@ -156,6 +156,14 @@ class _PlannedModule(nn.Module):
         not bump the parameter version, e.g. networks.py:32-34)."""
         self._force_repack = True
 
+    def train(self, mode=True):
+        # optim.FusedAdam updates the parameters through raw pointers (no `_version` bump): the packed
+        # copies made by the last training forward are one optimizer step stale, so a train <-> eval
+        # flip always re-packs before the next forward.
+        if mode != self.training:
+            self._force_repack = True
+        return super().train(mode)
+
     # nn.Module hooks that change parameter values behind our back
     def apply(self, fn):
         self._force_repack = True

@@ -114,6 +114,8 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
         rc = esr_grad_unpermute(&ops[i].u.unpermute, stream);
         break;
       case ESR_OP_PACK_BATCH: rc = esr_pack_conv_weights_batch(&ops[i].u.pack_batch, stream); break;
+      case ESR_OP_RDB_CHAIN: rc = esr_rdb_forward(&ops[i].u.rdb_chain, stream); break;
+      case ESR_OP_FRAG_GATHER: rc = esr_gather_fragments(&ops[i].u.frag_gather, stream); break;
       default: esr_set_error("esr_run_ops: op %d has unknown kind %d", i, ops[i].kind); return ESR_ERR_INVALID;
     }
     if (rc != ESR_OK) {

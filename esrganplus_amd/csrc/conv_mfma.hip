@@ -28,186 +28,9 @@
 #define ESR_NSA_MAX 2   // activation ring depth cap. A/B (profiles/r01_experiments.md): 3 (two K steps ahead) is 1.5 % SLOWER
 #endif
 
+#include "mfma_tile.h"
+
 namespace {
-
-template <typename T> __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b);
-
-template <> __device__ __forceinline__ void mma<_Float16>(f32x16& acc, const u32x4& a, const u32x4& b) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a),
-                                              __builtin_bit_cast(half8, b), acc, 0, 0, 0);
-}
-template <> __device__ __forceinline__ void mma<float>(f32x16& acc, const u32x4& a, const u32x4& b) {
-  const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
-}
-
-// 16 consecutive channels of one pixel <-> float[16]
-template <typename T> struct Px16;
-template <> struct Px16<_Float16> {
-  // lane half h owns group (2*cb + h): one 32-byte group
-  static __device__ __forceinline__ void load(const esr_g32& t, int b, int cb, int h, int64_t pix, float v[16]) {
-    if (2 * cb + h >= t.ngroups) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = 0.f;
-      return;
-    }
-    const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(2 * cb + h) * t.group_stride + pix * 32;
-    const u32x4 a = *(const u32x4*)p, c = *(const u32x4*)(p + 16);
-    const half8 x = __builtin_bit_cast(half8, a), y = __builtin_bit_cast(half8, c);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { v[i] = (float)x[i]; v[8 + i] = (float)y[i]; }
-  }
-  static __device__ __forceinline__ void store(const esr_g32& t, int b, int cb, int h, int64_t pix, const float v[16], int flavour = 0) {
-    if (2 * cb + h >= t.ngroups) return;
-    char* p = (char*)t.ptr + b * t.batch_stride + (int64_t)(2 * cb + h) * t.group_stride + pix * 32;
-    half8 x, y;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { x[i] = (_Float16)v[i]; y[i] = (_Float16)v[8 + i]; }
-    const u32x4 a = __builtin_bit_cast(u32x4, x), c = __builtin_bit_cast(u32x4, y);
-    if (flavour == 1) {          // non-temporal (measured +1 % on the forward bench, profiles/)
-      __builtin_nontemporal_store(a, (u32x4*)p);
-      __builtin_nontemporal_store(c, (u32x4*)(p + 16));
-    } else if (flavour == 3) {   // measurement-only (WRONG layout): each store instruction of a half-wave
-                                 // covers 512 contiguous bytes instead of every other 16 bytes of 1 KB
-      const int j = __lane_id() & 31;
-      char* row = p - j * 32;
-      *(u32x4*)(row + j * 16) = a;
-      *(u32x4*)(row + 512 + j * 16) = c;
-    } else {
-      *(u32x4*)p = a;
-      *(u32x4*)(p + 16) = c;
-    }
-  }
-};
-template <> struct Px16<float> {
-  // lane half h owns groups (4*cb + 2h) and (4*cb + 2h + 1)
-  static __device__ __forceinline__ void load(const esr_g32& t, int b, int cb, int h, int64_t pix, float v[16]) {
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
-      if (4 * cb + 2 * h + g < t.ngroups) {
-        const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(4 * cb + 2 * h + g) * t.group_stride + pix * 32;
-        a = *(const f32x4*)p; c = *(const f32x4*)(p + 16);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { v[8 * g + i] = a[i]; v[8 * g + 4 + i] = c[i]; }
-    }
-  }
-  static __device__ __forceinline__ void store(const esr_g32& t, int b, int cb, int h, int64_t pix, const float v[16], int flavour = 0) {
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      if (4 * cb + 2 * h + g >= t.ngroups) continue;
-      char* p = (char*)t.ptr + b * t.batch_stride + (int64_t)(4 * cb + 2 * h + g) * t.group_stride + pix * 32;
-      f32x4 a, c;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = v[8 * g + i]; c[i] = v[8 * g + 4 + i]; }
-      *(f32x4*)p = a;
-      *(f32x4*)(p + 16) = c;
-    }
-  }
-};
-
-// async global -> LDS copy of 16 bytes per lane (LDS-DMA): destination = wave-uniform LDS base
-// + lane*16, source = per-lane global address.  No VGPR round trip, no staging registers.
-__device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-#ifndef ESR_ACT_AUX
-#define ESR_ACT_AUX 0   // cache-policy bits of the ACTIVATION DMAs (A/B knob: 2 = nt, 1 = sc0, 16 = sc1)
-#endif
-__device__ __forceinline__ void dma16_act(const char* g, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, ESR_ACT_AUX);
-}
-
-// Philox seed: by value, or through device memory so a captured graph replays with a fresh seed
-__device__ __forceinline__ uint64_t noise_seed(const esr_conv& p) {
-  return p.seed_dev ? __builtin_nontemporal_load(p.seed_dev) : p.seed;
-}
-
-// Accumulators are 8 NAMED vector members (never an indexable array): every access is resolved at
-// compile time, so the register allocator keeps them in AGPRs for the whole kernel.  (An
-// `f32x16 acc[8]` that is indexed by a not-fully-unrolled loop anywhere — e.g. the epilogue — is
-// demoted to scratch and re-stored after every K step.)
-struct Acc8 { f32x16 a0, a1, a2, a3, a4, a5, a6, a7; };
-
-template <int R> __device__ __forceinline__ f32x16& accsel(Acc8& s) {
-  static_assert(R >= 0 && R < 8, "row");
-  if constexpr (R == 0) return s.a0;
-  else if constexpr (R == 1) return s.a1;
-  else if constexpr (R == 2) return s.a2;
-  else if constexpr (R == 3) return s.a3;
-  else if constexpr (R == 4) return s.a4;
-  else if constexpr (R == 5) return s.a5;
-  else if constexpr (R == 6) return s.a6;
-  else return s.a7;
-}
-
-__device__ __forceinline__ void acc_zero(Acc8& s) {
-  f32x16 z;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) z[e] = 0.f;
-  s.a0 = z; s.a1 = z; s.a2 = z; s.a3 = z; s.a4 = z; s.a5 = z; s.a6 = z; s.a7 = z;
-}
-
-__device__ __forceinline__ f32x16 pick8(const Acc8& s, int r) {   // r is wave-uniform
-  switch (r) {
-    case 0: return s.a0;
-    case 1: return s.a1;
-    case 2: return s.a2;
-    case 3: return s.a3;
-    case 4: return s.a4;
-    case 5: return s.a5;
-    case 6: return s.a6;
-    default: return s.a7;
-  }
-}
-
-template <typename F, int... I>
-__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
-  sfor_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// Raw (storage-typed) 16-channel pixel: 32 bytes for fp16, 64 for fp32.
-template <typename T> struct Raw16;
-template <> struct Raw16<_Float16> {
-  u32x4 q[2];
-  __device__ __forceinline__ void load(const esr_g32& t, int b, int cb, int h, int64_t pix) {
-    if (2 * cb + h >= t.ngroups) { q[0] = u32x4{0, 0, 0, 0}; q[1] = u32x4{0, 0, 0, 0}; return; }
-    const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(2 * cb + h) * t.group_stride + pix * 32;
-    q[0] = *(const u32x4*)p; q[1] = *(const u32x4*)(p + 16);
-  }
-  __device__ __forceinline__ void get(float v[16]) const {
-    const half8 x = __builtin_bit_cast(half8, q[0]), y = __builtin_bit_cast(half8, q[1]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { v[i] = (float)x[i]; v[8 + i] = (float)y[i]; }
-  }
-};
-template <> struct Raw16<float> {
-  f32x4 q[4];
-  __device__ __forceinline__ void load(const esr_g32& t, int b, int cb, int h, int64_t pix) {
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      q[2 * g] = f32x4{0.f, 0.f, 0.f, 0.f}; q[2 * g + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (4 * cb + 2 * h + g < t.ngroups) {
-        const char* p = (const char*)t.ptr + b * t.batch_stride + (int64_t)(4 * cb + 2 * h + g) * t.group_stride + pix * 32;
-        q[2 * g] = *(const f32x4*)p; q[2 * g + 1] = *(const f32x4*)(p + 16);
-      }
-    }
-  }
-  __device__ __forceinline__ void get(float v[16]) const {
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[4 * g + i] = q[g][i];
-  }
-};
 
 // Epilogue of one 32-cout block of a wave (R rows x 1 pixel x 16 couts per lane); operation order
 // as documented on esr_conv in esrgan_hip.h.  Two phases: (1) issue EVERY global load of all R rows
@@ -785,47 +608,6 @@ __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_c
   conv_body<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, BWD, PIPE>(p, smem, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
-// EXPERIMENT (measurement only): the five convs of one ResidualDenseBlock_5C in ONE launch, every
-// workgroup walking conv1..conv5 for its own 16x32 tile with only workgroup-local barriers.  The
-// halo pixels owned by neighbouring workgroups are NOT synchronised, so results are wrong — the
-// timing is the upper bound of what an image-synchronised persistent RDB kernel could gain.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void rdb_nosync_kernel(const esr_conv* convs, const int delay_ticks, const int nrep) {
-  using G1 = Geo<3, 1, 0, 4, 1, 1, 1, true, true>;
-  using G2 = Geo<3, 1, 0, 4, 1, 1, 2, true, false>;
-  constexpr int LDS = G1::LDS_BYTES > G2::LDS_BYTES ? G1::LDS_BYTES : G2::LDS_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[LDS];
-  // staggering probe: workgroups of odd images start `delay_ticks` (10 ns) late, so the two
-  // workgroups sharing a CU run their K loops / epilogues out of phase for the rest of the launch
-  if (delay_ticks > 0) {
-    const int tiles_per_img = ((convs[0].W + 31) / 32) * ((convs[0].H + 15) / 16);
-    int t;
-    { const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3); }
-    if ((t / tiles_per_img) & 1) {
-      const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-      while ((int64_t)(__builtin_amdgcn_s_memrealtime() - t0) < delay_ticks) __builtin_amdgcn_s_sleep(8);
-    }
-  }
-  for (int rep = 0; rep < nrep; ++rep) {
-    conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, false, false>(convs[0], smem, blockIdx.x, gridDim.x, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, true, false>(convs[1], smem, blockIdx.x, gridDim.x, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, false, false>(convs[2], smem, blockIdx.x, gridDim.x, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    conv_body<T, 3, 1, 0, 4, 1, 1, 1, true, false, false>(convs[3], smem, blockIdx.x, gridDim.x, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    conv_body<T, 3, 1, 0, 4, 1, 1, 2, true, false, false>(convs[4], smem, blockIdx.x, gridDim.x, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-}
-
 template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool PIPE = false>
 int launch(const esr_conv& p, hipStream_t st) {
   using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>;
@@ -889,15 +671,6 @@ int dispatch(const esr_conv& p, hipStream_t st) {
 }
 
 }  // namespace
-
-extern "C" int esr_rdb_nosync_probe(const esr_conv* dev_convs, int32_t tiles, esr_stream_t stream) {
-  // measurement-only knobs: ESR_PROBE_DELAY (10 ns ticks, odd images start late), ESR_PROBE_NREP (RDBs per launch)
-  const char* e = getenv("ESR_PROBE_DELAY");
-  const char* r = getenv("ESR_PROBE_NREP");
-  hipLaunchKernelGGL(rdb_nosync_kernel<_Float16>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, dev_convs,
-                     e ? atoi(e) : 0, r ? atoi(r) : 1);
-  return esr_check_launch("rdb_nosync_kernel");
-}
 
 extern "C" int esr_conv_forward(const esr_conv* p, esr_stream_t stream) {
   if (!p || !p->in.ptr || !p->w || p->cin_groups <= 0 || p->cout_blocks <= 0 || p->B <= 0 || p->H <= 0 || p->W <= 0) {

@@ -1,0 +1,696 @@
+// rdb_fused.hip — input-stationary, persistent ResidualDenseBlock_5C chain on the gfx950 matrix cores.
+//
+// Replaces, for a CHAIN of dense blocks (the RRDB trunk of RRDBNet, architecture.py:57-59, i.e.
+// 3 x nb ResidualDenseBlock_5C, block.py:232-268, with the RRDB tails of block.py:287-291 /
+// test_image/block.py:252-256), what conv_mfma.hip runs as 5 launches per block.
+//
+// Why another kernel.  Layer by layer every conv of a block re-reads its whole concat prefix:
+// (64+96+128+160+192) = 640 channel-reads per pixel for 192 channels of new data, all of it from beyond
+// the 4 MB L2 (a block's working set is 12.6 MB per XCD).  profiles/r01_*: conv time = (time of the
+// memory side alone) + (MFMA time), i.e. the launch is paced by the bytes it moves.  Here the roles are
+// swapped: the OUTPUTS stay put.  A workgroup (4 waves, ONE per SIMD, 512 registers each) owns a
+// 16x32-pixel tile and keeps the fp32 accumulators of ALL 192 output channels of the block in registers:
+// a wave owns 4 rows x 32 pixels x 6 cout blocks = 24 MFMA accumulators = 384 registers.  hipcc only ever
+// emits the AGPR form of v_mfma (256 accumulator registers at most, anything beyond is shuttled through
+// v_accvgpr copies), so the MFMAs are issued through inline asm with explicit register classes: conv3,
+// conv4, conv5 accumulate in the 256 AGPRs ("+a"), conv1 / conv2 (the first to retire) in 128 VGPRs
+// ("+v"), which leaves 128 VGPRs for fragments and addresses.  The block then runs as five PHASES, one
+// per newly available input slice:
+//     phase 1  stage x   (64 ch)  -> accumulate into conv1..conv5        (6 cout blocks)
+//     phase 2  stage x1  (32 ch)  -> conv2..conv5                        (5)
+//     phase 3  stage x2           -> conv3..conv5                        (4)
+//     phase 4  stage x3           -> conv4, conv5                        (3)
+//     phase 5  stage x4           -> conv5                               (2)
+// so every input channel is staged ONCE (192 channel-reads per pixel instead of 640) and each staged
+// B fragment feeds 3 kh x NB MFMAs instead of 3.  After phase p the finished conv_p leaves through the
+// usual fused epilogue (bias, LeakyReLU, + conv1x1(x) for x2, + x2 for x4, *0.2 + x, noise, RRDB tail).
+// The bias-free 1x1 (block.py:263) is computed between phases 1 and 2 from the tile's own x pixels
+// (no halo, no neighbour needed) into the registers conv1 just vacated — it fills the wait for the
+// neighbours' x1.
+//
+// The 3x3 taps of phase p+1 need x_p on a 1-pixel halo, i.e. from the 8 neighbouring tiles.  All tiles
+// of an image are co-resident (one workgroup per CU, <= 256 tiles per image) and run in lock step; each
+// publishes "phase e done" through a per-tile flag and polls its neighbours' flags before staging the
+// next slice.  The hand-off is placement independent (agent scope; cdna guide, Guideline 16 R1): payload
+// = write-through (sc1) 16-byte stores, every storing wave drains vmcnt, one lane stores the flag (relaxed,
+// agent scope); the consumer polls relaxed and then reads the payload with sc1 loads (LDS-DMA, L1
+// bypassed).  Spins are bounded; a time-out raises the abort word of the workspace and every workgroup
+// leaves.  Overwrite hazards: a slot written in phase e is read by the neighbours in phase e+1 only, and
+// is next overwritten in phase e+5, which the owner cannot reach before every neighbour published e+1.
+//
+// GEMM view per unit (K step c, column tap kw):  D[cout][pixel] += W[cout][(kh, cin16)] X[(kh, cin16)][pixel]
+//   A fragments: NB x 3 (kh) x 1 KB per unit, streamed (LDS-DMA, L2 resident) through a 4-slot ring;
+//   B fragments: one 18x34 halo tile of a 32-byte channel group per K step, 3-slot ring (2 steps ahead).
+// The accumulation order per output element (chunk, kw, kh) equals conv_mfma.hip's, so fp16 results are
+// bit-identical with the per-conv path.
+#include <cstdlib>
+#include <mutex>
+
+#include "mfma_tile.h"
+
+namespace {
+
+constexpr int R = 4;                        // output rows per wave
+constexpr int TH = 16, TW = 32;             // tile of a workgroup (4 waves stacked vertically)
+constexpr int IH = TH + 2, IW = TW + 2;     // staged halo tile
+constexpr int NT = 256;                     // 4 waves, one per SIMD
+constexpr int NSLOT = IH * IW * 2;          // 16-byte slots of one activation stage
+constexpr int NLD = (NSLOT + NT - 1) / NT;  // DMA rounds per stage (5)
+constexpr int ASLOT = NLD * NT * 16;        // 20480
+constexpr int AR = 3;                       // activation ring depth
+constexpr int WSLOT = 18 * 1024;            // weight unit (6 blocks x 3 kh fragments)
+constexpr int WR = 4;                       // weight ring depth (3 units ahead)
+constexpr int WOFF = AR * ASLOT;
+constexpr int LDS_CTRL = WOFF + WR * WSLOT;   // two control words behind the rings
+constexpr int LDS_BYTES = LDS_CTRL + 64;       // 135232
+constexpr int WS_HDR = 16;                  // workspace words before the per-tile flags
+enum { WS_TICKET = 0, WS_ABORT = 1 };
+
+// ---- 24 named accumulators per wave: [cout block 0..5][row 0..3] --------------------------------------
+// cout blocks of a dense block: 0..3 = conv1..conv4, 4/5 = conv5[0:32]/[32:64].
+struct Acc24 {
+  f32x16 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15, v16, v17, v18, v19, v20, v21, v22, v23;
+};
+template <int I> __device__ __forceinline__ f32x16& acc_at(Acc24& s) {
+  static_assert(I >= 0 && I < 24, "acc index");
+#define ESR_ACC_CASE(n) if constexpr (I == n) return s.v##n; else
+  ESR_ACC_CASE(0) ESR_ACC_CASE(1) ESR_ACC_CASE(2) ESR_ACC_CASE(3) ESR_ACC_CASE(4) ESR_ACC_CASE(5)
+  ESR_ACC_CASE(6) ESR_ACC_CASE(7) ESR_ACC_CASE(8) ESR_ACC_CASE(9) ESR_ACC_CASE(10) ESR_ACC_CASE(11)
+  ESR_ACC_CASE(12) ESR_ACC_CASE(13) ESR_ACC_CASE(14) ESR_ACC_CASE(15) ESR_ACC_CASE(16) ESR_ACC_CASE(17)
+  ESR_ACC_CASE(18) ESR_ACC_CASE(19) ESR_ACC_CASE(20) ESR_ACC_CASE(21) ESR_ACC_CASE(22)
+  return s.v23;
+#undef ESR_ACC_CASE
+}
+template <int BLK, int ROW> __device__ __forceinline__ f32x16& acc_br(Acc24& s) { return acc_at<BLK * R + ROW>(s); }
+
+template <int BLK> __device__ __forceinline__ void zero_block(Acc24& s) {
+  f32x16 z;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) z[e] = 0.f;
+  acc_br<BLK, 0>(s) = z; acc_br<BLK, 1>(s) = z; acc_br<BLK, 2>(s) = z; acc_br<BLK, 3>(s) = z;
+}
+
+// MFMA through inline asm with an explicit accumulator register class: AGPR (blocks 2..5) or VGPR
+// (blocks 0,1).  hipcc does not pad hazards of asm statements (cdna guide 5.7): accumulate chains
+// (same D as C) need none; before anything else reads or overwrites an accumulator the callers run
+// mfma_drain().  A/B come from ds_read (s_waitcnt is placed by the compiler through the operands).
+constexpr bool acc_in_agpr(int blk) { return blk >= 2; }
+template <typename T, bool AGPR> __device__ __forceinline__ void mma_cls(f32x16& acc, const u32x4& a, const u32x4& b) {
+  if constexpr (sizeof(T) == 2) {
+    if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  } else {
+    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(fa[t]), "v"(fb[t]));
+      else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(fa[t]), "v"(fb[t]));
+    }
+  }
+}
+// >= 18 wait states: covers "XDL write VGPR -> VALU / VMEM read or write" for 8- and 16-pass MFMAs
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm_dyn(int n) {   // n is wave-uniform
+  switch (n) {
+    case 0: wait_vm<0>(); break;   case 1: wait_vm<1>(); break;   case 2: wait_vm<2>(); break;
+    case 3: wait_vm<3>(); break;   case 4: wait_vm<4>(); break;   case 5: wait_vm<5>(); break;
+    case 6: wait_vm<6>(); break;   case 7: wait_vm<7>(); break;   case 8: wait_vm<8>(); break;
+    case 9: wait_vm<9>(); break;   case 10: wait_vm<10>(); break; case 11: wait_vm<11>(); break;
+    case 12: wait_vm<12>(); break; case 13: wait_vm<13>(); break; case 14: wait_vm<14>(); break;
+    default: wait_vm<15>(); break;
+  }
+}
+
+// agent-scope (L1-bypassing) LDS-DMA: the activations another workgroup just published
+__device__ __forceinline__ void dma16_sc1(const char* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 16);
+}
+
+// One G32 view of ONE image as a buffer resource (wave-uniform): 16-byte sc1 loads / stores.
+struct ImgView {
+  __amdgpu_buffer_rsrc_t r;
+  int gs;        // group stride (bytes)
+  int ng;        // groups addressable
+};
+__device__ __forceinline__ ImgView img_view(const esr_g32& v, int b, int g0 = 0) {
+  ImgView o;
+  char* base = (char*)v.ptr + (int64_t)b * v.batch_stride + (int64_t)g0 * v.group_stride;
+  o.r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+  o.gs = (int)v.group_stride;
+  o.ng = v.ngroups - g0;
+  return o;
+}
+
+// 16 consecutive channels (cout block cb, lane half h) of one pixel <-> float[16], through sc1 accesses
+template <typename T> struct Ch16;
+template <> struct Ch16<_Float16> {
+  static __device__ __forceinline__ void store(const ImgView& t, int cb, int h, int pixoff, const float v[16]) {
+    half8 x, y;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x[i] = (_Float16)v[i]; y[i] = (_Float16)v[8 + i]; }
+    const int off = (2 * cb + h) * t.gs + pixoff;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), t.r, off, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), t.r, off + 16, 0, 16);
+  }
+  struct Raw { u32x4 q[2]; };
+  static __device__ __forceinline__ void load(const ImgView& t, int cb, int h, int pixoff, Raw& r) {
+    const int off = (2 * cb + h) * t.gs + pixoff;
+    r.q[0] = __builtin_amdgcn_raw_buffer_load_b128(t.r, off, 0, 16);
+    r.q[1] = __builtin_amdgcn_raw_buffer_load_b128(t.r, off + 16, 0, 16);
+  }
+  static __device__ __forceinline__ void get(const Raw& r, float v[16]) {
+    const half8 x = __builtin_bit_cast(half8, r.q[0]), y = __builtin_bit_cast(half8, r.q[1]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = (float)x[i]; v[8 + i] = (float)y[i]; }
+  }
+};
+template <> struct Ch16<float> {
+  static __device__ __forceinline__ void store(const ImgView& t, int cb, int h, int pixoff, const float v[16]) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int off = (4 * cb + 2 * h + g) * t.gs + pixoff;
+      f32x4 a, c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = v[8 * g + i]; c[i] = v[8 * g + 4 + i]; }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), t.r, off, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, c), t.r, off + 16, 0, 16);
+    }
+  }
+  struct Raw { u32x4 q[4]; };
+  static __device__ __forceinline__ void load(const ImgView& t, int cb, int h, int pixoff, Raw& r) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int off = (4 * cb + 2 * h + g) * t.gs + pixoff;
+      r.q[2 * g] = __builtin_amdgcn_raw_buffer_load_b128(t.r, off, 0, 16);
+      r.q[2 * g + 1] = __builtin_amdgcn_raw_buffer_load_b128(t.r, off + 16, 0, 16);
+    }
+  }
+  static __device__ __forceinline__ void get(const Raw& r, float v[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 a = __builtin_bit_cast(f32x4, r.q[g]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[4 * g + i] = a[i];
+    }
+  }
+};
+
+template <typename T> struct Cfg {
+  static constexpr int CPG = DT<T>::CPG, GPB = DT<T>::GPB;
+  static constexpr int KX = 64 / CPG;      // K steps of the 64-channel block input
+  static constexpr int KD = 32 / CPG;      // K steps of one 32-channel dense slice
+  static constexpr int ksteps(int p) { return p == 1 ? KX : KD; }
+  static constexpr int nblk(int p) { return 7 - p; }
+  // byte offset of phase p (1..5) in the block's fused weight stream; phase_off(6) = the 1x1 fragments
+  static constexpr int phase_off(int p) {
+    int o = 0;
+    for (int q = 1; q < p; ++q) o += ksteps(q) * 3 * nblk(q) * 3 * 1024;
+    return o;
+  }
+  static constexpr int STREAM_BYTES = phase_off(6) + KX * 1024;
+};
+
+// per-workgroup constants of the tile in flight
+struct Tile {
+  int b, oy0, ox0;
+  int wave, lane, j, h;
+  int goff[NLD];     // per-lane source offsets of the stage DMA (bytes inside one group plane)
+  int colofs[3];     // per-lane B-fragment offsets of the three column taps
+};
+
+// ---- weights of unit u of a phase -> ring slot (u & 3) ---------------------------------------------
+template <int NF> __device__ __forceinline__ void issue_w(const char* wsrc, int u, char* smem, const Tile& t) {
+  const char* src = wsrc + ((int64_t)u * NF) * 1024 + t.lane * 16;
+  char* dst = smem + WOFF + (u & (WR - 1)) * WSLOT;
+#pragma unroll
+  for (int i = 0; i < (NF + 3) / 4; ++i) {
+    const int q = t.wave + 4 * i;
+    if (q < NF) dma16(src + q * 1024, dst + q * 1024);
+  }
+}
+// ---- activation stage (one 32-byte channel group, 18x34 halo tile) -> ring slot sa -----------------
+__device__ __forceinline__ void issue_a(const char* plane, int sa, char* smem, const Tile& t) {
+  char* dst = smem + sa * ASLOT + t.wave * 1024;
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) dma16_sc1(plane + t.goff[i], dst + NT * 16 * i);
+}
+
+// ---- the MFMAs of one unit of phase P: cout blocks P-1..5 x 3 kh taps x 4 rows ----------------------
+// Every LDS fragment read is inline asm as well: with a compiler-tracked ds_read outstanding hipcc puts
+// `s_waitcnt lgkmcnt(0)` in front of every asm MFMA.  A fragments are double buffered; block bi+1's
+// three fragments are requested after the 4th of block bi's 12 MFMAs (the buffer's previous readers,
+// block bi-1, are >= 4 MFMAs back; 8 MFMAs = 256 cycles cover the LDS latency) and waited for with
+// lgkmcnt(0) in front of block bi+1.
+template <int OFF> __device__ __forceinline__ void lds_read16(u32x4& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void lds_wait3(u32x4& a, u32x4& b, u32x4& c) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
+}
+template <typename T, int P>
+__device__ __forceinline__ void unit_mma(Acc24& acc, const uint32_t lds_b, const uint32_t lds_w) {
+  constexpr int NB = 7 - P;
+  u32x4 bf[R + 2], af[2][3];
+  sfor<R + 2>([&](auto IR) __attribute__((always_inline)) { lds_read16<decltype(IR)::value * IW * 32>(bf[decltype(IR)::value], lds_b); });
+  sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(af[0][decltype(KH)::value], lds_w); });
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]),
+               "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]));
+  sfor<NB>([&](auto BI) __attribute__((always_inline)) {
+    constexpr int bi = decltype(BI)::value;       // position in the unit's fragment list
+    constexpr int blk = P - 1 + bi;
+    constexpr int cur = bi & 1, nxt = cur ^ 1;
+    // the 12 (input row, kh) pairs in issue order: ir-major, rows r = ir - kh
+    sfor<R + 2>([&](auto IR) __attribute__((always_inline)) {
+      constexpr int ir = decltype(IR)::value;
+      sfor<3>([&](auto KH) __attribute__((always_inline)) {
+        constexpr int kh = decltype(KH)::value;
+        constexpr int r = ir - kh;
+        if constexpr (r >= 0 && r < R) mma_cls<T, acc_in_agpr(blk)>(acc_br<blk, r>(acc), af[cur][kh], bf[ir]);
+      });
+      if constexpr (ir == 2 && bi + 1 < NB) {     // after MFMA 6 of 12
+        sfor<3>([&](auto KH) __attribute__((always_inline)) {
+          lds_read16<((bi + 1) * 3 + decltype(KH)::value) * 1024>(af[nxt][decltype(KH)::value], lds_w);
+        });
+      }
+    });
+    if constexpr (bi + 1 < NB) lds_wait3(af[nxt][0], af[nxt][1], af[nxt][2]);
+  });
+}
+
+// ---- one phase: K steps x 3 column taps over NB cout blocks ----------------------------------------
+// The first three weight units are already in flight (issue_w_head, before the neighbour poll).
+template <int NB> __device__ __forceinline__ void issue_w_head(const char* wsrc, int K, char* smem, const Tile& t) {
+  issue_w<NB * 3>(wsrc, 0, smem, t);
+  issue_w<NB * 3>(wsrc, 1, smem, t);
+  issue_w<NB * 3>(wsrc, 2, smem, t);      // every phase has >= 6 units
+}
+
+template <typename T, int P>
+__device__ __forceinline__ void run_phase(Acc24& acc, const char* wsrc, const char* aplane, const int64_t a_gs,
+                                          const int K, char* smem, const Tile& t) {
+  constexpr int NB = 7 - P, NF = NB * 3;
+  const int NU = 3 * K;
+  const int nW = (NF + 3 - t.wave) >> 2;                 // weight DMAs this wave issues per unit
+  constexpr int nA = NLD;                                // activation DMAs per stage
+  issue_a(aplane, 0, smem, t);
+  if (K > 1) issue_a(aplane + a_gs, 1, smem, t);
+  int g1 = K > 1 ? nA : 0, g2 = 0;                       // DMAs issued in the previous two units
+  int sa = 0;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
+#pragma unroll 1
+  for (int c = 0; c < K; ++c) {
+    sfor<3>([&](auto KW) __attribute__((always_inline)) {
+      constexpr int kw = decltype(KW)::value;
+      const int u = 3 * c + kw;
+      // in-order return: unit u's weights (issued 3 units ago) and K step c's activations (6 units ago)
+      // have landed once only what was issued after them is outstanding
+      int n = g1 + g2;
+      if (kw == 0) n = (c == 0) ? g1 : n + (c + 1 < K ? nA : 0);
+      wait_vm_dyn(n);
+      __builtin_amdgcn_s_barrier();       // unit u visible to all waves; all waves done with unit u-1
+      int cnt = 0;
+      if (u + 3 < NU) { issue_w<NF>(wsrc, u + 3, smem, t); cnt += nW; }
+      if (kw == 0 && c + 2 < K) {
+        int sn = sa + 2; if (sn >= AR) sn -= AR;
+        issue_a(aplane + (int64_t)(c + 2) * a_gs, sn, smem, t);
+        cnt += nA;
+      }
+      g2 = g1; g1 = cnt;
+      const uint32_t lb = lds_rows + sa * ASLOT + t.colofs[kw];
+      const uint32_t lw = lds0 + WOFF + (u & (WR - 1)) * WSLOT + t.lane * 16;
+      unit_mma<T, P>(acc, lb, lw);
+    });
+    if (++sa == AR) sa = 0;
+  }
+}
+
+// ---- P = conv1x1(x) on the tile's own pixels (block.py:263), into cout block 0's registers ----------
+template <typename T>
+__device__ __forceinline__ void run_1x1(Acc24& acc, const char* w1, const char* aplane, const int64_t a_gs,
+                                        char* smem, const Tile& t) {
+  constexpr int K = Cfg<T>::KX;
+  // all K fragments -> weight slot 0 (wave w copies fragments w, w+4, ...)
+#pragma unroll
+  for (int i = 0; i < (K + 3) / 4; ++i) {
+    const int q = t.wave + 4 * i;
+    if (q < K) dma16(w1 + q * 1024 + t.lane * 16, smem + WOFF + q * 1024);
+  }
+  issue_a(aplane, 0, smem, t);
+  issue_a(aplane + a_gs, 1, smem, t);
+  int sa = 0;
+  const char* lds_rows = smem + t.wave * (R * IW * 32) + IW * 32 + t.colofs[1];   // centre tap: rows 1..4, col j+1
+#pragma unroll 1
+  for (int c = 0; c < K; ++c) {
+    if (c + 1 < K) wait_vm<NLD>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (c + 2 < K) {
+      int sn = sa + 2; if (sn >= AR) sn -= AR;
+      issue_a(aplane + (int64_t)(c + 2) * a_gs, sn, smem, t);
+    }
+    {                                       // the 1x1 lands in conv1's vacated registers (block 0)
+      const u32x4 a = *(const u32x4*)(smem + WOFF + c * 1024 + t.lane * 16);
+      const char* lb = lds_rows + sa * ASLOT;
+      u32x4 bq[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) bq[r] = *(const u32x4*)(lb + r * IW * 32);
+      mma_cls<T, acc_in_agpr(0)>(acc_br<0, 0>(acc), a, bq[0]);
+      mma_cls<T, acc_in_agpr(0)>(acc_br<0, 1>(acc), a, bq[1]);
+      mma_cls<T, acc_in_agpr(0)>(acc_br<0, 2>(acc), a, bq[2]);
+      mma_cls<T, acc_in_agpr(0)>(acc_br<0, 3>(acc), a, bq[3]);
+    }
+    if (++sa == AR) sa = 0;
+  }
+}
+
+__device__ __forceinline__ void trace_ev(const esr_rdb_chain& p, int tile, int& ev) {
+  if (p.trace && threadIdx.x == 0 && ev < 64) p.trace[(int64_t)tile * 64 + ev] = __builtin_amdgcn_s_memrealtime();
+  ++ev;
+}
+
+// ---- publish / consume ------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__device__ __forceinline__ void publish(unsigned* flags, int tile, unsigned epoch, const Tile& t) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its sc1 stores
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave 0, lanes 0..7 poll one neighbour each (relaxed, agent scope) until all reached `epoch`.
+// Returns false (whole workgroup) on abort / time-out.
+__device__ __forceinline__ bool wait_neighbours(unsigned* ws, int my_nbr_tile, unsigned epoch, char* smem, const Tile& t) {
+  if (t.wave == 0) {
+    bool ok = my_nbr_tile < 0;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    bool dead = false;
+    for (;;) {
+      if (!ok) ok = __hip_atomic_load((gu32*)(ws + WS_HDR + my_nbr_tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(2);
+      if ((__builtin_amdgcn_s_memrealtime() - t0) > 100000000ull ||      // 1 s of the 100 MHz counter
+          __hip_atomic_load((gu32*)(ws + WS_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        dead = true;
+        break;
+      }
+    }
+    if (t.lane == 0) {
+      if (dead) __hip_atomic_store((gu32*)(ws + WS_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *(volatile int*)(smem + LDS_CTRL + 16) = dead ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  const int dead = *(volatile int*)(smem + LDS_CTRL + 16);
+  return dead == 0;
+}
+
+// ---- epilogue of one finished 32-cout block ---------------------------------------------------------
+// MODE 0: v = lrelu(acc + bias)                               (x1, x3)
+// MODE 1: v = lrelu(acc + bias) + P (slot 0's accumulators)   (x2, block.py:263)
+// MODE 2: v = lrelu(acc + bias) + extra[own pixel]            (x4 = lrelu(conv4) + x2, block.py:266)
+// MODE 3: v = (acc + bias)*0.2 + x; noise1; [v = v*0.2 + res2; noise2]   (block.py:267-268, 291)
+template <typename T, int BLK, int MODE>
+__device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, const esr_rdb_block& blk, const float* bias,
+                                         const ImgView& out, int out_cb, const ImgView& extra, int extra_cb,
+                                         const ImgView& res2, bool has_res2, const Tile& t) {
+  using C16 = Ch16<T>;
+  const int ox = t.ox0 + t.j;
+  const int oyb = t.oy0 + t.wave * R;
+  f32x4 bq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bq[i] = *(const f32x4*)(bias + 16 * t.h + 4 * i);
+  const int wp32 = p.dense.wp * 32;
+  typename C16::Raw ex[R], r2[R];
+  if constexpr (MODE >= 2) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int oy = oyb + r < p.H ? oyb + r : p.H - 1;
+      const int po = (oy + 1) * wp32 + (ox < p.W ? ox + 1 : 1) * 32;
+      C16::load(extra, extra_cb, t.h, po, ex[r]);
+      if (MODE == 3 && has_res2) C16::load(res2, extra_cb, t.h, po, r2[r]);
+    }
+  }
+  const bool n1 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && blk.layer1 != ESR_NO_LAYER;
+  const bool n2 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && blk.layer2 != ESR_NO_LAYER && has_res2;
+  const uint64_t seed = p.seed_dev ? __builtin_nontemporal_load(p.seed_dev) : p.seed;
+  sfor<R>([&](auto RR) __attribute__((always_inline)) {
+    constexpr int r = decltype(RR)::value;
+    const int oy = oyb + r;
+    const f32x16 a = acc_br<BLK, r>(acc);
+    float v[16], tmp[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float x = a[e] + bq[e >> 2][e & 3];
+      if constexpr (MODE != 3) x = x > 0.f ? x : x * ESR_LRELU_SLOPE;
+      v[e] = x;
+    }
+    if constexpr (MODE == 1) {
+      const f32x16 a1 = acc_br<0, r>(acc);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += a1[e];
+    }
+    if constexpr (MODE == 2) {
+      C16::get(ex[r], tmp);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = v[e] * 1.0f + tmp[e];
+    }
+    if constexpr (MODE == 3) {
+      C16::get(ex[r], tmp);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = v[e] * 0.2f + tmp[e];
+      const uint32_t pix = (uint32_t)((t.b * p.H + oy) * p.W + ox);
+      if (n1) {
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(extra_cb * 8 + t.h * 4 + q), blk.layer1, seed, &tmp[4 * q]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);     // block.py:119-121
+      }
+      if (has_res2) {
+        C16::get(r2[r], tmp);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = v[e] * 0.2f + tmp[e];
+        if (n2) {
+#pragma unroll 1
+          for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(extra_cb * 8 + t.h * 4 + q), blk.layer2, seed, &tmp[4 * q]);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
+        }
+      }
+    }
+    if (oy < p.H && ox < p.W) C16::store(out, out_cb, t.h, (oy + 1) * wp32 + (ox + 1) * 32, v);
+  });
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p, const int ntiles, const int tiles_x,
+                                                          const int tiles_y) {
+  using CF = Cfg<T>;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  unsigned* const ws = (unsigned*)p.workspace;
+  unsigned* const flags = ws + WS_HDR;
+  Tile t;
+  t.lane = threadIdx.x & 63;
+  t.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  t.j = t.lane & 31;
+  t.h = t.lane >> 5;
+  const int tpi = tiles_x * tiles_y;
+  const int wp = p.dense.wp;
+
+  for (;;) {
+    // ---- claim the next tile (tickets go out in order, so an image's tiles are co-resident)
+    __syncthreads();
+    if (threadIdx.x == 0)
+      *(volatile int*)(smem + LDS_CTRL) = (int)__hip_atomic_fetch_add((gu32*)(ws + WS_TICKET), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int tile = __builtin_amdgcn_readfirstlane(*(volatile int*)(smem + LDS_CTRL));
+    if (tile >= ntiles) break;
+    t.b = tile / tpi;
+    const int rem = tile - t.b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    t.oy0 = ty * TH;
+    t.ox0 = tx * TW;
+    // the neighbour this lane polls (lanes 0..7 of wave 0)
+    int nbr_tile = -1;
+    if (t.lane < 8) {
+      const int k = t.lane < 4 ? t.lane : t.lane + 1;
+      const int ny = ty + k / 3 - 1, nx = tx + k % 3 - 1;
+      if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) nbr_tile = t.b * tpi + ny * tiles_x + nx;
+    }
+    // stage DMA map: LDS slot s = tid + 256*i  <-  (row, col, 16-byte half), halves swapped by (col>>3)&1
+    // on the SOURCE address so that ds_read_b128 B-fragment reads are bank-conflict free
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      int s = (int)threadIdx.x + NT * i;
+      if (s >= NSLOT) s = NSLOT - 1;          // tail lanes: harmless re-copy into the padding
+      const int row = s / (2 * IW), r2 = s - row * 2 * IW;
+      const int col = r2 >> 1, hs = r2 & 1, half = hs ^ ((col >> 3) & 1);
+      t.goff[i] = ((t.oy0 + row) * wp + t.ox0 + col) * 32 + half * 16;
+    }
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int col = t.j + kw;
+      t.colofs[kw] = col * 32 + ((t.h ^ ((col >> 3) & 1)) << 4);
+    }
+    const ImgView dense = img_view(p.dense, t.b);
+    const char* const dense_b = (const char*)p.dense.ptr + (int64_t)t.b * p.dense.batch_stride;
+    const int64_t d_gs = p.dense.group_stride;
+
+
+    unsigned epoch = 0;      // phases this tile has published
+    int ev = 0;
+    trace_ev(p, tile, ev);
+    for (int rb = 0; rb < p.n_blocks; ++rb) {
+      const esr_rdb_block& blk = p.blocks[rb];
+      const char* const w = (const char*)blk.w;
+      const char* const xin_b = (const char*)blk.x_in.ptr + (int64_t)t.b * blk.x_in.batch_stride;
+      const ImgView xin = img_view(blk.x_in, t.b), xout = img_view(blk.x_out, t.b);
+      const bool has_res2 = blk.res2.ptr != nullptr;
+      const ImgView res2 = img_view(has_res2 ? blk.res2 : blk.x_in, t.b);
+      Acc24 acc;        // dead across blocks: every accumulator is zeroed before its first phase
+      zero_block<0>(acc); zero_block<1>(acc); zero_block<2>(acc);
+      zero_block<3>(acc); zero_block<4>(acc); zero_block<5>(acc);
+
+      // ---------------- phase 1: x -> conv1..conv5
+      issue_w_head<6>(w + CF::phase_off(1), CF::KX, smem, t);
+      if (epoch > 0 && !wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+      trace_ev(p, tile, ev);
+      run_phase<T, 1>(acc, w + CF::phase_off(1), xin_b, blk.x_in.group_stride, CF::KX, smem, t);
+      trace_ev(p, tile, ev);
+      mfma_drain();
+      epilogue<T, 0, 0>(acc, p, blk, blk.bias[0], dense, 0, dense, 0, dense, false, t);       // x1
+      zero_block<0>(acc);        // conv1's registers now collect the 1x1
+      publish(flags, tile, ++epoch, t);
+      trace_ev(p, tile, ev);
+      // ---------------- P = conv1x1(x) on own pixels, then phase 2: x1 -> conv2..conv5
+      run_1x1<T>(acc, w + CF::phase_off(6), xin_b, blk.x_in.group_stride, smem, t);
+      trace_ev(p, tile, ev);
+      __syncthreads();                      // every wave done with the 1x1's LDS before phase 2 refills it
+      issue_w_head<5>(w + CF::phase_off(2), CF::KD, smem, t);
+      if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+      trace_ev(p, tile, ev);
+      run_phase<T, 2>(acc, w + CF::phase_off(2), dense_b, d_gs, CF::KD, smem, t);
+      trace_ev(p, tile, ev);
+      mfma_drain();
+      epilogue<T, 1, 1>(acc, p, blk, blk.bias[1], dense, 1, dense, 0, dense, false, t);     // x2
+      publish(flags, tile, ++epoch, t);
+      trace_ev(p, tile, ev);
+      // ---------------- phase 3: x2 -> conv3..conv5
+      issue_w_head<4>(w + CF::phase_off(3), CF::KD, smem, t);
+      if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+      trace_ev(p, tile, ev);
+      run_phase<T, 3>(acc, w + CF::phase_off(3), dense_b + CF::KD * d_gs, d_gs, CF::KD, smem, t);
+      trace_ev(p, tile, ev);
+      mfma_drain();
+      epilogue<T, 2, 0>(acc, p, blk, blk.bias[2], dense, 2, dense, 0, dense, false, t);     // x3
+      publish(flags, tile, ++epoch, t);
+      trace_ev(p, tile, ev);
+      // ---------------- phase 4: x3 -> conv4, conv5
+      issue_w_head<3>(w + CF::phase_off(4), CF::KD, smem, t);
+      if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+      trace_ev(p, tile, ev);
+      run_phase<T, 4>(acc, w + CF::phase_off(4), dense_b + 2 * CF::KD * d_gs, d_gs, CF::KD, smem, t);
+      trace_ev(p, tile, ev);
+      mfma_drain();
+      epilogue<T, 3, 2>(acc, p, blk, blk.bias[3], dense, 3, dense, 1, dense, false, t);     // x4 (+ x2)
+      publish(flags, tile, ++epoch, t);
+      trace_ev(p, tile, ev);
+      // ---------------- phase 5: x4 -> conv5; block tail (+ RRDB tail)
+      issue_w_head<2>(w + CF::phase_off(5), CF::KD, smem, t);
+      if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+      trace_ev(p, tile, ev);
+      run_phase<T, 5>(acc, w + CF::phase_off(5), dense_b + 3 * CF::KD * d_gs, d_gs, CF::KD, smem, t);
+      trace_ev(p, tile, ev);
+      mfma_drain();
+      epilogue<T, 4, 3>(acc, p, blk, blk.bias[4], xout, 0, xin, 0, res2, has_res2, t);
+      epilogue<T, 5, 3>(acc, p, blk, blk.bias[4] + 32, xout, 1, xin, 1, res2, has_res2, t);
+      publish(flags, tile, ++epoch, t);
+      trace_ev(p, tile, ev);
+    }
+  }
+}
+
+int g_num_cus = 0;
+std::once_flag g_cu_once;
+int num_cus() {
+  std::call_once(g_cu_once, [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
+    if (g_num_cus <= 0) g_num_cus = 256;
+  });
+  return g_num_cus;
+}
+
+bool same_geometry(const esr_g32& a, const esr_g32& b) { return a.wp == b.wp; }
+
+}  // namespace
+
+extern "C" size_t esr_rdb_weight_stream_bytes(int32_t dtype) {
+  return dtype == ESR_F16 ? (size_t)Cfg<_Float16>::STREAM_BYTES : (size_t)Cfg<float>::STREAM_BYTES;
+}
+
+extern "C" size_t esr_rdb_workspace_bytes(int32_t B, int32_t H, int32_t W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  const size_t tiles = (size_t)B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  return (WS_HDR + tiles) * sizeof(uint32_t);
+}
+
+extern "C" int esr_rdb_max_tiles_per_image(void) { return num_cus(); }
+
+extern "C" int esr_rdb_forward(const esr_rdb_chain* p, esr_stream_t stream) {
+  if (!p || !p->blocks || p->n_blocks <= 0 || !p->dense.ptr || !p->workspace || p->B <= 0 || p->H <= 0 || p->W <= 0) {
+    esr_set_error("esr_rdb_forward: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  if (p->noise_mode != ESR_NOISE_OFF && p->noise_mode != ESR_NOISE_PHILOX) {
+    esr_set_error("esr_rdb_forward: noise_mode must be OFF or PHILOX (explicit z: use the per-conv path)");
+    return ESR_ERR_UNSUPPORTED;
+  }
+  const int tiles_x = (p->W + TW - 1) / TW, tiles_y = (p->H + TH - 1) / TH;
+  const int tpi = tiles_x * tiles_y, ntiles = tpi * p->B;
+  const int cus = num_cus();
+  if (tpi > cus) {
+    esr_set_error("esr_rdb_forward: %d tiles per image > %d CUs (all tiles of an image must be co-resident)", tpi, cus);
+    return ESR_ERR_UNSUPPORTED;
+  }
+  if (p->workspace_bytes < esr_rdb_workspace_bytes(p->B, p->H, p->W)) {
+    esr_set_error("esr_rdb_forward: workspace too small");
+    return ESR_ERR_INVALID;
+  }
+  const int gpb = p->dtype == ESR_F16 ? 2 : 4;
+  if (p->dense.ngroups < 4 * gpb) { esr_set_error("esr_rdb_forward: dense scratch needs 128 channels"); return ESR_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  // flags / ticket / abort word restart at zero on every call (a memset node under graph capture)
+  if (hipMemsetAsync(p->workspace, 0, esr_rdb_workspace_bytes(p->B, p->H, p->W), st) != hipSuccess) {
+    esr_set_error("esr_rdb_forward: hipMemsetAsync failed");
+    return ESR_ERR_LAUNCH;
+  }
+  const int grid = ntiles < cus ? ntiles : cus;
+  if (p->dtype == ESR_F16) hipLaunchKernelGGL(rdb_chain_kernel<_Float16>, dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y);
+  else if (p->dtype == ESR_F32) hipLaunchKernelGGL(rdb_chain_kernel<float>, dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y);
+  else { esr_set_error("esr_rdb_forward: bad dtype %d", p->dtype); return ESR_ERR_INVALID; }
+  return esr_check_launch("rdb_chain_kernel");
+}
+
+// Fused weight stream of a block = 1 KB fragments gathered from the per-conv packed weights
+// (esr_pack_conv_weights order [cout_block][cin_group][kh][kw][lane][16 B]).
+namespace {
+__global__ void frag_gather_kernel(const esr_frag_gather g) {
+  const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= g.n) return;
+  const int lane = threadIdx.x & 63;
+  const u32x4 v = *(const u32x4*)((const char*)g.src_base + g.src_off[f] + lane * 16);
+  *(u32x4*)((char*)g.dst + f * 1024 + lane * 16) = v;
+}
+}  // namespace
+
+extern "C" int esr_gather_fragments(const esr_frag_gather* g, esr_stream_t stream) {
+  if (!g || !g->src_off || !g->src_base || !g->dst || g->n <= 0) {
+    esr_set_error("esr_gather_fragments: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(frag_gather_kernel, dim3((unsigned)((g->n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *g);
+  return esr_check_launch("frag_gather_kernel");
+}

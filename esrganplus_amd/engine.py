@@ -111,6 +111,7 @@ class WeightPack:
         self._ptrs = None
         self.ops = None
         self.generation = 0      # bumped when any pointer handed out may have changed
+        self.pack_count = 0      # bumped every time the arena is re-packed (RdbStreams re-gathers)
 
     def _check_params(self):
         for key, w, b in self.convs:
@@ -154,6 +155,69 @@ class WeightPack:
                 for src, dst in self._bias_copies:
                     dst.copy_(src)
             self._sig = sig
+            self.pack_count += 1
+
+
+class RdbStreams:
+    """Fused weight streams of dense blocks for esr_rdb_forward (include/esrgan_hip.h, esr_rdb_block): per
+    block the 1 KB MFMA fragments of conv1..conv5 + conv1x1 re-ordered by (phase, K step, column tap,
+    conv, kh) — a pure gather of fragments out of the per-conv packed arena of `wp` (WeightPack), run
+    as ONE esr_gather_fragments launch right after every re-pack."""
+
+    def __init__(self, wp, prefixes):
+        self.wp, self.prefixes = wp, list(prefixes)
+        self.cpg = wp.cpg
+        self.stream_bytes = L.lib().esr_rdb_weight_stream_bytes(wp.esr_dtype)
+        self.arena = torch.zeros(len(self.prefixes) * self.stream_bytes, dtype=torch.uint8, device=wp.device)
+        self._gen = None
+        self.ops = None
+
+    def w_ptr(self, i):
+        return self.arena.data_ptr() + i * self.stream_bytes
+
+    def _table(self):
+        cpg, base = self.cpg, self.wp.arena.data_ptr()
+        kx, kd = 64 // cpg, 32 // cpg
+        offs = []
+        for p in self.prefixes:
+            ent = [self.wp.entries[p + '.conv%d.0' % k] for k in range(1, 6)]
+            nch = [(64 + 32 * k) // cpg for k in range(5)]            # input chunks of conv1..conv5
+            for ph in range(1, 6):                                   # phase = input slice x, x1..x4
+                c0 = 0 if ph == 1 else kx + (ph - 2) * kd
+                for c in range(kx if ph == 1 else kd):
+                    for kw in range(3):
+                        for blk in range(ph - 1, 6):                 # conv ph..5 (conv5: two cout blocks)
+                            k, cb = (blk, 0) if blk < 4 else (4, blk - 4)
+                            for kh in range(3):
+                                offs.append(ent[k].w_ptr - base + (((cb * nch[k] + c0 + c) * 3 + kh) * 3 + kw) * 1024)
+            e1 = self.wp.entries[p + '.conv1x1']
+            for c in range(kx):
+                offs.append(e1.w_ptr - base + c * 1024)
+        assert len(offs) * 1024 == len(self.prefixes) * self.stream_bytes, (len(offs), self.stream_bytes)
+        return offs
+
+    def ensure(self, stream, force=False):
+        """Call after wp.ensure(): re-gathers when the packed arena was rewritten."""
+        if self.ops is None:
+            self._tab = torch.tensor(self._table(), dtype=torch.int64, device=self.wp.device)
+            g = L.esr_frag_gather()
+            g.src_off, g.src_base, g.dst, g.n = (self._tab.data_ptr(), self.wp.arena.data_ptr(),
+                                                 self.arena.data_ptr(), self._tab.numel())
+            self.ops = L.OpList()
+            self.ops.add(L.OP_FRAG_GATHER, 'frag_gather', g)
+        gen = (self.wp.generation, self.wp.pack_count)
+        if force or gen != self._gen:
+            self.ops.run(stream)
+            self._gen = gen
+
+
+def rdb_chain_ok(B, H, W, noise, explicit_z):
+    """The fused dense-block chain handles eval / fused-Philox passes whose images have at most
+    esr_rdb_max_tiles_per_image() 16x32 tiles (all tiles of an image are co-resident, one per CU)."""
+    if os.environ.get('ESR_RDB_FUSED', '1') == '0' or (noise and explicit_z):
+        return False
+    tpi = ((H + 15) // 16) * ((W + 31) // 32)
+    return tpi <= L.lib().esr_rdb_max_tiles_per_image()
 
 
 def _conv(dtype_e, B, H, W, src, src_ch, dst, cw, act=L.ACT_NONE, ks=None, stride=1, upsample=0):
@@ -195,8 +259,11 @@ class Plan:
         self.out_op = None       # index of the op producing the NCHW output
         self.out_shape = None
         self.noise_ops = []      # (op index, which) of convs carrying a noise epilogue
+        self.chain_ops = []      # indices of OP_RDB_CHAIN ops (noise mode / seed set per run)
+        self.streams = None      # RdbStreams feeding the chain ops
         self.z_ops = []          # layout ops that import explicit z tensors, in noise-layer order
         self.wgen = None
+        self.chain_noise = False
 
     def run(self, x, out, stream, seed=0, zs=None):
         arr = self.ops.array()
@@ -207,6 +274,10 @@ class Plan:
         else:
             o.u.layout.nchw = out.data_ptr()
         mode = L.NOISE_OFF
+        for i in self.chain_ops:
+            ch = arr[i].u.rdb_chain
+            ch.noise_mode = L.NOISE_PHILOX if self.chain_noise else L.NOISE_OFF
+            ch.seed = seed
         if self.noise_ops:
             if zs is not None:
                 assert len(zs) == len(self.z_ops), (len(zs), len(self.z_ops))
@@ -218,6 +289,8 @@ class Plan:
             for i in self.noise_ops:
                 arr[i].u.conv.noise_mode = mode
                 arr[i].u.conv.seed = seed
+        if self.streams is not None:
+            self.streams.ensure(stream)
         if mode != L.NOISE_EXPLICIT and self.z_ops:
             # explicit-z import ops are recorded first; skip them when z is not supplied
             first = max(self.z_ops) + 1
@@ -321,6 +394,49 @@ class Builder:
         self.rdb(prefix + '.RDB2', x1, x2)
         self.rdb(prefix + '.RDB3', x2, x0, rrdb_x=x0, rrdb_noise=(self.variant == 'test_image'))
 
+    def rdb_chain(self, specs):
+        """ONE fused launch for a chain of dense blocks.  specs: list of (prefix, x_in, x_out, res2 or None,
+        rrdb_noise) over 64-channel G32 buffers; the 128-channel dense scratch is shared."""
+        P = self.plan
+        if P.streams is None:
+            P.streams = RdbStreams(self.wp, [s[0] for s in specs])
+            base = 0
+        else:
+            base = len(P.streams.prefixes)
+            raise NotImplementedError('one chain per plan')
+        dense = self.buf(128)
+        blocks = (L.esr_rdb_block * len(specs))()
+        ent = self.wp.entries
+        for i, (prefix, xi, xo, r2, rrdb_noise) in enumerate(specs):
+            b = blocks[i]
+            b.w = P.streams.w_ptr(base + i)
+            for k in range(5):
+                b.bias[k] = ent[prefix + '.conv%d.0' % (k + 1)].bias_ptr
+            b.x_in, b.x_out = xi.view(0, 64), xo.view(0, 64)
+            if r2 is not None:
+                b.res2 = r2.view(0, 64)
+            b.layer1 = b.layer2 = L.NO_LAYER
+            if self.noise:
+                b.layer1 = self.n_noise
+                self.n_noise += 1
+                if r2 is not None and rrdb_noise:
+                    b.layer2 = self.n_noise
+                    self.n_noise += 1
+        blk_t = torch.frombuffer(bytearray(bytes(blocks)), dtype=torch.uint8).to(self.device)
+        ws_bytes = L.lib().esr_rdb_workspace_bytes(self.B, self.H, self.W)
+        ws = torch.zeros((ws_bytes + 3) // 4, dtype=torch.int32, device=self.device)
+        P.bufs.extend([blk_t, ws])
+        ch = L.esr_rdb_chain()
+        ch.dtype, ch.B, ch.H, ch.W = self.dt_e, self.B, self.H, self.W
+        ch.n_blocks, ch.noise_mode, ch.sigma = len(specs), L.NOISE_OFF, SIGMA
+        ch.dense = dense.view(0, 128)
+        ch.blocks, ch.workspace, ch.workspace_bytes = blk_t.data_ptr(), ws.data_ptr(), ws_bytes
+        i = P.ops.add(L.OP_RDB_CHAIN, 'rdb_chain', ch)
+        P.chain_ops.append(i)
+        P.chain_noise = self.noise
+        P.chain_ws = ws
+        return i
+
     def n_noise_layers(self, nb):
         return (4 if self.variant == 'test_image' else 3) * nb if self.noise else 0
 
@@ -335,13 +451,29 @@ class Builder:
             self.alloc_z(self.n_noise_layers(nb))
         xin = self.buf(in_nc)
         fea = self.buf(64)
-        x0, x1, x2 = self.buf(192), self.buf(192), self.buf(192)
         P.in_op = self.import_nchw(xin, in_nc)
-        c = _conv(d, B, H, W, xin.view(0), in_nc, x0.view(0, 64), e['model.0'])
-        c.aux_out = fea.view(0, 64)          # keep fea for the trunk shortcut (block.py:84-86)
-        P.ops.add_conv(c)
-        for i in range(nb):
-            self.rrdb('model.1.sub.%d' % i, x0, x1, x2)
+        if nb and rdb_chain_ok(B, H, W, self.noise, explicit_z):
+            # fused trunk: two 64-channel slots + the chain's 128-channel dense scratch.  Per RRDB:
+            # RDB1 xa -> xb, RDB2 xb -> xb (in place), RDB3 xb -> xa with the RRDB tail reading xa.
+            xa, xb = self.buf(64), self.buf(64)
+            c = _conv(d, B, H, W, xin.view(0), in_nc, xa.view(0, 64), e['model.0'])
+            c.aux_out = fea.view(0, 64)
+            P.ops.add_conv(c)
+            specs = []
+            for i in range(nb):
+                pre = 'model.1.sub.%d' % i
+                specs.append((pre + '.RDB1', xa, xb, None, False))
+                specs.append((pre + '.RDB2', xb, xb, None, False))
+                specs.append((pre + '.RDB3', xb, xa, xa, self.variant == 'test_image'))
+            self.rdb_chain(specs)
+            x0, x1 = xa, xb
+        else:
+            x0, x1, x2 = self.buf(192), self.buf(192), self.buf(192)
+            c = _conv(d, B, H, W, xin.view(0), in_nc, x0.view(0, 64), e['model.0'])
+            c.aux_out = fea.view(0, 64)          # keep fea for the trunk shortcut (block.py:84-86)
+            P.ops.add_conv(c)
+            for i in range(nb):
+                self.rrdb('model.1.sub.%d' % i, x0, x1, x2)
         c = _conv(d, B, H, W, x0.view(0), 64, x1.view(0, 64), e['model.1.sub.%d' % nb])
         c.res1, c.alpha = fea.view(0, 64), 1.0
         P.ops.add_conv(c)
@@ -381,6 +513,18 @@ def build_block_plan(kind, wp, B, H, W, dtype, device, noise, variant, explicit_
         n_noise = 1 if kind == 'rdb' else (4 if variant == 'test_image' else 3)
     if explicit_z and noise:
         bld.alloc_z(n_noise)
+    if rdb_chain_ok(B, H, W, noise, explicit_z):
+        xa, xb = bld.buf(64), bld.buf(64)
+        P.in_op = bld.import_nchw(xa, 64)
+        if kind == 'rdb':
+            bld.rdb_chain([('rdb', xa, xb, None, False)])
+            P.out_op = bld.export_nchw(xb, 64)
+        else:
+            bld.rdb_chain([('rrdb.RDB1', xa, xb, None, False), ('rrdb.RDB2', xb, xb, None, False),
+                           ('rrdb.RDB3', xb, xa, xa, variant == 'test_image')])
+            P.out_op = bld.export_nchw(xa, 64)
+        P.out_shape = (B, 64, H, W)
+        return P
     x0, x1 = bld.buf(192), bld.buf(192)
     P.in_op = bld.import_nchw(x0, 64)
     if kind == 'rdb':

@@ -268,9 +268,58 @@ typedef struct esr_adam {
   float lr, beta1, beta2, eps, bc1, bc2, grad_scale, weight_decay;
 } esr_adam;
 
+/* ---- fused ResidualDenseBlock_5C chain (rdb_fused.hip) -------------------------------------------
+ * ONE persistent launch runs n_blocks dense blocks (block.py:260-268) back to back on every 16x32
+ * tile, the fp32 accumulators of all 192 output channels of the block in flight held in registers
+ * ("input stationary": each input slice x, x1..x4 is staged once and feeds every later conv), with
+ * the 1-pixel halos of x1..x4 / the block output exchanged between neighbouring tiles inside the
+ * launch.  The RRDB tail (block.py:291: out*0.2 + x_rrdb; test_image/block.py:256 adds a noise
+ * layer) is the second residual stage of a block whose res2 is set.
+ *   x1 = lrelu(conv1(x));  x2 = lrelu(conv2(x,x1)) + conv1x1(x);  x3 = lrelu(conv3(x..x2));
+ *   x4 = lrelu(conv4(x..x3)) + x2;  y = noise1(conv5(x..x4)*0.2 + x);  [y = noise2(y*0.2 + res2)]
+ * Weights: one fused stream per block (esr_rdb_weight_stream_bytes), 1 KB MFMA A fragments in the
+ * order the phases consume them:  for phase p = 1..5 (input slice x, x1, x2, x3, x4), K step c of
+ * the slice, column tap kw, conv k = p..5 (conv5: both cout blocks), kh: fragment
+ * packed(conv k)[cout_block][chunk0(p)+c][kh][kw]; then the 1x1's chunks.  Build it from the
+ * per-conv packed weights with esr_gather_fragments.
+ * All views share one geometry (same wp / H / W); x_out may alias x_in or res2 (pixel-local). */
+typedef struct esr_rdb_block {
+  const void* w;            /* fused weight stream of this block */
+  const float* bias[5];     /* fp32 biases of conv1..conv4 (32 each) and conv5 (64): the nn.Parameters themselves */
+  esr_g32 x_in;             /* 64-channel block input */
+  esr_g32 x_out;            /* 64-channel block output */
+  esr_g32 res2;             /* RRDB input of the fused RRDB tail; ptr NULL = plain dense block */
+  uint32_t layer1, layer2;  /* Philox stream ids of the block noise / the RRDB-tail noise; 0xFFFFFFFF = off */
+} esr_rdb_block;
+
+typedef struct esr_rdb_chain {
+  int32_t dtype, B, H, W;
+  int32_t n_blocks;
+  int32_t noise_mode;       /* ESR_NOISE_OFF or ESR_NOISE_PHILOX (explicit z: per-conv path) */
+  float sigma;
+  int32_t _pad;
+  uint64_t seed;
+  const uint64_t* seed_dev; /* as esr_conv.seed_dev */
+  esr_g32 dense;            /* 128-channel scratch: x1..x4 of the block in flight */
+  const esr_rdb_block* blocks;  /* DEVICE array of n_blocks entries */
+  void* workspace;          /* esr_rdb_workspace_bytes(B,H,W) bytes of device memory; word 1 != 0 after the
+                               launch = a bounded spin timed out (results invalid) */
+  size_t workspace_bytes;
+  uint64_t* trace;          /* measurement only (NULL = off): per tile 64 x uint64 time stamps (100 MHz) */
+} esr_rdb_chain;
+
+/* 1 KB fragment gather: dst[f] = src_base[src_off[f]] for f < n (src_off: DEVICE int64 byte offsets). */
+typedef struct esr_frag_gather {
+  const int64_t* src_off;
+  const void* src_base;
+  void* dst;
+  int64_t n;
+} esr_frag_gather;
+
 enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_NOISE_FILL = 4,
                    ESR_OP_WGRAD = 5, ESR_OP_BN = 6, ESR_OP_POOL = 7, ESR_OP_LINEAR = 8,
-                   ESR_OP_UNPERMUTE = 9, ESR_OP_PACK_BATCH = 10 };
+                   ESR_OP_UNPERMUTE = 9, ESR_OP_PACK_BATCH = 10,
+                   ESR_OP_RDB_CHAIN = 11, ESR_OP_FRAG_GATHER = 12 };
 
 /* esr_op.flags */
 #define ESR_OPF_SIDE 1   /* on a run of consecutive ESR_OP_WGRAD ops: launch the run on the library's side
@@ -294,6 +343,8 @@ typedef struct esr_op {
     esr_linear linear;
     esr_unpermute unpermute;
     esr_pack_batch pack_batch;
+    esr_rdb_chain rdb_chain;
+    esr_frag_gather frag_gather;
   } u;
 } esr_op;
 
@@ -318,6 +369,12 @@ int esr_grad_unpermute(const esr_unpermute* p, esr_stream_t stream);
 int esr_adam_step(const esr_adam* p, esr_stream_t stream);
 int esr_resample_axis(const esr_resample* p, esr_stream_t stream);
 int esr_pack_conv_weights_batch(const esr_pack_batch* p, esr_stream_t stream);
+/* Fused dense-block chain (replaces 5 x n_blocks esr_conv_forward launches; block.py:260-268,287-291). */
+int esr_rdb_forward(const esr_rdb_chain* p, esr_stream_t stream);
+size_t esr_rdb_workspace_bytes(int32_t B, int32_t H, int32_t W);
+size_t esr_rdb_weight_stream_bytes(int32_t dtype);
+int esr_rdb_max_tiles_per_image(void);   /* 16x32 tiles of ONE image must not exceed this (= CUs) */
+int esr_gather_fragments(const esr_frag_gather* g, esr_stream_t stream);
 
 /* Run a recorded list of ops back to back on `stream` (one host call per network pass; this is
  * what RRDBNet.forward — architecture.py:76-78 — becomes). */
@@ -338,9 +395,6 @@ int esr_graph_destroy(esr_graph_t g);
  * stream, and writes each op's elapsed milliseconds to ms_out[n].  This is the one entry point that
  * creates events and synchronises; never call it under graph capture. */
 int esr_run_ops_timed(const esr_op* ops, int32_t n, esr_stream_t stream, float* ms_out);
-
-/* Measurement-only probe (results are NOT valid): see conv_mfma.hip rdb_nosync_kernel. */
-int esr_rdb_nosync_probe(const esr_conv* dev_convs, int32_t tiles, esr_stream_t stream);
 
 const char* esr_last_error(void);
 int esr_abi_version(void);
