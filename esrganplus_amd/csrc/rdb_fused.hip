@@ -57,12 +57,13 @@ constexpr int NT = 256;                     // 4 waves, one per SIMD
 constexpr int NSLOT = IH * IW * 2;          // 16-byte slots of one activation stage
 constexpr int NLD = (NSLOT + NT - 1) / NT;  // DMA rounds per stage (5)
 constexpr int ASLOT = NLD * NT * 16;        // 20480
-constexpr int AR = 3;                       // activation ring depth
+constexpr int AR = 4;                       // activation slots: all stages of a 64-channel fp16 input are resident
 constexpr int WSLOT = 18 * 1024;            // weight unit (6 blocks x 3 kh fragments)
 constexpr int WR = 4;                       // weight ring depth (3 units ahead)
 constexpr int WOFF = AR * ASLOT;
 constexpr int LDS_CTRL = WOFF + WR * WSLOT;   // two control words behind the rings
-constexpr int LDS_BYTES = LDS_CTRL + 64;       // 135232
+constexpr int LDS_BYTES = LDS_CTRL + 64;       // 155712
+constexpr int NHALO = 2 * 2 * IW + 2 * 2 * TH;  // 16-byte slots of the 1-pixel halo ring of one stage (200)
 constexpr int WS_HDR = 16;                  // workspace words before the per-tile flags
 enum { WS_TICKET = 0, WS_ABORT = 1 };
 
@@ -83,26 +84,32 @@ template <int I> __device__ __forceinline__ f32x16& acc_at(Acc24& s) {
 }
 template <int BLK, int ROW> __device__ __forceinline__ f32x16& acc_br(Acc24& s) { return acc_at<BLK * R + ROW>(s); }
 
-template <int BLK> __device__ __forceinline__ void zero_block(Acc24& s) {
-  f32x16 z;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) z[e] = 0.f;
-  acc_br<BLK, 0>(s) = z; acc_br<BLK, 1>(s) = z; acc_br<BLK, 2>(s) = z; acc_br<BLK, 3>(s) = z;
-}
-
 // MFMA through inline asm with an explicit accumulator register class: AGPR (blocks 2..5) or VGPR
 // (blocks 0,1).  hipcc does not pad hazards of asm statements (cdna guide 5.7): accumulate chains
 // (same D as C) need none; before anything else reads or overwrites an accumulator the callers run
 // mfma_drain().  A/B come from ds_read (s_waitcnt is placed by the compiler through the operands).
 constexpr bool acc_in_agpr(int blk) { return blk >= 2; }
-template <typename T, bool AGPR> __device__ __forceinline__ void mma_cls(f32x16& acc, const u32x4& a, const u32x4& b) {
+// FIRST: the accumulator's first MFMA of a block takes the inline constant 0 as SrcC and a write-only
+// output, so accumulators are never zeroed by VALU code (hipcc materialises such zeros lazily with
+// v_mov copies BETWEEN the asm MFMAs, where nothing pads the VALU-write -> MFMA-read hazard).
+template <typename T, bool AGPR, bool FIRST = false>
+__device__ __forceinline__ void mma_cls(f32x16& acc, const u32x4& a, const u32x4& b) {
   if constexpr (sizeof(T) == 2) {
-    if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    if constexpr (FIRST) {
+      if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+    } else {
+      if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    }
   } else {
     const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+    if constexpr (FIRST) {
+      if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(fa[0]), "v"(fb[0]));
+      else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(fa[0]), "v"(fb[0]));
+    }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = FIRST ? 1 : 0; t < 4; ++t) {
       if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(fa[t]), "v"(fb[t]));
       else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(fa[t]), "v"(fb[t]));
     }
@@ -154,6 +161,18 @@ template <> struct Ch16<_Float16> {
     const int off = (2 * cb + h) * t.gs + pixoff;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), t.r, off, 0, 16);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), t.r, off + 16, 0, 16);
+  }
+  // packed row: the lane's 16 channels as stored (2 x 16 bytes)
+  static __device__ __forceinline__ void pack(const float v[16], u32x4 (&q)[2]) {
+    half8 x, y;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x[i] = (_Float16)v[i]; y[i] = (_Float16)v[8 + i]; }
+    q[0] = __builtin_bit_cast(u32x4, x); q[1] = __builtin_bit_cast(u32x4, y);
+  }
+  static __device__ __forceinline__ void store_packed(const ImgView& t, int cb, int h, int pixoff, const u32x4 (&q)[2]) {
+    const int off = (2 * cb + h) * t.gs + pixoff;
+    __builtin_amdgcn_raw_buffer_store_b128(q[0], t.r, off, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(q[1], t.r, off + 16, 0, 16);
   }
   struct Raw { u32x4 q[2]; };
   static __device__ __forceinline__ void load(const ImgView& t, int cb, int h, int pixoff, Raw& r) {
@@ -217,8 +236,13 @@ template <typename T> struct Cfg {
 struct Tile {
   int b, oy0, ox0;
   int wave, lane, j, h;
-  int goff[NLD];     // per-lane source offsets of the stage DMA (bytes inside one group plane)
+  int wp;            // row pitch (pixels) of every view
   int colofs[3];     // per-lane B-fragment offsets of the three column taps
+  // LDS-resident path (fp16): the 1-pixel halo ring of a stage = 200 16-byte slots, one per thread
+  int halo_src;      // byte offset inside a group plane (-1: this thread has no slot)
+  int halo_dst;      // byte offset inside an activation slot
+  int own_px;        // this lane's own pixel (row 4*wave, column j) inside an activation slot, half 0
+  int own_swz;       // 16 if the two halves of that pixel are swapped in the LDS image
 };
 
 // ---- weights of unit u of a phase -> ring slot (u & 3) ---------------------------------------------
@@ -233,9 +257,39 @@ template <int NF> __device__ __forceinline__ void issue_w(const char* wsrc, int 
 }
 // ---- activation stage (one 32-byte channel group, 18x34 halo tile) -> ring slot sa -----------------
 __device__ __forceinline__ void issue_a(const char* plane, int sa, char* smem, const Tile& t) {
+  // LDS slot s = tid + 256*i  <-  (row, col, 16-byte half), halves swapped by (col>>3)&1 on the SOURCE address
+  // so that ds_read_b128 B-fragment reads are bank-conflict free.  Offsets are recomputed per call: this
+  // path only stages a chain's first input (and the fp32 reference path), and 5 live registers cost more.
   char* dst = smem + sa * ASLOT + t.wave * 1024;
 #pragma unroll
-  for (int i = 0; i < NLD; ++i) dma16_sc1(plane + t.goff[i], dst + NT * 16 * i);
+  for (int i = 0; i < NLD; ++i) {
+    int s = (int)threadIdx.x + NT * i;
+    if (s >= NSLOT) s = NSLOT - 1;            // tail lanes: harmless re-copy into the padding
+    const int row = s / (2 * IW), r2 = s - row * 2 * IW;
+    const int col = r2 >> 1, hs = r2 & 1, half = hs ^ ((col >> 3) & 1);
+    dma16_sc1(plane + ((t.oy0 + row) * t.wp + t.ox0 + col) * 32 + half * 16, dst + NT * 16 * i);
+  }
+}
+
+// ---- LDS-resident activations (fp16 path) -----------------------------------------------------------
+// A tile's own 16x32 pixels of a slice never come back from memory: the epilogue that produces them also
+// writes them into the stage slots the next phase reads (slot = channel group of the slice).  Only the
+// 1-pixel ring around the tile is fetched (sc1 loads, after the neighbours published): one 16-byte load
+// + one ds_write per thread and stage.
+template <int K> __device__ __forceinline__ void halo_fetch(const ImgView& v, int g0, char* smem, const Tile& t) {
+  if (t.halo_src >= 0) {
+    u32x4 q[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) q[c] = __builtin_amdgcn_raw_buffer_load_b128(v.r, (g0 + c) * v.gs + t.halo_src, 0, 16);
+#pragma unroll
+    for (int c = 0; c < K; ++c) *(u32x4*)(smem + c * ASLOT + t.halo_dst) = q[c];
+  }
+}
+// the lane's packed 16 channels of row r (own pixel) -> stage slot `slot`
+__device__ __forceinline__ void lds_put_row(char* smem, int slot, int r, const u32x4 (&q)[2], const Tile& t) {
+  char* px = smem + slot * ASLOT + t.own_px + r * (IW * 32);
+  *(u32x4*)(px + t.own_swz) = q[0];
+  *(u32x4*)(px + (t.own_swz ^ 16)) = q[1];
 }
 
 // ---- the MFMAs of one unit of phase P: cout blocks P-1..5 x 3 kh taps x 4 rows ----------------------
@@ -250,7 +304,7 @@ template <int OFF> __device__ __forceinline__ void lds_read16(u32x4& d, uint32_t
 __device__ __forceinline__ void lds_wait3(u32x4& a, u32x4& b, u32x4& c) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
 }
-template <typename T, int P>
+template <typename T, int P, bool FIRST = false>
 __device__ __forceinline__ void unit_mma(Acc24& acc, const uint32_t lds_b, const uint32_t lds_w) {
   constexpr int NB = 7 - P;
   u32x4 bf[R + 2], af[2][3];
@@ -268,7 +322,7 @@ __device__ __forceinline__ void unit_mma(Acc24& acc, const uint32_t lds_b, const
       sfor<3>([&](auto KH) __attribute__((always_inline)) {
         constexpr int kh = decltype(KH)::value;
         constexpr int r = ir - kh;
-        if constexpr (r >= 0 && r < R) mma_cls<T, acc_in_agpr(blk)>(acc_br<blk, r>(acc), af[cur][kh], bf[ir]);
+        if constexpr (r >= 0 && r < R) mma_cls<T, acc_in_agpr(blk), FIRST && kh == 0>(acc_br<blk, r>(acc), af[cur][kh], bf[ir]);
       });
       if constexpr (ir == 2 && bi + 1 < NB) {     // after MFMA 6 of 12
         sfor<3>([&](auto KH) __attribute__((always_inline)) {
@@ -301,15 +355,18 @@ __device__ __forceinline__ void run_phase(Acc24& acc, const char* wsrc, const ch
   int sa = 0;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
-#pragma unroll 1
-  for (int c = 0; c < K; ++c) {
+  // one K step = 3 units.  The block's very first K step (phase 1, c = 0) is peeled: its first unit writes
+  // the accumulators (SrcC = 0) and must not share a control-flow join with the accumulating form (the phi
+  // of a fully allocated AGPR file is resolved through scratch).
+  auto kstep = [&](const int c, auto FIRSTC) __attribute__((always_inline)) {
+    constexpr bool firstc = decltype(FIRSTC)::value;
     sfor<3>([&](auto KW) __attribute__((always_inline)) {
       constexpr int kw = decltype(KW)::value;
       const int u = 3 * c + kw;
       // in-order return: unit u's weights (issued 3 units ago) and K step c's activations (6 units ago)
       // have landed once only what was issued after them is outstanding
       int n = g1 + g2;
-      if (kw == 0) n = (c == 0) ? g1 : n + (c + 1 < K ? nA : 0);
+      if (kw == 0) n = firstc ? g1 : n + (c + 1 < K ? nA : 0);
       wait_vm_dyn(n);
       __builtin_amdgcn_s_barrier();       // unit u visible to all waves; all waves done with unit u-1
       int cnt = 0;
@@ -322,10 +379,66 @@ __device__ __forceinline__ void run_phase(Acc24& acc, const char* wsrc, const ch
       g2 = g1; g1 = cnt;
       const uint32_t lb = lds_rows + sa * ASLOT + t.colofs[kw];
       const uint32_t lw = lds0 + WOFF + (u & (WR - 1)) * WSLOT + t.lane * 16;
-      unit_mma<T, P>(acc, lb, lw);
+      unit_mma<T, P, P == 1 && firstc && kw == 0>(acc, lb, lw);
     });
     if (++sa == AR) sa = 0;
-  }
+  };
+  kstep(0, std::true_type{});
+#pragma unroll 1
+  for (int c = 1; c < K; ++c) kstep(c, std::false_type{});
+}
+
+// Resident form: the K stages of the slice already sit in activation slots 0..K-1; only weights stream.
+template <typename T, int P>
+__device__ __forceinline__ void run_phase_res(Acc24& acc, const char* wsrc, const int K, char* smem, const Tile& t) {
+  constexpr int NB = 7 - P, NF = NB * 3;
+  const int NU = 3 * K;
+  const int nW = (NF + 3 - t.wave) >> 2;
+  int g1 = 0, g2 = 0;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
+  auto kstep = [&](const int c, auto FIRSTC) __attribute__((always_inline)) {   // see run_phase
+    constexpr bool firstc = decltype(FIRSTC)::value;
+    sfor<3>([&](auto KW) __attribute__((always_inline)) {
+      constexpr int kw = decltype(KW)::value;
+      const int u = 3 * c + kw;
+      wait_vm_dyn(g1 + g2);               // unit u's weights were issued 3 units ago
+      __builtin_amdgcn_s_barrier();
+      int cnt = 0;
+      if (u + 3 < NU) { issue_w<NF>(wsrc, u + 3, smem, t); cnt = nW; }
+      g2 = g1; g1 = cnt;
+      const uint32_t lb = lds_rows + c * ASLOT + t.colofs[kw];
+      const uint32_t lw = lds0 + WOFF + (u & (WR - 1)) * WSLOT + t.lane * 16;
+      unit_mma<T, P, P == 1 && firstc && kw == 0>(acc, lb, lw);
+    });
+  };
+  kstep(0, std::true_type{});
+#pragma unroll 1
+  for (int c = 1; c < K; ++c) kstep(c, std::false_type{});
+  __builtin_amdgcn_s_barrier();           // every wave done with the last unit's slots
+}
+
+// P = conv1x1(x) from the resident x stages (slots 0..KX-1), 1x1 fragments in weight slot 3
+template <typename T>
+__device__ __forceinline__ void run_1x1_res(Acc24& acc, char* smem, const Tile& t) {
+  constexpr int K = Cfg<T>::KX;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t lb = lds0 + t.wave * (R * IW * 32) + IW * 32 + t.colofs[1];   // centre tap: rows 1..4, col j+1
+  const uint32_t lw = lds0 + WOFF + 3 * WSLOT + t.lane * 16;
+  sfor<K>([&](auto CI) __attribute__((always_inline)) {
+    constexpr int c = decltype(CI)::value;
+    u32x4 a, b0, b1, b2, b3;
+    lds_read16<c * 1024>(a, lw);
+    lds_read16<c * ASLOT>(b0, lb);
+    lds_read16<c * ASLOT + IW * 32>(b1, lb);
+    lds_read16<c * ASLOT + 2 * IW * 32>(b2, lb);
+    lds_read16<c * ASLOT + 3 * IW * 32>(b3, lb);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+    mma_cls<T, acc_in_agpr(0), c == 0>(acc_br<0, 0>(acc), a, b0);
+    mma_cls<T, acc_in_agpr(0), c == 0>(acc_br<0, 1>(acc), a, b1);
+    mma_cls<T, acc_in_agpr(0), c == 0>(acc_br<0, 2>(acc), a, b2);
+    mma_cls<T, acc_in_agpr(0), c == 0>(acc_br<0, 3>(acc), a, b3);
+  });
 }
 
 // ---- P = conv1x1(x) on the tile's own pixels (block.py:263), into cout block 0's registers ----------
@@ -357,10 +470,17 @@ __device__ __forceinline__ void run_1x1(Acc24& acc, const char* w1, const char* 
       u32x4 bq[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) bq[r] = *(const u32x4*)(lb + r * IW * 32);
-      mma_cls<T, acc_in_agpr(0)>(acc_br<0, 0>(acc), a, bq[0]);
-      mma_cls<T, acc_in_agpr(0)>(acc_br<0, 1>(acc), a, bq[1]);
-      mma_cls<T, acc_in_agpr(0)>(acc_br<0, 2>(acc), a, bq[2]);
-      mma_cls<T, acc_in_agpr(0)>(acc_br<0, 3>(acc), a, bq[3]);
+      if (c == 0) {
+        mma_cls<T, acc_in_agpr(0), true>(acc_br<0, 0>(acc), a, bq[0]);
+        mma_cls<T, acc_in_agpr(0), true>(acc_br<0, 1>(acc), a, bq[1]);
+        mma_cls<T, acc_in_agpr(0), true>(acc_br<0, 2>(acc), a, bq[2]);
+        mma_cls<T, acc_in_agpr(0), true>(acc_br<0, 3>(acc), a, bq[3]);
+      } else {
+        mma_cls<T, acc_in_agpr(0)>(acc_br<0, 0>(acc), a, bq[0]);
+        mma_cls<T, acc_in_agpr(0)>(acc_br<0, 1>(acc), a, bq[1]);
+        mma_cls<T, acc_in_agpr(0)>(acc_br<0, 2>(acc), a, bq[2]);
+        mma_cls<T, acc_in_agpr(0)>(acc_br<0, 3>(acc), a, bq[3]);
+      }
     }
     if (++sa == AR) sa = 0;
   }
@@ -409,13 +529,32 @@ __device__ __forceinline__ bool wait_neighbours(unsigned* ws, int my_nbr_tile, u
 
 // ---- epilogue of one finished 32-cout block ---------------------------------------------------------
 // MODE 0: v = lrelu(acc + bias)                               (x1, x3)
-// MODE 1: v = lrelu(acc + bias) + P (slot 0's accumulators)   (x2, block.py:263)
-// MODE 2: v = lrelu(acc + bias) + extra[own pixel]            (x4 = lrelu(conv4) + x2, block.py:266)
-// MODE 3: v = (acc + bias)*0.2 + x; noise1; [v = v*0.2 + res2; noise2]   (block.py:267-268, 291)
-template <typename T, int BLK, int MODE>
+// MODE 1: v = lrelu(acc + bias) + P (block 0's accumulators)  (x2, block.py:263)
+// MODE 2: v = lrelu(acc + bias) + ex[own pixel]               (x4 = lrelu(conv4) + x2, block.py:266)
+// MODE 3: v = (acc + bias)*0.2 + ex; noise1; [v = v*0.2 + r2; noise2]   (block.py:267-268, 291)
+// ex / r2 = the lane's own pixels of 4 rows in storage form, fetched by load_rows() well ahead of use
+// (a conditional load inside the row loop makes hipcc wait for every load separately) or kept from the
+// epilogue that produced them.
+// LW (fp16 resident path), bit 0: also write the lane's pixels into activation slots slot0 + h of the LDS
+// (the next phase's stage); bit 1: hand them back in `keep` (conv1: the 1x1 still reads x in those slots;
+// conv2: x2 is the residual of x4).
+template <typename T> struct RowsRaw { typename Ch16<T>::Raw q[R]; };
+
+template <typename T>
+__device__ __forceinline__ void load_rows(const ImgView& v, int cb, const esr_rdb_chain& p, const Tile& t, RowsRaw<T>& o) {
+  const int ox = t.ox0 + t.j, oyb = t.oy0 + t.wave * R, wp32 = p.dense.wp * 32;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int oy = oyb + r < p.H ? oyb + r : p.H - 1;            // clamped: rows / columns past the image are not used
+    Ch16<T>::load(v, cb, t.h, (oy + 1) * wp32 + (ox < p.W ? ox + 1 : 1) * 32, o.q[r]);
+  }
+}
+
+template <typename T, int BLK, int MODE, int LW = 0>
 __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, const esr_rdb_block& blk, const float* bias,
-                                         const ImgView& out, int out_cb, const ImgView& extra, int extra_cb,
-                                         const ImgView& res2, bool has_res2, const Tile& t) {
+                                         const ImgView& out, int out_cb, int ch_cb, const RowsRaw<T>* ex,
+                                         const RowsRaw<T>* r2, bool has_res2, const Tile& t, char* smem = nullptr,
+                                         int slot0 = 0, RowsRaw<T>* keep = nullptr) {
   using C16 = Ch16<T>;
   const int ox = t.ox0 + t.j;
   const int oyb = t.oy0 + t.wave * R;
@@ -423,16 +562,6 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
 #pragma unroll
   for (int i = 0; i < 4; ++i) bq[i] = *(const f32x4*)(bias + 16 * t.h + 4 * i);
   const int wp32 = p.dense.wp * 32;
-  typename C16::Raw ex[R], r2[R];
-  if constexpr (MODE >= 2) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int oy = oyb + r < p.H ? oyb + r : p.H - 1;
-      const int po = (oy + 1) * wp32 + (ox < p.W ? ox + 1 : 1) * 32;
-      C16::load(extra, extra_cb, t.h, po, ex[r]);
-      if (MODE == 3 && has_res2) C16::load(res2, extra_cb, t.h, po, r2[r]);
-    }
-  }
   const bool n1 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && blk.layer1 != ESR_NO_LAYER;
   const bool n2 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && blk.layer2 != ESR_NO_LAYER && has_res2;
   const uint64_t seed = p.seed_dev ? __builtin_nontemporal_load(p.seed_dev) : p.seed;
@@ -453,34 +582,46 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
       for (int e = 0; e < 16; ++e) v[e] += a1[e];
     }
     if constexpr (MODE == 2) {
-      C16::get(ex[r], tmp);
+      C16::get(ex->q[r], tmp);
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = v[e] * 1.0f + tmp[e];
     }
     if constexpr (MODE == 3) {
-      C16::get(ex[r], tmp);
+      C16::get(ex->q[r], tmp);
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = v[e] * 0.2f + tmp[e];
       const uint32_t pix = (uint32_t)((t.b * p.H + oy) * p.W + ox);
       if (n1) {
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(extra_cb * 8 + t.h * 4 + q), blk.layer1, seed, &tmp[4 * q]);
+        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + t.h * 4 + q), blk.layer1, seed, &tmp[4 * q]);
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);     // block.py:119-121
       }
       if (has_res2) {
-        C16::get(r2[r], tmp);
+        C16::get(r2->q[r], tmp);
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = v[e] * 0.2f + tmp[e];
         if (n2) {
 #pragma unroll 1
-          for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(extra_cb * 8 + t.h * 4 + q), blk.layer2, seed, &tmp[4 * q]);
+          for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + t.h * 4 + q), blk.layer2, seed, &tmp[4 * q]);
 #pragma unroll
           for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
         }
       }
     }
-    if (oy < p.H && ox < p.W) C16::store(out, out_cb, t.h, (oy + 1) * wp32 + (ox + 1) * 32, v);
+    // pixels beyond the image: offset 2^31 lies past num_records (2^31 - 1), the buffer range check drops the store
+    const bool inside = oy < p.H && ox < p.W;
+    const int po = (oy + 1) * wp32 + (ox + 1) * 32;
+    if constexpr (LW == 0) {
+      C16::store(out, inside ? out_cb : 0, t.h, inside ? po : (int)0x80000000u, v);
+    } else {
+      typename C16::Raw q;
+      C16::pack(v, q.q);
+      C16::store_packed(out, inside ? out_cb : 0, t.h, inside ? po : (int)0x80000000u, q.q);
+      if (!inside) { q.q[0] = u32x4{0, 0, 0, 0}; q.q[1] = u32x4{0, 0, 0, 0}; }   // beyond the image: the zero padding
+      if constexpr (LW & 1) lds_put_row(smem, slot0 + t.h, r, q.q, t);
+      if constexpr (LW & 2) keep->q[r] = q;
+    }
   });
 }
 
@@ -518,20 +659,22 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       const int ny = ty + k / 3 - 1, nx = tx + k % 3 - 1;
       if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) nbr_tile = t.b * tpi + ny * tiles_x + nx;
     }
-    // stage DMA map: LDS slot s = tid + 256*i  <-  (row, col, 16-byte half), halves swapped by (col>>3)&1
-    // on the SOURCE address so that ds_read_b128 B-fragment reads are bank-conflict free
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      int s = (int)threadIdx.x + NT * i;
-      if (s >= NSLOT) s = NSLOT - 1;          // tail lanes: harmless re-copy into the padding
-      const int row = s / (2 * IW), r2 = s - row * 2 * IW;
-      const int col = r2 >> 1, hs = r2 & 1, half = hs ^ ((col >> 3) & 1);
-      t.goff[i] = ((t.oy0 + row) * wp + t.ox0 + col) * 32 + half * 16;
-    }
+    t.wp = wp;
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
       const int col = t.j + kw;
       t.colofs[kw] = col * 32 + ((t.h ^ ((col >> 3) & 1)) << 4);
+    }
+    {
+      // halo ring slot of this thread: rows 0 / 17 (34 pixels each), then columns 0 / 33 of rows 1..16
+      const int i = (int)threadIdx.x;
+      int row, col, hs;
+      if (i < 4 * IW) { const int s = i % (2 * IW); row = i < 2 * IW ? 0 : IH - 1; col = s >> 1; hs = s & 1; }
+      else { const int s = (i - 4 * IW) % (2 * TH); row = 1 + (s >> 1); col = i < 4 * IW + 2 * TH ? 0 : IW - 1; hs = s & 1; }
+      t.halo_src = i < NHALO ? ((t.oy0 + row) * wp + t.ox0 + col) * 32 + ((hs ^ ((col >> 3) & 1)) << 4) : -1;
+      t.halo_dst = (row * IW + col) * 32 + hs * 16;
+      t.own_px = ((t.wave * R + 1) * IW + t.j + 1) * 32;
+      t.own_swz = (((t.j + 1) >> 3) & 1) << 4;
     }
     const ImgView dense = img_view(p.dense, t.b);
     const char* const dense_b = (const char*)p.dense.ptr + (int64_t)t.b * p.dense.batch_stride;
@@ -548,10 +691,100 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       const ImgView xin = img_view(blk.x_in, t.b), xout = img_view(blk.x_out, t.b);
       const bool has_res2 = blk.res2.ptr != nullptr;
       const ImgView res2 = img_view(has_res2 ? blk.res2 : blk.x_in, t.b);
-      Acc24 acc;        // dead across blocks: every accumulator is zeroed before its first phase
-      zero_block<0>(acc); zero_block<1>(acc); zero_block<2>(acc);
-      zero_block<3>(acc); zero_block<4>(acc); zero_block<5>(acc);
+      Acc24 acc;        // never zeroed: each accumulator's first MFMA of the block takes SrcC = 0
+      constexpr bool RES = sizeof(T) == 2;      // fp16: LDS-resident slices (fp32 stages by DMA, 8 K steps of x)
+      const char* const wnext = rb + 1 < p.n_blocks ? (const char*)p.blocks[rb + 1].w : nullptr;
 
+      if constexpr (RES) {
+        // =========================== fp16: own pixels stay in the LDS ===========================
+        // ---------------- phase 1: x -> conv1..conv5
+        if (rb == 0) {
+          // the chain's input comes from another launch: stage all of x (with halo) by DMA
+          issue_w_head<6>(w + CF::phase_off(1), CF::KX, smem, t);
+          sfor<CF::KX>([&](auto CI) __attribute__((always_inline)) {
+            issue_a(xin_b + decltype(CI)::value * blk.x_in.group_stride, decltype(CI)::value, smem, t);
+          });
+          wait_vm<0>();
+        } else {
+          // own pixels were written by the previous block's epilogue; weights are in flight already
+          if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+          halo_fetch<CF::KX>(xin, 0, smem, t);
+        }
+        __syncthreads();
+        trace_ev(p, tile, ev);
+        run_phase_res<T, 1>(acc, w + CF::phase_off(1), CF::KX, smem, t);
+        trace_ev(p, tile, ev);
+        issue_w_head<5>(w + CF::phase_off(2), CF::KD, smem, t);
+#pragma unroll
+        for (int i = 0; i < (CF::KX + 3) / 4; ++i) {        // the 1x1's fragments -> weight slot 3
+          const int q = t.wave + 4 * i;
+          if (q < CF::KX) dma16(w + CF::phase_off(6) + q * 1024 + t.lane * 16, smem + WOFF + 3 * WSLOT + q * 1024);
+        }
+        mfma_drain();
+        RowsRaw<T> x1, x2;
+        epilogue<T, 0, 0, 2>(acc, p, blk, blk.bias[0], dense, 0, 0, nullptr, nullptr, false, t, smem, 0, &x1);     // x1
+        publish(flags, tile, ++epoch, t);
+        trace_ev(p, tile, ev);
+        // ---------------- P = conv1x1(x) from the resident x, then phase 2: x1 -> conv2..conv5
+        run_1x1_res<T>(acc, smem, t);
+        __builtin_amdgcn_s_barrier();          // every wave done reading x
+#pragma unroll
+        for (int r = 0; r < R; ++r) lds_put_row(smem, t.h, r, x1.q[r].q, t);
+        trace_ev(p, tile, ev);
+        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+        halo_fetch<CF::KD>(dense, 0, smem, t);
+        __syncthreads();
+        trace_ev(p, tile, ev);
+        run_phase_res<T, 2>(acc, w + CF::phase_off(2), CF::KD, smem, t);
+        trace_ev(p, tile, ev);
+        issue_w_head<4>(w + CF::phase_off(3), CF::KD, smem, t);
+        mfma_drain();
+        epilogue<T, 1, 1, 3>(acc, p, blk, blk.bias[1], dense, 1, 0, nullptr, nullptr, false, t, smem, 0, &x2);  // x2 (kept: residual of x4)
+        publish(flags, tile, ++epoch, t);
+        trace_ev(p, tile, ev);
+        // ---------------- phase 3: x2 -> conv3..conv5
+        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+        halo_fetch<CF::KD>(dense, CF::KD, smem, t);
+        __syncthreads();
+        trace_ev(p, tile, ev);
+        run_phase_res<T, 3>(acc, w + CF::phase_off(3), CF::KD, smem, t);
+        trace_ev(p, tile, ev);
+        issue_w_head<3>(w + CF::phase_off(4), CF::KD, smem, t);
+        mfma_drain();
+        epilogue<T, 2, 0, 1>(acc, p, blk, blk.bias[2], dense, 2, 0, nullptr, nullptr, false, t, smem, 0);       // x3
+        publish(flags, tile, ++epoch, t);
+        trace_ev(p, tile, ev);
+        // ---------------- phase 4: x3 -> conv4, conv5
+        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+        halo_fetch<CF::KD>(dense, 2 * CF::KD, smem, t);
+        __syncthreads();
+        trace_ev(p, tile, ev);
+        run_phase_res<T, 4>(acc, w + CF::phase_off(4), CF::KD, smem, t);
+        trace_ev(p, tile, ev);
+        issue_w_head<2>(w + CF::phase_off(5), CF::KD, smem, t);
+        mfma_drain();
+        epilogue<T, 3, 2, 1>(acc, p, blk, blk.bias[3], dense, 3, 0, &x2, nullptr, false, t, smem, 0);           // x4 (+ x2)
+        publish(flags, tile, ++epoch, t);
+        trace_ev(p, tile, ev);
+        // ---------------- phase 5: x4 -> conv5; block tail (+ RRDB tail)
+        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+        halo_fetch<CF::KD>(dense, 3 * CF::KD, smem, t);
+        __syncthreads();
+        trace_ev(p, tile, ev);
+        // the block tail's residuals (own pixels of x and of the RRDB input): requested now, used after the phase
+        RowsRaw<T> tx0, tx1, tr0, tr1;
+        load_rows<T>(xin, 0, p, t, tx0); load_rows<T>(xin, 1, p, t, tx1);
+        load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1);
+        run_phase_res<T, 5>(acc, w + CF::phase_off(5), CF::KD, smem, t);
+        trace_ev(p, tile, ev);
+        if (wnext) issue_w_head<6>(wnext + CF::phase_off(1), CF::KX, smem, t);   // next block's first weights
+        mfma_drain();
+        epilogue<T, 4, 3, 1>(acc, p, blk, blk.bias[4], xout, 0, 0, &tx0, &tr0, has_res2, t, smem, 0);
+        epilogue<T, 5, 3, 1>(acc, p, blk, blk.bias[4] + 32, xout, 1, 1, &tx1, &tr1, has_res2, t, smem, 2);
+        publish(flags, tile, ++epoch, t);
+        trace_ev(p, tile, ev);
+      } else {
+      // =========================== fp32: every stage by DMA ===========================
       // ---------------- phase 1: x -> conv1..conv5
       issue_w_head<6>(w + CF::phase_off(1), CF::KX, smem, t);
       if (epoch > 0 && !wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
@@ -559,8 +792,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       run_phase<T, 1>(acc, w + CF::phase_off(1), xin_b, blk.x_in.group_stride, CF::KX, smem, t);
       trace_ev(p, tile, ev);
       mfma_drain();
-      epilogue<T, 0, 0>(acc, p, blk, blk.bias[0], dense, 0, dense, 0, dense, false, t);       // x1
-      zero_block<0>(acc);        // conv1's registers now collect the 1x1
+      epilogue<T, 0, 0>(acc, p, blk, blk.bias[0], dense, 0, 0, nullptr, nullptr, false, t);       // x1
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- P = conv1x1(x) on own pixels, then phase 2: x1 -> conv2..conv5
@@ -573,7 +805,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       run_phase<T, 2>(acc, w + CF::phase_off(2), dense_b, d_gs, CF::KD, smem, t);
       trace_ev(p, tile, ev);
       mfma_drain();
-      epilogue<T, 1, 1>(acc, p, blk, blk.bias[1], dense, 1, dense, 0, dense, false, t);     // x2
+      epilogue<T, 1, 1>(acc, p, blk, blk.bias[1], dense, 1, 0, nullptr, nullptr, false, t);     // x2
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- phase 3: x2 -> conv3..conv5
@@ -583,7 +815,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       run_phase<T, 3>(acc, w + CF::phase_off(3), dense_b + CF::KD * d_gs, d_gs, CF::KD, smem, t);
       trace_ev(p, tile, ev);
       mfma_drain();
-      epilogue<T, 2, 0>(acc, p, blk, blk.bias[2], dense, 2, dense, 0, dense, false, t);     // x3
+      epilogue<T, 2, 0>(acc, p, blk, blk.bias[2], dense, 2, 0, nullptr, nullptr, false, t);     // x3
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- phase 4: x3 -> conv4, conv5
@@ -593,7 +825,8 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       run_phase<T, 4>(acc, w + CF::phase_off(4), dense_b + 2 * CF::KD * d_gs, d_gs, CF::KD, smem, t);
       trace_ev(p, tile, ev);
       mfma_drain();
-      epilogue<T, 3, 2>(acc, p, blk, blk.bias[3], dense, 3, dense, 1, dense, false, t);     // x4 (+ x2)
+      { RowsRaw<T> x2r; load_rows<T>(dense, 1, p, t, x2r);
+        epilogue<T, 3, 2>(acc, p, blk, blk.bias[3], dense, 3, 0, &x2r, nullptr, false, t); }     // x4 (+ x2)
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- phase 5: x4 -> conv5; block tail (+ RRDB tail)
@@ -603,10 +836,14 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       run_phase<T, 5>(acc, w + CF::phase_off(5), dense_b + 3 * CF::KD * d_gs, d_gs, CF::KD, smem, t);
       trace_ev(p, tile, ev);
       mfma_drain();
-      epilogue<T, 4, 3>(acc, p, blk, blk.bias[4], xout, 0, xin, 0, res2, has_res2, t);
-      epilogue<T, 5, 3>(acc, p, blk, blk.bias[4] + 32, xout, 1, xin, 1, res2, has_res2, t);
+      { RowsRaw<T> tx0, tx1, tr0, tr1;
+        load_rows<T>(xin, 0, p, t, tx0); load_rows<T>(xin, 1, p, t, tx1);
+        load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1);
+        epilogue<T, 4, 3>(acc, p, blk, blk.bias[4], xout, 0, 0, &tx0, &tr0, has_res2, t);
+        epilogue<T, 5, 3>(acc, p, blk, blk.bias[4] + 32, xout, 1, 1, &tx1, &tr1, has_res2, t); }
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
+      }
     }
   }
 }

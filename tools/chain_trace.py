@@ -1,0 +1,47 @@
+"""Per-phase timeline of the fused RDB-chain kernel (esr_rdb_chain.trace): where a tile's time goes.
+Usage: python tools/chain_trace.py [batch] [H] [W]"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, '.')
+from esrganplus_amd import architecture as arch, synth, _lib as L
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+nb = 2
+dev = torch.device('cuda:0')
+net = arch.RRDBNet(3, 3, 64, nb).to(dev).eval().set_precision('fp16')
+x = torch.rand(B, 3, H, W, device=dev)
+with torch.no_grad():
+    net(x)
+    plan = [p for p in net._plans.values() if p.chain_ops][0]
+    ntiles = B * ((H + 15) // 16) * ((W + 31) // 32)
+    tr = torch.zeros(ntiles * 64, dtype=torch.int64, device=dev)
+    arr = plan.ops.array()
+    arr[plan.chain_ops[0]].u.rdb_chain.trace = tr.data_ptr()
+    for _ in range(3):
+        net(x)
+    torch.cuda.synchronize()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(10):
+        net(x)
+    t1.record(); torch.cuda.synchronize()
+    print('net forward (nb=%d) %.3f ms' % (nb, t0.elapsed_time(t1) / 10))
+t = tr.cpu().numpy().reshape(ntiles, 64).astype(np.int64)
+names = ['wait1', 'phase1', 'ep1+pub', '1x1', 'wait2', 'phase2', 'ep2+pub', 'wait3', 'phase3', 'ep3+pub',
+         'wait4', 'phase4', 'ep4+pub', 'wait5', 'phase5', 'ep5+pub']
+d = np.diff(t[:, :1 + 16 * 3], axis=1) / 100.0     # us (100 MHz counter)
+print('tiles %d; per-RDB timeline (us), mean over tiles [min..max]; RDB 0 / 1 / 2' % ntiles)
+for r in range(3):
+    tot = 0.0
+    print('--- RDB %d' % r)
+    for i, n in enumerate(names):
+        col = d[:, 16 * r + i]
+        tot += col.mean()
+        print('  %-8s %7.2f  [%6.2f .. %6.2f]' % (n, col.mean(), col.min(), col.max()))
+    print('  total    %7.2f' % tot)
+first, last = t[:, 0].min(), t[:, 16 * 3].max()
+print('start skew over tiles: %.2f us; rounds: first-round tiles start %.2f, second-round %.2f' % (
+    (t[:, 0].max() - first) / 100.0, 0.0, (np.sort(t[:, 0])[ntiles // 2] - first) / 100.0))
