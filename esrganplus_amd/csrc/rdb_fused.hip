@@ -119,7 +119,12 @@ __device__ __forceinline__ void mma_cls(f32x16& acc, const u32x4& a, const u32x4
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void wait_vm_dyn(int n) {   // n is wave-uniform
+__device__ __forceinline__ void wait_vm_dyn(int n) {   // n is wave-uniform; conservative above 47
+  if (n >= 16) {
+    if (n >= 32) { if (n >= 40) wait_vm<40>(); else wait_vm<32>(); }
+    else { if (n >= 24) wait_vm<24>(); else wait_vm<16>(); }
+    return;
+  }
   switch (n) {
     case 0: wait_vm<0>(); break;   case 1: wait_vm<1>(); break;   case 2: wait_vm<2>(); break;
     case 3: wait_vm<3>(); break;   case 4: wait_vm<4>(); break;   case 5: wait_vm<5>(); break;
@@ -304,8 +309,12 @@ template <int OFF> __device__ __forceinline__ void lds_read16(u32x4& d, uint32_t
 __device__ __forceinline__ void lds_wait3(u32x4& a, u32x4& b, u32x4& c) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
 }
-template <typename T, int P, bool FIRST = false>
-__device__ __forceinline__ void unit_mma(Acc24& acc, const uint32_t lds_b, const uint32_t lds_w) {
+struct NoIssue { __device__ __forceinline__ void operator()(int) const {} };
+// `issue(i)`, i = 0..4: the wave's i-th weight DMA of the unit it prefetches; called BETWEEN the cout
+// blocks' MFMA groups so that the DMA issue time hides under the matrix pipe (one wave per SIMD: any
+// instruction that is not in an MFMA's shadow is lost time).
+template <typename T, int P, bool FIRST = false, typename ISSUE = NoIssue>
+__device__ __forceinline__ void unit_mma(Acc24& acc, const uint32_t lds_b, const uint32_t lds_w, ISSUE&& issue = NoIssue{}) {
   constexpr int NB = 7 - P;
   u32x4 bf[R + 2], af[2][3];
   sfor<R + 2>([&](auto IR) __attribute__((always_inline)) { lds_read16<decltype(IR)::value * IW * 32>(bf[decltype(IR)::value], lds_b); });
@@ -331,6 +340,13 @@ __device__ __forceinline__ void unit_mma(Acc24& acc, const uint32_t lds_b, const
       }
     });
     if constexpr (bi + 1 < NB) lds_wait3(af[nxt][0], af[nxt][1], af[nxt][2]);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(bi);
+    if constexpr (bi + 1 == NB) {
+#pragma unroll
+      for (int i = NB; i < 5; ++i) issue(i);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   });
 }
 
@@ -388,43 +404,94 @@ __device__ __forceinline__ void run_phase(Acc24& acc, const char* wsrc, const ch
   for (int c = 1; c < K; ++c) kstep(c, std::false_type{});
 }
 
-// Resident form: the K stages of the slice already sit in activation slots 0..K-1; only weights stream.
+// Resident form: the K stages of the slice already sit in activation slots 0..K-1; only weights stream,
+// and they stream CONTINUOUSLY across phases and blocks: the unit consumed now sits in ring slot gu & 3,
+// and while it runs the wave issues (between its MFMA groups) its share of the unit 3 places further down
+// the stream — during a phase's last K step those are the next phase's first units (after phase 1 the
+// 1x1's fragments come first; after phase 5 the next block's phase 1).
+struct WStream {
+  const char* w;       // this block's fused weight stream
+  const char* wnext;   // the next block's (nullptr: none)
+  int gu;              // running unit counter (ring slot = gu & 3)
+  int g1, g2;          // DMAs this wave issued during the previous two units
+};
+template <typename T> struct StreamItem { const char* src; int nf; };
+// the item that is 3 places after unit (c, kw) of phase P
+template <typename T, int P, int KW>
+__device__ __forceinline__ StreamItem<T> item_after(const WStream& s, const int c, const bool lastc) {
+  using CF = Cfg<T>;
+  constexpr int NF = (7 - P) * 3;
+  if (!lastc) return {s.w + CF::phase_off(P) + (int64_t)(3 * c + KW + 3) * NF * 1024, NF};
+  if constexpr (P == 1) {
+    if constexpr (KW == 0) return {s.w + CF::phase_off(6), CF::KX};                       // the 1x1
+    else return {s.w + CF::phase_off(2) + (KW - 1) * 15 * 1024, 15};
+  } else if constexpr (P < 5) {
+    constexpr int NFN = (6 - P) * 3;
+    return {s.w + CF::phase_off(P + 1) + KW * NFN * 1024, NFN};
+  } else {
+    return {s.wnext ? s.wnext + KW * 18 * 1024 : nullptr, s.wnext ? 18 : 0};
+  }
+}
 template <typename T, int P>
-__device__ __forceinline__ void run_phase_res(Acc24& acc, const char* wsrc, const int K, char* smem, const Tile& t) {
-  constexpr int NB = 7 - P, NF = NB * 3;
-  const int NU = 3 * K;
-  const int nW = (NF + 3 - t.wave) >> 2;
-  int g1 = 0, g2 = 0;
+__device__ __forceinline__ void run_phase_res(Acc24& acc, WStream& s, int older, char* smem, const Tile& t) {
+  using CF = Cfg<T>;
+  constexpr int K = CF::ksteps(P);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
-  auto kstep = [&](const int c, auto FIRSTC) __attribute__((always_inline)) {   // see run_phase
-    constexpr bool firstc = decltype(FIRSTC)::value;
+  auto kstep = [&](const int c, auto FIRSTC, auto LASTC) __attribute__((always_inline)) {   // see run_phase
+    constexpr bool firstc = decltype(FIRSTC)::value, lastc = decltype(LASTC)::value;
     sfor<3>([&](auto KW) __attribute__((always_inline)) {
       constexpr int kw = decltype(KW)::value;
-      const int u = 3 * c + kw;
-      wait_vm_dyn(g1 + g2);               // unit u's weights were issued 3 units ago
-      __builtin_amdgcn_s_barrier();
-      int cnt = 0;
-      if (u + 3 < NU) { issue_w<NF>(wsrc, u + 3, smem, t); cnt = nW; }
-      g2 = g1; g1 = cnt;
+      // this unit's weights were issued 3 units ago; `older` = loads requested before the phase began
+      // (the block tail's residuals) that may stay in flight while the units consumed predate them
+      wait_vm_dyn(s.g1 + s.g2 + ((firstc && older) ? older : 0));
+      __builtin_amdgcn_s_barrier();       // unit visible to all waves; all waves done with the previous unit
+      const StreamItem<T> it = item_after<T, P, kw>(s, c, lastc);
+      char* const dst = smem + WOFF + ((s.gu + 3) & (WR - 1)) * WSLOT;
+      const char* const src = it.src + t.lane * 16;
+      const int nf = it.nf;
       const uint32_t lb = lds_rows + c * ASLOT + t.colofs[kw];
-      const uint32_t lw = lds0 + WOFF + (u & (WR - 1)) * WSLOT + t.lane * 16;
-      unit_mma<T, P, P == 1 && firstc && kw == 0>(acc, lb, lw);
+      const uint32_t lw = lds0 + WOFF + (s.gu & (WR - 1)) * WSLOT + t.lane * 16;
+      unit_mma<T, P, P == 1 && firstc && kw == 0>(acc, lb, lw, [&](int i) __attribute__((always_inline)) {
+        const int q = t.wave + 4 * i;
+        if (q < nf) dma16(src + q * 1024, dst + q * 1024);
+      });
+      s.g2 = s.g1;
+      s.g1 = (nf + 3 - t.wave) >> 2;
+      ++s.gu;
     });
   };
-  kstep(0, std::true_type{});
+  if constexpr (K == 1) kstep(0, std::true_type{}, std::true_type{});
+  else {
+    kstep(0, std::true_type{}, std::false_type{});
 #pragma unroll 1
-  for (int c = 1; c < K; ++c) kstep(c, std::false_type{});
+    for (int c = 1; c < K - 1; ++c) kstep(c, std::false_type{}, std::false_type{});
+    kstep(K - 1, std::false_type{}, std::true_type{});
+  }
   __builtin_amdgcn_s_barrier();           // every wave done with the last unit's slots
 }
 
-// P = conv1x1(x) from the resident x stages (slots 0..KX-1), 1x1 fragments in weight slot 3
+// P = conv1x1(x) from the resident x stages (slots 0..KX-1); its fragments are one unit of the weight
+// stream (between phase 1 and phase 2) and it issues phase 2's third unit.
 template <typename T>
-__device__ __forceinline__ void run_1x1_res(Acc24& acc, char* smem, const Tile& t) {
-  constexpr int K = Cfg<T>::KX;
+__device__ __forceinline__ void run_1x1_res(Acc24& acc, WStream& s, char* smem, const Tile& t) {
+  using CF = Cfg<T>;
+  constexpr int K = CF::KX;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lb = lds0 + t.wave * (R * IW * 32) + IW * 32 + t.colofs[1];   // centre tap: rows 1..4, col j+1
-  const uint32_t lw = lds0 + WOFF + 3 * WSLOT + t.lane * 16;
+  const uint32_t lw = lds0 + WOFF + (s.gu & (WR - 1)) * WSLOT + t.lane * 16;
+  {
+    const char* src = s.w + CF::phase_off(2) + 2 * 15 * 1024 + t.lane * 16;
+    char* dst = smem + WOFF + ((s.gu + 3) & (WR - 1)) * WSLOT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = t.wave + 4 * i;
+      if (q < 15) dma16(src + q * 1024, dst + q * 1024);
+    }
+    s.g2 = s.g1;
+    s.g1 = (15 + 3 - t.wave) >> 2;
+    ++s.gu;
+  }
   sfor<K>([&](auto CI) __attribute__((always_inline)) {
     constexpr int c = decltype(CI)::value;
     u32x4 a, b0, b1, b2, b3;
@@ -486,23 +553,28 @@ __device__ __forceinline__ void run_1x1(Acc24& acc, const char* w1, const char* 
   }
 }
 
+// measurement only: time stamps (100 MHz) of the tile's SECOND block (the first one stages x differently)
 __device__ __forceinline__ void trace_ev(const esr_rdb_chain& p, int tile, int& ev) {
-  if (p.trace && threadIdx.x == 0 && ev < 64) p.trace[(int64_t)tile * 64 + ev] = __builtin_amdgcn_s_memrealtime();
-  ++ev;
+  if (p.trace && threadIdx.x == 0 && ev >= 0 && ev < 64) p.trace[(int64_t)tile * 64 + ev] = __builtin_amdgcn_s_memrealtime();
+  if (ev >= 0) ++ev;
 }
 
 // ---- publish / consume ------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) unsigned gu32;
 
-__device__ __forceinline__ void publish(unsigned* flags, int tile, unsigned epoch, const Tile& t) {
+__device__ __forceinline__ void publish(unsigned* flags, int tile, unsigned epoch, const Tile& t,
+                                        const esr_rdb_chain* tp = nullptr, int* ev = nullptr) {
+  if (tp) trace_ev(*tp, tile, *ev);                      // epilogue done (stores issued)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its sc1 stores
+  if (tp) trace_ev(*tp, tile, *ev);                      // own stores drained
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // wave 0, lanes 0..7 poll one neighbour each (relaxed, agent scope) until all reached `epoch`.
 // Returns false (whole workgroup) on abort / time-out.
-__device__ __forceinline__ bool wait_neighbours(unsigned* ws, int my_nbr_tile, unsigned epoch, char* smem, const Tile& t) {
+__device__ __forceinline__ bool wait_neighbours(unsigned* ws, int my_nbr_tile, unsigned epoch, char* smem, const Tile& t,
+                                                const esr_rdb_chain* tp = nullptr, int* ev = nullptr, int tile_ = 0) {
   if (t.wave == 0) {
     bool ok = my_nbr_tile < 0;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
@@ -522,6 +594,7 @@ __device__ __forceinline__ bool wait_neighbours(unsigned* ws, int my_nbr_tile, u
       *(volatile int*)(smem + LDS_CTRL + 16) = dead ? 1 : 0;
     }
   }
+  if (tp) trace_ev(*tp, tile_, *ev);                     // neighbours' flags seen (wave 0)
   __syncthreads();
   const int dead = *(volatile int*)(smem + LDS_CTRL + 16);
   return dead == 0;
@@ -682,10 +755,12 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
 
 
     unsigned epoch = 0;      // phases this tile has published
-    int ev = 0;
-    trace_ev(p, tile, ev);
+    WStream ws_{};
+    int ev = -1;
     for (int rb = 0; rb < p.n_blocks; ++rb) {
       const esr_rdb_block& blk = p.blocks[rb];
+      ev = rb == 1 ? 0 : -1;
+      trace_ev(p, tile, ev);
       const char* const w = (const char*)blk.w;
       const char* const xin_b = (const char*)blk.x_in.ptr + (int64_t)t.b * blk.x_in.batch_stride;
       const ImgView xin = img_view(blk.x_in, t.b), xout = img_view(blk.x_out, t.b);
@@ -697,91 +772,100 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
 
       if constexpr (RES) {
         // =========================== fp16: own pixels stay in the LDS ===========================
+        ws_.w = w;
+        ws_.wnext = wnext;
         // ---------------- phase 1: x -> conv1..conv5
         if (rb == 0) {
-          // the chain's input comes from another launch: stage all of x (with halo) by DMA
-          issue_w_head<6>(w + CF::phase_off(1), CF::KX, smem, t);
+          // the chain's input comes from another launch: stage all of x (with halo) by DMA, and start
+          // the weight stream (its first three units)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const char* src = w + CF::phase_off(1) + i * 18 * 1024 + t.lane * 16;
+            char* dst = smem + WOFF + ((ws_.gu + i) & (WR - 1)) * WSLOT;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+              const int q = t.wave + 4 * j;
+              if (q < 18) dma16(src + q * 1024, dst + q * 1024);
+            }
+          }
           sfor<CF::KX>([&](auto CI) __attribute__((always_inline)) {
             issue_a(xin_b + decltype(CI)::value * blk.x_in.group_stride, decltype(CI)::value, smem, t);
           });
           wait_vm<0>();
         } else {
           // own pixels were written by the previous block's epilogue; weights are in flight already
-          if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+          if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
           halo_fetch<CF::KX>(xin, 0, smem, t);
         }
         __syncthreads();
+        ws_.g1 = ws_.g2 = 0;
         trace_ev(p, tile, ev);
-        run_phase_res<T, 1>(acc, w + CF::phase_off(1), CF::KX, smem, t);
+        run_phase_res<T, 1>(acc, ws_, 0, smem, t);
         trace_ev(p, tile, ev);
-        issue_w_head<5>(w + CF::phase_off(2), CF::KD, smem, t);
-#pragma unroll
-        for (int i = 0; i < (CF::KX + 3) / 4; ++i) {        // the 1x1's fragments -> weight slot 3
-          const int q = t.wave + 4 * i;
-          if (q < CF::KX) dma16(w + CF::phase_off(6) + q * 1024 + t.lane * 16, smem + WOFF + 3 * WSLOT + q * 1024);
-        }
         mfma_drain();
         RowsRaw<T> x1, x2;
         epilogue<T, 0, 0, 2>(acc, p, blk, blk.bias[0], dense, 0, 0, nullptr, nullptr, false, t, smem, 0, &x1);     // x1
-        publish(flags, tile, ++epoch, t);
+        publish(flags, tile, ++epoch, t, &p, &ev);
+        ws_.g1 = ws_.g2 = 0;
         trace_ev(p, tile, ev);
         // ---------------- P = conv1x1(x) from the resident x, then phase 2: x1 -> conv2..conv5
-        run_1x1_res<T>(acc, smem, t);
+        run_1x1_res<T>(acc, ws_, smem, t);
         __builtin_amdgcn_s_barrier();          // every wave done reading x
 #pragma unroll
         for (int r = 0; r < R; ++r) lds_put_row(smem, t.h, r, x1.q[r].q, t);
         trace_ev(p, tile, ev);
-        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, 0, smem, t);
         __syncthreads();
         trace_ev(p, tile, ev);
-        run_phase_res<T, 2>(acc, w + CF::phase_off(2), CF::KD, smem, t);
+        run_phase_res<T, 2>(acc, ws_, 0, smem, t);
         trace_ev(p, tile, ev);
-        issue_w_head<4>(w + CF::phase_off(3), CF::KD, smem, t);
         mfma_drain();
         epilogue<T, 1, 1, 3>(acc, p, blk, blk.bias[1], dense, 1, 0, nullptr, nullptr, false, t, smem, 0, &x2);  // x2 (kept: residual of x4)
-        publish(flags, tile, ++epoch, t);
+        publish(flags, tile, ++epoch, t, &p, &ev);
+        ws_.g1 = ws_.g2 = 0;
         trace_ev(p, tile, ev);
         // ---------------- phase 3: x2 -> conv3..conv5
-        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, CF::KD, smem, t);
         __syncthreads();
         trace_ev(p, tile, ev);
-        run_phase_res<T, 3>(acc, w + CF::phase_off(3), CF::KD, smem, t);
+        run_phase_res<T, 3>(acc, ws_, 0, smem, t);
         trace_ev(p, tile, ev);
-        issue_w_head<3>(w + CF::phase_off(4), CF::KD, smem, t);
         mfma_drain();
         epilogue<T, 2, 0, 1>(acc, p, blk, blk.bias[2], dense, 2, 0, nullptr, nullptr, false, t, smem, 0);       // x3
-        publish(flags, tile, ++epoch, t);
+        publish(flags, tile, ++epoch, t, &p, &ev);
+        ws_.g1 = ws_.g2 = 0;
         trace_ev(p, tile, ev);
         // ---------------- phase 4: x3 -> conv4, conv5
-        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, 2 * CF::KD, smem, t);
         __syncthreads();
-        trace_ev(p, tile, ev);
-        run_phase_res<T, 4>(acc, w + CF::phase_off(4), CF::KD, smem, t);
-        trace_ev(p, tile, ev);
-        issue_w_head<2>(w + CF::phase_off(5), CF::KD, smem, t);
-        mfma_drain();
-        epilogue<T, 3, 2, 1>(acc, p, blk, blk.bias[3], dense, 3, 0, &x2, nullptr, false, t, smem, 0);           // x4 (+ x2)
-        publish(flags, tile, ++epoch, t);
-        trace_ev(p, tile, ev);
-        // ---------------- phase 5: x4 -> conv5; block tail (+ RRDB tail)
-        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
-        halo_fetch<CF::KD>(dense, 3 * CF::KD, smem, t);
-        __syncthreads();
-        trace_ev(p, tile, ev);
-        // the block tail's residuals (own pixels of x and of the RRDB input): requested now, used after the phase
+        // the block tail's residuals (own pixels of x and of the RRDB input): requested now, two phases
+        // ahead of their use (the first K step of phase 4 lets them stay in flight)
         RowsRaw<T> tx0, tx1, tr0, tr1;
         load_rows<T>(xin, 0, p, t, tx0); load_rows<T>(xin, 1, p, t, tx1);
         load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1);
-        run_phase_res<T, 5>(acc, w + CF::phase_off(5), CF::KD, smem, t);
         trace_ev(p, tile, ev);
-        if (wnext) issue_w_head<6>(wnext + CF::phase_off(1), CF::KX, smem, t);   // next block's first weights
+        run_phase_res<T, 4>(acc, ws_, 32, smem, t);
+        trace_ev(p, tile, ev);
+        mfma_drain();
+        epilogue<T, 3, 2, 1>(acc, p, blk, blk.bias[3], dense, 3, 0, &x2, nullptr, false, t, smem, 0);           // x4 (+ x2)
+        publish(flags, tile, ++epoch, t, &p, &ev);
+        ws_.g1 = ws_.g2 = 0;
+        trace_ev(p, tile, ev);
+        // ---------------- phase 5: x4 -> conv5; block tail (+ RRDB tail)
+        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
+        halo_fetch<CF::KD>(dense, 3 * CF::KD, smem, t);
+        __syncthreads();
+        trace_ev(p, tile, ev);
+        run_phase_res<T, 5>(acc, ws_, 0, smem, t);
+        trace_ev(p, tile, ev);
         mfma_drain();
         epilogue<T, 4, 3, 1>(acc, p, blk, blk.bias[4], xout, 0, 0, &tx0, &tr0, has_res2, t, smem, 0);
         epilogue<T, 5, 3, 1>(acc, p, blk, blk.bias[4] + 32, xout, 1, 1, &tx1, &tr1, has_res2, t, smem, 2);
-        publish(flags, tile, ++epoch, t);
+        publish(flags, tile, ++epoch, t, &p, &ev);
+        ws_.g1 = ws_.g2 = 0;
         trace_ev(p, tile, ev);
       } else {
       // =========================== fp32: every stage by DMA ===========================

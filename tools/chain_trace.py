@@ -30,18 +30,14 @@ with torch.no_grad():
     t1.record(); torch.cuda.synchronize()
     print('net forward (nb=%d) %.3f ms' % (nb, t0.elapsed_time(t1) / 10))
 t = tr.cpu().numpy().reshape(ntiles, 64).astype(np.int64)
-names = ['wait1', 'phase1', 'ep1+pub', '1x1', 'wait2', 'phase2', 'ep2+pub', 'wait3', 'phase3', 'ep3+pub',
-         'wait4', 'phase4', 'ep4+pub', 'wait5', 'phase5', 'ep5+pub']
-d = np.diff(t[:, :1 + 16 * 3], axis=1) / 100.0     # us (100 MHz counter)
-print('tiles %d; per-RDB timeline (us), mean over tiles [min..max]; RDB 0 / 1 / 2' % ntiles)
-for r in range(3):
-    tot = 0.0
-    print('--- RDB %d' % r)
-    for i, n in enumerate(names):
-        col = d[:, 16 * r + i]
-        tot += col.mean()
-        print('  %-8s %7.2f  [%6.2f .. %6.2f]' % (n, col.mean(), col.min(), col.max()))
-    print('  total    %7.2f' % tot)
-first, last = t[:, 0].min(), t[:, 16 * 3].max()
-print('start skew over tiles: %.2f us; rounds: first-round tiles start %.2f, second-round %.2f' % (
-    (t[:, 0].max() - first) / 100.0, 0.0, (np.sort(t[:, 0])[ntiles // 2] - first) / 100.0))
+names = ['poll1', 'halo1', 'phase1', 'ep1', 'drain1', 'flag', '1x1+put', 'poll2', 'halo2', 'phase2', 'ep2', 'drain2', 'flag',
+         'poll3', 'halo3', 'phase3', 'ep3', 'drain3', 'flag', 'poll4', 'halo4+tail', 'phase4', 'ep4', 'drain4', 'flag',
+         'poll5', 'halo5', 'phase5', 'ep5', 'drain5', 'flag']
+d = np.diff(t[:, :len(names) + 1], axis=1) / 100.0     # us (100 MHz counter)
+print('tiles %d; timeline of each tile\'s second block (us), mean over tiles [min..max]' % ntiles)
+tot = 0.0
+for i, n in enumerate(names):
+    col = d[:, i]
+    tot += col.mean()
+    print('  %-10s %7.2f  [%6.2f .. %6.2f]' % (n, col.mean(), col.min(), col.max()))
+print('  total      %7.2f' % tot)
