@@ -138,7 +138,7 @@ class esr_rdb_block(C.Structure):
 
 class esr_rdb_chain(C.Structure):
     _fields_ = [('dtype', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
-                ('n_blocks', C.c_int32), ('noise_mode', C.c_int32), ('sigma', C.c_float), ('_pad', C.c_int32),
+                ('n_blocks', C.c_int32), ('noise_mode', C.c_int32), ('sigma', C.c_float), ('save_dense', C.c_int32),
                 ('seed', C.c_uint64), ('seed_dev', C.c_void_p), ('dense', esr_g32), ('blocks', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('trace', C.c_void_p)]
 

@@ -147,11 +147,19 @@ struct ImgView {
   int gs;        // group stride (bytes)
   int ng;        // groups addressable
 };
+// hipcc wraps every buffer access whose descriptor it cannot PROVE wave-uniform in a waterfall loop
+// (readfirstlane x4 + compare + saveexec, cdna guide T20) — and anything that went through the LDS or a
+// block-table load counts as divergent.  Descriptor inputs therefore pass through readfirstlane once.
+__device__ __forceinline__ char* uniform_ptr(const void* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (char*)(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ ImgView img_view(const esr_g32& v, int b, int g0 = 0) {
   ImgView o;
-  char* base = (char*)v.ptr + (int64_t)b * v.batch_stride + (int64_t)g0 * v.group_stride;
+  char* base = uniform_ptr((char*)v.ptr + (int64_t)b * v.batch_stride + (int64_t)g0 * v.group_stride);
   o.r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
-  o.gs = (int)v.group_stride;
+  o.gs = __builtin_amdgcn_readfirstlane((int)v.group_stride);
   o.ng = v.ngroups - g0;
   return o;
 }
@@ -632,8 +640,11 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
   const int ox = t.ox0 + t.j;
   const int oyb = t.oy0 + t.wave * R;
   f32x4 bq[4];
+  {
+    const f32x4* bp = (const f32x4*)(uniform_ptr(bias)) + 4 * t.h;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) bq[i] = *(const f32x4*)(bias + 16 * t.h + 4 * i);
+    for (int i = 0; i < 4; ++i) bq[i] = bp[i];
+  }
   const int wp32 = p.dense.wp * 32;
   const bool n1 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && blk.layer1 != ESR_NO_LAYER;
   const bool n2 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && blk.layer2 != ESR_NO_LAYER && has_res2;
@@ -646,7 +657,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       float x = a[e] + bq[e >> 2][e & 3];
-      if constexpr (MODE != 3) x = x > 0.f ? x : x * ESR_LRELU_SLOPE;
+      if constexpr (MODE != 3) x = __builtin_fmaxf(x, x * ESR_LRELU_SLOPE);     // LeakyReLU(0.2) = max(x, 0.2 x)
       v[e] = x;
     }
     if constexpr (MODE == 1) {
@@ -690,7 +701,12 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
     } else {
       typename C16::Raw q;
       C16::pack(v, q.q);
-      C16::store_packed(out, inside ? out_cb : 0, t.h, inside ? po : (int)0x80000000u, q.q);
+      // x1..x4 are only ever read back as HALO pixels by the neighbouring tiles (the tile's own pixels stay
+      // in the LDS / registers): unless the caller wants the dense slices in memory (save_dense), only the
+      // tile's border pixels are stored — 82 % fewer bytes through the lock-stepped store bursts
+      const bool edge = MODE == 3 || p.save_dense || t.j == 0 || t.j == TW - 1 || (t.wave == 0 && r == 0) ||
+                        (t.wave == NT / 64 - 1 && r == R - 1);
+      C16::store_packed(out, (inside && edge) ? out_cb : 0, t.h, (inside && edge) ? po : (int)0x80000000u, q.q);
       if (!inside) { q.q[0] = u32x4{0, 0, 0, 0}; q.q[1] = u32x4{0, 0, 0, 0}; }   // beyond the image: the zero padding
       if constexpr (LW & 1) lds_put_row(smem, slot0 + t.h, r, q.q, t);
       if constexpr (LW & 2) keep->q[r] = q;

@@ -297,7 +297,8 @@ typedef struct esr_rdb_chain {
   int32_t n_blocks;
   int32_t noise_mode;       /* ESR_NOISE_OFF or ESR_NOISE_PHILOX (explicit z: per-conv path) */
   float sigma;
-  int32_t _pad;
+  int32_t save_dense;       /* 0: fp16 path stores only each tile's border pixels of x1..x4 (all the launch itself
+                               re-reads); 1: the whole slices reach `dense` (e.g. to inspect / save activations) */
   uint64_t seed;
   const uint64_t* seed_dev; /* as esr_conv.seed_dev */
   esr_g32 dense;            /* 128-channel scratch: x1..x4 of the block in flight */
