@@ -321,7 +321,7 @@ struct NoIssue { __device__ __forceinline__ void operator()(int) const {} };
 // `issue(i)`, i = 0..4: the wave's i-th weight DMA of the unit it prefetches; called BETWEEN the cout
 // blocks' MFMA groups so that the DMA issue time hides under the matrix pipe (one wave per SIMD: any
 // instruction that is not in an MFMA's shadow is lost time).
-template <typename T, int P, bool FIRST = false, typename ISSUE = NoIssue>
+template <typename T, int P, bool FIRST = false, bool CARRY45 = false, typename ISSUE = NoIssue>
 __device__ __forceinline__ void unit_mma(Acc24& acc, const uint32_t lds_b, const uint32_t lds_w, ISSUE&& issue = NoIssue{}) {
   constexpr int NB = 7 - P;
   u32x4 bf[R + 2], af[2][3];
@@ -339,7 +339,7 @@ __device__ __forceinline__ void unit_mma(Acc24& acc, const uint32_t lds_b, const
       sfor<3>([&](auto KH) __attribute__((always_inline)) {
         constexpr int kh = decltype(KH)::value;
         constexpr int r = ir - kh;
-        if constexpr (r >= 0 && r < R) mma_cls<T, acc_in_agpr(blk), FIRST && kh == 0>(acc_br<blk, r>(acc), af[cur][kh], bf[ir]);
+        if constexpr (r >= 0 && r < R) mma_cls<T, acc_in_agpr(blk), FIRST && kh == 0 && !(CARRY45 && blk >= 4)>(acc_br<blk, r>(acc), af[cur][kh], bf[ir]);
       });
       if constexpr (ir == 2 && bi + 1 < NB) {     // after MFMA 6 of 12
         sfor<3>([&](auto KH) __attribute__((always_inline)) {
@@ -460,7 +460,7 @@ __device__ __forceinline__ void run_phase_res(Acc24& acc, WStream& s, int older,
       const int nf = it.nf;
       const uint32_t lb = lds_rows + c * ASLOT + t.colofs[kw];
       const uint32_t lw = lds0 + WOFF + (s.gu & (WR - 1)) * WSLOT + t.lane * 16;
-      unit_mma<T, P, P == 1 && firstc && kw == 0>(acc, lb, lw, [&](int i) __attribute__((always_inline)) {
+      unit_mma<T, P, P == 1 && firstc && kw == 0, true>(acc, lb, lw, [&](int i) __attribute__((always_inline)) {
         const int q = t.wave + 4 * i;
         if (q < nf) dma16(src + q * 1024, dst + q * 1024);
       });
@@ -635,7 +635,8 @@ template <typename T, int BLK, int MODE, int LW = 0>
 __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, const esr_rdb_block& blk, const float* bias,
                                          const ImgView& out, int out_cb, int ch_cb, const RowsRaw<T>* ex,
                                          const RowsRaw<T>* r2, bool has_res2, const Tile& t, char* smem = nullptr,
-                                         int slot0 = 0, RowsRaw<T>* keep = nullptr) {
+                                         int slot0 = 0, RowsRaw<T>* keep = nullptr, float carry_scale = 0.f,
+                                         bool full_store = true) {
   using C16 = Ch16<T>;
   const int ox = t.ox0 + t.j;
   const int oyb = t.oy0 + t.wave * R;
@@ -671,9 +672,14 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
       for (int e = 0; e < 16; ++e) v[e] = v[e] * 1.0f + tmp[e];
     }
     if constexpr (MODE == 3) {
-      C16::get(ex->q[r], tmp);
+      if (ex) {                    // explicit residual (fp32 path, noise): out = conv5*0.2 + x
+        C16::get(ex->q[r], tmp);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = v[e] * 0.2f + tmp[e];
+        for (int e = 0; e < 16; ++e) v[e] = v[e] * 0.2f + tmp[e];
+      } else {                     // folded: the accumulators started at 5 x
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] *= 0.2f;
+      }
       const uint32_t pix = (uint32_t)((t.b * p.H + oy) * p.W + ox);
       if (n1) {
 #pragma unroll 1
@@ -704,12 +710,22 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
       // x1..x4 are only ever read back as HALO pixels by the neighbouring tiles (the tile's own pixels stay
       // in the LDS / registers): unless the caller wants the dense slices in memory (save_dense), only the
       // tile's border pixels are stored — 82 % fewer bytes through the lock-stepped store bursts
-      const bool edge = MODE == 3 || p.save_dense || t.j == 0 || t.j == TW - 1 || (t.wave == 0 && r == 0) ||
+      const bool edge = (MODE == 3 && full_store) || p.save_dense || t.j == 0 || t.j == TW - 1 || (t.wave == 0 && r == 0) ||
                         (t.wave == NT / 64 - 1 && r == R - 1);
       C16::store_packed(out, (inside && edge) ? out_cb : 0, t.h, (inside && edge) ? po : (int)0x80000000u, q.q);
       if (!inside) { q.q[0] = u32x4{0, 0, 0, 0}; q.q[1] = u32x4{0, 0, 0, 0}; }   // beyond the image: the zero padding
       if constexpr (LW & 1) lds_put_row(smem, slot0 + t.h, r, q.q, t);
       if constexpr (LW & 2) keep->q[r] = q;
+      if constexpr (MODE == 3) {
+        // carry into the next block: its conv5 accumulators start at 5 x (x = this output AS STORED), so
+        // that block's tail `conv5*0.2 + x` needs no residual read (zero when it adds x explicitly)
+        float xs[16];
+        C16::get(q, xs);
+        f32x16 nx;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) nx[e] = carry_scale * xs[e];
+        acc_br<BLK, r>(acc) = nx;
+      }
     }
   });
 }
@@ -772,7 +788,32 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
 
     unsigned epoch = 0;      // phases this tile has published
     WStream ws_{};
+    Acc24 acc;               // never zeroed: an accumulator's first MFMA of a block takes SrcC = 0 — except conv5's
+                             // (fp16 path), which carry 5 x in from the previous block's epilogue
     int ev = -1;
+    if constexpr (sizeof(T) == 2) {
+      // conv5's accumulators of the FIRST block start at 5 x (zero when the tail adds x explicitly, i.e. with
+      // noise); later blocks get theirs from the previous epilogue.  Done ahead of the block loop: a second
+      // definition inside it would join the carried one through scratch copies.
+      const ImgView xin0 = img_view(p.blocks[0].x_in, t.b);
+      const bool noisy = p.noise_mode != ESR_NOISE_OFF;
+      RowsRaw<T> c0, c1;
+      load_rows<T>(xin0, 0, p, t, c0); load_rows<T>(xin0, 1, p, t, c1);
+      const float cs = noisy ? 0.f : 5.f;
+      sfor<R>([&](auto RR) __attribute__((always_inline)) {
+        constexpr int r = decltype(RR)::value;
+        float xs[16];
+        f32x16 nx;
+        Ch16<T>::get(c0.q[r], xs);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) nx[e] = cs * xs[e];
+        acc_br<4, r>(acc) = nx;
+        Ch16<T>::get(c1.q[r], xs);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) nx[e] = cs * xs[e];
+        acc_br<5, r>(acc) = nx;
+      });
+    }
     for (int rb = 0; rb < p.n_blocks; ++rb) {
       const esr_rdb_block& blk = p.blocks[rb];
       ev = rb == 1 ? 0 : -1;
@@ -781,8 +822,9 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       const char* const xin_b = (const char*)blk.x_in.ptr + (int64_t)t.b * blk.x_in.batch_stride;
       const ImgView xin = img_view(blk.x_in, t.b), xout = img_view(blk.x_out, t.b);
       const bool has_res2 = blk.res2.ptr != nullptr;
+      const bool noisy = p.noise_mode != ESR_NOISE_OFF;
+      const bool full_out = (blk.flags & ESR_RDB_FULL_OUT) != 0 || noisy || p.save_dense;
       const ImgView res2 = img_view(has_res2 ? blk.res2 : blk.x_in, t.b);
-      Acc24 acc;        // never zeroed: each accumulator's first MFMA of the block takes SrcC = 0
       constexpr bool RES = sizeof(T) == 2;      // fp16: LDS-resident slices (fp32 stages by DMA, 8 K steps of x)
       const char* const wnext = rb + 1 < p.n_blocks ? (const char*)p.blocks[rb + 1].w : nullptr;
 
@@ -857,13 +899,8 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, 2 * CF::KD, smem, t);
         __syncthreads();
-        // the block tail's residuals (own pixels of x and of the RRDB input): requested now, two phases
-        // ahead of their use (the first K step of phase 4 lets them stay in flight)
-        RowsRaw<T> tx0, tx1, tr0, tr1;
-        load_rows<T>(xin, 0, p, t, tx0); load_rows<T>(xin, 1, p, t, tx1);
-        load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1);
         trace_ev(p, tile, ev);
-        run_phase_res<T, 4>(acc, ws_, 32, smem, t);
+        run_phase_res<T, 4>(acc, ws_, 0, smem, t);
         trace_ev(p, tile, ev);
         mfma_drain();
         epilogue<T, 3, 2, 1>(acc, p, blk, blk.bias[3], dense, 3, 0, &x2, nullptr, false, t, smem, 0);           // x4 (+ x2)
@@ -874,12 +911,19 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, 3 * CF::KD, smem, t);
         __syncthreads();
+        // the block tail's residuals: x only when it is added explicitly (noise), the RRDB input for every
+        // third block; requested here, used after the phase (its first K step lets them stay in flight)
+        RowsRaw<T> tx0, tx1, tr0, tr1;
+        if (noisy) { load_rows<T>(xin, 0, p, t, tx0); load_rows<T>(xin, 1, p, t, tx1); }
+        if (has_res2) { load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1); }
         trace_ev(p, tile, ev);
-        run_phase_res<T, 5>(acc, ws_, 0, smem, t);
+        run_phase_res<T, 5>(acc, ws_, 32, smem, t);
         trace_ev(p, tile, ev);
         mfma_drain();
-        epilogue<T, 4, 3, 1>(acc, p, blk, blk.bias[4], xout, 0, 0, &tx0, &tr0, has_res2, t, smem, 0);
-        epilogue<T, 5, 3, 1>(acc, p, blk, blk.bias[4] + 32, xout, 1, 1, &tx1, &tr1, has_res2, t, smem, 2);
+        epilogue<T, 4, 3, 1>(acc, p, blk, blk.bias[4], xout, 0, 0, noisy ? &tx0 : nullptr, &tr0, has_res2, t, smem, 0, nullptr,
+                             noisy ? 0.f : 5.f, full_out);
+        epilogue<T, 5, 3, 1>(acc, p, blk, blk.bias[4] + 32, xout, 1, 1, noisy ? &tx1 : nullptr, &tr1, has_res2, t, smem, 2, nullptr,
+                             noisy ? 0.f : 5.f, full_out);
         publish(flags, tile, ++epoch, t, &p, &ev);
         ws_.g1 = ws_.g2 = 0;
         trace_ev(p, tile, ev);

@@ -416,6 +416,9 @@ class Builder:
             if r2 is not None:
                 b.res2 = r2.view(0, 64)
             b.layer1 = b.layer2 = L.NO_LAYER
+            # the output must be complete in memory when it is the chain's result or a later RRDB input
+            later_res2 = any(s[3] is xo for s in specs[i + 1:])
+            b.flags = L.RDB_FULL_OUT if (i == len(specs) - 1 or later_res2) else 0
             if self.noise:
                 b.layer1 = self.n_noise
                 self.n_noise += 1

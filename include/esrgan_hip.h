@@ -290,7 +290,13 @@ typedef struct esr_rdb_block {
   esr_g32 x_out;            /* 64-channel block output */
   esr_g32 res2;             /* RRDB input of the fused RRDB tail; ptr NULL = plain dense block */
   uint32_t layer1, layer2;  /* Philox stream ids of the block noise / the RRDB-tail noise; 0xFFFFFFFF = off */
+  uint32_t flags;           /* ESR_RDB_FULL_OUT: every pixel of x_out must reach memory — the chain's last block, or an
+                               output that is read again as a later block's res2.  Otherwise (fp16, no noise) only the
+                               tiles' border pixels are stored: the next block takes its input from the LDS and its
+                               `+ x` residual from the accumulators this block's epilogue primes with 5 x */
+  uint32_t _pad;
 } esr_rdb_block;
+#define ESR_RDB_FULL_OUT 1u
 
 typedef struct esr_rdb_chain {
   int32_t dtype, B, H, W;
