@@ -647,8 +647,9 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
     for (int i = 0; i < 4; ++i) bq[i] = bp[i];
   }
   const int wp32 = p.dense.wp * 32;
-  const bool n1 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && blk.layer1 != ESR_NO_LAYER;
-  const bool n2 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && blk.layer2 != ESR_NO_LAYER && has_res2;
+  const uint32_t layer1 = __builtin_amdgcn_readfirstlane(blk.layer1), layer2 = __builtin_amdgcn_readfirstlane(blk.layer2);
+  const bool n1 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && layer1 != ESR_NO_LAYER;
+  const bool n2 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && layer2 != ESR_NO_LAYER && has_res2;
   const uint64_t seed = p.seed_dev ? __builtin_nontemporal_load(p.seed_dev) : p.seed;
   sfor<R>([&](auto RR) __attribute__((always_inline)) {
     constexpr int r = decltype(RR)::value;
@@ -683,7 +684,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
       const uint32_t pix = (uint32_t)((t.b * p.H + oy) * p.W + ox);
       if (n1) {
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + t.h * 4 + q), blk.layer1, seed, &tmp[4 * q]);
+        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + t.h * 4 + q), layer1, seed, &tmp[4 * q]);
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);     // block.py:119-121
       }
@@ -693,7 +694,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
         for (int e = 0; e < 16; ++e) v[e] = v[e] * 0.2f + tmp[e];
         if (n2) {
 #pragma unroll 1
-          for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + t.h * 4 + q), blk.layer2, seed, &tmp[4 * q]);
+          for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + t.h * 4 + q), layer2, seed, &tmp[4 * q]);
 #pragma unroll
           for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
         }
@@ -821,9 +822,12 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       const char* const w = (const char*)blk.w;
       const char* const xin_b = (const char*)blk.x_in.ptr + (int64_t)t.b * blk.x_in.batch_stride;
       const ImgView xin = img_view(blk.x_in, t.b), xout = img_view(blk.x_out, t.b);
-      const bool has_res2 = blk.res2.ptr != nullptr;
+      // block-table fields are wave-uniform, but only readfirstlane makes that provable: without it every
+      // test on them becomes an exec-masked region instead of a scalar branch
+      const bool has_res2 = __builtin_amdgcn_readfirstlane((int)(blk.res2.ptr != nullptr)) != 0;
       const bool noisy = p.noise_mode != ESR_NOISE_OFF;
-      const bool full_out = (blk.flags & ESR_RDB_FULL_OUT) != 0 || noisy || p.save_dense;
+      const bool full_out = __builtin_amdgcn_readfirstlane((int)((blk.flags & ESR_RDB_FULL_OUT) != 0)) != 0 || noisy || p.save_dense;
+      const uint32_t layer1 = __builtin_amdgcn_readfirstlane(blk.layer1), layer2 = __builtin_amdgcn_readfirstlane(blk.layer2);
       const ImgView res2 = img_view(has_res2 ? blk.res2 : blk.x_in, t.b);
       constexpr bool RES = sizeof(T) == 2;      // fp16: LDS-resident slices (fp32 stages by DMA, 8 K steps of x)
       const char* const wnext = rb + 1 < p.n_blocks ? (const char*)p.blocks[rb + 1].w : nullptr;
