@@ -631,8 +631,23 @@ __device__ __forceinline__ void load_rows(const ImgView& v, int cb, const esr_rd
   }
 }
 
+struct Bias16 { f32x4 q[4]; };
+// the lane's 16 biases of a cout block (bias = wave-uniform pointer): requested at the START of the phase
+// whose epilogue adds them — a load placed in the epilogue itself exposes a memory round trip per phase
+__device__ __forceinline__ void load_bias(const float* bias, const Tile& t, Bias16& b) {
+  const f32x4* bp = (const f32x4*)bias + 4 * t.h;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b.q[i] = bp[i];
+}
+// the block-table entry's scalars, read ONCE per block into SGPRs (a field referenced through the table is
+// re-loaded with a vector load + full wait wherever it is used)
+struct BlkS {
+  const float* bias[5];
+  uint32_t layer1, layer2;
+  bool has_res2, full_out;
+};
 template <typename T, int BLK, int MODE, int LW = 0>
-__device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, const esr_rdb_block& blk, const float* bias,
+__device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, const BlkS& blk, const Bias16& bias,
                                          const ImgView& out, int out_cb, int ch_cb, const RowsRaw<T>* ex,
                                          const RowsRaw<T>* r2, bool has_res2, const Tile& t, char* smem = nullptr,
                                          int slot0 = 0, RowsRaw<T>* keep = nullptr, float carry_scale = 0.f,
@@ -640,17 +655,13 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
   using C16 = Ch16<T>;
   const int ox = t.ox0 + t.j;
   const int oyb = t.oy0 + t.wave * R;
-  f32x4 bq[4];
-  {
-    const f32x4* bp = (const f32x4*)(uniform_ptr(bias)) + 4 * t.h;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bq[i] = bp[i];
-  }
+  const f32x4 (&bq)[4] = bias.q;
   const int wp32 = p.dense.wp * 32;
-  const uint32_t layer1 = __builtin_amdgcn_readfirstlane(blk.layer1), layer2 = __builtin_amdgcn_readfirstlane(blk.layer2);
+  const uint32_t layer1 = blk.layer1, layer2 = blk.layer2;
   const bool n1 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && layer1 != ESR_NO_LAYER;
   const bool n2 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && layer2 != ESR_NO_LAYER && has_res2;
-  const uint64_t seed = p.seed_dev ? __builtin_nontemporal_load(p.seed_dev) : p.seed;
+  uint64_t seed = p.seed;
+  if ((n1 || n2) && p.seed_dev) seed = __builtin_nontemporal_load(p.seed_dev);
   sfor<R>([&](auto RR) __attribute__((always_inline)) {
     constexpr int r = decltype(RR)::value;
     const int oy = oyb + r;
@@ -819,15 +830,20 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       const esr_rdb_block& blk = p.blocks[rb];
       ev = rb == 1 ? 0 : -1;
       trace_ev(p, tile, ev);
-      const char* const w = (const char*)blk.w;
+      const char* const w = uniform_ptr(blk.w);
       const char* const xin_b = (const char*)blk.x_in.ptr + (int64_t)t.b * blk.x_in.batch_stride;
       const ImgView xin = img_view(blk.x_in, t.b), xout = img_view(blk.x_out, t.b);
       // block-table fields are wave-uniform, but only readfirstlane makes that provable: without it every
-      // test on them becomes an exec-masked region instead of a scalar branch
-      const bool has_res2 = __builtin_amdgcn_readfirstlane((int)(blk.res2.ptr != nullptr)) != 0;
+      // test on them becomes an exec-masked region and every use a fresh vector load
       const bool noisy = p.noise_mode != ESR_NOISE_OFF;
-      const bool full_out = __builtin_amdgcn_readfirstlane((int)((blk.flags & ESR_RDB_FULL_OUT) != 0)) != 0 || noisy || p.save_dense;
-      const uint32_t layer1 = __builtin_amdgcn_readfirstlane(blk.layer1), layer2 = __builtin_amdgcn_readfirstlane(blk.layer2);
+      BlkS bs;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) bs.bias[i] = (const float*)uniform_ptr(blk.bias[i]);
+      bs.layer1 = __builtin_amdgcn_readfirstlane(blk.layer1);
+      bs.layer2 = __builtin_amdgcn_readfirstlane(blk.layer2);
+      bs.has_res2 = __builtin_amdgcn_readfirstlane((int)(blk.res2.ptr != nullptr)) != 0;
+      bs.full_out = __builtin_amdgcn_readfirstlane((int)((blk.flags & ESR_RDB_FULL_OUT) != 0)) != 0 || noisy || p.save_dense;
+      const bool has_res2 = bs.has_res2, full_out = bs.full_out;
       const ImgView res2 = img_view(has_res2 ? blk.res2 : blk.x_in, t.b);
       constexpr bool RES = sizeof(T) == 2;      // fp16: LDS-resident slices (fp32 stages by DMA, 8 K steps of x)
       const char* const wnext = rb + 1 < p.n_blocks ? (const char*)p.blocks[rb + 1].w : nullptr;
@@ -861,12 +877,14 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         }
         __syncthreads();
         ws_.g1 = ws_.g2 = 0;
+        Bias16 b1, b2, b3, b4, b5a, b5b;
+        load_bias(bs.bias[0], t, b1);
         trace_ev(p, tile, ev);
-        run_phase_res<T, 1>(acc, ws_, 0, smem, t);
+        run_phase_res<T, 1>(acc, ws_, 4, smem, t);
         trace_ev(p, tile, ev);
         mfma_drain();
         RowsRaw<T> x1, x2;
-        epilogue<T, 0, 0, 2>(acc, p, blk, blk.bias[0], dense, 0, 0, nullptr, nullptr, false, t, smem, 0, &x1);     // x1
+        epilogue<T, 0, 0, 2>(acc, p, bs, b1, dense, 0, 0, nullptr, nullptr, false, t, smem, 0, &x1);     // x1
         publish(flags, tile, ++epoch, t, &p, &ev);
         ws_.g1 = ws_.g2 = 0;
         trace_ev(p, tile, ev);
@@ -879,11 +897,12 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, 0, smem, t);
         __syncthreads();
+        load_bias(bs.bias[1], t, b2);
         trace_ev(p, tile, ev);
-        run_phase_res<T, 2>(acc, ws_, 0, smem, t);
+        run_phase_res<T, 2>(acc, ws_, 4, smem, t);
         trace_ev(p, tile, ev);
         mfma_drain();
-        epilogue<T, 1, 1, 3>(acc, p, blk, blk.bias[1], dense, 1, 0, nullptr, nullptr, false, t, smem, 0, &x2);  // x2 (kept: residual of x4)
+        epilogue<T, 1, 1, 3>(acc, p, bs, b2, dense, 1, 0, nullptr, nullptr, false, t, smem, 0, &x2);  // x2 (kept: residual of x4)
         publish(flags, tile, ++epoch, t, &p, &ev);
         ws_.g1 = ws_.g2 = 0;
         trace_ev(p, tile, ev);
@@ -891,11 +910,12 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, CF::KD, smem, t);
         __syncthreads();
+        load_bias(bs.bias[2], t, b3);
         trace_ev(p, tile, ev);
-        run_phase_res<T, 3>(acc, ws_, 0, smem, t);
+        run_phase_res<T, 3>(acc, ws_, 4, smem, t);
         trace_ev(p, tile, ev);
         mfma_drain();
-        epilogue<T, 2, 0, 1>(acc, p, blk, blk.bias[2], dense, 2, 0, nullptr, nullptr, false, t, smem, 0);       // x3
+        epilogue<T, 2, 0, 1>(acc, p, bs, b3, dense, 2, 0, nullptr, nullptr, false, t, smem, 0);       // x3
         publish(flags, tile, ++epoch, t, &p, &ev);
         ws_.g1 = ws_.g2 = 0;
         trace_ev(p, tile, ev);
@@ -903,11 +923,12 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, 2 * CF::KD, smem, t);
         __syncthreads();
+        load_bias(bs.bias[3], t, b4);
         trace_ev(p, tile, ev);
-        run_phase_res<T, 4>(acc, ws_, 0, smem, t);
+        run_phase_res<T, 4>(acc, ws_, 4, smem, t);
         trace_ev(p, tile, ev);
         mfma_drain();
-        epilogue<T, 3, 2, 1>(acc, p, blk, blk.bias[3], dense, 3, 0, &x2, nullptr, false, t, smem, 0);           // x4 (+ x2)
+        epilogue<T, 3, 2, 1>(acc, p, bs, b4, dense, 3, 0, &x2, nullptr, false, t, smem, 0);           // x4 (+ x2)
         publish(flags, tile, ++epoch, t, &p, &ev);
         ws_.g1 = ws_.g2 = 0;
         trace_ev(p, tile, ev);
@@ -918,21 +939,26 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         // the block tail's residuals: x only when it is added explicitly (noise), the RRDB input for every
         // third block; requested here, used after the phase (its first K step lets them stay in flight)
         RowsRaw<T> tx0, tx1, tr0, tr1;
-        if (noisy) { load_rows<T>(xin, 0, p, t, tx0); load_rows<T>(xin, 1, p, t, tx1); }
+        load_bias(bs.bias[4], t, b5a);
+        load_bias(bs.bias[4] + 32, t, b5b);
         if (has_res2) { load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1); }
         trace_ev(p, tile, ev);
-        run_phase_res<T, 5>(acc, ws_, 32, smem, t);
+        run_phase_res<T, 5>(acc, ws_, 24, smem, t);
+        if (noisy) { load_rows<T>(xin, 0, p, t, tx0); load_rows<T>(xin, 1, p, t, tx1); }   // rare path: latency exposed
         trace_ev(p, tile, ev);
         mfma_drain();
-        epilogue<T, 4, 3, 1>(acc, p, blk, blk.bias[4], xout, 0, 0, noisy ? &tx0 : nullptr, &tr0, has_res2, t, smem, 0, nullptr,
+        epilogue<T, 4, 3, 1>(acc, p, bs, b5a, xout, 0, 0, noisy ? &tx0 : nullptr, &tr0, has_res2, t, smem, 0, nullptr,
                              noisy ? 0.f : 5.f, full_out);
-        epilogue<T, 5, 3, 1>(acc, p, blk, blk.bias[4] + 32, xout, 1, 1, noisy ? &tx1 : nullptr, &tr1, has_res2, t, smem, 2, nullptr,
+        epilogue<T, 5, 3, 1>(acc, p, bs, b5b, xout, 1, 1, noisy ? &tx1 : nullptr, &tr1, has_res2, t, smem, 2, nullptr,
                              noisy ? 0.f : 5.f, full_out);
         publish(flags, tile, ++epoch, t, &p, &ev);
         ws_.g1 = ws_.g2 = 0;
         trace_ev(p, tile, ev);
       } else {
       // =========================== fp32: every stage by DMA ===========================
+      Bias16 fb[6];
+      for (int i = 0; i < 5; ++i) load_bias(bs.bias[i], t, fb[i]);
+      load_bias(bs.bias[4] + 32, t, fb[5]);
       // ---------------- phase 1: x -> conv1..conv5
       issue_w_head<6>(w + CF::phase_off(1), CF::KX, smem, t);
       if (epoch > 0 && !wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
@@ -940,7 +966,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       run_phase<T, 1>(acc, w + CF::phase_off(1), xin_b, blk.x_in.group_stride, CF::KX, smem, t);
       trace_ev(p, tile, ev);
       mfma_drain();
-      epilogue<T, 0, 0>(acc, p, blk, blk.bias[0], dense, 0, 0, nullptr, nullptr, false, t);       // x1
+      epilogue<T, 0, 0>(acc, p, bs, fb[0], dense, 0, 0, nullptr, nullptr, false, t);       // x1
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- P = conv1x1(x) on own pixels, then phase 2: x1 -> conv2..conv5
@@ -953,7 +979,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       run_phase<T, 2>(acc, w + CF::phase_off(2), dense_b, d_gs, CF::KD, smem, t);
       trace_ev(p, tile, ev);
       mfma_drain();
-      epilogue<T, 1, 1>(acc, p, blk, blk.bias[1], dense, 1, 0, nullptr, nullptr, false, t);     // x2
+      epilogue<T, 1, 1>(acc, p, bs, fb[1], dense, 1, 0, nullptr, nullptr, false, t);     // x2
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- phase 3: x2 -> conv3..conv5
@@ -963,7 +989,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       run_phase<T, 3>(acc, w + CF::phase_off(3), dense_b + CF::KD * d_gs, d_gs, CF::KD, smem, t);
       trace_ev(p, tile, ev);
       mfma_drain();
-      epilogue<T, 2, 0>(acc, p, blk, blk.bias[2], dense, 2, 0, nullptr, nullptr, false, t);     // x3
+      epilogue<T, 2, 0>(acc, p, bs, fb[2], dense, 2, 0, nullptr, nullptr, false, t);     // x3
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- phase 4: x3 -> conv4, conv5
@@ -974,7 +1000,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       trace_ev(p, tile, ev);
       mfma_drain();
       { RowsRaw<T> x2r; load_rows<T>(dense, 1, p, t, x2r);
-        epilogue<T, 3, 2>(acc, p, blk, blk.bias[3], dense, 3, 0, &x2r, nullptr, false, t); }     // x4 (+ x2)
+        epilogue<T, 3, 2>(acc, p, bs, fb[3], dense, 3, 0, &x2r, nullptr, false, t); }     // x4 (+ x2)
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- phase 5: x4 -> conv5; block tail (+ RRDB tail)
@@ -987,8 +1013,8 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       { RowsRaw<T> tx0, tx1, tr0, tr1;
         load_rows<T>(xin, 0, p, t, tx0); load_rows<T>(xin, 1, p, t, tx1);
         load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1);
-        epilogue<T, 4, 3>(acc, p, blk, blk.bias[4], xout, 0, 0, &tx0, &tr0, has_res2, t);
-        epilogue<T, 5, 3>(acc, p, blk, blk.bias[4] + 32, xout, 1, 1, &tx1, &tr1, has_res2, t); }
+        epilogue<T, 4, 3>(acc, p, bs, fb[4], xout, 0, 0, &tx0, &tr0, has_res2, t);
+        epilogue<T, 5, 3>(acc, p, bs, fb[5], xout, 1, 1, &tx1, &tr1, has_res2, t); }
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       }
