@@ -25,6 +25,8 @@ import torch  # noqa: E402
 NB, BATCH, LR = 23, 16, 128
 MAC_PER_LR_PIXEL = 18068160            # SURVEY.md §8d [probe]: conv MACs of RRDBNet x4 forward
 PEAK_F16_TFLOPS = 2500.0               # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
+# conv MACs per pixel of one ResidualDenseBlock_5C: conv1..conv5 3x3 + the 1x1 (block.py:239-258)
+RDB_MAC_PER_PIXEL = 9 * 32 * (64 + 96 + 128 + 160) + 9 * 64 * 192 + 64 * 32
 
 
 def conv_flops(c):
@@ -39,6 +41,11 @@ def describe_plan(net, plan):
     ent = {e.w_ptr: e for e in net._wp[(net.precision, str(next(net.parameters()).device))].entries.values()}
     out = []
     for o in plan.ops.ops:
+        if o.kind == L.OP_RDB_CHAIN:
+            # the fused dense-block chain (rdb_fused.hip): n_blocks x ResidualDenseBlock_5C, block.py:260-268
+            ch = o.u.rdb_chain
+            out.append(('rdb_chain', 2.0 * RDB_MAC_PER_PIXEL * ch.n_blocks * ch.B * ch.H * ch.W))
+            continue
         if o.kind != L.OP_CONV:
             out.append(('layout', 0.0))
             continue
@@ -244,6 +251,42 @@ def gtrain_bench(args, world, rank, dev, dist):
         dist.destroy_process_group()
 
 
+def fwd_bwd_probe(args, dev, steps=5):
+    """BASELINE.json's metric string says "fwd+bwd": the same workload as `value` (batch 16 of 128x128 LR, fp16)
+    with the generator in training mode — GaussianNoise on, every activation kept, L1 loss against a synthetic
+    HR target, loss-scaled backward through every conv (dgrad + wgrad); no optimizer step.  Reported next to
+    the forward headline, not instead of it (north_star's roofline target is on the forward)."""
+    import torch.nn.functional as F
+    from esrganplus_amd import architecture as arch, synth
+    netG = arch.RRDBNet(3, 3, 64, NB).to(dev).train().set_precision('fp16')
+    netG.load_state_dict(synth.rrdbnet_state_dict(NB, 0, gain=0.5))
+    lr = synth.image_batch(300, args.batch, 3, args.lr, args.lr, name='bench.fb.lr').to(dev)
+    hr = synth.image_batch(301, args.batch, 3, 4 * args.lr, 4 * args.lr, name='bench.fb.hr').to(dev)
+
+    def step():
+        for q in netG.parameters():
+            q.grad = None
+        loss = F.l1_loss(netG(lr), hr)
+        (loss * 1024.0).backward()
+        return loss
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(loss).all()
+    fl = 3.0 * 2.0 * MAC_PER_LR_PIXEL * args.batch * args.lr * args.lr      # fwd + dgrad + wgrad
+    return {'ms_per_step': round(dt * 1e3, 3), 'value': round(args.batch * (4 * args.lr) ** 2 / 1e6 / dt, 2),
+            'unit': 'HR-Mpix/s', 'tflops': round(fl / dt / 1e12, 1),
+            'frac_of_f16_mfma_peak': round(fl / dt / 1e12 / PEAK_F16_TFLOPS, 4), 'steps': steps,
+            'what': 'RRDBNet x4 train-mode forward (noise on) + backward (dgrad + wgrad, loss scale 1024), '
+                    'batch %d of %dx%d LR, fp16, no optimizer step' % (args.batch, args.lr, args.lr)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -252,6 +295,7 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--lr', type=int, default=LR)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fwd-bwd', action='store_true', help='forward mode: skip the fwd+bwd side measurement')
     ap.add_argument('--mode', choices=['forward', 'train', 'gtrain'], default='forward',
                     help="'forward' = BASELINE configs[1] (the headline metric); 'train' = configs[2]/[3]: "
                          'full ESRGAN+ step, batch 16 of 32x32 LR per GPU, DP over RCCL; '
@@ -354,15 +398,18 @@ def main():
         tot_ms = sum(a[0] for a in agg.values()) / reps
         t_ms, fl, n = agg[dom]
         ach = fl / (t_ms * 1e-3) / 1e12
-        traffic = None
-        try:      # PMC-measured HBM-side bytes per launch (separate rocprofv3 --pmc passes, committed)
+        traffic, traffic_src = None, None
+        try:      # PMC-measured HBM-side bytes per launch: NOT measured by this run — the committed summary of
+            #         separate rocprofv3 --pmc passes over this same command (MI355X_MICROARCH.md HBM section)
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')))
             if dom in tj and args.batch == BATCH and args.lr == LR:
                 traffic = tj[dom]['read_bytes'] + tj[dom]['write_bytes']
+                traffic_src = 'profiles/roofline_traffic.json (%s)' % tj.get('_source', 'rocprofv3 --pmc')
         except (OSError, ValueError, KeyError):
             pass
         res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_F16_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
+                           'traffic_source': traffic_src,
                            'launches_per_step': n // reps, 'avg_launch_us': round(t_ms / n * 1e3, 2),
                            'share_of_step_time': round(t_ms / reps / tot_ms, 3)}
         if traffic:
@@ -390,6 +437,11 @@ def main():
             Fn._FWD_STREAMS = old_streams
             res['two_stream_variant'] = {'value': round(hr_mpix_per_step / dt2, 2), 'ms_per_step': round(dt2 * 1e3, 4),
                                          'identical_output': bool(torch.equal(y, y2))}
+        if world == 1 and not args.no_fwd_bwd:
+            del y
+            net = None
+            torch.cuda.empty_cache()
+            res['fwd_bwd'] = fwd_bwd_probe(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)
