@@ -642,8 +642,10 @@ int dispatch(const esr_conv& p, hipStream_t st) {
       // Few workgroups (training tiles: at most one per CU): nothing else hides a wave's barrier / LDS
       // round trip / DMA issue, so the hand-pipelined K loop pays (0.87 -> ~0.55 us per K step);
       // with two lock-stepped workgroups per CU streaming at the fabric limit it does not (r01_experiments.md)
-      static const int pipe_max = [] { const char* e = getenv("ESR_PIPE_MAX_TILES"); return e ? atoi(e) : 256; }();
-      if (tiles <= pipe_max) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false, true>(p, st);
+      // debug_flags bit 6 / bit 7 select the instantiation per call (plain loop / pipelined), so that every
+      // golden test can run both; default: pipelined up to 256 tiles
+      const bool pipe = (p.debug_flags & 128) ? true : ((p.debug_flags & 64) ? false : tiles <= 256);
+      if (pipe) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false, true>(p, st);
       return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false>(p, st);
     }
     // Several cout blocks: grid.y walks them, ONE per workgroup on small grids (training tiles: twice

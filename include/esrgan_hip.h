@@ -89,7 +89,9 @@ typedef struct esr_conv {
   esr_g32 out2;        /* dgrad: masked output */
   int32_t nchw_out_c;  /* >0: ALSO store the first nchw_out_c channels as fp32 NCHW */
   float* nchw_out;     /* [B][nchw_out_c][H][W] */
-  int32_t debug_flags; /* measurement only: 1 = skip epilogue, 2 = skip MFMAs, 4 = skip activation DMA */
+  int32_t debug_flags; /* measurement only: 1 = skip epilogue, 2 = skip MFMAs, 4 = skip activation DMA;
+                          test hooks (results valid): 64 = force the plain K loop, 128 = force the hand-pipelined
+                          K loop of the 32-cout 3x3 conv (default: pipelined up to 256 tiles) */
   int32_t mask_cb_begin; /* mask/out2 apply to cout blocks >= this one, indexed from it */
   float gamma;          /* third stage (backward chains): out3 = v * gamma * (1 + sigma*z3) */
   uint32_t layer3;      /* philox stream id of z3 (0xFFFFFFFF = no noise on out3) */
