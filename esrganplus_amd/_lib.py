@@ -117,7 +117,16 @@ class esr_adam(C.Structure):
     _fields_ = [('entries', C.c_void_p), ('blocks', C.c_void_p), ('nblocks', C.c_int32), ('_pad', C.c_int32),
                 ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),
                 ('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
-                ('bc1', C.c_float), ('bc2', C.c_float), ('grad_scale', C.c_float), ('weight_decay', C.c_float)]
+                ('bc1', C.c_float), ('bc2', C.c_float), ('grad_scale', C.c_float), ('weight_decay', C.c_float),
+                ('amp_state', C.c_void_p)]
+
+
+AMP_CHECK, AMP_UPDATE = 0, 1
+
+
+class esr_amp(C.Structure):
+    _fields_ = [('mode', C.c_int32), ('interval', C.c_int32), ('state', C.c_void_p), ('grad', C.c_void_p),
+                ('n', C.c_int64), ('growth', C.c_float), ('backoff', C.c_float)]
 
 
 class esr_resample(C.Structure):
@@ -165,7 +174,7 @@ class esr_op(C.Structure):
 # every symbol include/esrgan_hip.h declares (tests check the .so exports all of them)
 EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_pack_conv_weights',
            'esr_convert_layout', 'esr_fill_noise', 'esr_conv_wgrad', 'esr_conv_wgrad_multi', 'esr_batchnorm', 'esr_maxpool2',
-           'esr_linear_op', 'esr_grad_unpermute', 'esr_adam_step', 'esr_resample_axis', 'esr_pack_conv_weights_batch', 'esr_pack_pieces',
+           'esr_linear_op', 'esr_grad_unpermute', 'esr_adam_step', 'esr_amp_step', 'esr_resample_axis', 'esr_pack_conv_weights_batch', 'esr_pack_pieces',
            'esr_run_ops', 'esr_run_ops_timed', 'esr_graph_create', 'esr_graph_launch', 'esr_graph_destroy', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op', 'esr_rdb_forward', 'esr_rdb_workspace_bytes', 'esr_rdb_weight_stream_bytes',
            'esr_rdb_max_tiles_per_image', 'esr_gather_fragments']
@@ -216,7 +225,7 @@ def lib():
                          ('esr_convert_layout', esr_layout), ('esr_fill_noise', esr_noise_fill),
                          ('esr_conv_wgrad', esr_wgrad), ('esr_batchnorm', esr_bn),
                          ('esr_maxpool2', esr_pool), ('esr_linear_op', esr_linear),
-                         ('esr_grad_unpermute', esr_unpermute), ('esr_adam_step', esr_adam), ('esr_resample_axis', esr_resample),
+                         ('esr_grad_unpermute', esr_unpermute), ('esr_adam_step', esr_adam), ('esr_amp_step', esr_amp), ('esr_resample_axis', esr_resample),
                          ('esr_pack_conv_weights_batch', esr_pack_batch), ('esr_rdb_forward', esr_rdb_chain),
                          ('esr_gather_fragments', esr_frag_gather)):
             getattr(L, name).argtypes = [C.POINTER(st), C.c_void_p]

@@ -295,9 +295,14 @@ __global__ __launch_bounds__(256) void adam_kernel(const esr_adam a) {
   const esr_adam_entry e = a.entries[blk.entry];
   const int64_t end = min((int64_t)blk.first + ESR_ADAM_BLOCK_ELEMS, e.n);
   const float step = a.lr / a.bc1, rs2 = rsqrtf(a.bc2), omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
+  float gs = a.grad_scale;
+  if (a.amp_state) {                       // dynamic loss scaling: skip the step on overflow, else un-scale
+    if (a.amp_state[1] != 0.f) return;
+    gs /= a.amp_state[0];
+  }
   for (int64_t i = blk.first + threadIdx.x; i < end; i += 256) {
     float p = e.p[i];
-    float g = a.grad[e.goff + i] * a.grad_scale;
+    float g = a.grad[e.goff + i] * gs;
     if (a.weight_decay != 0.f) g += a.weight_decay * p;
     const float m = a.beta1 * a.exp_avg[e.goff + i] + omb1 * g;
     const float v = a.beta2 * a.exp_avg_sq[e.goff + i] + omb2 * g * g;
@@ -307,6 +312,38 @@ __global__ __launch_bounds__(256) void adam_kernel(const esr_adam a) {
   }
 }
 }  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void amp_check_kernel(const esr_amp a) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+    const float g = a.grad[i];
+    bad |= !(fabsf(g) <= 3.4028234e38f);        // inf or nan
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) a.state[1] = 1.f;   // benign race: every writer stores the same value
+}
+__global__ void amp_update_kernel(const esr_amp a) {
+  float s = a.state[0], good = a.state[2];
+  if (a.state[1] != 0.f) { s *= a.backoff; good = 0.f; }
+  else if (++good >= (float)a.interval) { s *= a.growth; good = 0.f; }
+  a.state[0] = s; a.state[1] = 0.f; a.state[2] = good;
+}
+}  // namespace
+
+extern "C" int esr_amp_step(const esr_amp* p, esr_stream_t stream) {
+  if (!p || !p->state || (p->mode == ESR_AMP_CHECK && (!p->grad || p->n <= 0)) ||
+      (p->mode == ESR_AMP_UPDATE && (p->interval <= 0 || !(p->growth >= 1.f) || !(p->backoff > 0.f && p->backoff <= 1.f)))) {
+    esr_set_error("esr_amp_step: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  if (p->mode == ESR_AMP_CHECK) {
+    const int64_t blocks = (p->n + 256 * 16 - 1) / (256 * 16);
+    hipLaunchKernelGGL(amp_check_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, *p);
+  } else if (p->mode == ESR_AMP_UPDATE) {
+    hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, *p);
+  } else { esr_set_error("esr_amp_step: bad mode %d", p->mode); return ESR_ERR_INVALID; }
+  return esr_check_launch("amp_kernel");
+}
 
 extern "C" int esr_adam_step(const esr_adam* p, esr_stream_t stream) {
   if (!p || !p->entries || !p->blocks || p->nblocks <= 0 || !p->grad || !p->exp_avg || !p->exp_avg_sq ||

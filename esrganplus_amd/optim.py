@@ -65,6 +65,11 @@ class FusedAdam(torch.optim.Optimizer):
         """The gradients as one flat fp32 tensor in parameter order: zero-copy when they already are
         views tiling one buffer in that order (what the fused backward nodes emit), else staged."""
         g0 = params[0].grad
+        if g0 is None:
+            # torch.optim.Adam skips a parameter whose grad is None; the flat kernel cannot leave single tensors
+            # out of its tables, so this has to be said instead of silently moving them by their momentum
+            raise L.HipExtensionError('FusedAdam: a parameter of the group has no gradient while others do; '
+                                      'freeze it (requires_grad=False) or give it its own optimizer')
         base = g0.storage_offset()
         ok = g0.dtype == torch.float32
         if ok:
@@ -81,13 +86,18 @@ class FusedAdam(torch.optim.Optimizer):
         if st['stage'] is None:
             st['stage'] = torch.zeros(st['total'], device=params[0].device)
         views = [st['stage'][o:o + n].view_as(p) for p, o, n in zip(params, st['goff'], st['sizes'])]
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+        if any(p.grad is None for p in params):
+            raise L.HipExtensionError('FusedAdam: a parameter of the group has no gradient while others do; '
+                                      'freeze it (requires_grad=False) or give it its own optimizer')
+        grads = [p.grad for p in params]
         torch._foreach_copy_(views, [g.to(torch.float32) for g in grads])
         return st['stage']
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
-        """``grad_scale`` multiplies every gradient on the fly (1/loss_scale under loss scaling)."""
+    def step(self, closure=None, grad_scale=1.0, scaler=None):
+        """``grad_scale`` multiplies every gradient on the fly (1/loss_scale under static loss scaling).
+        ``scaler`` (DynamicLossScaler): the gradients are checked for inf / nan first and the whole update is
+        skipped on the device when one is found; otherwise they are divided by the current scale."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -99,6 +109,8 @@ class FusedAdam(torch.optim.Optimizer):
                 continue
             st = self._group_state(gi, params)
             flat = self._flat_grad(st, params)
+            if scaler is not None:
+                scaler.check(flat, stream)
             st['step'] += 1
             b1, b2 = group['betas']
             a = L.esr_adam()
@@ -107,6 +119,7 @@ class FusedAdam(torch.optim.Optimizer):
             a.lr, a.beta1, a.beta2, a.eps = group['lr'], b1, b2, group['eps']
             a.bc1, a.bc2 = 1.0 - math.pow(b1, st['step']), 1.0 - math.pow(b2, st['step'])
             a.grad_scale, a.weight_decay = grad_scale, group['weight_decay']
+            a.amp_state = scaler.state.data_ptr() if scaler is not None else None
             L.check(L.lib().esr_adam_step(C.byref(a), C.c_void_p(stream)), 'esr_adam_step')
         return loss
 
@@ -149,3 +162,29 @@ class FusedAdam(torch.optim.Optimizer):
                     st['step'] = int(float(ent['step']))
                 idx += 1
 
+
+
+class DynamicLossScaler:
+    """Loss scaling for the fp16 training path with overflow skip, entirely on the device (no ``.item()``):
+    ``loss * scaler.scale`` before ``backward()``; ``optimizer.step(scaler=scaler)`` checks the gradients and
+    skips the update when they hold an inf / nan; ``update()`` once per iteration halves the scale after an
+    overflow and doubles it after ``interval`` clean steps (the torch.amp.GradScaler policy)."""
+
+    def __init__(self, device, init_scale=1024.0, growth=2.0, backoff=0.5, interval=2000):
+        self.state = torch.tensor([init_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+        self.growth, self.backoff, self.interval = growth, backoff, interval
+
+    @property
+    def scale(self):
+        return self.state[0]            # a 0-dim DEVICE tensor: multiplying the loss by it needs no sync
+
+    def check(self, flat, stream=None):
+        a = L.esr_amp()
+        a.mode, a.state, a.grad, a.n = L.AMP_CHECK, self.state.data_ptr(), flat.data_ptr(), flat.numel()
+        L.check(L.lib().esr_amp_step(C.byref(a), C.c_void_p(stream or E.current_stream())), 'esr_amp_step')
+
+    def update(self, stream=None):
+        a = L.esr_amp()
+        a.mode, a.state, a.interval = L.AMP_UPDATE, self.state.data_ptr(), self.interval
+        a.growth, a.backoff = self.growth, self.backoff
+        L.check(L.lib().esr_amp_step(C.byref(a), C.c_void_p(stream or E.current_stream())), 'esr_amp_step')

@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from . import dp as DP
-from .optim import FusedAdam
+from .optim import FusedAdam, DynamicLossScaler
 
 
 def bce_logits(x, target_is_real):
@@ -27,7 +27,13 @@ class ESRGANPlusStep:
                  pixel_weight=1e-2, feature_weight=1.0, gan_weight=5e-3, loss_scale=1.0):
         self.netG, self.netD, self.netF = netG, netD, netF
         self.l_pix_w, self.l_fea_w, self.l_gan_w = pixel_weight, feature_weight, gan_weight
-        self.loss_scale = loss_scale          # static loss scale for the fp16 path (1.0 for fp32)
+        # fp16 path: 'dynamic' (default policy of the scaler: start at 1024, halve on overflow and skip that step,
+        # double after 2000 clean steps) or a fixed number (1.0 for fp32).  Nothing here synchronises with the host.
+        self.scaler = None
+        if loss_scale == 'dynamic':
+            self.scaler = DynamicLossScaler(next(netG.parameters()).device)
+            loss_scale = 1.0
+        self.loss_scale = loss_scale
         # one fused launch per optimizer (optim.FusedAdam == torch.optim.Adam arithmetic; it stays a
         # torch.optim.Optimizer, so the reference's MultiStepLR schedulers attach unchanged)
         self.optimizer_G = FusedAdam([p for p in netG.parameters() if p.requires_grad],
@@ -59,7 +65,7 @@ class ESRGANPlusStep:
         l_g_gan = self.l_gan_w * (bce_logits(pred_d_real - mean(pred_g_fake), False) +
                                   bce_logits(pred_g_fake - mean(pred_d_real), True)) / 2
         l_g_total = l_g_pix + l_g_fea + l_g_gan
-        (l_g_total * self.loss_scale).backward()
+        (l_g_total * (self.scaler.scale if self.scaler else self.loss_scale)).backward()
         self.exG.start()                      # RCCL all-reduce of G grads overlaps the D pass below
         # ---------------- D ----------------
         for p in netD.parameters():
@@ -70,13 +76,15 @@ class ESRGANPlusStep:
         l_d_real = bce_logits(pred_d_real - mean(pred_d_fake), True)
         l_d_fake = bce_logits(pred_d_fake - mean(pred_d_real), False)
         l_d_total = (l_d_real + l_d_fake) / 2
-        (l_d_total * self.loss_scale).backward()
+        (l_d_total * (self.scaler.scale if self.scaler else self.loss_scale)).backward()
         self.exD.start()
         inv = 1.0 / self.loss_scale          # the loss-scale division rides inside the Adam kernel
         self.exG.wait()
-        self.optimizer_G.step(grad_scale=inv)
+        self.optimizer_G.step(grad_scale=inv, scaler=self.scaler)
         self.exD.wait()
-        self.optimizer_D.step(grad_scale=inv)
+        self.optimizer_D.step(grad_scale=inv, scaler=self.scaler)
+        if self.scaler:
+            self.scaler.update()
         logs = dict(l_g_pix=l_g_pix, l_g_fea=l_g_fea, l_g_gan=l_g_gan, l_d_real=l_d_real,
                     l_d_fake=l_d_fake, D_real=pred_d_real.detach().mean(), D_fake=pred_d_fake.detach().mean())
         if sync_log:      # the reference calls .item() on every loss each step (SRRaGAN_model.py:171-186)

@@ -268,7 +268,25 @@ typedef struct esr_adam {
   float* exp_avg;         /* flat first / second moments, same offsets as grad */
   float* exp_avg_sq;
   float lr, beta1, beta2, eps, bc1, bc2, grad_scale, weight_decay;
+  const float* amp_state; /* NULL, or the DEVICE state of dynamic loss scaling (esr_amp): gradients are additionally
+                             divided by amp_state[0] (the loss scale), and the whole update is skipped — weights and
+                             moments untouched — while amp_state[1] != 0 (a non-finite gradient was found).  No host
+                             synchronisation anywhere: the fp16 train path's overflow handling */
 } esr_adam;
+
+/* Dynamic loss scaling for the fp16 training path (new capability; the reference trains in fp32 only).
+ * state = DEVICE float[4] {scale, found_nonfinite, good_steps, -}.
+ *   ESR_AMP_CHECK   found |= any(!isfinite(grad[0..n)))             (after the backward / gradient exchange)
+ *   ESR_AMP_UPDATE  found ? (scale *= backoff, good = 0) : (++good == interval ? (scale *= growth, good = 0) : -);
+ *                   found = 0                                         (once per step, after the optimizers)    */
+enum esr_amp_mode { ESR_AMP_CHECK = 0, ESR_AMP_UPDATE = 1 };
+typedef struct esr_amp {
+  int32_t mode, interval;
+  float* state;
+  const float* grad;
+  int64_t n;
+  float growth, backoff;
+} esr_amp;
 
 /* ---- fused ResidualDenseBlock_5C chain (rdb_fused.hip) -------------------------------------------
  * ONE persistent launch runs n_blocks dense blocks (block.py:260-268) back to back on every 16x32
@@ -376,6 +394,7 @@ int esr_maxpool2(const esr_pool* p, esr_stream_t stream);
 int esr_linear_op(const esr_linear* p, esr_stream_t stream);
 int esr_grad_unpermute(const esr_unpermute* p, esr_stream_t stream);
 int esr_adam_step(const esr_adam* p, esr_stream_t stream);
+int esr_amp_step(const esr_amp* p, esr_stream_t stream);
 int esr_resample_axis(const esr_resample* p, esr_stream_t stream);
 int esr_pack_conv_weights_batch(const esr_pack_batch* p, esr_stream_t stream);
 /* Fused dense-block chain (replaces 5 x n_blocks esr_conv_forward launches; block.py:260-268,287-291). */

@@ -160,3 +160,128 @@ def test_fused_adam_state_dict_interchanges_with_torch_adam(dev, tmp_path):
             s.step()
     for a, b, c in zip(pf, pt, pn):
         assert (a - b).abs().max().item() <= 2e-6 and (a - c).abs().max().item() <= 1e-7
+
+
+def _step_nets(dev, prec):
+    from esrganplus_amd import architecture as arch
+    sdG, sdD = synth.rrdbnet_state_dict(nb=2, seed=30), synth.discriminator_state_dict(seed=31)
+    netG = arch.RRDBNet(3, 3, 64, 2).to(dev).train().set_precision(prec)
+    netD = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision(prec)
+    netF = arch.VGGFeatureExtractor(34, False, True, dev).to(dev).eval().set_precision(prec)
+    netG.load_state_dict(sdG, strict=True)
+    netD.load_state_dict(sdD, strict=True)
+    netF.load_state_dict(synth.vgg19_state_dict(6, 34), strict=False)
+    return netG, netD, netF, sdG, sdD
+
+
+@pytest.mark.parametrize('scale', [1024.0, 'dynamic'])
+def test_optimize_parameters_step_fp16_loss_scaled(dev, scale):
+    """BASELINE configs[2] as stated — the same golden `optimize_parameters` step in fp16 storage with loss
+    scaling (static 1024, and the dynamic scaler): losses within 2e-2 relative of the reference's fp32 values,
+    the first Adam update agrees in sign with the reference's on >= 95 % of a weight tensor, everything finite."""
+    from esrganplus_amd import train
+    from oracle import ref_torch as RT
+    g = dict(np.load('tests/golden/train_step.npz'))
+    netG, netD, netF, sdG, sdD = _step_nets(dev, 'fp16')
+    lr = synth.image_batch(30, 4, 3, 32, 32, name='step.lr').to(dev)
+    hr = synth.image_batch(30, 4, 3, 128, 128, name='step.hr').to(dev)
+    z = [synth.normal_like(9, 'step.z.%d' % i, s).to(dev) for i, s in enumerate(RT.noise_shapes(lr.shape, 2, 'codes'))]
+    st = train.ESRGANPlusStep(netG, netD, netF, loss_scale=scale)
+    log = st.step(lr, hr, z=z)
+    for k in ('l_g_pix', 'l_g_fea', 'l_g_gan', 'l_d_real', 'l_d_fake'):
+        ref = float(g['log_' + k])
+        print('%-9s hip fp16 %.6e  ref %.6e' % (k, log[k], ref))
+        assert np.isfinite(log[k]) and abs(log[k] - ref) <= 2e-2 * max(1e-3, abs(ref)), k
+    pg = dict(netG.named_parameters())
+    for k, v in pg.items():
+        assert torch.isfinite(v).all(), k
+    d = (pg['model.0.weight'].detach().cpu() - sdG['model.0.weight']).numpy()
+    agree = np.mean(np.sign(d) == np.sign(g['G_delta_model.0.weight']))
+    print('sign agreement of the first Adam update (fp16, scale %s): %.4f' % (scale, agree))
+    assert agree >= 0.95
+    pd = dict(netD.named_parameters())
+    dd = (pd['classifier.2.weight'].detach().cpu() - sdD['classifier.2.weight']).numpy()
+    assert np.mean(np.sign(dd) == np.sign(g['D_delta_classifier.2.weight'])) >= 0.95
+    if scale == 'dynamic':
+        assert float(st.scaler.state[0]) == 1024.0 and float(st.scaler.state[1]) == 0.0 and float(st.scaler.state[2]) == 1.0
+
+
+def test_dynamic_loss_scaler_skips_overflow_step(dev):
+    """An inf in the gradients must leave weights AND Adam moments untouched and halve the scale; the next clean
+    step updates normally; after `interval` clean steps the scale doubles.  All decided on the device."""
+    from esrganplus_amd.optim import FusedAdam, DynamicLossScaler
+    torch.manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in [(64, 3, 3, 3), (64,), (5000,)]]
+    ref = [p.detach().clone() for p in ps]
+    opt = FusedAdam(ps, lr=1e-2)
+    sc = DynamicLossScaler(dev, init_scale=256.0, interval=2)
+    for p in ps:
+        p.grad = torch.randn_like(p) * 256.0
+    ps[2].grad[17] = float('inf')
+    opt.step(scaler=sc)
+    sc.update()
+    for p, r in zip(ps, ref):
+        assert torch.equal(p.detach(), r)
+    assert float(sc.state[0]) == 128.0 and float(opt._g[0]['exp_avg'].abs().max()) == 0.0
+    for it in range(2):
+        for p in ps:
+            p.grad = torch.randn_like(p) * 128.0
+        opt.step(scaler=sc)
+        sc.update()
+    assert all(not torch.equal(p.detach(), r) for p, r in zip(ps, ref))
+    assert float(sc.state[0]) == 256.0 and all(torch.isfinite(p).all() for p in ps)
+
+
+@pytest.mark.parametrize('size', [192, 256])
+def test_generator_training_tiles_192_256_vs_oracle(dev, size):
+    """BASELINE configs[4] tile sizes (mixed 128/192/256 LR tiles; nb=2 here): noise-on generator forward +
+    backward with an L1 loss on ONE 192^2 / 256^2 tile, fp32, against the oracle under autograd with the same
+    Philox z — output 1e-4, parameter gradients 1e-2 relative (LeakyReLU mask flips, see test_gpu_rdb_chain)."""
+    import torch.nn.functional as F
+    from esrganplus_amd import architecture as arch, ops
+    from oracle import ref_torch as RT
+    nb = 2
+    sd = synth.rrdbnet_state_dict(nb=nb, seed=52)
+    net = arch.RRDBNet(3, 3, 64, nb).to(dev).train()
+    net.load_state_dict(sd, strict=True)
+    lr = synth.image_batch(52, 1, 3, size, size, name='gt.lr').to(dev)
+    hr = synth.image_batch(53, 1, 3, 4 * size, 4 * size, name='gt.hr').to(dev)
+    torch.manual_seed(7)
+    y = net(lr)
+    loss = F.l1_loss(y, hr)
+    loss.backward()
+    torch.manual_seed(7)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    z = [ops.philox_normal(s, seed, i, dev).cpu() for i, s in enumerate(RT.noise_shapes(lr.shape, nb, 'codes'))]
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yr = RT.rrdbnet_forward(lr.cpu(), sdr, nb, z, 'codes')
+    lr_ref = F.l1_loss(yr, hr.cpu())
+    lr_ref.backward()
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() <= 1e-4
+    assert abs(float(loss.detach()) - float(lr_ref.detach())) <= 1e-5
+    for k, p in net.named_parameters():
+        ref = sdr[k].grad
+        err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+        assert err <= 1e-2, (k, err)
+
+
+def test_eval_after_fused_adam_uses_updated_weights(dev):
+    """optim.FusedAdam writes the parameters through raw pointers (no version bump): eval() right after a training
+    step must re-pack, i.e. validation runs the model that `state_dict()` would save."""
+    from esrganplus_amd import architecture as arch
+    from esrganplus_amd.optim import FusedAdam
+    for prec in ('fp32', 'fp16'):
+        net = arch.RRDBNet(3, 3, 64, 1).to(dev).train().set_precision(prec)
+        net.load_state_dict(synth.rrdbnet_state_dict(nb=1, seed=8))
+        opt = FusedAdam(net.parameters(), lr=1e-2)
+        x = synth.image_batch(8, 2, 3, 24, 40, name='stale.x').to(dev)
+        net(x).mean().backward()
+        opt.step()
+        net.eval()
+        with torch.no_grad():
+            y = net(x)
+            fresh = arch.RRDBNet(3, 3, 64, 1).to(dev).eval().set_precision(prec)
+            fresh.load_state_dict(net.state_dict())
+            y2 = fresh(x)
+        assert torch.equal(y, y2), prec
