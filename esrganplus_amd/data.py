@@ -95,28 +95,47 @@ def imresize(img, scale, antialiasing=True):
 
 
 def paired_random_crop(lr, hr, lr_size, scale):
-    """LRHR_dataset.py:96-103 on NCHW batches: one crop window per call, same `random` call order."""
+    """LRHR_dataset.py:96-103 on NCHW batches.  The reference's ``__getitem__`` draws one window PER SAMPLE
+    (two ``random.randint`` calls each, in sample order); a batch does the same — B independent windows, the
+    same consumption of Python's ``random`` stream as B dataset items.  A 3-D tensor is one sample."""
+    single = lr.dim() == 3
+    if single:
+        lr, hr = lr[None], hr[None]
     h, w = lr.shape[-2:]
-    rnd_h = random.randint(0, max(0, h - lr_size))
-    rnd_w = random.randint(0, max(0, w - lr_size))
     hs = lr_size * scale
-    rh, rw = int(rnd_h * scale), int(rnd_w * scale)
-    return (lr[..., rnd_h:rnd_h + lr_size, rnd_w:rnd_w + lr_size],
-            hr[..., rh:rh + hs, rw:rw + hs])
+    outl, outh = [], []
+    for b in range(lr.shape[0]):
+        rnd_h = random.randint(0, max(0, h - lr_size))
+        rnd_w = random.randint(0, max(0, w - lr_size))
+        rh, rw = int(rnd_h * scale), int(rnd_w * scale)
+        outl.append(lr[b, :, rnd_h:rnd_h + lr_size, rnd_w:rnd_w + lr_size])
+        outh.append(hr[b, :, rh:rh + hs, rw:rw + hs])
+    if single:
+        return outl[0], outh[0]
+    return torch.stack(outl), torch.stack(outh)
 
 
 def augment(img_list, hflip=True, rot=True):
-    """util.py:94-106 for [...,H,W] tensors: horizontal flip, vertical flip, transpose."""
-    hflip = hflip and random.random() < 0.5
-    vflip = rot and random.random() < 0.5
-    rot90 = rot and random.random() < 0.5
+    """util.py:94-106: horizontal flip, vertical flip, transpose.  For NCHW batches the three coin flips are
+    drawn per SAMPLE (as B dataset items would), applied to the same sample of every tensor in ``img_list``;
+    [C,H,W] tensors are one sample.  Batches need square images when ``rot`` is on (a transposed sample must
+    stack with an un-transposed one), which the reference's fixed-size crops guarantee."""
+    if img_list[0].dim() == 3:
+        return [t[0] for t in augment([t[None] for t in img_list], hflip, rot)]
+    B = img_list[0].shape[0]
+    flags = []
+    for _ in range(B):
+        hf = hflip and random.random() < 0.5
+        vf = rot and random.random() < 0.5
+        r9 = rot and random.random() < 0.5
+        flags.append((hf, vf, r9))
 
-    def _aug(t):
-        if hflip:
+    def _aug(t, f):
+        if f[0]:
             t = t.flip(-1)
-        if vflip:
+        if f[1]:
             t = t.flip(-2)
-        if rot90:
+        if f[2]:
             t = t.transpose(-1, -2)
         return t
-    return [_aug(t) for t in img_list]
+    return [torch.stack([_aug(t[b], flags[b]) for b in range(B)]) for t in img_list]

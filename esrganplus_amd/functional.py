@@ -8,8 +8,14 @@ from . import _lib as L
 
 
 def _draw_seed():
-    # torch's CPU generator -> reproducible under torch.manual_seed (utils/util.py:43-47)
-    return int(torch.randint(0, 2 ** 62, (1,)).item())
+    """Philox key of one training forward: torch's CPU generator (reproducible under torch.manual_seed,
+    utils/util.py:43-47) mixed with the data-parallel rank — every rank seeds torch identically
+    (set_random_seed), and identical keys would inject the SAME GaussianNoise field into the ranks' different
+    local batches instead of independent noise over the global batch."""
+    s = int(torch.randint(0, 2 ** 62, (1,)).item())
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        s = (s ^ (torch.distributed.get_rank() * 0x9E3779B97F4A7C15)) & (2 ** 62 - 1)
+    return s
 
 
 def _needs_grad(module, x):
@@ -133,6 +139,9 @@ def _grad_views(tp):
     return [t.view(sh) for t, sh in zip(flat.split(meta[0]), meta[1])]
 
 
+MAX_TRAIN_SHAPES = 4    # shapes whose training plans (saved activations) a module keeps
+
+
 class _PlanLease:
     """Marks a TrainPlan busy while an autograd graph still references its saved activations."""
 
@@ -151,7 +160,21 @@ class _PlanLease:
 
 def _train_plan(net, wp, dp, B, H, W, dev, noise, explicit):
     key = ('train', B, H, W, net.precision, noise, explicit, wp.generation, str(dev))
-    pool = net._plans.setdefault(key, [])
+    pool = net._plans.get(key)
+    if pool is None:
+        # every shape keeps a full set of saved activations alive: bound the number of shapes (LRU over the
+        # train keys; a pool with a plan still referenced by a live autograd graph is never dropped)
+        tkeys = [k for k in net._plans if isinstance(k, tuple) and k and k[0] == 'train']
+        while len(tkeys) >= MAX_TRAIN_SHAPES:
+            victim = next((k for k in tkeys if not any(tp.busy for tp in net._plans[k])), None)
+            if victim is None:
+                break
+            del net._plans[victim]
+            tkeys.remove(victim)
+        pool = []
+    else:
+        del net._plans[key]              # re-insert below: most recently used last
+    net._plans[key] = pool
     for tp in pool:
         if not tp.busy:
             return tp

@@ -83,3 +83,24 @@ def test_gpu_imresize_rejects_cpu_tensors():
     from esrganplus_amd import data as D
     with pytest.raises(Exception):
         D.imresize(torch.zeros(3, 8, 8), 0.5)
+
+
+def test_crop_and_augment_draw_per_sample():
+    """A batch consumes Python's `random` stream exactly like B dataset items (LRHR_dataset.__getitem__ draws
+    per sample): windows / flips differ between the samples of a batch and equal the per-item results."""
+    from esrganplus_amd import data as D
+    B = 6
+    lr = torch.arange(B * 40 * 48, dtype=torch.float32).reshape(B, 1, 40, 48)
+    hr = torch.arange(B * 160 * 192, dtype=torch.float32).reshape(B, 1, 160, 192)
+    random.seed(11)
+    lb, hb = D.paired_random_crop(lr, hr, 32, 4)
+    random.seed(11)
+    per = [D.paired_random_crop(lr[b], hr[b], 32, 4) for b in range(B)]
+    assert all(torch.equal(lb[b], per[b][0]) and torch.equal(hb[b], per[b][1]) for b in range(B))
+    offs = {(float(lb[b, 0, 0, 0]) - b * 40 * 48) for b in range(B)}
+    assert len(offs) > 1                      # not one shared window
+    random.seed(5)
+    ab = D.augment([lb, hb], True, True)
+    random.seed(5)
+    pa = [D.augment([lb[b], hb[b]], True, True) for b in range(B)]
+    assert all(torch.equal(ab[0][b], pa[b][0]) and torch.equal(ab[1][b], pa[b][1]) for b in range(B))
