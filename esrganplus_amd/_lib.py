@@ -141,7 +141,7 @@ class esr_pack_batch(C.Structure):
 
 
 class esr_rdb_block(C.Structure):
-    _fields_ = [('w', C.c_void_p), ('bias', C.c_void_p * 5), ('x_in', esr_g32), ('x_out', esr_g32),
+    _fields_ = [('w', C.c_void_p), ('bias', C.c_void_p), ('x_in', esr_g32), ('x_out', esr_g32),
                 ('res2', esr_g32), ('layer1', C.c_uint32), ('layer2', C.c_uint32), ('flags', C.c_uint32),
                 ('_pad', C.c_uint32)]
 
@@ -157,7 +157,8 @@ class esr_rdb_chain(C.Structure):
 
 
 class esr_frag_gather(C.Structure):
-    _fields_ = [('src_off', C.c_void_p), ('src_base', C.c_void_p), ('dst', C.c_void_p), ('n', C.c_int64)]
+    _fields_ = [('src_off', C.c_void_p), ('src_base', C.c_void_p), ('dst', C.c_void_p), ('n', C.c_int64),
+                ('piece_bytes', C.c_int32), ('_pad', C.c_int32)]
 
 
 class _op_union(C.Union):

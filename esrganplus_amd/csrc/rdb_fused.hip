@@ -642,7 +642,7 @@ __device__ __forceinline__ void load_bias(const float* bias, const Tile& t, Bias
 // the block-table entry's scalars, read ONCE per block into SGPRs (a field referenced through the table is
 // re-loaded with a vector load + full wait wherever it is used)
 struct BlkS {
-  const float* bias[5];
+  const float* bias;       // [192]: conv1..conv4 (32 each), conv5 (64)
   uint32_t layer1, layer2;
   bool has_res2, full_out;
 };
@@ -837,8 +837,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       // test on them becomes an exec-masked region and every use a fresh vector load
       const bool noisy = p.noise_mode != ESR_NOISE_OFF;
       BlkS bs;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) bs.bias[i] = (const float*)uniform_ptr(blk.bias[i]);
+      bs.bias = (const float*)uniform_ptr(blk.bias);
       bs.layer1 = __builtin_amdgcn_readfirstlane(blk.layer1);
       bs.layer2 = __builtin_amdgcn_readfirstlane(blk.layer2);
       bs.has_res2 = __builtin_amdgcn_readfirstlane((int)(blk.res2.ptr != nullptr)) != 0;
@@ -878,7 +877,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         __syncthreads();
         ws_.g1 = ws_.g2 = 0;
         Bias16 b1, b2, b3, b4, b5a, b5b;
-        load_bias(bs.bias[0], t, b1);
+        load_bias(bs.bias + 0, t, b1);
         trace_ev(p, tile, ev);
         run_phase_res<T, 1>(acc, ws_, 4, smem, t);
         trace_ev(p, tile, ev);
@@ -897,7 +896,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, 0, smem, t);
         __syncthreads();
-        load_bias(bs.bias[1], t, b2);
+        load_bias(bs.bias + 32, t, b2);
         trace_ev(p, tile, ev);
         run_phase_res<T, 2>(acc, ws_, 4, smem, t);
         trace_ev(p, tile, ev);
@@ -910,7 +909,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, CF::KD, smem, t);
         __syncthreads();
-        load_bias(bs.bias[2], t, b3);
+        load_bias(bs.bias + 64, t, b3);
         trace_ev(p, tile, ev);
         run_phase_res<T, 3>(acc, ws_, 4, smem, t);
         trace_ev(p, tile, ev);
@@ -923,7 +922,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, 2 * CF::KD, smem, t);
         __syncthreads();
-        load_bias(bs.bias[3], t, b4);
+        load_bias(bs.bias + 96, t, b4);
         trace_ev(p, tile, ev);
         run_phase_res<T, 4>(acc, ws_, 4, smem, t);
         trace_ev(p, tile, ev);
@@ -939,8 +938,8 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         // the block tail's residuals: x only when it is added explicitly (noise), the RRDB input for every
         // third block; requested here, used after the phase (its first K step lets them stay in flight)
         RowsRaw<T> tx0, tx1, tr0, tr1;
-        load_bias(bs.bias[4], t, b5a);
-        load_bias(bs.bias[4] + 32, t, b5b);
+        load_bias(bs.bias + 128, t, b5a);
+        load_bias(bs.bias + 160, t, b5b);
         if (has_res2) { load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1); }
         trace_ev(p, tile, ev);
         run_phase_res<T, 5>(acc, ws_, 24, smem, t);
@@ -957,8 +956,8 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       } else {
       // =========================== fp32: every stage by DMA ===========================
       Bias16 fb[6];
-      for (int i = 0; i < 5; ++i) load_bias(bs.bias[i], t, fb[i]);
-      load_bias(bs.bias[4] + 32, t, fb[5]);
+      for (int i = 0; i < 5; ++i) load_bias(bs.bias + 32 * i, t, fb[i]);
+      load_bias(bs.bias + 160, t, fb[5]);
       // ---------------- phase 1: x -> conv1..conv5
       issue_w_head<6>(w + CF::phase_off(1), CF::KX, smem, t);
       if (epoch > 0 && !wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
@@ -1088,20 +1087,23 @@ extern "C" int esr_rdb_forward(const esr_rdb_chain* p, esr_stream_t stream) {
 // Fused weight stream of a block = 1 KB fragments gathered from the per-conv packed weights
 // (esr_pack_conv_weights order [cout_block][cin_group][kh][kw][lane][16 B]).
 namespace {
-__global__ void frag_gather_kernel(const esr_frag_gather g) {
-  const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ void frag_gather_kernel(const esr_frag_gather g, const int lanes_per_piece) {
+  const int ppb = 256 / lanes_per_piece;                       // pieces per 256-thread block
+  const int64_t f = (int64_t)blockIdx.x * ppb + (int)threadIdx.x / lanes_per_piece;
   if (f >= g.n) return;
-  const int lane = threadIdx.x & 63;
+  const int lane = (int)threadIdx.x % lanes_per_piece;
   const u32x4 v = *(const u32x4*)((const char*)g.src_base + g.src_off[f] + lane * 16);
-  *(u32x4*)((char*)g.dst + f * 1024 + lane * 16) = v;
+  *(u32x4*)((char*)g.dst + f * (lanes_per_piece * 16) + lane * 16) = v;
 }
 }  // namespace
 
 extern "C" int esr_gather_fragments(const esr_frag_gather* g, esr_stream_t stream) {
-  if (!g || !g->src_off || !g->src_base || !g->dst || g->n <= 0) {
+  const int pb = g ? (g->piece_bytes ? g->piece_bytes : 1024) : 0;
+  if (!g || !g->src_off || !g->dst || g->n <= 0 || pb < 16 || pb > 4096 || (pb & (pb - 1))) {
     esr_set_error("esr_gather_fragments: invalid arguments");
     return ESR_ERR_INVALID;
   }
-  hipLaunchKernelGGL(frag_gather_kernel, dim3((unsigned)((g->n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *g);
+  const int lpp = pb / 16, ppb = 256 / lpp;
+  hipLaunchKernelGGL(frag_gather_kernel, dim3((unsigned)((g->n + ppb - 1) / ppb)), dim3(256), 0, (hipStream_t)stream, *g, lpp);
   return esr_check_launch("frag_gather_kernel");
 }

@@ -169,11 +169,15 @@ class RdbStreams:
         self.cpg = wp.cpg
         self.stream_bytes = L.lib().esr_rdb_weight_stream_bytes(wp.esr_dtype)
         self.arena = torch.zeros(len(self.prefixes) * self.stream_bytes, dtype=torch.uint8, device=wp.device)
+        self.bias = torch.zeros(len(self.prefixes) * 192, dtype=torch.float32, device=wp.device)   # [block][192]
         self._gen = None
         self.ops = None
 
     def w_ptr(self, i):
         return self.arena.data_ptr() + i * self.stream_bytes
+
+    def bias_ptr(self, i):
+        return self.bias.data_ptr() + i * 192 * 4
 
     def _table(self):
         cpg, base = self.cpg, self.wp.arena.data_ptr()
@@ -205,6 +209,17 @@ class RdbStreams:
                                                  self.arena.data_ptr(), self._tab.numel())
             self.ops = L.OpList()
             self.ops.add(L.OP_FRAG_GATHER, 'frag_gather', g)
+            # the biases of a block as one [192] vector: 128-byte pieces straight from the nn.Parameters
+            boffs = []
+            for p in self.prefixes:
+                for k in range(1, 6):
+                    bp = self.wp.entries[p + '.conv%d.0' % k].bias_ptr
+                    boffs += [bp + 128 * q for q in range(2 if k == 5 else 1)]
+            self._btab = torch.tensor(boffs, dtype=torch.int64, device=self.wp.device)
+            gb = L.esr_frag_gather()
+            gb.src_off, gb.src_base, gb.dst, gb.n, gb.piece_bytes = self._btab.data_ptr(), None, self.bias.data_ptr(), len(boffs), 128
+            self.ops.add(L.OP_FRAG_GATHER, 'frag_gather', gb)
+            self._bias_src = tuple(boffs)
         gen = (self.wp.generation, self.wp.pack_count)
         if force or gen != self._gen:
             self.ops.run(stream)
@@ -410,8 +425,7 @@ class Builder:
         for i, (prefix, xi, xo, r2, rrdb_noise) in enumerate(specs):
             b = blocks[i]
             b.w = P.streams.w_ptr(base + i)
-            for k in range(5):
-                b.bias[k] = ent[prefix + '.conv%d.0' % (k + 1)].bias_ptr
+            b.bias = P.streams.bias_ptr(base + i)
             b.x_in, b.x_out = xi.view(0, 64), xo.view(0, 64)
             if r2 is not None:
                 b.res2 = r2.view(0, 64)

@@ -305,7 +305,8 @@ typedef struct esr_amp {
  * All views share one geometry (same wp / H / W); x_out may alias x_in or res2 (pixel-local). */
 typedef struct esr_rdb_block {
   const void* w;            /* fused weight stream of this block */
-  const float* bias[5];     /* fp32 biases of conv1..conv4 (32 each) and conv5 (64): the nn.Parameters themselves */
+  const float* bias;        /* fp32 [192]: biases of conv1..conv4 (32 each) then conv5 (64), gathered by the caller
+                               (esr_gather_fragments with piece_bytes = 128 does it in one launch for a whole net) */
   esr_g32 x_in;             /* 64-channel block input */
   esr_g32 x_out;            /* 64-channel block output */
   esr_g32 res2;             /* RRDB input of the fused RRDB tail; ptr NULL = plain dense block */
@@ -335,12 +336,15 @@ typedef struct esr_rdb_chain {
   uint64_t* trace;          /* measurement only (NULL = off): per tile 64 x uint64 time stamps (100 MHz) */
 } esr_rdb_chain;
 
-/* 1 KB fragment gather: dst[f] = src_base[src_off[f]] for f < n (src_off: DEVICE int64 byte offsets). */
+/* Piece gather: dst[f * piece_bytes ..] = src_base[src_off[f] ..] for f < n (src_off: DEVICE int64 byte offsets;
+ * src_base may be NULL, then they are absolute addresses).  piece_bytes: power of two in 16..4096, 0 = 1024 (one MFMA
+ * A fragment). */
 typedef struct esr_frag_gather {
   const int64_t* src_off;
   const void* src_base;
   void* dst;
   int64_t n;
+  int32_t piece_bytes, _pad;
 } esr_frag_gather;
 
 enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_NOISE_FILL = 4,
