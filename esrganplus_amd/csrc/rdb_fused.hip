@@ -48,6 +48,10 @@
 
 #include "mfma_tile.h"
 
+#ifndef ESR_ABL
+#define ESR_ABL 0   // timing ablations (development only; results are wrong when non-zero)
+#endif
+
 namespace {
 
 constexpr int R = 4;                        // output rows per wave
@@ -358,6 +362,57 @@ __device__ __forceinline__ void unit_mma(Acc24& acc, const uint32_t lds_b, const
   });
 }
 
+// Pipelined form (resident path): units run back to back.  The B fragments and the first A fragments of unit
+// u+1 are requested during unit u's LAST cout block — after `mid()`, the next unit's DMA wait + barrier, which
+// therefore hides under the remaining MFMAs — so a unit opens straight with its MFMAs.  Without this a unit pays
+// wait + barrier + first-fragment LDS latency (~280 cycles, 37 units per block) with the matrix pipe idle.
+struct UFrags { u32x4 bf[R + 2]; u32x4 a0[3]; };
+template <typename T, int P, bool FIRST, bool PRE, bool NXT, typename ISSUE, typename MID>
+__device__ __forceinline__ void unit_mma_p(Acc24& acc, UFrags& cur, UFrags& nxt, const uint32_t lds_b, const uint32_t lds_w,
+                                           const uint32_t lds_b_n, const uint32_t lds_w_n, ISSUE&& issue, MID&& mid) {
+  constexpr int NB = 7 - P;
+  u32x4 afb[3];                                   // A fragments of the odd blocks; even blocks use cur.a0
+  if constexpr (!PRE) {
+    sfor<R + 2>([&](auto IR) __attribute__((always_inline)) { lds_read16<decltype(IR)::value * IW * 32>(cur.bf[decltype(IR)::value], lds_b); });
+    sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(cur.a0[decltype(KH)::value], lds_w); });
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur.bf[0]), "+v"(cur.bf[1]), "+v"(cur.bf[2]), "+v"(cur.bf[3]), "+v"(cur.bf[4]),
+               "+v"(cur.bf[5]), "+v"(cur.a0[0]), "+v"(cur.a0[1]), "+v"(cur.a0[2]));
+  sfor<NB>([&](auto BI) __attribute__((always_inline)) {
+    constexpr int bi = decltype(BI)::value;
+    constexpr int blk = P - 1 + bi;
+    u32x4 (&af)[3] = (bi & 1) ? afb : cur.a0;
+    u32x4 (&an)[3] = (bi & 1) ? cur.a0 : afb;
+    sfor<R + 2>([&](auto IR) __attribute__((always_inline)) {
+      constexpr int ir = decltype(IR)::value;
+      sfor<3>([&](auto KH) __attribute__((always_inline)) {
+        constexpr int kh = decltype(KH)::value;
+        constexpr int r = ir - kh;
+        if constexpr (r >= 0 && r < R) mma_cls<T, acc_in_agpr(blk), FIRST && kh == 0 && blk < 4>(acc_br<blk, r>(acc), af[kh], cur.bf[ir]);
+      });
+      if constexpr (ir == 2) {                    // after MFMA 6 of 12
+        if constexpr (bi + 1 < NB && !(ESR_ABL & 2)) {
+          sfor<3>([&](auto KH) __attribute__((always_inline)) {
+            lds_read16<((bi + 1) * 3 + decltype(KH)::value) * 1024>(an[decltype(KH)::value], lds_w);
+          });
+        } else if constexpr (NXT) {
+          if constexpr (!(ESR_ABL & 8)) mid();
+          if constexpr (!(ESR_ABL & 4)) sfor<R + 2>([&](auto IR2) __attribute__((always_inline)) { lds_read16<decltype(IR2)::value * IW * 32>(nxt.bf[decltype(IR2)::value], lds_b_n); });
+          sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(nxt.a0[decltype(KH)::value], lds_w_n); });
+        }
+      }
+    });
+    if constexpr (bi + 1 < NB) lds_wait3(an[0], an[1], an[2]);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(bi);
+    if constexpr (bi + 1 == NB) {
+#pragma unroll
+      for (int i = NB; i < 5; ++i) issue(i);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
 // ---- one phase: K steps x 3 column taps over NB cout blocks ----------------------------------------
 // The first three weight units are already in flight (issue_w_head, before the neighbour poll).
 template <int NB> __device__ __forceinline__ void issue_w_head(const char* wsrc, int K, char* smem, const Tile& t) {
@@ -443,39 +498,47 @@ __device__ __forceinline__ StreamItem<T> item_after(const WStream& s, const int 
 template <typename T, int P>
 __device__ __forceinline__ void run_phase_res(Acc24& acc, WStream& s, int older, char* smem, const Tile& t) {
   using CF = Cfg<T>;
-  constexpr int K = CF::ksteps(P);
+  constexpr int K = CF::ksteps(P), NU = 3 * K;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
-  auto kstep = [&](const int c, auto FIRSTC, auto LASTC) __attribute__((always_inline)) {   // see run_phase
-    constexpr bool firstc = decltype(FIRSTC)::value, lastc = decltype(LASTC)::value;
+  UFrags fa, fb;
+  // unit 0: its weights were issued before the phase began (`older` = loads requested since then — bias,
+  // tail residuals — may stay in flight)
+  wait_vm_dyn(s.g1 + s.g2 + older);
+  __builtin_amdgcn_s_barrier();
+  sfor<K>([&](auto CI) __attribute__((always_inline)) {
+    constexpr int c = decltype(CI)::value;
     sfor<3>([&](auto KW) __attribute__((always_inline)) {
       constexpr int kw = decltype(KW)::value;
-      // this unit's weights were issued 3 units ago; `older` = loads requested before the phase began
-      // (the block tail's residuals) that may stay in flight while the units consumed predate them
-      wait_vm_dyn(s.g1 + s.g2 + ((firstc && older) ? older : 0));
-      __builtin_amdgcn_s_barrier();       // unit visible to all waves; all waves done with the previous unit
+      constexpr int u = 3 * c + kw;
+      constexpr bool lastc = c == K - 1;
+      constexpr int cn = kw == 2 ? c + 1 : c, kwn = kw == 2 ? 0 : kw + 1;      // the next unit
       const StreamItem<T> it = item_after<T, P, kw>(s, c, lastc);
       char* const dst = smem + WOFF + ((s.gu + 3) & (WR - 1)) * WSLOT;
       const char* const src = it.src + t.lane * 16;
       const int nf = it.nf;
       const uint32_t lb = lds_rows + c * ASLOT + t.colofs[kw];
       const uint32_t lw = lds0 + WOFF + (s.gu & (WR - 1)) * WSLOT + t.lane * 16;
-      unit_mma<T, P, P == 1 && firstc && kw == 0, true>(acc, lb, lw, [&](int i) __attribute__((always_inline)) {
+      const uint32_t lbn = lds_rows + cn * ASLOT + t.colofs[kwn];
+      const uint32_t lwn = lds0 + WOFF + ((s.gu + 1) & (WR - 1)) * WSLOT + t.lane * 16;
+      int cnt = 0;                         // DMAs this wave has issued during this unit
+      auto issue = [&](int i) __attribute__((always_inline)) {
         const int q = t.wave + 4 * i;
-        if (q < nf) dma16(src + q * 1024, dst + q * 1024);
-      });
+        if (q < nf && !(ESR_ABL & 1)) { dma16(src + q * 1024, dst + q * 1024); ++cnt; }
+      };
+      auto mid = [&]() __attribute__((always_inline)) {
+        // the next unit's weights were issued two units ago: everything since may stay in flight
+        wait_vm_dyn(s.g1 + cnt + ((u + 1 <= 2) ? older : 0));
+        __builtin_amdgcn_s_barrier();      // next unit visible to all waves; all waves past this unit's LDS reads
+      };
+      UFrags& cur = (u & 1) ? fb : fa;
+      UFrags& nxt = (u & 1) ? fa : fb;
+      unit_mma_p<T, P, P == 1 && u == 0, (u > 0), (u + 1 < NU)>(acc, cur, nxt, lb, lw, lbn, lwn, issue, mid);
       s.g2 = s.g1;
-      s.g1 = (nf + 3 - t.wave) >> 2;
+      s.g1 = cnt;
       ++s.gu;
     });
-  };
-  if constexpr (K == 1) kstep(0, std::true_type{}, std::true_type{});
-  else {
-    kstep(0, std::true_type{}, std::false_type{});
-#pragma unroll 1
-    for (int c = 1; c < K - 1; ++c) kstep(c, std::false_type{}, std::false_type{});
-    kstep(K - 1, std::false_type{}, std::true_type{});
-  }
+  });
   __builtin_amdgcn_s_barrier();           // every wave done with the last unit's slots
 }
 
@@ -563,7 +626,7 @@ __device__ __forceinline__ void run_1x1(Acc24& acc, const char* w1, const char* 
 
 // measurement only: time stamps (100 MHz) of the tile's SECOND block (the first one stages x differently)
 __device__ __forceinline__ void trace_ev(const esr_rdb_chain& p, int tile, int& ev) {
-  if (p.trace && threadIdx.x == 0 && ev >= 0 && ev < 64) p.trace[(int64_t)tile * 64 + ev] = __builtin_amdgcn_s_memrealtime();
+  if (p.trace && threadIdx.x == 0 && ev >= 0 && ev < 64) p.trace[(int64_t)tile * 64 + ev] = (ESR_ABL & 16) ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();
   if (ev >= 0) ++ev;
 }
 
