@@ -293,13 +293,13 @@ __device__ __forceinline__ void issue_a(const char* plane, int sa, char* smem, c
 // writes them into the stage slots the next phase reads (slot = channel group of the slice).  Only the
 // 1-pixel ring around the tile is fetched (sc1 loads, after the neighbours published): one 16-byte load
 // + one ds_write per thread and stage.
-template <int K> __device__ __forceinline__ void halo_fetch(const ImgView& v, int g0, char* smem, const Tile& t) {
+template <int K> __device__ __forceinline__ void halo_fetch(const ImgView& v, int g0, char* smem, const Tile& t, int slot0 = 0) {
   if (t.halo_src >= 0) {
     u32x4 q[K];
 #pragma unroll
     for (int c = 0; c < K; ++c) q[c] = __builtin_amdgcn_raw_buffer_load_b128(v.r, (g0 + c) * v.gs + t.halo_src, 0, 16);
 #pragma unroll
-    for (int c = 0; c < K; ++c) *(u32x4*)(smem + c * ASLOT + t.halo_dst) = q[c];
+    for (int c = 0; c < K; ++c) *(u32x4*)(smem + (slot0 + c) * ASLOT + t.halo_dst) = q[c];
   }
 }
 // the lane's packed 16 channels of row r (own pixel) -> stage slot `slot`
@@ -362,52 +362,142 @@ __device__ __forceinline__ void unit_mma(Acc24& acc, const uint32_t lds_b, const
   });
 }
 
-// Pipelined form (resident path): units run back to back.  The B fragments and the first A fragments of unit
-// u+1 are requested during unit u's LAST cout block — after `mid()`, the next unit's DMA wait + barrier, which
-// therefore hides under the remaining MFMAs — so a unit opens straight with its MFMAs.  Without this a unit pays
-// wait + barrier + first-fragment LDS latency (~280 cycles, 37 units per block) with the matrix pipe idle.
-struct UFrags { u32x4 bf[R + 2]; u32x4 a0[3]; };
-template <typename T, int P, bool FIRST, bool PRE, bool NXT, typename ISSUE, typename MID>
-__device__ __forceinline__ void unit_mma_p(Acc24& acc, UFrags& cur, UFrags& nxt, const uint32_t lds_b, const uint32_t lds_w,
-                                           const uint32_t lds_b_n, const uint32_t lds_w_n, ISSUE&& issue, MID&& mid) {
-  constexpr int NB = 7 - P;
-  u32x4 afb[3];                                   // A fragments of the odd blocks; even blocks use cur.a0
-  if constexpr (!PRE) {
-    sfor<R + 2>([&](auto IR) __attribute__((always_inline)) { lds_read16<decltype(IR)::value * IW * 32>(cur.bf[decltype(IR)::value], lds_b); });
-    sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(cur.a0[decltype(KH)::value], lds_w); });
+// ---- resident path (fp16): the unit schedule of a dense block ----------------------------------------
+// The five convs of a block form a dependent chain: conv_p -> epilogue (x_p) -> halo exchange with the 8
+// neighbouring tiles -> conv_{p+1}.  Of a phase's MFMAs (stage x_{p-1} into conv_p..conv5) only conv_p's
+// are on that chain, so every phase is split:
+//     crit_p   stage x_{p-1} -> conv_p only                 (cout block p-1; conv5: blocks 4, 5)
+//     epilogue x_p: border pixels to memory, own pixels to the LDS
+//     bulk_p   stage x_{p-1} -> conv_{p+1}..conv5           (blocks p..5) — nothing waits for these, so the
+//              hand-off hides under them: the stores drain while the first bulk units run, the flag goes out
+//              at the second unit's barrier, and the neighbours' flags are long up when the bulk ends
+//     poll, fetch x_p's halo ring, crit_{p+1} ...
+// Units (one weight-ring slot each, in stream order; K = 4 K-steps for x, 2 for x1..x4):
+//     crit_p (p<5): K units (c)      = 3 kw x 1 block x 3 kh  =  9 fragments, 36 MFMAs
+//     bulk_p (p<5): 3K units (c, kw) = (5-p)+1 blocks x 3 kh  = 15/12/9/6 fragments
+//     1x1         : 1 unit after bulk_1 (K fragments)
+//     crit_5      : 3K units (c, kw) = 2 blocks x 3 kh        =  6 fragments
+// Stage slots: x -> 0..3; x1 -> 0,1 (after the 1x1 has read x); x2 -> 2,3; x3 -> 0,1; x4 -> 2,3; the block
+// output -> 0..3.  A stage is overwritten only after the bulk that read its predecessor in those slots.
+enum { U_CRIT = 0, U_BULK = 1, U_ONE = 2 };
+struct UDesc { int kind, P, c, kw, nf, off; };        // off: fragments from the start of the block's stream
+template <typename T> struct Sched {
+  using CF = Cfg<T>;
+  // idx < 0: {.., nf = number of units, off = fragments of the whole stream}
+  static constexpr UDesc at(int idx) {
+    int i = 0, off = 0;
+    for (int P = 1; P <= 5; ++P) {
+      const int K = CF::ksteps(P);
+      if (P < 5) {
+        for (int c = 0; c < K; ++c) { if (i == idx) return {U_CRIT, P, c, 0, 9, off}; ++i; off += 9; }
+        const int nf = (6 - P) * 3;
+        for (int c = 0; c < K; ++c)
+          for (int kw = 0; kw < 3; ++kw) { if (i == idx) return {U_BULK, P, c, kw, nf, off}; ++i; off += nf; }
+        if (P == 1) { if (i == idx) return {U_ONE, 1, 0, 0, CF::KX, off}; ++i; off += CF::KX; }
+      } else {
+        for (int c = 0; c < K; ++c)
+          for (int kw = 0; kw < 3; ++kw) { if (i == idx) return {U_CRIT, 5, c, kw, 6, off}; ++i; off += 6; }
+      }
+    }
+    return {-1, 0, 0, 0, i, off};
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur.bf[0]), "+v"(cur.bf[1]), "+v"(cur.bf[2]), "+v"(cur.bf[3]), "+v"(cur.bf[4]),
-               "+v"(cur.bf[5]), "+v"(cur.a0[0]), "+v"(cur.a0[1]), "+v"(cur.a0[2]));
-  sfor<NB>([&](auto BI) __attribute__((always_inline)) {
-    constexpr int bi = decltype(BI)::value;
-    constexpr int blk = P - 1 + bi;
-    u32x4 (&af)[3] = (bi & 1) ? afb : cur.a0;
-    u32x4 (&an)[3] = (bi & 1) ? cur.a0 : afb;
+  static constexpr int N = at(-1).nf;
+  static constexpr int first(int kind, int P) {
+    for (int i = 0; i < N; ++i) if (at(i).kind == kind && at(i).P == P) return i;
+    return -1;
+  }
+  static constexpr int end(int kind, int P) {
+    int e = -1;
+    for (int i = 0; i < N; ++i) if (at(i).kind == kind && at(i).P == P) e = i + 1;
+    return e;
+  }
+  static constexpr int nkw(const UDesc d) { return (d.kind == U_CRIT && d.P < 5) ? 3 : 1; }     // B-fragment sets
+  static constexpr int nblk(const UDesc d) { return d.kind == U_BULK ? 6 - d.P : (d.P < 5 ? 1 : 2); }
+  static constexpr int blk0(const UDesc d) { return d.kind == U_BULK ? d.P : d.P - 1; }
+  static constexpr int slot(const UDesc d) { return ((d.P == 3 || d.P == 5) ? 2 : 0) + d.c; }  // stage slot
+  // fragments of unit j, continuing into the next block's stream (none: that block does not exist)
+  static constexpr int nf_at(int j, bool has_next) { return j < N ? at(j).nf : (has_next ? at(j - N).nf : 0); }
+  // Counted waits.  Unit i's weights are requested during unit i-3 (wave w copies fragments w, w+4, ..: one
+  // per step, the rest after the last step), so every wave has requested AT LEAST nf >> 2 fragments of a unit.
+  // Vector memory operations retire in order: `vmcnt(n)` with n = the requests certainly issued SINCE the
+  // wanted ones proves those landed whatever else (epilogue stores, bias / halo loads) is in flight as well.
+  //   top(i): before unit i, units i+1 and i+2 were requested since;
+  //   mid(i): opening unit i+1 inside unit i's last step: unit i+2, and unit i+3's first steps(i)-1 requests.
+  static constexpr int steps(int i) { return nkw(at(i)) * nblk(at(i)); }
+  static constexpr int wait_top(int i, bool has_next) { return (nf_at(i + 1, has_next) >> 2) + (nf_at(i + 2, has_next) >> 2); }
+  static constexpr int wait_mid(int i, bool has_next) {
+    const int part = nf_at(i + 3, has_next) >> 2, done = steps(i) - 1;
+    return (nf_at(i + 2, has_next) >> 2) + (part < done ? part : done);
+  }
+  // B-fragment sets consumed by units [i0, i): which of the two register sets unit i starts on
+  static constexpr int parity(int i0, int i) {
+    int p = 0;
+    for (int u = i0; u < i; ++u) p += nkw(at(u));
+    return p & 1;
+  }
+};
+
+// One unit = NKW x NBLK steps of 12 MFMAs (3 kh x 4 rows against one set of 6 B fragments).  Units run back
+// to back: the B fragments and first A fragments of the NEXT unit are requested during this unit's last
+// step — after `mid()`, the next unit's DMA wait + barrier, which therefore hides under the remaining
+// MFMAs — into the other register set, so a unit opens straight with its MFMAs.
+struct UFrags { u32x4 bf[R + 2]; u32x4 a0[3]; };
+template <typename T, int BLK0, int NBLK, int NKW, bool FIRST, bool PRE, bool NXT, int PAR, typename ISSUE, typename MID>
+__device__ __forceinline__ void unit_steps(Acc24& acc, UFrags (&f)[2], const uint32_t (&lb)[3], const uint32_t lw,
+                                           const uint32_t lbn, const uint32_t lwn, ISSUE&& issue, MID&& mid) {
+  constexpr int NS = NKW * NBLK;
+  constexpr int NPAR = (PAR + NKW) & 1;           // the set the next unit starts on
+  static_assert(NKW == 1 || NKW == 3, "the next unit's set must differ from this unit's last");
+  u32x4 afb[3];                                   // A fragments of the odd steps; even steps use f[PAR].a0
+  u32x4 (&a0)[3] = f[PAR].a0;
+  if constexpr (!PRE) {
+    sfor<R + 2>([&](auto IR) __attribute__((always_inline)) { lds_read16<decltype(IR)::value * IW * 32>(f[PAR].bf[decltype(IR)::value], lb[0]); });
+    sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(a0[decltype(KH)::value], lw); });
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[PAR].bf[0]), "+v"(f[PAR].bf[1]), "+v"(f[PAR].bf[2]), "+v"(f[PAR].bf[3]),
+               "+v"(f[PAR].bf[4]), "+v"(f[PAR].bf[5]), "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]));
+  sfor<NS>([&](auto SI) __attribute__((always_inline)) {
+    constexpr int s = decltype(SI)::value;
+    constexpr int kwi = s / NBLK, bi = s % NBLK, blk = BLK0 + bi;
+    constexpr int set = (PAR + kwi) & 1;
+    constexpr bool newset = s + 1 < NS && (s + 1) / NBLK != kwi;    // the next step reads another column tap
+    u32x4 (&af)[3] = (s & 1) ? afb : a0;
+    u32x4 (&an)[3] = (s & 1) ? a0 : afb;
+    u32x4 (&bf)[R + 2] = f[set].bf;
+    u32x4 (&bn)[R + 2] = f[set ^ 1].bf;
     sfor<R + 2>([&](auto IR) __attribute__((always_inline)) {
       constexpr int ir = decltype(IR)::value;
       sfor<3>([&](auto KH) __attribute__((always_inline)) {
         constexpr int kh = decltype(KH)::value;
         constexpr int r = ir - kh;
-        if constexpr (r >= 0 && r < R) mma_cls<T, acc_in_agpr(blk), FIRST && kh == 0 && blk < 4>(acc_br<blk, r>(acc), af[kh], cur.bf[ir]);
+        if constexpr (r >= 0 && r < R) mma_cls<T, acc_in_agpr(blk), FIRST && kwi == 0 && kh == 0 && blk < 4>(acc_br<blk, r>(acc), af[kh], bf[ir]);
       });
+      if constexpr (ir == 1 && newset && !(ESR_ABL & 4)) {     // after MFMA 3 of 12: the other set's last readers are a step back
+        sfor<R + 2>([&](auto IR2) __attribute__((always_inline)) { lds_read16<decltype(IR2)::value * IW * 32>(bn[decltype(IR2)::value], lb[newset ? kwi + 1 : 0]); });
+      }
       if constexpr (ir == 2) {                    // after MFMA 6 of 12
-        if constexpr (bi + 1 < NB && !(ESR_ABL & 2)) {
-          sfor<3>([&](auto KH) __attribute__((always_inline)) {
-            lds_read16<((bi + 1) * 3 + decltype(KH)::value) * 1024>(an[decltype(KH)::value], lds_w);
-          });
+        if constexpr (s + 1 < NS) {
+          if constexpr (!(ESR_ABL & 2))
+            sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<((s + 1) * 3 + decltype(KH)::value) * 1024>(an[decltype(KH)::value], lw); });
         } else if constexpr (NXT) {
           if constexpr (!(ESR_ABL & 8)) mid();
-          if constexpr (!(ESR_ABL & 4)) sfor<R + 2>([&](auto IR2) __attribute__((always_inline)) { lds_read16<decltype(IR2)::value * IW * 32>(nxt.bf[decltype(IR2)::value], lds_b_n); });
-          sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(nxt.a0[decltype(KH)::value], lds_w_n); });
+          if constexpr (!(ESR_ABL & 4))
+            sfor<R + 2>([&](auto IR2) __attribute__((always_inline)) { lds_read16<decltype(IR2)::value * IW * 32>(f[NPAR].bf[decltype(IR2)::value], lbn); });
+          sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(f[NPAR].a0[decltype(KH)::value], lwn); });
         }
       }
     });
-    if constexpr (bi + 1 < NB) lds_wait3(an[0], an[1], an[2]);
+    if constexpr (s + 1 < NS) {
+      if constexpr (newset)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]), "+v"(bn[4]), "+v"(bn[5]),
+                     "+v"(an[0]), "+v"(an[1]), "+v"(an[2]));
+      else lds_wait3(an[0], an[1], an[2]);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    issue(bi);
-    if constexpr (bi + 1 == NB) {
+    issue(s);
+    if constexpr (s + 1 == NS) {
 #pragma unroll
-      for (int i = NB; i < 5; ++i) issue(i);
+      for (int i = NS; i < 5; ++i) issue(i);
     }
     __builtin_amdgcn_sched_barrier(0);
   });
@@ -467,102 +557,86 @@ __device__ __forceinline__ void run_phase(Acc24& acc, const char* wsrc, const ch
   for (int c = 1; c < K; ++c) kstep(c, std::false_type{});
 }
 
-// Resident form: the K stages of the slice already sit in activation slots 0..K-1; only weights stream,
-// and they stream CONTINUOUSLY across phases and blocks: the unit consumed now sits in ring slot gu & 3,
-// and while it runs the wave issues (between its MFMA groups) its share of the unit 3 places further down
-// the stream — during a phase's last K step those are the next phase's first units (after phase 1 the
-// 1x1's fragments come first; after phase 5 the next block's phase 1).
+// Resident form: the stages sit in activation slots (Sched::slot); only weights stream, and they stream
+// CONTINUOUSLY across units, phases and blocks: unit i of a block sits in ring slot (ring + i) & 3, and while
+// it runs the wave issues (between its steps) its share of the unit 3 places further down the schedule (the
+// next block's stream after this block's last units).  Everything about a unit except the ring position and
+// "is there a next block" is a compile-time constant: the units execute once per block out of a cold
+// instruction cache, where every data-dependent branch costs a fetch round trip.
 struct WStream {
   const char* w;       // this block's fused weight stream
   const char* wnext;   // the next block's (nullptr: none)
-  int gu;              // running unit counter (ring slot = gu & 3)
-  int g1, g2;          // DMAs this wave issued during the previous two units
+  int ring;            // ring slot of this block's unit 0
 };
-template <typename T> struct StreamItem { const char* src; int nf; };
-// the item that is 3 places after unit (c, kw) of phase P
-template <typename T, int P, int KW>
-__device__ __forceinline__ StreamItem<T> item_after(const WStream& s, const int c, const bool lastc) {
-  using CF = Cfg<T>;
-  constexpr int NF = (7 - P) * 3;
-  if (!lastc) return {s.w + CF::phase_off(P) + (int64_t)(3 * c + KW + 3) * NF * 1024, NF};
-  if constexpr (P == 1) {
-    if constexpr (KW == 0) return {s.w + CF::phase_off(6), CF::KX};                       // the 1x1
-    else return {s.w + CF::phase_off(2) + (KW - 1) * 15 * 1024, 15};
-  } else if constexpr (P < 5) {
-    constexpr int NFN = (6 - P) * 3;
-    return {s.w + CF::phase_off(P + 1) + KW * NFN * 1024, NFN};
-  } else {
-    return {s.wnext ? s.wnext + KW * 18 * 1024 : nullptr, s.wnext ? 18 : 0};
+template <typename T, int A, int B> __device__ __forceinline__ void wait_units(const WStream& s) {
+  if constexpr (A == B) wait_vm<A>();
+  else { if (s.wnext) wait_vm<A>(); else wait_vm<B>(); }
+}
+// this wave's share of the unit 3 places after unit I: step i's request (q = wave + 4 i)
+template <typename T, int I>
+__device__ __forceinline__ void issue_ahead(const WStream& s, const Tile& t, char* smem, int i) {
+  using S = Sched<T>;
+  constexpr int J = I + 3;
+  constexpr bool wrap = J >= S::N;
+  constexpr UDesc dj = S::at(wrap ? J - S::N : J);
+  if (ESR_ABL & 1) return;
+  if (4 * i >= dj.nf) return;
+  if (wrap && !s.wnext) return;
+  const int q = t.wave + 4 * i;
+  if (4 * i + 3 < dj.nf || q < dj.nf) {
+    const char* src = (wrap ? s.wnext : s.w) + (dj.off + q) * 1024 + t.lane * 16;
+    char* dst = smem + WOFF + ((s.ring + J) & (WR - 1)) * WSLOT + q * 1024;
+    dma16(src, dst);
   }
 }
-template <typename T, int P>
-__device__ __forceinline__ void run_phase_res(Acc24& acc, WStream& s, int older, char* smem, const Tile& t) {
-  using CF = Cfg<T>;
-  constexpr int K = CF::ksteps(P), NU = 3 * K;
+// units [I0, I1) of the schedule, back to back.  `hook(I)` runs inside unit I after the barrier that opens
+// unit I+1 (every wave has waited for everything older than unit I+2's requests by then).
+struct NoHook { template <typename X> __device__ __forceinline__ void operator()(X) const {} };
+template <typename T, int I0, int I1, typename HOOK = NoHook>
+__device__ __forceinline__ void run_units(Acc24& acc, const WStream& s, char* smem, const Tile& t, HOOK&& hook = NoHook{}) {
+  using S = Sched<T>;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
-  UFrags fa, fb;
-  // unit 0: its weights were issued before the phase began (`older` = loads requested since then — bias,
-  // tail residuals — may stay in flight)
-  wait_vm_dyn(s.g1 + s.g2 + older);
+  UFrags f[2];
+  wait_units<T, S::wait_top(I0, true), S::wait_top(I0, false)>(s);      // the first unit's weights
   __builtin_amdgcn_s_barrier();
-  sfor<K>([&](auto CI) __attribute__((always_inline)) {
-    constexpr int c = decltype(CI)::value;
-    sfor<3>([&](auto KW) __attribute__((always_inline)) {
-      constexpr int kw = decltype(KW)::value;
-      constexpr int u = 3 * c + kw;
-      constexpr bool lastc = c == K - 1;
-      constexpr int cn = kw == 2 ? c + 1 : c, kwn = kw == 2 ? 0 : kw + 1;      // the next unit
-      const StreamItem<T> it = item_after<T, P, kw>(s, c, lastc);
-      char* const dst = smem + WOFF + ((s.gu + 3) & (WR - 1)) * WSLOT;
-      const char* const src = it.src + t.lane * 16;
-      const int nf = it.nf;
-      const uint32_t lb = lds_rows + c * ASLOT + t.colofs[kw];
-      const uint32_t lw = lds0 + WOFF + (s.gu & (WR - 1)) * WSLOT + t.lane * 16;
-      const uint32_t lbn = lds_rows + cn * ASLOT + t.colofs[kwn];
-      const uint32_t lwn = lds0 + WOFF + ((s.gu + 1) & (WR - 1)) * WSLOT + t.lane * 16;
-      int cnt = 0;                         // DMAs this wave has issued during this unit
-      auto issue = [&](int i) __attribute__((always_inline)) {
-        const int q = t.wave + 4 * i;
-        if (q < nf && !(ESR_ABL & 1)) { dma16(src + q * 1024, dst + q * 1024); ++cnt; }
-      };
-      auto mid = [&]() __attribute__((always_inline)) {
-        // the next unit's weights were issued two units ago: everything since may stay in flight
-        wait_vm_dyn(s.g1 + cnt + ((u + 1 <= 2) ? older : 0));
-        __builtin_amdgcn_s_barrier();      // next unit visible to all waves; all waves past this unit's LDS reads
-      };
-      UFrags& cur = (u & 1) ? fb : fa;
-      UFrags& nxt = (u & 1) ? fa : fb;
-      unit_mma_p<T, P, P == 1 && u == 0, (u > 0), (u + 1 < NU)>(acc, cur, nxt, lb, lw, lbn, lwn, issue, mid);
-      s.g2 = s.g1;
-      s.g1 = cnt;
-      ++s.gu;
-    });
+  sfor<I1 - I0>([&](auto II) __attribute__((always_inline)) {
+    constexpr int I = I0 + decltype(II)::value;
+    constexpr UDesc d = S::at(I);
+    constexpr UDesc dn = S::at(I + 1 < I1 ? I + 1 : I);
+    constexpr int NKW = S::nkw(d);
+    const uint32_t lrow = lds_rows + S::slot(d) * ASLOT;
+    const uint32_t lb[3] = {lrow + t.colofs[NKW == 3 ? 0 : d.kw], lrow + t.colofs[1], lrow + t.colofs[2]};
+    const uint32_t lw = lds0 + WOFF + ((s.ring + I) & (WR - 1)) * WSLOT + t.lane * 16;
+    const uint32_t lbn = lds_rows + S::slot(dn) * ASLOT + t.colofs[S::nkw(dn) == 3 ? 0 : dn.kw];
+    const uint32_t lwn = lds0 + WOFF + ((s.ring + I + 1) & (WR - 1)) * WSLOT + t.lane * 16;
+    auto issue = [&](int i) __attribute__((always_inline)) { issue_ahead<T, I>(s, t, smem, i); };
+    auto mid = [&]() __attribute__((always_inline)) {
+      wait_units<T, S::wait_mid(I, true), S::wait_mid(I, false)>(s);   // the next unit's weights
+      __builtin_amdgcn_s_barrier();        // next unit visible to all waves; all waves past this unit's LDS reads
+      hook(std::integral_constant<int, I>{});
+    };
+    unit_steps<T, S::blk0(d), S::nblk(d), NKW, (d.P == 1 && d.c == 0 && d.kw == 0), (I > I0), (I + 1 < I1), S::parity(I0, I)>(
+        acc, f, lb, lw, lbn, lwn, issue, mid);
   });
-  __builtin_amdgcn_s_barrier();           // every wave done with the last unit's slots
+  __builtin_amdgcn_s_barrier();            // every wave done with the last unit's slots
 }
 
 // P = conv1x1(x) from the resident x stages (slots 0..KX-1); its fragments are one unit of the weight
-// stream (between phase 1 and phase 2) and it issues phase 2's third unit.
+// stream (after bulk_1).
 template <typename T>
-__device__ __forceinline__ void run_1x1_res(Acc24& acc, WStream& s, char* smem, const Tile& t) {
+__device__ __forceinline__ void run_1x1_res(Acc24& acc, const WStream& s, char* smem, const Tile& t) {
   using CF = Cfg<T>;
+  using S = Sched<T>;
   constexpr int K = CF::KX;
+  constexpr int I = S::first(U_ONE, 1);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lb = lds0 + t.wave * (R * IW * 32) + IW * 32 + t.colofs[1];   // centre tap: rows 1..4, col j+1
-  const uint32_t lw = lds0 + WOFF + (s.gu & (WR - 1)) * WSLOT + t.lane * 16;
-  {
-    const char* src = s.w + CF::phase_off(2) + 2 * 15 * 1024 + t.lane * 16;
-    char* dst = smem + WOFF + ((s.gu + 3) & (WR - 1)) * WSLOT;
+  const uint32_t lw = lds0 + WOFF + ((s.ring + I) & (WR - 1)) * WSLOT + t.lane * 16;
+  wait_units<T, S::wait_top(I, true), S::wait_top(I, false)>(s);
+  __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = t.wave + 4 * i;
-      if (q < 15) dma16(src + q * 1024, dst + q * 1024);
-    }
-    s.g2 = s.g1;
-    s.g1 = (15 + 3 - t.wave) >> 2;
-    ++s.gu;
-  }
+  for (int i = 0; i < 5; ++i) issue_ahead<T, I>(s, t, smem, i);
   sfor<K>([&](auto CI) __attribute__((always_inline)) {
     constexpr int c = decltype(CI)::value;
     u32x4 a, b0, b1, b2, b3;
@@ -709,7 +783,10 @@ struct BlkS {
   uint32_t layer1, layer2;
   bool has_res2, full_out;
 };
-template <typename T, int BLK, int MODE, int LW = 0>
+// NOISE (MODE 3): false = the instantiation without the Philox layers and the explicit `+ x` (the fp16 path's
+// common case takes it through one uniform branch: the tail is executed once per block out of a cold
+// instruction cache, so what is not needed should not be in the way)
+template <typename T, int BLK, int MODE, int LW = 0, bool NOISE = true>
 __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, const BlkS& blk, const Bias16& bias,
                                          const ImgView& out, int out_cb, int ch_cb, const RowsRaw<T>* ex,
                                          const RowsRaw<T>* r2, bool has_res2, const Tile& t, char* smem = nullptr,
@@ -721,8 +798,8 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
   const f32x4 (&bq)[4] = bias.q;
   const int wp32 = p.dense.wp * 32;
   const uint32_t layer1 = blk.layer1, layer2 = blk.layer2;
-  const bool n1 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && layer1 != ESR_NO_LAYER;
-  const bool n2 = MODE == 3 && p.noise_mode == ESR_NOISE_PHILOX && layer2 != ESR_NO_LAYER && has_res2;
+  const bool n1 = MODE == 3 && NOISE && p.noise_mode == ESR_NOISE_PHILOX && layer1 != ESR_NO_LAYER;
+  const bool n2 = MODE == 3 && NOISE && p.noise_mode == ESR_NOISE_PHILOX && layer2 != ESR_NO_LAYER && has_res2;
   uint64_t seed = p.seed;
   if ((n1 || n2) && p.seed_dev) seed = __builtin_nontemporal_load(p.seed_dev);
   sfor<R>([&](auto RR) __attribute__((always_inline)) {
@@ -747,7 +824,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
       for (int e = 0; e < 16; ++e) v[e] = v[e] * 1.0f + tmp[e];
     }
     if constexpr (MODE == 3) {
-      if (ex) {                    // explicit residual (fp32 path, noise): out = conv5*0.2 + x
+      if (NOISE && ex) {           // explicit residual (fp32 path, noise): out = conv5*0.2 + x
         C16::get(ex->q[r], tmp);
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = v[e] * 0.2f + tmp[e];
@@ -912,22 +989,29 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
 
       if constexpr (RES) {
         // =========================== fp16: own pixels stay in the LDS ===========================
+        using S = Sched<T>;
         ws_.w = w;
         ws_.wnext = wnext;
-        // ---------------- phase 1: x -> conv1..conv5
+        // publish from inside a bulk: at the barrier that opens the bulk's THIRD unit every wave has waited
+        // for everything older than the first two bulk units' DMAs, i.e. for the epilogue's stores
+        auto publish_at = [&](auto IDX, auto AT) __attribute__((always_inline)) {
+          if constexpr (decltype(IDX)::value == decltype(AT)::value) {
+            if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        };
         if (rb == 0) {
           // the chain's input comes from another launch: stage all of x (with halo) by DMA, and start
           // the weight stream (its first three units)
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const char* src = w + CF::phase_off(1) + i * 18 * 1024 + t.lane * 16;
-            char* dst = smem + WOFF + ((ws_.gu + i) & (WR - 1)) * WSLOT;
+          sfor<3>([&](auto UI) __attribute__((always_inline)) {
+            constexpr UDesc d = S::at(decltype(UI)::value);
+            const char* src = w + d.off * 1024 + t.lane * 16;
+            char* dst = smem + WOFF + ((ws_.ring + decltype(UI)::value) & (WR - 1)) * WSLOT;
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
               const int q = t.wave + 4 * j;
-              if (q < 18) dma16(src + q * 1024, dst + q * 1024);
+              if (q < d.nf) dma16(src + q * 1024, dst + q * 1024);
             }
-          }
+          });
           sfor<CF::KX>([&](auto CI) __attribute__((always_inline)) {
             issue_a(xin_b + decltype(CI)::value * blk.x_in.group_stride, decltype(CI)::value, smem, t);
           });
@@ -938,83 +1022,90 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
           halo_fetch<CF::KX>(xin, 0, smem, t);
         }
         __syncthreads();
-        ws_.g1 = ws_.g2 = 0;
         Bias16 b1, b2, b3, b4, b5a, b5b;
         load_bias(bs.bias + 0, t, b1);
         trace_ev(p, tile, ev);
-        run_phase_res<T, 1>(acc, ws_, 4, smem, t);
+        // ---------------- conv1
+        run_units<T, S::first(U_CRIT, 1), S::end(U_CRIT, 1)>(acc, ws_, smem, t);
         trace_ev(p, tile, ev);
         mfma_drain();
         RowsRaw<T> x1, x2;
-        epilogue<T, 0, 0, 2>(acc, p, bs, b1, dense, 0, 0, nullptr, nullptr, false, t, smem, 0, &x1);     // x1
-        publish(flags, tile, ++epoch, t, &p, &ev);
-        ws_.g1 = ws_.g2 = 0;
+        epilogue<T, 0, 0, 2>(acc, p, bs, b1, dense, 0, 0, nullptr, nullptr, false, t, smem, 0, &x1);     // x1 (kept: x still occupies its slots)
+        load_bias(bs.bias + 32, t, b2);
+        ++epoch;
         trace_ev(p, tile, ev);
-        // ---------------- P = conv1x1(x) from the resident x, then phase 2: x1 -> conv2..conv5
+        run_units<T, S::first(U_BULK, 1), S::end(U_BULK, 1)>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { publish_at(IDX, std::integral_constant<int, S::first(U_BULK, 1) + 1>{}); });
+        trace_ev(p, tile, ev);
+        // ---------------- P = conv1x1(x) from the resident x; then x1 may take x's slots
         run_1x1_res<T>(acc, ws_, smem, t);
         __builtin_amdgcn_s_barrier();          // every wave done reading x
 #pragma unroll
         for (int r = 0; r < R; ++r) lds_put_row(smem, t.h, r, x1.q[r].q, t);
         trace_ev(p, tile, ev);
         if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
-        halo_fetch<CF::KD>(dense, 0, smem, t);
+        halo_fetch<CF::KD>(dense, 0, smem, t, 0);
         __syncthreads();
-        load_bias(bs.bias + 32, t, b2);
         trace_ev(p, tile, ev);
-        run_phase_res<T, 2>(acc, ws_, 4, smem, t);
+        // ---------------- conv2
+        run_units<T, S::first(U_CRIT, 2), S::end(U_CRIT, 2)>(acc, ws_, smem, t);
         trace_ev(p, tile, ev);
         mfma_drain();
-        epilogue<T, 1, 1, 3>(acc, p, bs, b2, dense, 1, 0, nullptr, nullptr, false, t, smem, 0, &x2);  // x2 (kept: residual of x4)
-        publish(flags, tile, ++epoch, t, &p, &ev);
-        ws_.g1 = ws_.g2 = 0;
-        trace_ev(p, tile, ev);
-        // ---------------- phase 3: x2 -> conv3..conv5
-        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
-        halo_fetch<CF::KD>(dense, CF::KD, smem, t);
-        __syncthreads();
+        epilogue<T, 1, 1, 3>(acc, p, bs, b2, dense, 1, 0, nullptr, nullptr, false, t, smem, 2, &x2);  // x2 (kept: residual of x4)
         load_bias(bs.bias + 64, t, b3);
+        ++epoch;
         trace_ev(p, tile, ev);
-        run_phase_res<T, 3>(acc, ws_, 4, smem, t);
+        run_units<T, S::first(U_BULK, 2), S::end(U_BULK, 2)>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { publish_at(IDX, std::integral_constant<int, S::first(U_BULK, 2) + 1>{}); });
+        trace_ev(p, tile, ev);
+        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
+        halo_fetch<CF::KD>(dense, CF::KD, smem, t, 2);
+        __syncthreads();
+        trace_ev(p, tile, ev);
+        // ---------------- conv3
+        run_units<T, S::first(U_CRIT, 3), S::end(U_CRIT, 3)>(acc, ws_, smem, t);
         trace_ev(p, tile, ev);
         mfma_drain();
         epilogue<T, 2, 0, 1>(acc, p, bs, b3, dense, 2, 0, nullptr, nullptr, false, t, smem, 0);       // x3
-        publish(flags, tile, ++epoch, t, &p, &ev);
-        ws_.g1 = ws_.g2 = 0;
-        trace_ev(p, tile, ev);
-        // ---------------- phase 4: x3 -> conv4, conv5
-        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
-        halo_fetch<CF::KD>(dense, 2 * CF::KD, smem, t);
-        __syncthreads();
         load_bias(bs.bias + 96, t, b4);
+        ++epoch;
         trace_ev(p, tile, ev);
-        run_phase_res<T, 4>(acc, ws_, 4, smem, t);
+        run_units<T, S::first(U_BULK, 3), S::end(U_BULK, 3)>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { publish_at(IDX, std::integral_constant<int, S::first(U_BULK, 3) + 1>{}); });
+        trace_ev(p, tile, ev);
+        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
+        halo_fetch<CF::KD>(dense, 2 * CF::KD, smem, t, 0);
+        __syncthreads();
+        trace_ev(p, tile, ev);
+        // ---------------- conv4
+        run_units<T, S::first(U_CRIT, 4), S::end(U_CRIT, 4)>(acc, ws_, smem, t);
         trace_ev(p, tile, ev);
         mfma_drain();
-        epilogue<T, 3, 2, 1>(acc, p, bs, b4, dense, 3, 0, &x2, nullptr, false, t, smem, 0);           // x4 (+ x2)
-        publish(flags, tile, ++epoch, t, &p, &ev);
-        ws_.g1 = ws_.g2 = 0;
-        trace_ev(p, tile, ev);
-        // ---------------- phase 5: x4 -> conv5; block tail (+ RRDB tail)
-        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
-        halo_fetch<CF::KD>(dense, 3 * CF::KD, smem, t);
-        __syncthreads();
-        // the block tail's residuals: x only when it is added explicitly (noise), the RRDB input for every
-        // third block; requested here, used after the phase (its first K step lets them stay in flight)
+        epilogue<T, 3, 2, 1>(acc, p, bs, b4, dense, 3, 0, &x2, nullptr, false, t, smem, 2);           // x4 (+ x2)
+        // the block tail's operands: requested here, used after conv5
         RowsRaw<T> tx0, tx1, tr0, tr1;
         load_bias(bs.bias + 128, t, b5a);
         load_bias(bs.bias + 160, t, b5b);
         if (has_res2) { load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1); }
+        ++epoch;
         trace_ev(p, tile, ev);
-        run_phase_res<T, 5>(acc, ws_, 24, smem, t);
+        run_units<T, S::first(U_BULK, 4), S::end(U_BULK, 4)>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { publish_at(IDX, std::integral_constant<int, S::first(U_BULK, 4) + 1>{}); if constexpr ((ESR_ABL & 32) != 0) trace_ev(p, tile, ev); });
+        trace_ev(p, tile, ev);
+        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
+        halo_fetch<CF::KD>(dense, 3 * CF::KD, smem, t, 2);
+        __syncthreads();
+        trace_ev(p, tile, ev);
+        // ---------------- conv5; block tail (+ RRDB tail)
+        run_units<T, S::first(U_CRIT, 5), S::end(U_CRIT, 5)>(acc, ws_, smem, t);
         if (noisy) { load_rows<T>(xin, 0, p, t, tx0); load_rows<T>(xin, 1, p, t, tx1); }   // rare path: latency exposed
         trace_ev(p, tile, ev);
         mfma_drain();
-        epilogue<T, 4, 3, 1>(acc, p, bs, b5a, xout, 0, 0, noisy ? &tx0 : nullptr, &tr0, has_res2, t, smem, 0, nullptr,
-                             noisy ? 0.f : 5.f, full_out);
-        epilogue<T, 5, 3, 1>(acc, p, bs, b5b, xout, 1, 1, noisy ? &tx1 : nullptr, &tr1, has_res2, t, smem, 2, nullptr,
-                             noisy ? 0.f : 5.f, full_out);
+        if (noisy) {
+          epilogue<T, 4, 3, 1, true>(acc, p, bs, b5a, xout, 0, 0, &tx0, &tr0, has_res2, t, smem, 0, nullptr, 0.f, full_out);
+          epilogue<T, 5, 3, 1, true>(acc, p, bs, b5b, xout, 1, 1, &tx1, &tr1, has_res2, t, smem, 2, nullptr, 0.f, full_out);
+        } else {
+          epilogue<T, 4, 3, 1, false>(acc, p, bs, b5a, xout, 0, 0, nullptr, &tr0, has_res2, t, smem, 0, nullptr, 5.f, full_out);
+          epilogue<T, 5, 3, 1, false>(acc, p, bs, b5b, xout, 1, 1, nullptr, &tr1, has_res2, t, smem, 2, nullptr, 5.f, full_out);
+        }
         publish(flags, tile, ++epoch, t, &p, &ev);
-        ws_.g1 = ws_.g2 = 0;
+        ws_.ring = (ws_.ring + S::N) & (WR - 1);
         trace_ev(p, tile, ev);
       } else {
       // =========================== fp32: every stage by DMA ===========================

@@ -160,9 +160,9 @@ class WeightPack:
 
 class RdbStreams:
     """Fused weight streams of dense blocks for esr_rdb_forward (include/esrgan_hip.h, esr_rdb_block): per
-    block the 1 KB MFMA fragments of conv1..conv5 + conv1x1 re-ordered by (phase, K step, column tap,
-    conv, kh) — a pure gather of fragments out of the per-conv packed arena of `wp` (WeightPack), run
-    as ONE esr_gather_fragments launch right after every re-pack."""
+    block the 1 KB MFMA fragments of conv1..conv5 + conv1x1 in the order the kernel's units consume them
+    (esr_rdb_block.w in include/esrgan_hip.h) — a pure gather of fragments out of the per-conv packed arena
+    of `wp` (WeightPack), run as ONE esr_gather_fragments launch right after every re-pack."""
 
     def __init__(self, wp, prefixes):
         self.wp, self.prefixes = wp, list(prefixes)
@@ -186,17 +186,37 @@ class RdbStreams:
         for p in self.prefixes:
             ent = [self.wp.entries[p + '.conv%d.0' % k] for k in range(1, 6)]
             nch = [(64 + 32 * k) // cpg for k in range(5)]            # input chunks of conv1..conv5
+
+            def frag(blk, c, kh, kw):                                # cout block 0..5 = conv1..conv4, conv5[0:32], conv5[32:64]
+                k, cb = (blk, 0) if blk < 4 else (4, blk - 4)
+                return ent[k].w_ptr - base + (((cb * nch[k] + c) * 3 + kh) * 3 + kw) * 1024
+            e1 = self.wp.entries[p + '.conv1x1']
+            one = [e1.w_ptr - base + c * 1024 for c in range(kx)]
             for ph in range(1, 6):                                   # phase = input slice x, x1..x4
                 c0 = 0 if ph == 1 else kx + (ph - 2) * kd
-                for c in range(kx if ph == 1 else kd):
-                    for kw in range(3):
-                        for blk in range(ph - 1, 6):                 # conv ph..5 (conv5: two cout blocks)
-                            k, cb = (blk, 0) if blk < 4 else (4, blk - 4)
-                            for kh in range(3):
-                                offs.append(ent[k].w_ptr - base + (((cb * nch[k] + c0 + c) * 3 + kh) * 3 + kw) * 1024)
-            e1 = self.wp.entries[p + '.conv1x1']
-            for c in range(kx):
-                offs.append(e1.w_ptr - base + c * 1024)
+                ks = kx if ph == 1 else kd
+                if cpg == 8:
+                    # fp32: units (K step, column tap) over conv ph..5, the 1x1 at the end of the stream
+                    for c in range(ks):
+                        for kw in range(3):
+                            offs += [frag(blk, c0 + c, kh, kw) for blk in range(ph - 1, 6) for kh in range(3)]
+                    continue
+                # fp16 (rdb_fused.hip, Sched): crit_p = conv_p alone, one unit per K step (3 kw x 3 kh); bulk_p =
+                # conv_{p+1}..conv5, one unit per (K step, kw); the 1x1 after bulk_1; phase 5 = conv5's two blocks
+                if ph < 5:
+                    for c in range(ks):
+                        offs += [frag(ph - 1, c0 + c, kh, kw) for kw in range(3) for kh in range(3)]
+                    for c in range(ks):
+                        for kw in range(3):
+                            offs += [frag(blk, c0 + c, kh, kw) for blk in range(ph, 6) for kh in range(3)]
+                    if ph == 1:
+                        offs += one
+                else:
+                    for c in range(ks):
+                        for kw in range(3):
+                            offs += [frag(blk, c0 + c, kh, kw) for blk in (4, 5) for kh in range(3)]
+            if cpg == 8:
+                offs += one
         assert len(offs) * 1024 == len(self.prefixes) * self.stream_bytes, (len(offs), self.stream_bytes)
         return offs
 

@@ -297,11 +297,15 @@ typedef struct esr_amp {
  * layer) is the second residual stage of a block whose res2 is set.
  *   x1 = lrelu(conv1(x));  x2 = lrelu(conv2(x,x1)) + conv1x1(x);  x3 = lrelu(conv3(x..x2));
  *   x4 = lrelu(conv4(x..x3)) + x2;  y = noise1(conv5(x..x4)*0.2 + x);  [y = noise2(y*0.2 + res2)]
- * Weights: one fused stream per block (esr_rdb_weight_stream_bytes), 1 KB MFMA A fragments in the
- * order the phases consume them:  for phase p = 1..5 (input slice x, x1, x2, x3, x4), K step c of
- * the slice, column tap kw, conv k = p..5 (conv5: both cout blocks), kh: fragment
- * packed(conv k)[cout_block][chunk0(p)+c][kh][kw]; then the 1x1's chunks.  Build it from the
- * per-conv packed weights with esr_gather_fragments.
+ * Weights: one fused stream per block (esr_rdb_weight_stream_bytes), 1 KB MFMA A fragments
+ * F(blk, c, kh, kw) = packed(conv)[cout_block][chunk c][kh][kw] (blk 0..3 = conv1..conv4, 4/5 = conv5's
+ * two cout blocks) in the order the kernel consumes them.  With c running over the K steps (chunks) of
+ * the input slice of phase p = 1..5 (x, x1, x2, x3, x4):
+ *   ESR_F32:  for p, c, kw, blk = p-1..5, kh: F;  then the 1x1's chunks.
+ *   ESR_F16:  for p = 1..4: [for c, kw, kh: F(p-1)]  [for c, kw, blk = p..5, kh: F]  (after p = 1: the
+ *             1x1's chunks);  p = 5: for c, kw, blk = 4..5, kh: F.
+ *             (conv_p alone first, so that its epilogue and halo hand-off overlap the remaining convs.)
+ * Build it from the per-conv packed weights with esr_gather_fragments.
  * All views share one geometry (same wp / H / W); x_out may alias x_in or res2 (pixel-local). */
 typedef struct esr_rdb_block {
   const void* w;            /* fused weight stream of this block */

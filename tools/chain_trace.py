@@ -30,9 +30,13 @@ with torch.no_grad():
     t1.record(); torch.cuda.synchronize()
     print('net forward (nb=%d) %.3f ms' % (nb, t0.elapsed_time(t1) / 10))
 t = tr.cpu().numpy().reshape(ntiles, 64).astype(np.int64)
-names = ['poll1', 'halo1', 'phase1', 'ep1', 'drain1', 'flag', '1x1+put', 'poll2', 'halo2', 'phase2', 'ep2', 'drain2', 'flag',
-         'poll3', 'halo3', 'phase3', 'ep3', 'drain3', 'flag', 'poll4', 'halo4+tail', 'phase4', 'ep4', 'drain4', 'flag',
-         'poll5', 'halo5', 'phase5', 'ep5', 'drain5', 'flag']
+names = ['poll1', 'halo1', 'crit1', 'ep1', 'bulk1', '1x1+put', 'poll2', 'halo2', 'crit2', 'ep2', 'bulk2',
+         'poll3', 'halo3', 'crit3', 'ep3', 'bulk3', 'poll4', 'halo4', 'crit4', 'ep4+tail', 'bulk4',
+         'poll5', 'halo5', 'crit5', 'ep5', 'drain5', 'flag']
+import os
+if os.environ.get('ESR_TRACE_BULK4'):          # build with -DESR_ABL=32: time stamps at the unit boundaries of bulk4
+    i = names.index('bulk4')
+    names[i:i + 1] = ['b4.u%d' % u for u in range(5)] + ['b4.u5']
 d = np.diff(t[:, :len(names) + 1], axis=1) / 100.0     # us (100 MHz counter)
 print('tiles %d; timeline of each tile\'s second block (us), mean over tiles [min..max]' % ntiles)
 tot = 0.0
