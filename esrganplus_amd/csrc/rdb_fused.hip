@@ -66,7 +66,8 @@ constexpr int WSLOT = 18 * 1024;            // weight unit (6 blocks x 3 kh frag
 constexpr int WR = 4;                       // weight ring depth (3 units ahead)
 constexpr int WOFF = AR * ASLOT;
 constexpr int LDS_CTRL = WOFF + WR * WSLOT;   // two control words behind the rings
-constexpr int LDS_BYTES = LDS_CTRL + 64;       // 155712
+constexpr int LDS_BIAS = LDS_CTRL + 64;        // fp16 path: the block's 192 biases (fp32)
+constexpr int LDS_BYTES = LDS_BIAS + 192 * 4;  // 156480
 constexpr int NHALO = 2 * 2 * IW + 2 * 2 * TH;  // 16-byte slots of the 1-pixel halo ring of one stage (200)
 constexpr int WS_HDR = 16;                  // workspace words before the per-tile flags
 enum { WS_TICKET = 0, WS_ABORT = 1 };
@@ -249,22 +250,52 @@ template <typename T> struct Cfg {
   static constexpr int STREAM_BYTES = phase_off(6) + KX * 1024;
 };
 
-// per-workgroup constants of the tile in flight
+// The tile in flight.  Only wave-uniform values live here (SGPRs).  Everything per lane is RE-DERIVED from the
+// lane id where it is used: a per-lane constant computed once per tile is a VGPR that lives across the whole
+// block loop, i.e. across the MFMA segments where all registers are taken — hipcc spills it and reloads it at
+// every use, and with weight DMAs in flight each scratch reload is a full `vmcnt(0)` drain.  The lane id itself
+// costs nothing to keep: v_mbcnt derives it from EXEC (volatile asm, so that the values derived from it are
+// not hoisted back out of the loops into long-lived registers).
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 struct Tile {
   int b, oy0, ox0;
-  int wave, lane, j, h;
+  int ty, tx, tiles_y, tiles_x;
+  int wave;
   int wp;            // row pitch (pixels) of every view
-  int colofs[3];     // per-lane B-fragment offsets of the three column taps
-  // LDS-resident path (fp16): the 1-pixel halo ring of a stage = 200 16-byte slots, one per thread
-  int halo_src;      // byte offset inside a group plane (-1: this thread has no slot)
-  int halo_dst;      // byte offset inside an activation slot
-  int own_px;        // this lane's own pixel (row 4*wave, column j) inside an activation slot, half 0
-  int own_swz;       // 16 if the two halves of that pixel are swapped in the LDS image
+  __device__ __forceinline__ int lane() const { return fresh_lane(); }
+  __device__ __forceinline__ int tid() const { return wave * 64 + fresh_lane(); }
+  // per-lane B-fragment offset of column tap kw (pixel j + kw, half h; halves swapped by (col >> 3) & 1)
+  static __device__ __forceinline__ int colofs(int lane, int kw) {
+    const int col = (lane & 31) + kw;
+    return col * 32 + (((lane >> 5) ^ ((col >> 3) & 1)) << 4);
+  }
+  // this lane's own pixel (row 4*wave, column j) inside an activation slot, half 0; swz = 16 if the two halves
+  // of that pixel are swapped in the LDS image
+  __device__ __forceinline__ void own(int lane, int& px, int& swz) const {
+    const int j = lane & 31;
+    px = ((wave * R + 1) * IW + j + 1) * 32;
+    swz = (((j + 1) >> 3) & 1) << 4;
+  }
+  // LDS-resident path (fp16): the 1-pixel halo ring of a stage = 200 16-byte slots, one per thread: rows 0 / 17
+  // (34 pixels each), then columns 0 / 33 of rows 1..16.  src: byte offset inside a group plane (-1: this
+  // thread has no slot); dst: byte offset inside an activation slot
+  __device__ __forceinline__ void halo(int& src, int& dst) const {
+    const int i = tid();
+    int row, col, hs;
+    if (i < 4 * IW) { const int s = i % (2 * IW); row = i < 2 * IW ? 0 : IH - 1; col = s >> 1; hs = s & 1; }
+    else { const int s = (i - 4 * IW) % (2 * TH); row = 1 + (s >> 1); col = i < 4 * IW + 2 * TH ? 0 : IW - 1; hs = s & 1; }
+    src = i < NHALO ? ((oy0 + row) * wp + ox0 + col) * 32 + ((hs ^ ((col >> 3) & 1)) << 4) : -1;
+    dst = (row * IW + col) * 32 + hs * 16;
+  }
 };
 
 // ---- weights of unit u of a phase -> ring slot (u & 3) ---------------------------------------------
 template <int NF> __device__ __forceinline__ void issue_w(const char* wsrc, int u, char* smem, const Tile& t) {
-  const char* src = wsrc + ((int64_t)u * NF) * 1024 + t.lane * 16;
+  const char* src = wsrc + ((int64_t)u * NF) * 1024 + t.lane() * 16;
   char* dst = smem + WOFF + (u & (WR - 1)) * WSLOT;
 #pragma unroll
   for (int i = 0; i < (NF + 3) / 4; ++i) {
@@ -278,9 +309,10 @@ __device__ __forceinline__ void issue_a(const char* plane, int sa, char* smem, c
   // so that ds_read_b128 B-fragment reads are bank-conflict free.  Offsets are recomputed per call: this
   // path only stages a chain's first input (and the fp32 reference path), and 5 live registers cost more.
   char* dst = smem + sa * ASLOT + t.wave * 1024;
+  const int tid = t.tid();
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    int s = (int)threadIdx.x + NT * i;
+    int s = tid + NT * i;
     if (s >= NSLOT) s = NSLOT - 1;            // tail lanes: harmless re-copy into the padding
     const int row = s / (2 * IW), r2 = s - row * 2 * IW;
     const int col = r2 >> 1, hs = r2 & 1, half = hs ^ ((col >> 3) & 1);
@@ -294,19 +326,34 @@ __device__ __forceinline__ void issue_a(const char* plane, int sa, char* smem, c
 // 1-pixel ring around the tile is fetched (sc1 loads, after the neighbours published): one 16-byte load
 // + one ds_write per thread and stage.
 template <int K> __device__ __forceinline__ void halo_fetch(const ImgView& v, int g0, char* smem, const Tile& t, int slot0 = 0) {
-  if (t.halo_src >= 0) {
+  int hsrc, hdst;
+  t.halo(hsrc, hdst);
+  if (hsrc >= 0) {
     u32x4 q[K];
 #pragma unroll
-    for (int c = 0; c < K; ++c) q[c] = __builtin_amdgcn_raw_buffer_load_b128(v.r, (g0 + c) * v.gs + t.halo_src, 0, 16);
+    for (int c = 0; c < K; ++c) q[c] = __builtin_amdgcn_raw_buffer_load_b128(v.r, (g0 + c) * v.gs + hsrc, 0, 16);
 #pragma unroll
-    for (int c = 0; c < K; ++c) *(u32x4*)(smem + (slot0 + c) * ASLOT + t.halo_dst) = q[c];
+    for (int c = 0; c < K; ++c) *(u32x4*)(smem + (slot0 + c) * ASLOT + hdst) = q[c];
   }
 }
 // the lane's packed 16 channels of row r (own pixel) -> stage slot `slot`
-__device__ __forceinline__ void lds_put_row(char* smem, int slot, int r, const u32x4 (&q)[2], const Tile& t) {
-  char* px = smem + slot * ASLOT + t.own_px + r * (IW * 32);
-  *(u32x4*)(px + t.own_swz) = q[0];
-  *(u32x4*)(px + (t.own_swz ^ 16)) = q[1];
+__device__ __forceinline__ void lds_put_row(char* smem, int slot, int r, const u32x4 (&q)[2], int own_px, int own_swz) {
+  char* px = smem + slot * ASLOT + own_px + r * (IW * 32);
+  *(u32x4*)(px + own_swz) = q[0];
+  *(u32x4*)(px + (own_swz ^ 16)) = q[1];
+}
+
+// .. and back (the lane's own pixel as the epilogue stored it)
+template <typename RAW> __device__ __forceinline__ void lds_get_rows(const char* smem, int slot0, RAW (&q)[R], const Tile& t) {
+  const int lane = t.lane();
+  int own_px, own_swz;
+  t.own(lane, own_px, own_swz);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const char* px = smem + (slot0 + (lane >> 5)) * ASLOT + own_px + r * (IW * 32);
+    q[r].q[0] = *(const u32x4*)(px + own_swz);
+    q[r].q[1] = *(const u32x4*)(px + (own_swz ^ 16));
+  }
 }
 
 // ---- the MFMAs of one unit of phase P: cout blocks P-1..5 x 3 kh taps x 4 rows ----------------------
@@ -429,42 +476,46 @@ template <typename T> struct Sched {
     const int part = nf_at(i + 3, has_next) >> 2, done = steps(i) - 1;
     return (nf_at(i + 2, has_next) >> 2) + (part < done ? part : done);
   }
-  // B-fragment sets consumed by units [i0, i): which of the two register sets unit i starts on
+  // steps of units [i0, i): which of the two A-fragment register sets unit i starts on
   static constexpr int parity(int i0, int i) {
     int p = 0;
-    for (int u = i0; u < i; ++u) p += nkw(at(u));
+    for (int u = i0; u < i; ++u) p += steps(u);
     return p & 1;
   }
 };
 
-// One unit = NKW x NBLK steps of 12 MFMAs (3 kh x 4 rows against one set of 6 B fragments).  Units run back
-// to back: the B fragments and first A fragments of the NEXT unit are requested during this unit's last
-// step — after `mid()`, the next unit's DMA wait + barrier, which therefore hides under the remaining
-// MFMAs — into the other register set, so a unit opens straight with its MFMAs.
-struct UFrags { u32x4 bf[R + 2]; u32x4 a0[3]; };
+// One unit = NKW x NBLK steps of 12 MFMAs (3 kh x 4 rows against one set of 6 B fragments).  Fragments sit
+// in ONE set of B registers and two of A (48 registers), refilled in place as their last reader has issued:
+// a step's MFMAs 1..6 read B rows 0..2, MFMAs 7..12 rows 3..5, so when the next step (or unit) reads another
+// column tap its rows 0..2 are requested after MFMA 6 — together with its A fragments, into the other A set
+// — and its rows 3..5 after MFMA 12; the wait in front of a step leaves those last three reads in flight
+// (`lgkmcnt(3)`: LDS operations return in order), they are first needed 6 MFMAs later.
+// Units run back to back: the next unit's first fragments are requested the same way during this unit's
+// last step — after `mid()`, the next unit's DMA wait + barrier, which therefore hides under the remaining
+// MFMAs — so a unit opens straight with its MFMAs.  PAR = the A set the unit starts on.
+struct UFrags { u32x4 bf[R + 2]; u32x4 a[2][3]; };
 template <typename T, int BLK0, int NBLK, int NKW, bool FIRST, bool PRE, bool NXT, int PAR, typename ISSUE, typename MID>
-__device__ __forceinline__ void unit_steps(Acc24& acc, UFrags (&f)[2], const uint32_t (&lb)[3], const uint32_t lw,
+__device__ __forceinline__ void unit_steps(Acc24& acc, UFrags& f, const uint32_t (&lb)[3], const uint32_t lw,
                                            const uint32_t lbn, const uint32_t lwn, ISSUE&& issue, MID&& mid) {
   constexpr int NS = NKW * NBLK;
-  constexpr int NPAR = (PAR + NKW) & 1;           // the set the next unit starts on
-  static_assert(NKW == 1 || NKW == 3, "the next unit's set must differ from this unit's last");
-  u32x4 afb[3];                                   // A fragments of the odd steps; even steps use f[PAR].a0
-  u32x4 (&a0)[3] = f[PAR].a0;
+  u32x4 (&bf)[R + 2] = f.bf;
   if constexpr (!PRE) {
-    sfor<R + 2>([&](auto IR) __attribute__((always_inline)) { lds_read16<decltype(IR)::value * IW * 32>(f[PAR].bf[decltype(IR)::value], lb[0]); });
-    sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(a0[decltype(KH)::value], lw); });
+    sfor<R + 2>([&](auto IR) __attribute__((always_inline)) { lds_read16<decltype(IR)::value * IW * 32>(bf[decltype(IR)::value], lb[0]); });
+    sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(f.a[PAR][decltype(KH)::value], lw); });
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[PAR].bf[0]), "+v"(f[PAR].bf[1]), "+v"(f[PAR].bf[2]), "+v"(f[PAR].bf[3]),
-               "+v"(f[PAR].bf[4]), "+v"(f[PAR].bf[5]), "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]));
   sfor<NS>([&](auto SI) __attribute__((always_inline)) {
     constexpr int s = decltype(SI)::value;
     constexpr int kwi = s / NBLK, bi = s % NBLK, blk = BLK0 + bi;
-    constexpr int set = (PAR + kwi) & 1;
-    constexpr bool newset = s + 1 < NS && (s + 1) / NBLK != kwi;    // the next step reads another column tap
-    u32x4 (&af)[3] = (s & 1) ? afb : a0;
-    u32x4 (&an)[3] = (s & 1) ? a0 : afb;
-    u32x4 (&bf)[R + 2] = f[set].bf;
-    u32x4 (&bn)[R + 2] = f[set ^ 1].bf;
+    constexpr bool fresh = s == 0 ? PRE : (s / NBLK != (s - 1) / NBLK);   // B rows 3..5 of this step still in flight
+    constexpr bool newset = s + 1 < NS && (s + 1) / NBLK != kwi;          // the next step reads another column tap
+    u32x4 (&af)[3] = f.a[(PAR + s) & 1];
+    u32x4 (&an)[3] = f.a[(PAR + s + 1) & 1];
+    // this step's A fragments and B rows 0..2
+    if constexpr (fresh) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]));
+    else if constexpr (s == 0)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]),
+                   "+v"(af[0]), "+v"(af[1]), "+v"(af[2]));
+    else lds_wait3(af[0], af[1], af[2]);
     sfor<R + 2>([&](auto IR) __attribute__((always_inline)) {
       constexpr int ir = decltype(IR)::value;
       sfor<3>([&](auto KH) __attribute__((always_inline)) {
@@ -472,27 +523,26 @@ __device__ __forceinline__ void unit_steps(Acc24& acc, UFrags (&f)[2], const uin
         constexpr int r = ir - kh;
         if constexpr (r >= 0 && r < R) mma_cls<T, acc_in_agpr(blk), FIRST && kwi == 0 && kh == 0 && blk < 4>(acc_br<blk, r>(acc), af[kh], bf[ir]);
       });
-      if constexpr (ir == 1 && newset && !(ESR_ABL & 4)) {     // after MFMA 3 of 12: the other set's last readers are a step back
-        sfor<R + 2>([&](auto IR2) __attribute__((always_inline)) { lds_read16<decltype(IR2)::value * IW * 32>(bn[decltype(IR2)::value], lb[newset ? kwi + 1 : 0]); });
-      }
       if constexpr (ir == 2) {                    // after MFMA 6 of 12
+        if constexpr (fresh) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]));
         if constexpr (s + 1 < NS) {
+          if constexpr (newset && !(ESR_ABL & 4))
+            sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<decltype(IR2)::value * IW * 32>(bf[decltype(IR2)::value], lb[newset ? kwi + 1 : 0]); });
           if constexpr (!(ESR_ABL & 2))
             sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<((s + 1) * 3 + decltype(KH)::value) * 1024>(an[decltype(KH)::value], lw); });
         } else if constexpr (NXT) {
           if constexpr (!(ESR_ABL & 8)) mid();
           if constexpr (!(ESR_ABL & 4))
-            sfor<R + 2>([&](auto IR2) __attribute__((always_inline)) { lds_read16<decltype(IR2)::value * IW * 32>(f[NPAR].bf[decltype(IR2)::value], lbn); });
-          sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(f[NPAR].a0[decltype(KH)::value], lwn); });
+            sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<decltype(IR2)::value * IW * 32>(bf[decltype(IR2)::value], lbn); });
+          sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(an[decltype(KH)::value], lwn); });
         }
       }
     });
-    if constexpr (s + 1 < NS) {
-      if constexpr (newset)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]), "+v"(bn[4]), "+v"(bn[5]),
-                     "+v"(an[0]), "+v"(an[1]), "+v"(an[2]));
-      else lds_wait3(an[0], an[1], an[2]);
-    }
+    // after MFMA 12: rows 3..5 of the next column tap
+    if constexpr (newset && !(ESR_ABL & 4))
+      sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<(3 + decltype(IR2)::value) * IW * 32>(bf[3 + decltype(IR2)::value], lb[newset ? kwi + 1 : 0]); });
+    if constexpr (s + 1 == NS && NXT && !(ESR_ABL & 4))
+      sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<(3 + decltype(IR2)::value) * IW * 32>(bf[3 + decltype(IR2)::value], lbn); });
     __builtin_amdgcn_sched_barrier(0);
     issue(s);
     if constexpr (s + 1 == NS) {
@@ -522,6 +572,7 @@ __device__ __forceinline__ void run_phase(Acc24& acc, const char* wsrc, const ch
   if (K > 1) issue_a(aplane + a_gs, 1, smem, t);
   int g1 = K > 1 ? nA : 0, g2 = 0;                       // DMAs issued in the previous two units
   int sa = 0;
+  const int lane = t.lane();
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
   // one K step = 3 units.  The block's very first K step (phase 1, c = 0) is peeled: its first unit writes
@@ -546,8 +597,8 @@ __device__ __forceinline__ void run_phase(Acc24& acc, const char* wsrc, const ch
         cnt += nA;
       }
       g2 = g1; g1 = cnt;
-      const uint32_t lb = lds_rows + sa * ASLOT + t.colofs[kw];
-      const uint32_t lw = lds0 + WOFF + (u & (WR - 1)) * WSLOT + t.lane * 16;
+      const uint32_t lb = lds_rows + sa * ASLOT + Tile::colofs(lane, kw);
+      const uint32_t lw = lds0 + WOFF + (u & (WR - 1)) * WSLOT + lane * 16;
       unit_mma<T, P, P == 1 && firstc && kw == 0>(acc, lb, lw);
     });
     if (++sa == AR) sa = 0;
@@ -574,7 +625,7 @@ template <typename T, int A, int B> __device__ __forceinline__ void wait_units(c
 }
 // this wave's share of the unit 3 places after unit I: step i's request (q = wave + 4 i)
 template <typename T, int I>
-__device__ __forceinline__ void issue_ahead(const WStream& s, const Tile& t, char* smem, int i) {
+__device__ __forceinline__ void issue_ahead(const WStream& s, const Tile& t, char* smem, int i, int lane16) {
   using S = Sched<T>;
   constexpr int J = I + 3;
   constexpr bool wrap = J >= S::N;
@@ -584,7 +635,7 @@ __device__ __forceinline__ void issue_ahead(const WStream& s, const Tile& t, cha
   if (wrap && !s.wnext) return;
   const int q = t.wave + 4 * i;
   if (4 * i + 3 < dj.nf || q < dj.nf) {
-    const char* src = (wrap ? s.wnext : s.w) + (dj.off + q) * 1024 + t.lane * 16;
+    const char* src = (wrap ? s.wnext : s.w) + (dj.off + q) * 1024 + lane16;
     char* dst = smem + WOFF + ((s.ring + J) & (WR - 1)) * WSLOT + q * 1024;
     dma16(src, dst);
   }
@@ -597,7 +648,9 @@ __device__ __forceinline__ void run_units(Acc24& acc, const WStream& s, char* sm
   using S = Sched<T>;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
-  UFrags f[2];
+  UFrags f;
+  const int lane = t.lane(), lane16 = lane * 16;
+  const int colofs[3] = {Tile::colofs(lane, 0), Tile::colofs(lane, 1), Tile::colofs(lane, 2)};
   wait_units<T, S::wait_top(I0, true), S::wait_top(I0, false)>(s);      // the first unit's weights
   __builtin_amdgcn_s_barrier();
   sfor<I1 - I0>([&](auto II) __attribute__((always_inline)) {
@@ -606,11 +659,11 @@ __device__ __forceinline__ void run_units(Acc24& acc, const WStream& s, char* sm
     constexpr UDesc dn = S::at(I + 1 < I1 ? I + 1 : I);
     constexpr int NKW = S::nkw(d);
     const uint32_t lrow = lds_rows + S::slot(d) * ASLOT;
-    const uint32_t lb[3] = {lrow + t.colofs[NKW == 3 ? 0 : d.kw], lrow + t.colofs[1], lrow + t.colofs[2]};
-    const uint32_t lw = lds0 + WOFF + ((s.ring + I) & (WR - 1)) * WSLOT + t.lane * 16;
-    const uint32_t lbn = lds_rows + S::slot(dn) * ASLOT + t.colofs[S::nkw(dn) == 3 ? 0 : dn.kw];
-    const uint32_t lwn = lds0 + WOFF + ((s.ring + I + 1) & (WR - 1)) * WSLOT + t.lane * 16;
-    auto issue = [&](int i) __attribute__((always_inline)) { issue_ahead<T, I>(s, t, smem, i); };
+    const uint32_t lb[3] = {lrow + colofs[NKW == 3 ? 0 : d.kw], lrow + colofs[1], lrow + colofs[2]};
+    const uint32_t lw = lds0 + WOFF + ((s.ring + I) & (WR - 1)) * WSLOT + lane16;
+    const uint32_t lbn = lds_rows + S::slot(dn) * ASLOT + colofs[S::nkw(dn) == 3 ? 0 : dn.kw];
+    const uint32_t lwn = lds0 + WOFF + ((s.ring + I + 1) & (WR - 1)) * WSLOT + lane16;
+    auto issue = [&](int i) __attribute__((always_inline)) { issue_ahead<T, I>(s, t, smem, i, lane16); };
     auto mid = [&]() __attribute__((always_inline)) {
       wait_units<T, S::wait_mid(I, true), S::wait_mid(I, false)>(s);   // the next unit's weights
       __builtin_amdgcn_s_barrier();        // next unit visible to all waves; all waves past this unit's LDS reads
@@ -631,12 +684,13 @@ __device__ __forceinline__ void run_1x1_res(Acc24& acc, const WStream& s, char* 
   constexpr int K = CF::KX;
   constexpr int I = S::first(U_ONE, 1);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const uint32_t lb = lds0 + t.wave * (R * IW * 32) + IW * 32 + t.colofs[1];   // centre tap: rows 1..4, col j+1
-  const uint32_t lw = lds0 + WOFF + ((s.ring + I) & (WR - 1)) * WSLOT + t.lane * 16;
+  const int lane = t.lane();
+  const uint32_t lb = lds0 + t.wave * (R * IW * 32) + IW * 32 + Tile::colofs(lane, 1);   // centre tap: rows 1..4, col j+1
+  const uint32_t lw = lds0 + WOFF + ((s.ring + I) & (WR - 1)) * WSLOT + lane * 16;
   wait_units<T, S::wait_top(I, true), S::wait_top(I, false)>(s);
   __builtin_amdgcn_s_barrier();
 #pragma unroll
-  for (int i = 0; i < 5; ++i) issue_ahead<T, I>(s, t, smem, i);
+  for (int i = 0; i < 5; ++i) issue_ahead<T, I>(s, t, smem, i, lane * 16);
   sfor<K>([&](auto CI) __attribute__((always_inline)) {
     constexpr int c = decltype(CI)::value;
     u32x4 a, b0, b1, b2, b3;
@@ -658,16 +712,17 @@ template <typename T>
 __device__ __forceinline__ void run_1x1(Acc24& acc, const char* w1, const char* aplane, const int64_t a_gs,
                                         char* smem, const Tile& t) {
   constexpr int K = Cfg<T>::KX;
+  const int lane = t.lane();
   // all K fragments -> weight slot 0 (wave w copies fragments w, w+4, ...)
 #pragma unroll
   for (int i = 0; i < (K + 3) / 4; ++i) {
     const int q = t.wave + 4 * i;
-    if (q < K) dma16(w1 + q * 1024 + t.lane * 16, smem + WOFF + q * 1024);
+    if (q < K) dma16(w1 + q * 1024 + lane * 16, smem + WOFF + q * 1024);
   }
   issue_a(aplane, 0, smem, t);
   issue_a(aplane + a_gs, 1, smem, t);
   int sa = 0;
-  const char* lds_rows = smem + t.wave * (R * IW * 32) + IW * 32 + t.colofs[1];   // centre tap: rows 1..4, col j+1
+  const char* lds_rows = smem + t.wave * (R * IW * 32) + IW * 32 + Tile::colofs(lane, 1);   // centre tap: rows 1..4, col j+1
 #pragma unroll 1
   for (int c = 0; c < K; ++c) {
     if (c + 1 < K) wait_vm<NLD>(); else wait_vm<0>();
@@ -677,7 +732,7 @@ __device__ __forceinline__ void run_1x1(Acc24& acc, const char* w1, const char* 
       issue_a(aplane + (int64_t)(c + 2) * a_gs, sn, smem, t);
     }
     {                                       // the 1x1 lands in conv1's vacated registers (block 0)
-      const u32x4 a = *(const u32x4*)(smem + WOFF + c * 1024 + t.lane * 16);
+      const u32x4 a = *(const u32x4*)(smem + WOFF + c * 1024 + lane * 16);
       const char* lb = lds_rows + sa * ASLOT;
       u32x4 bq[R];
 #pragma unroll
@@ -700,7 +755,7 @@ __device__ __forceinline__ void run_1x1(Acc24& acc, const char* w1, const char* 
 
 // measurement only: time stamps (100 MHz) of the tile's SECOND block (the first one stages x differently)
 __device__ __forceinline__ void trace_ev(const esr_rdb_chain& p, int tile, int& ev) {
-  if (p.trace && threadIdx.x == 0 && ev >= 0 && ev < 64) p.trace[(int64_t)tile * 64 + ev] = (ESR_ABL & 16) ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();
+  if (p.trace && ev >= 0 && ev < 64 && threadIdx.x == 0) p.trace[(int64_t)tile * 64 + ev] = (ESR_ABL & 16) ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();
   if (ev >= 0) ++ev;
 }
 
@@ -718,9 +773,17 @@ __device__ __forceinline__ void publish(unsigned* flags, int tile, unsigned epoc
 
 // wave 0, lanes 0..7 poll one neighbour each (relaxed, agent scope) until all reached `epoch`.
 // Returns false (whole workgroup) on abort / time-out.
-__device__ __forceinline__ bool wait_neighbours(unsigned* ws, int my_nbr_tile, unsigned epoch, char* smem, const Tile& t,
+__device__ __forceinline__ bool wait_neighbours(unsigned* ws, unsigned epoch, char* smem, const Tile& t,
                                                 const esr_rdb_chain* tp = nullptr, int* ev = nullptr, int tile_ = 0) {
   if (t.wave == 0) {
+    // the neighbour this lane polls (lanes 0..7)
+    const int lane = t.lane();
+    int my_nbr_tile = -1;
+    if (lane < 8) {
+      const int k = lane < 4 ? lane : lane + 1;
+      const int ny = t.ty + k / 3 - 1, nx = t.tx + k % 3 - 1;
+      if (ny >= 0 && ny < t.tiles_y && nx >= 0 && nx < t.tiles_x) my_nbr_tile = (t.b * t.tiles_y + ny) * t.tiles_x + nx;
+    }
     bool ok = my_nbr_tile < 0;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     bool dead = false;
@@ -734,7 +797,7 @@ __device__ __forceinline__ bool wait_neighbours(unsigned* ws, int my_nbr_tile, u
         break;
       }
     }
-    if (t.lane == 0) {
+    if (lane == 0) {
       if (dead) __hip_atomic_store((gu32*)(ws + WS_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *(volatile int*)(smem + LDS_CTRL + 16) = dead ? 1 : 0;
     }
@@ -760,11 +823,12 @@ template <typename T> struct RowsRaw { typename Ch16<T>::Raw q[R]; };
 
 template <typename T>
 __device__ __forceinline__ void load_rows(const ImgView& v, int cb, const esr_rdb_chain& p, const Tile& t, RowsRaw<T>& o) {
-  const int ox = t.ox0 + t.j, oyb = t.oy0 + t.wave * R, wp32 = p.dense.wp * 32;
+  const int lane = t.lane();
+  const int ox = t.ox0 + (lane & 31), oyb = t.oy0 + t.wave * R, wp32 = p.dense.wp * 32;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int oy = oyb + r < p.H ? oyb + r : p.H - 1;            // clamped: rows / columns past the image are not used
-    Ch16<T>::load(v, cb, t.h, (oy + 1) * wp32 + (ox < p.W ? ox + 1 : 1) * 32, o.q[r]);
+    Ch16<T>::load(v, cb, lane >> 5, (oy + 1) * wp32 + (ox < p.W ? ox + 1 : 1) * 32, o.q[r]);
   }
 }
 
@@ -772,7 +836,19 @@ struct Bias16 { f32x4 q[4]; };
 // the lane's 16 biases of a cout block (bias = wave-uniform pointer): requested at the START of the phase
 // whose epilogue adds them — a load placed in the epilogue itself exposes a memory round trip per phase
 __device__ __forceinline__ void load_bias(const float* bias, const Tile& t, Bias16& b) {
-  const f32x4* bp = (const f32x4*)bias + 4 * t.h;
+  const f32x4* bp = (const f32x4*)bias + 4 * (t.lane() >> 5);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b.q[i] = bp[i];
+}
+// fp16 path: the block's biases sit in the LDS (copied by DMA at the top of the block): a register copy would
+// be a vector-memory load whose first use makes hipcc drain every weight DMA in flight (vmcnt(0))
+__device__ __forceinline__ void stage_bias(const float* bias, char* smem, const Tile& t) {
+  if (t.wave < 3)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bias + t.wave * 64 + t.lane()),
+                                     (__attribute__((address_space(3))) void*)(smem + LDS_BIAS + t.wave * 256), 4, 0, 0);
+}
+__device__ __forceinline__ void lds_bias(const char* smem, int first, const Tile& t, Bias16& b) {
+  const f32x4* bp = (const f32x4*)(smem + LDS_BIAS + first * 4) + 4 * (t.lane() >> 5);
 #pragma unroll
   for (int i = 0; i < 4; ++i) b.q[i] = bp[i];
 }
@@ -793,7 +869,10 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
                                          int slot0 = 0, RowsRaw<T>* keep = nullptr, float carry_scale = 0.f,
                                          bool full_store = true) {
   using C16 = Ch16<T>;
-  const int ox = t.ox0 + t.j;
+  const int lane = t.lane(), tj = lane & 31, th = lane >> 5;
+  int own_px = 0, own_swz = 0;
+  if constexpr ((LW & 1) != 0) t.own(lane, own_px, own_swz);
+  const int ox = t.ox0 + tj;
   const int oyb = t.oy0 + t.wave * R;
   const f32x4 (&bq)[4] = bias.q;
   const int wp32 = p.dense.wp * 32;
@@ -835,7 +914,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
       const uint32_t pix = (uint32_t)((t.b * p.H + oy) * p.W + ox);
       if (n1) {
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + t.h * 4 + q), layer1, seed, &tmp[4 * q]);
+        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + th * 4 + q), layer1, seed, &tmp[4 * q]);
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);     // block.py:119-121
       }
@@ -845,7 +924,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
         for (int e = 0; e < 16; ++e) v[e] = v[e] * 0.2f + tmp[e];
         if (n2) {
 #pragma unroll 1
-          for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + t.h * 4 + q), layer2, seed, &tmp[4 * q]);
+          for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + th * 4 + q), layer2, seed, &tmp[4 * q]);
 #pragma unroll
           for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
         }
@@ -855,18 +934,18 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
     const bool inside = oy < p.H && ox < p.W;
     const int po = (oy + 1) * wp32 + (ox + 1) * 32;
     if constexpr (LW == 0) {
-      C16::store(out, inside ? out_cb : 0, t.h, inside ? po : (int)0x80000000u, v);
+      C16::store(out, inside ? out_cb : 0, th, inside ? po : (int)0x80000000u, v);
     } else {
       typename C16::Raw q;
       C16::pack(v, q.q);
       // x1..x4 are only ever read back as HALO pixels by the neighbouring tiles (the tile's own pixels stay
       // in the LDS / registers): unless the caller wants the dense slices in memory (save_dense), only the
       // tile's border pixels are stored — 82 % fewer bytes through the lock-stepped store bursts
-      const bool edge = (MODE == 3 && full_store) || p.save_dense || t.j == 0 || t.j == TW - 1 || (t.wave == 0 && r == 0) ||
+      const bool edge = (MODE == 3 && full_store) || p.save_dense || tj == 0 || tj == TW - 1 || (t.wave == 0 && r == 0) ||
                         (t.wave == NT / 64 - 1 && r == R - 1);
-      C16::store_packed(out, (inside && edge) ? out_cb : 0, t.h, (inside && edge) ? po : (int)0x80000000u, q.q);
+      C16::store_packed(out, (inside && edge) ? out_cb : 0, th, (inside && edge) ? po : (int)0x80000000u, q.q);
       if (!inside) { q.q[0] = u32x4{0, 0, 0, 0}; q.q[1] = u32x4{0, 0, 0, 0}; }   // beyond the image: the zero padding
-      if constexpr (LW & 1) lds_put_row(smem, slot0 + t.h, r, q.q, t);
+      if constexpr (LW & 1) lds_put_row(smem, slot0 + th, r, q.q, own_px, own_swz);
       if constexpr (LW & 2) keep->q[r] = q;
       if constexpr (MODE == 3) {
         // carry into the next block: its conv5 accumulators start at 5 x (x = this output AS STORED), so
@@ -890,10 +969,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
   unsigned* const ws = (unsigned*)p.workspace;
   unsigned* const flags = ws + WS_HDR;
   Tile t;
-  t.lane = threadIdx.x & 63;
   t.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  t.j = t.lane & 31;
-  t.h = t.lane >> 5;
   const int tpi = tiles_x * tiles_y;
   const int wp = p.dense.wp;
 
@@ -909,30 +985,8 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
     const int rem = tile - t.b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
     t.oy0 = ty * TH;
     t.ox0 = tx * TW;
-    // the neighbour this lane polls (lanes 0..7 of wave 0)
-    int nbr_tile = -1;
-    if (t.lane < 8) {
-      const int k = t.lane < 4 ? t.lane : t.lane + 1;
-      const int ny = ty + k / 3 - 1, nx = tx + k % 3 - 1;
-      if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) nbr_tile = t.b * tpi + ny * tiles_x + nx;
-    }
+    t.ty = ty; t.tx = tx; t.tiles_y = tiles_y; t.tiles_x = tiles_x;
     t.wp = wp;
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int col = t.j + kw;
-      t.colofs[kw] = col * 32 + ((t.h ^ ((col >> 3) & 1)) << 4);
-    }
-    {
-      // halo ring slot of this thread: rows 0 / 17 (34 pixels each), then columns 0 / 33 of rows 1..16
-      const int i = (int)threadIdx.x;
-      int row, col, hs;
-      if (i < 4 * IW) { const int s = i % (2 * IW); row = i < 2 * IW ? 0 : IH - 1; col = s >> 1; hs = s & 1; }
-      else { const int s = (i - 4 * IW) % (2 * TH); row = 1 + (s >> 1); col = i < 4 * IW + 2 * TH ? 0 : IW - 1; hs = s & 1; }
-      t.halo_src = i < NHALO ? ((t.oy0 + row) * wp + t.ox0 + col) * 32 + ((hs ^ ((col >> 3) & 1)) << 4) : -1;
-      t.halo_dst = (row * IW + col) * 32 + hs * 16;
-      t.own_px = ((t.wave * R + 1) * IW + t.j + 1) * 32;
-      t.own_swz = (((t.j + 1) >> 3) & 1) << 4;
-    }
     const ImgView dense = img_view(p.dense, t.b);
     const char* const dense_b = (const char*)p.dense.ptr + (int64_t)t.b * p.dense.batch_stride;
     const int64_t d_gs = p.dense.group_stride;
@@ -999,12 +1053,13 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
             if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         };
+        stage_bias(bs.bias, smem, t);          // every wave is past the previous block's tail (publish)
         if (rb == 0) {
           // the chain's input comes from another launch: stage all of x (with halo) by DMA, and start
           // the weight stream (its first three units)
           sfor<3>([&](auto UI) __attribute__((always_inline)) {
             constexpr UDesc d = S::at(decltype(UI)::value);
-            const char* src = w + d.off * 1024 + t.lane * 16;
+            const char* src = w + d.off * 1024 + t.lane() * 16;
             char* dst = smem + WOFF + ((ws_.ring + decltype(UI)::value) & (WR - 1)) * WSLOT;
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
@@ -1018,20 +1073,19 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
           wait_vm<0>();
         } else {
           // own pixels were written by the previous block's epilogue; weights are in flight already
-          if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
+          if (!wait_neighbours(ws, epoch, smem, t, &p, &ev, tile)) return;
           halo_fetch<CF::KX>(xin, 0, smem, t);
         }
         __syncthreads();
-        Bias16 b1, b2, b3, b4, b5a, b5b;
-        load_bias(bs.bias + 0, t, b1);
+        Bias16 bb;
         trace_ev(p, tile, ev);
         // ---------------- conv1
         run_units<T, S::first(U_CRIT, 1), S::end(U_CRIT, 1)>(acc, ws_, smem, t);
         trace_ev(p, tile, ev);
+        lds_bias(smem, 0, t, bb);
         mfma_drain();
         RowsRaw<T> x1, x2;
-        epilogue<T, 0, 0, 2>(acc, p, bs, b1, dense, 0, 0, nullptr, nullptr, false, t, smem, 0, &x1);     // x1 (kept: x still occupies its slots)
-        load_bias(bs.bias + 32, t, b2);
+        epilogue<T, 0, 0, 2>(acc, p, bs, bb, dense, 0, 0, nullptr, nullptr, false, t, smem, 0, &x1);     // x1 (kept: x still occupies its slots)
         ++epoch;
         trace_ev(p, tile, ev);
         run_units<T, S::first(U_BULK, 1), S::end(U_BULK, 1)>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { publish_at(IDX, std::integral_constant<int, S::first(U_BULK, 1) + 1>{}); });
@@ -1039,70 +1093,74 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         // ---------------- P = conv1x1(x) from the resident x; then x1 may take x's slots
         run_1x1_res<T>(acc, ws_, smem, t);
         __builtin_amdgcn_s_barrier();          // every wave done reading x
+        { const int lane = t.lane(); int opx, osw; t.own(lane, opx, osw);
 #pragma unroll
-        for (int r = 0; r < R; ++r) lds_put_row(smem, t.h, r, x1.q[r].q, t);
+          for (int r = 0; r < R; ++r) lds_put_row(smem, lane >> 5, r, x1.q[r].q, opx, osw); }
         trace_ev(p, tile, ev);
-        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
+        if (!wait_neighbours(ws, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, 0, smem, t, 0);
         __syncthreads();
         trace_ev(p, tile, ev);
         // ---------------- conv2
         run_units<T, S::first(U_CRIT, 2), S::end(U_CRIT, 2)>(acc, ws_, smem, t);
         trace_ev(p, tile, ev);
+        lds_bias(smem, 32, t, bb);
         mfma_drain();
-        epilogue<T, 1, 1, 3>(acc, p, bs, b2, dense, 1, 0, nullptr, nullptr, false, t, smem, 2, &x2);  // x2 (kept: residual of x4)
-        load_bias(bs.bias + 64, t, b3);
+        epilogue<T, 1, 1, 1>(acc, p, bs, bb, dense, 1, 0, nullptr, nullptr, false, t, smem, 2);       // x2
         ++epoch;
         trace_ev(p, tile, ev);
         run_units<T, S::first(U_BULK, 2), S::end(U_BULK, 2)>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { publish_at(IDX, std::integral_constant<int, S::first(U_BULK, 2) + 1>{}); });
         trace_ev(p, tile, ev);
-        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
+        if (!wait_neighbours(ws, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, CF::KD, smem, t, 2);
         __syncthreads();
         trace_ev(p, tile, ev);
         // ---------------- conv3
         run_units<T, S::first(U_CRIT, 3), S::end(U_CRIT, 3)>(acc, ws_, smem, t);
         trace_ev(p, tile, ev);
+        lds_bias(smem, 64, t, bb);
         mfma_drain();
-        epilogue<T, 2, 0, 1>(acc, p, bs, b3, dense, 2, 0, nullptr, nullptr, false, t, smem, 0);       // x3
-        load_bias(bs.bias + 96, t, b4);
+        epilogue<T, 2, 0, 1>(acc, p, bs, bb, dense, 2, 0, nullptr, nullptr, false, t, smem, 0);       // x3
         ++epoch;
         trace_ev(p, tile, ev);
         run_units<T, S::first(U_BULK, 3), S::end(U_BULK, 3)>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { publish_at(IDX, std::integral_constant<int, S::first(U_BULK, 3) + 1>{}); });
         trace_ev(p, tile, ev);
-        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
+        if (!wait_neighbours(ws, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, 2 * CF::KD, smem, t, 0);
         __syncthreads();
         trace_ev(p, tile, ev);
         // ---------------- conv4
         run_units<T, S::first(U_CRIT, 4), S::end(U_CRIT, 4)>(acc, ws_, smem, t);
         trace_ev(p, tile, ev);
+        lds_bias(smem, 96, t, bb);
+        lds_get_rows(smem, 2, x2.q, t);   // x2's own pixels still sit in the slots x4 is about to take
         mfma_drain();
-        epilogue<T, 3, 2, 1>(acc, p, bs, b4, dense, 3, 0, &x2, nullptr, false, t, smem, 2);           // x4 (+ x2)
-        // the block tail's operands: requested here, used after conv5
+        epilogue<T, 3, 2, 1>(acc, p, bs, bb, dense, 3, 0, &x2, nullptr, false, t, smem, 2);           // x4 (+ x2)
         RowsRaw<T> tx0, tx1, tr0, tr1;
-        load_bias(bs.bias + 128, t, b5a);
-        load_bias(bs.bias + 160, t, b5b);
-        if (has_res2) { load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1); }
         ++epoch;
         trace_ev(p, tile, ev);
         run_units<T, S::first(U_BULK, 4), S::end(U_BULK, 4)>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { publish_at(IDX, std::integral_constant<int, S::first(U_BULK, 4) + 1>{}); if constexpr ((ESR_ABL & 32) != 0) trace_ev(p, tile, ev); });
         trace_ev(p, tile, ev);
-        if (!wait_neighbours(ws, nbr_tile, epoch, smem, t, &p, &ev, tile)) return;
+        if (!wait_neighbours(ws, epoch, smem, t, &p, &ev, tile)) return;
         halo_fetch<CF::KD>(dense, 3 * CF::KD, smem, t, 2);
         __syncthreads();
+        // the block tail's residual (every third block): requested here, used after conv5
+        if (has_res2) { load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1); }
         trace_ev(p, tile, ev);
         // ---------------- conv5; block tail (+ RRDB tail)
         run_units<T, S::first(U_CRIT, 5), S::end(U_CRIT, 5)>(acc, ws_, smem, t);
         if (noisy) { load_rows<T>(xin, 0, p, t, tx0); load_rows<T>(xin, 1, p, t, tx1); }   // rare path: latency exposed
         trace_ev(p, tile, ev);
         mfma_drain();
+        Bias16 bb2;
+        lds_bias(smem, 128, t, bb);
+        lds_bias(smem, 160, t, bb2);
         if (noisy) {
-          epilogue<T, 4, 3, 1, true>(acc, p, bs, b5a, xout, 0, 0, &tx0, &tr0, has_res2, t, smem, 0, nullptr, 0.f, full_out);
-          epilogue<T, 5, 3, 1, true>(acc, p, bs, b5b, xout, 1, 1, &tx1, &tr1, has_res2, t, smem, 2, nullptr, 0.f, full_out);
+          epilogue<T, 4, 3, 1, true>(acc, p, bs, bb, xout, 0, 0, &tx0, &tr0, has_res2, t, smem, 0, nullptr, 0.f, full_out);
+          epilogue<T, 5, 3, 1, true>(acc, p, bs, bb2, xout, 1, 1, &tx1, &tr1, has_res2, t, smem, 2, nullptr, 0.f, full_out);
         } else {
-          epilogue<T, 4, 3, 1, false>(acc, p, bs, b5a, xout, 0, 0, nullptr, &tr0, has_res2, t, smem, 0, nullptr, 5.f, full_out);
-          epilogue<T, 5, 3, 1, false>(acc, p, bs, b5b, xout, 1, 1, nullptr, &tr1, has_res2, t, smem, 2, nullptr, 5.f, full_out);
+          epilogue<T, 4, 3, 1, false>(acc, p, bs, bb, xout, 0, 0, nullptr, &tr0, has_res2, t, smem, 0, nullptr, 5.f, full_out);
+          epilogue<T, 5, 3, 1, false>(acc, p, bs, bb2, xout, 1, 1, nullptr, &tr1, has_res2, t, smem, 2, nullptr, 5.f, full_out);
         }
         publish(flags, tile, ++epoch, t, &p, &ev);
         ws_.ring = (ws_.ring + S::N) & (WR - 1);
@@ -1114,7 +1172,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       load_bias(bs.bias + 160, t, fb[5]);
       // ---------------- phase 1: x -> conv1..conv5
       issue_w_head<6>(w + CF::phase_off(1), CF::KX, smem, t);
-      if (epoch > 0 && !wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+      if (epoch > 0 && !wait_neighbours(ws, epoch, smem, t)) return;
       trace_ev(p, tile, ev);
       run_phase<T, 1>(acc, w + CF::phase_off(1), xin_b, blk.x_in.group_stride, CF::KX, smem, t);
       trace_ev(p, tile, ev);
@@ -1127,7 +1185,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       trace_ev(p, tile, ev);
       __syncthreads();                      // every wave done with the 1x1's LDS before phase 2 refills it
       issue_w_head<5>(w + CF::phase_off(2), CF::KD, smem, t);
-      if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+      if (!wait_neighbours(ws, epoch, smem, t)) return;
       trace_ev(p, tile, ev);
       run_phase<T, 2>(acc, w + CF::phase_off(2), dense_b, d_gs, CF::KD, smem, t);
       trace_ev(p, tile, ev);
@@ -1137,7 +1195,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       trace_ev(p, tile, ev);
       // ---------------- phase 3: x2 -> conv3..conv5
       issue_w_head<4>(w + CF::phase_off(3), CF::KD, smem, t);
-      if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+      if (!wait_neighbours(ws, epoch, smem, t)) return;
       trace_ev(p, tile, ev);
       run_phase<T, 3>(acc, w + CF::phase_off(3), dense_b + CF::KD * d_gs, d_gs, CF::KD, smem, t);
       trace_ev(p, tile, ev);
@@ -1147,7 +1205,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       trace_ev(p, tile, ev);
       // ---------------- phase 4: x3 -> conv4, conv5
       issue_w_head<3>(w + CF::phase_off(4), CF::KD, smem, t);
-      if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+      if (!wait_neighbours(ws, epoch, smem, t)) return;
       trace_ev(p, tile, ev);
       run_phase<T, 4>(acc, w + CF::phase_off(4), dense_b + 2 * CF::KD * d_gs, d_gs, CF::KD, smem, t);
       trace_ev(p, tile, ev);
@@ -1158,7 +1216,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       trace_ev(p, tile, ev);
       // ---------------- phase 5: x4 -> conv5; block tail (+ RRDB tail)
       issue_w_head<2>(w + CF::phase_off(5), CF::KD, smem, t);
-      if (!wait_neighbours(ws, nbr_tile, epoch, smem, t)) return;
+      if (!wait_neighbours(ws, epoch, smem, t)) return;
       trace_ev(p, tile, ev);
       run_phase<T, 5>(acc, w + CF::phase_off(5), dense_b + 3 * CF::KD * d_gs, d_gs, CF::KD, smem, t);
       trace_ev(p, tile, ev);
