@@ -67,7 +67,9 @@ constexpr int WR = 4;                       // weight ring depth (3 units ahead)
 constexpr int WOFF = AR * ASLOT;
 constexpr int LDS_CTRL = WOFF + WR * WSLOT;   // two control words behind the rings
 constexpr int LDS_BIAS = LDS_CTRL + 64;        // fp16 path: the block's 192 biases (fp32)
-constexpr int LDS_BYTES = LDS_BIAS + 192 * 4;  // 156480
+constexpr int LDS_FLAGS = LDS_BIAS + 192 * 4;  // fp16 path: the neighbours' flags as wave 0 last fetched them (64 words)
+constexpr int LDS_HALO = LDS_FLAGS + 256;      // fp16 path: per thread {source, destination} offset of its halo slot
+constexpr int LDS_BYTES = LDS_HALO + NT * 8;   // 158784
 constexpr int NHALO = 2 * 2 * IW + 2 * 2 * TH;  // 16-byte slots of the 1-pixel halo ring of one stage (200)
 constexpr int WS_HDR = 16;                  // workspace words before the per-tile flags
 enum { WS_TICKET = 0, WS_ABORT = 1 };
@@ -325,16 +327,25 @@ __device__ __forceinline__ void issue_a(const char* plane, int sa, char* smem, c
 // writes them into the stage slots the next phase reads (slot = channel group of the slice).  Only the
 // 1-pixel ring around the tile is fetched (sc1 loads, after the neighbours published): one 16-byte load
 // + one ds_write per thread and stage.
+template <int K> struct HaloRegs { u32x4 q[K]; };
+template <int K> __device__ __forceinline__ void halo_issue(const ImgView& v, int g0, int hsrc, HaloRegs<K>& h) {
+  // threads without a slot read (and later drop) the view's first bytes: a branch around the loads would
+  // also fence them off from the MFMAs they are meant to hide under
+#pragma unroll
+  for (int c = 0; c < K; ++c) h.q[c] = __builtin_amdgcn_raw_buffer_load_b128(v.r, hsrc >= 0 ? (g0 + c) * v.gs + hsrc : 0, 0, 16);
+}
+template <int K> __device__ __forceinline__ void halo_put(char* smem, int slot0, int hsrc, int hdst, const HaloRegs<K>& h) {
+  if (hsrc >= 0) {
+#pragma unroll
+    for (int c = 0; c < K; ++c) *(u32x4*)(smem + (slot0 + c) * ASLOT + hdst) = h.q[c];
+  }
+}
 template <int K> __device__ __forceinline__ void halo_fetch(const ImgView& v, int g0, char* smem, const Tile& t, int slot0 = 0) {
+  HaloRegs<K> h;
   int hsrc, hdst;
   t.halo(hsrc, hdst);
-  if (hsrc >= 0) {
-    u32x4 q[K];
-#pragma unroll
-    for (int c = 0; c < K; ++c) q[c] = __builtin_amdgcn_raw_buffer_load_b128(v.r, (g0 + c) * v.gs + hsrc, 0, 16);
-#pragma unroll
-    for (int c = 0; c < K; ++c) *(u32x4*)(smem + (slot0 + c) * ASLOT + hdst) = q[c];
-  }
+  halo_issue<K>(v, g0, hsrc, h);
+  halo_put<K>(smem, slot0, hsrc, hdst, h);
 }
 // the lane's packed 16 channels of row r (own pixel) -> stage slot `slot`
 __device__ __forceinline__ void lds_put_row(char* smem, int slot, int r, const u32x4 (&q)[2], int own_px, int own_swz) {
@@ -475,6 +486,19 @@ template <typename T> struct Sched {
   static constexpr int wait_mid(int i, bool has_next) {
     const int part = nf_at(i + 3, has_next) >> 2, done = steps(i) - 1;
     return (nf_at(i + 2, has_next) >> 2) + (part < done ? part : done);
+  }
+  // mid(i) of the FIRST unit after an epilogue, strict form: nothing but this unit's own requests may still be
+  // in flight, i.e. the epilogue's stores (older than those, younger than unit i+2's requests) have landed
+  static constexpr int wait_mid_strict(int i, bool has_next) {
+    const int part = nf_at(i + 3, has_next) >> 2, done = steps(i) - 1;
+    return part < done ? part : done;
+  }
+  // the requests WAVE 0 issues between the barrier inside unit i and the barrier inside unit i+1 (wave 0 copies
+  // fragments 0, 4, ..: (nf + 3) >> 2 of a unit, one per step)
+  static constexpr int w0_between(int i, bool has_next) {
+    const int ci = (nf_at(i + 3, has_next) + 3) >> 2, di = steps(i) - 1;
+    const int cn = (nf_at(i + 4, has_next) + 3) >> 2, dn = steps(i + 1) - 1;
+    return ci - (ci < di ? ci : di) + (cn < dn ? cn : dn);
   }
   // steps of units [i0, i): which of the two A-fragment register sets unit i starts on
   static constexpr int parity(int i0, int i) {
@@ -643,7 +667,7 @@ __device__ __forceinline__ void issue_ahead(const WStream& s, const Tile& t, cha
 // units [I0, I1) of the schedule, back to back.  `hook(I)` runs inside unit I after the barrier that opens
 // unit I+1 (every wave has waited for everything older than unit I+2's requests by then).
 struct NoHook { template <typename X> __device__ __forceinline__ void operator()(X) const {} };
-template <typename T, int I0, int I1, typename HOOK = NoHook>
+template <typename T, int I0, int I1, bool STRICT0 = false, typename HOOK = NoHook>
 __device__ __forceinline__ void run_units(Acc24& acc, const WStream& s, char* smem, const Tile& t, HOOK&& hook = NoHook{}) {
   using S = Sched<T>;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -665,7 +689,8 @@ __device__ __forceinline__ void run_units(Acc24& acc, const WStream& s, char* sm
     const uint32_t lwn = lds0 + WOFF + ((s.ring + I + 1) & (WR - 1)) * WSLOT + lane16;
     auto issue = [&](int i) __attribute__((always_inline)) { issue_ahead<T, I>(s, t, smem, i, lane16); };
     auto mid = [&]() __attribute__((always_inline)) {
-      wait_units<T, S::wait_mid(I, true), S::wait_mid(I, false)>(s);   // the next unit's weights
+      if constexpr (STRICT0 && I == I0) wait_units<T, S::wait_mid_strict(I, true), S::wait_mid_strict(I, false)>(s);
+      else wait_units<T, S::wait_mid(I, true), S::wait_mid(I, false)>(s);   // the next unit's weights
       __builtin_amdgcn_s_barrier();        // next unit visible to all waves; all waves past this unit's LDS reads
       hook(std::integral_constant<int, I>{});
     };
@@ -787,12 +812,12 @@ __device__ __forceinline__ bool wait_neighbours(unsigned* ws, unsigned epoch, ch
     bool ok = my_nbr_tile < 0;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     bool dead = false;
-    for (;;) {
+    for (unsigned it = 1;; ++it) {
       if (!ok) ok = __hip_atomic_load((gu32*)(ws + WS_HDR + my_nbr_tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
       if (__all(ok)) break;
-      __builtin_amdgcn_s_sleep(2);
-      if ((__builtin_amdgcn_s_memrealtime() - t0) > 100000000ull ||      // 1 s of the 100 MHz counter
-          __hip_atomic_load((gu32*)(ws + WS_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      // the abort word is a second dependent round trip: look at it (and at the clock) every 16th turn only
+      if ((it & 15u) == 0u && ((__builtin_amdgcn_s_memrealtime() - t0) > 100000000ull ||      // 1 s of the 100 MHz counter
+                               __hip_atomic_load((gu32*)(ws + WS_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
         dead = true;
         break;
       }
@@ -806,6 +831,35 @@ __device__ __forceinline__ bool wait_neighbours(unsigned* ws, unsigned epoch, ch
   __syncthreads();
   const int dead = *(volatile int*)(smem + LDS_CTRL + 16);
   return dead == 0;
+}
+
+// Non-blocking form for the bulks (wave 0 only): the 8 flags are fetched by LDS-DMA into LDS_FLAGS — no
+// register result, hence nothing to wait for — and looked at two units later with plain LDS reads: a flag that
+// has not landed yet simply still shows its older (smaller) value and sends the tile through the blocking
+// poll after the bulk.  LDS accesses here are inline asm: hipcc orders a visible LDS access after every
+// LDS-DMA in flight with `vmcnt(0)`, which would drain the weight stream.
+__device__ __forceinline__ void poll_issue(unsigned* ws, int tile, char* smem, const Tile& t) {
+  const int lane = t.lane();
+  int nbr = tile;                                         // no neighbour: the tile's own flag (already up)
+  if (lane < 8) {
+    const int k = lane < 4 ? lane : lane + 1;
+    const int ny = t.ty + k / 3 - 1, nx = t.tx + k % 3 - 1;
+    if (ny >= 0 && ny < t.tiles_y && nx >= 0 && nx < t.tiles_x) nbr = (t.b * t.tiles_y + ny) * t.tiles_x + nx;
+  }
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws + WS_HDR + nbr),
+                                   (__attribute__((address_space(3))) void*)(smem + LDS_FLAGS), 4, 0, 16);
+}
+__device__ __forceinline__ unsigned lds_peek(uint32_t addr) {
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void poll_check(unsigned epoch, char* smem, const Tile& t) {
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int lane = t.lane();
+  const bool ok = __all(lds_peek(lds0 + LDS_FLAGS + lane * 4) >= epoch);
+  const unsigned tag = ok ? epoch : 0u;
+  if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + LDS_CTRL + 32), "v"(tag) : "memory");
 }
 
 // ---- epilogue of one finished 32-cout block ---------------------------------------------------------
@@ -975,6 +1029,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
 
   for (;;) {
     // ---- claim the next tile (tickets go out in order, so an image's tiles are co-resident)
+    if (threadIdx.x < 64) ((volatile unsigned*)(smem + LDS_FLAGS))[threadIdx.x] = 0u;   // flags restart at 0 with the tile
     __syncthreads();
     if (threadIdx.x == 0)
       *(volatile int*)(smem + LDS_CTRL) = (int)__hip_atomic_fetch_add((gu32*)(ws + WS_TICKET), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -987,6 +1042,11 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
     t.ox0 = tx * TW;
     t.ty = ty; t.tx = tx; t.tiles_y = tiles_y; t.tiles_x = tiles_x;
     t.wp = wp;
+    if constexpr (sizeof(T) == 2) {   // each thread's halo source offset, for the requests issued from inside the bulks
+      int hsrc, hdst;
+      t.halo(hsrc, hdst);
+      *(volatile int*)(smem + LDS_HALO + t.tid() * 8) = hsrc;
+    }
     const ImgView dense = img_view(p.dense, t.b);
     const char* const dense_b = (const char*)p.dense.ptr + (int64_t)t.b * p.dense.batch_stride;
     const int64_t d_gs = p.dense.group_stride;
@@ -1046,12 +1106,41 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         using S = Sched<T>;
         ws_.w = w;
         ws_.wnext = wnext;
-        // publish from inside a bulk: at the barrier that opens the bulk's THIRD unit every wave has waited
-        // for everything older than the first two bulk units' DMAs, i.e. for the epilogue's stores
-        auto publish_at = [&](auto IDX, auto AT) __attribute__((always_inline)) {
-          if constexpr (decltype(IDX)::value == decltype(AT)::value) {
+        // The hand-off of x_p runs INSIDE bulk_p (hooks at the barriers that open the bulk's next units):
+        //   unit 0: every wave has waited for its epilogue stores (strict wait) -> thread 0 raises the flag;
+        //   5th unit from the end: wave 0 requests the 8 neighbours' flags;  3rd: it looks at them -> LDS word;
+        //   2nd: all up -> every halo thread requests its 16 bytes per stage; they land under the last unit.
+        // A neighbour that is late (flag not up yet at unit 3) sends the tile through the blocking poll after
+        // the bulk instead.
+        int early = 0;
+        HaloRegs<CF::KD> hq;
+        auto bulk_hook = [&](auto IDX, auto FIRST_, auto END_, int g0) __attribute__((always_inline)) {
+          constexpr int I = decltype(IDX)::value, rel = I - decltype(FIRST_)::value, left = decltype(END_)::value - 1 - I;
+          if constexpr (rel == 0) {
             if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else if constexpr (left == 4 && !(ESR_ABL & 64)) {
+            if (t.wave == 0) poll_issue(ws, tile, smem, t);
+          } else if constexpr (left == 2 && !(ESR_ABL & 64)) {
+            if (t.wave == 0) poll_check(epoch, smem, t);
+          } else if constexpr (left == 1 && !(ESR_ABL & 64)) {
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+            early = __builtin_amdgcn_readfirstlane((int)(lds_peek(lds0 + LDS_CTRL + 32) == epoch));
+            if (early) halo_issue<CF::KD>(dense, g0, (int)lds_peek(lds0 + LDS_HALO + t.tid() * 8), hq);
           }
+        };
+        // after the bulk: the halo of stage g0 into slots slot0..
+        auto finish_halo = [&](int g0, int slot0) __attribute__((always_inline)) -> bool {
+          int hsrc, hdst;
+          t.halo(hsrc, hdst);
+          if (!early) {
+            if (!wait_neighbours(ws, epoch, smem, t, &p, &ev, tile)) return false;
+            halo_issue<CF::KD>(dense, g0, hsrc, hq);
+          } else {
+            trace_ev(p, tile, ev);
+          }
+          halo_put<CF::KD>(smem, slot0, hsrc, hdst, hq);
+          __syncthreads();
+          return true;
         };
         stage_bias(bs.bias, smem, t);          // every wave is past the previous block's tail (publish)
         if (rb == 0) {
@@ -1088,7 +1177,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         epilogue<T, 0, 0, 2>(acc, p, bs, bb, dense, 0, 0, nullptr, nullptr, false, t, smem, 0, &x1);     // x1 (kept: x still occupies its slots)
         ++epoch;
         trace_ev(p, tile, ev);
-        run_units<T, S::first(U_BULK, 1), S::end(U_BULK, 1)>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { publish_at(IDX, std::integral_constant<int, S::first(U_BULK, 1) + 1>{}); });
+        run_units<T, S::first(U_BULK, 1), S::end(U_BULK, 1), true>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 1)>{}, std::integral_constant<int, S::end(U_BULK, 1)>{}, 0); });
         trace_ev(p, tile, ev);
         // ---------------- P = conv1x1(x) from the resident x; then x1 may take x's slots
         run_1x1_res<T>(acc, ws_, smem, t);
@@ -1097,9 +1186,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
 #pragma unroll
           for (int r = 0; r < R; ++r) lds_put_row(smem, lane >> 5, r, x1.q[r].q, opx, osw); }
         trace_ev(p, tile, ev);
-        if (!wait_neighbours(ws, epoch, smem, t, &p, &ev, tile)) return;
-        halo_fetch<CF::KD>(dense, 0, smem, t, 0);
-        __syncthreads();
+        if (!finish_halo(0, 0)) return;
         trace_ev(p, tile, ev);
         // ---------------- conv2
         run_units<T, S::first(U_CRIT, 2), S::end(U_CRIT, 2)>(acc, ws_, smem, t);
@@ -1109,11 +1196,9 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         epilogue<T, 1, 1, 1>(acc, p, bs, bb, dense, 1, 0, nullptr, nullptr, false, t, smem, 2);       // x2
         ++epoch;
         trace_ev(p, tile, ev);
-        run_units<T, S::first(U_BULK, 2), S::end(U_BULK, 2)>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { publish_at(IDX, std::integral_constant<int, S::first(U_BULK, 2) + 1>{}); });
+        run_units<T, S::first(U_BULK, 2), S::end(U_BULK, 2), true>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 2)>{}, std::integral_constant<int, S::end(U_BULK, 2)>{}, CF::KD); });
         trace_ev(p, tile, ev);
-        if (!wait_neighbours(ws, epoch, smem, t, &p, &ev, tile)) return;
-        halo_fetch<CF::KD>(dense, CF::KD, smem, t, 2);
-        __syncthreads();
+        if (!finish_halo(CF::KD, 2)) return;
         trace_ev(p, tile, ev);
         // ---------------- conv3
         run_units<T, S::first(U_CRIT, 3), S::end(U_CRIT, 3)>(acc, ws_, smem, t);
@@ -1123,11 +1208,9 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         epilogue<T, 2, 0, 1>(acc, p, bs, bb, dense, 2, 0, nullptr, nullptr, false, t, smem, 0);       // x3
         ++epoch;
         trace_ev(p, tile, ev);
-        run_units<T, S::first(U_BULK, 3), S::end(U_BULK, 3)>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { publish_at(IDX, std::integral_constant<int, S::first(U_BULK, 3) + 1>{}); });
+        run_units<T, S::first(U_BULK, 3), S::end(U_BULK, 3), true>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD); });
         trace_ev(p, tile, ev);
-        if (!wait_neighbours(ws, epoch, smem, t, &p, &ev, tile)) return;
-        halo_fetch<CF::KD>(dense, 2 * CF::KD, smem, t, 0);
-        __syncthreads();
+        if (!finish_halo(2 * CF::KD, 0)) return;
         trace_ev(p, tile, ev);
         // ---------------- conv4
         run_units<T, S::first(U_CRIT, 4), S::end(U_CRIT, 4)>(acc, ws_, smem, t);
@@ -1139,11 +1222,9 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         RowsRaw<T> tx0, tx1, tr0, tr1;
         ++epoch;
         trace_ev(p, tile, ev);
-        run_units<T, S::first(U_BULK, 4), S::end(U_BULK, 4)>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { publish_at(IDX, std::integral_constant<int, S::first(U_BULK, 4) + 1>{}); if constexpr ((ESR_ABL & 32) != 0) trace_ev(p, tile, ev); });
+        run_units<T, S::first(U_BULK, 4), S::end(U_BULK, 4), true>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD); });
         trace_ev(p, tile, ev);
-        if (!wait_neighbours(ws, epoch, smem, t, &p, &ev, tile)) return;
-        halo_fetch<CF::KD>(dense, 3 * CF::KD, smem, t, 2);
-        __syncthreads();
+        if (!finish_halo(3 * CF::KD, 2)) return;
         // the block tail's residual (every third block): requested here, used after conv5
         if (has_res2) { load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1); }
         trace_ev(p, tile, ev);
