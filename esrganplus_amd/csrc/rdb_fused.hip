@@ -493,13 +493,6 @@ template <typename T> struct Sched {
     const int part = nf_at(i + 3, has_next) >> 2, done = steps(i) - 1;
     return part < done ? part : done;
   }
-  // the requests WAVE 0 issues between the barrier inside unit i and the barrier inside unit i+1 (wave 0 copies
-  // fragments 0, 4, ..: (nf + 3) >> 2 of a unit, one per step)
-  static constexpr int w0_between(int i, bool has_next) {
-    const int ci = (nf_at(i + 3, has_next) + 3) >> 2, di = steps(i) - 1;
-    const int cn = (nf_at(i + 4, has_next) + 3) >> 2, dn = steps(i + 1) - 1;
-    return ci - (ci < di ? ci : di) + (cn < dn ? cn : dn);
-  }
   // steps of units [i0, i): which of the two A-fragment register sets unit i starts on
   static constexpr int parity(int i0, int i) {
     int p = 0;
@@ -568,11 +561,9 @@ __device__ __forceinline__ void unit_steps(Acc24& acc, UFrags& f, const uint32_t
     if constexpr (s + 1 == NS && NXT && !(ESR_ABL & 4))
       sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<(3 + decltype(IR2)::value) * IW * 32>(bf[3 + decltype(IR2)::value], lbn); });
     __builtin_amdgcn_sched_barrier(0);
-    issue(s);
-    if constexpr (s + 1 == NS) {
-#pragma unroll
-      for (int i = NS; i < 5; ++i) issue(i);
-    }
+    issue(std::integral_constant<int, s>{});
+    if constexpr (s + 1 == NS && NS < 4)
+      sfor<4 - NS>([&](auto X) __attribute__((always_inline)) { issue(std::integral_constant<int, NS + decltype(X)::value>{}); });
     __builtin_amdgcn_sched_barrier(0);
   });
 }
@@ -647,22 +638,38 @@ template <typename T, int A, int B> __device__ __forceinline__ void wait_units(c
   if constexpr (A == B) wait_vm<A>();
   else { if (s.wnext) wait_vm<A>(); else wait_vm<B>(); }
 }
-// this wave's share of the unit 3 places after unit I: step i's request (q = wave + 4 i)
+// This wave's share of the unit 3 places after unit I: the nf fragments of a unit are split into four
+// contiguous runs, wave w copies fragments [w nf / 4, (w+1) nf / 4) — at least nf >> 2, at most 4 — one per
+// step.  Source and LDS address of a run are set up ONCE per unit; the requests themselves differ only in the
+// instruction's immediate offset, which the LDS-DMA adds to the global AND the LDS address (i * 1024 here): a
+// request is one instruction in the shadow of the MFMA issued before it, not an address computation.
+struct Ahead { const char* src; char* dst; int cnt; };
 template <typename T, int I>
-__device__ __forceinline__ void issue_ahead(const WStream& s, const Tile& t, char* smem, int i, int lane16) {
+__device__ __forceinline__ Ahead ahead_of(const WStream& s, const Tile& t, char* smem, uint32_t lane16) {
   using S = Sched<T>;
   constexpr int J = I + 3;
   constexpr bool wrap = J >= S::N;
   constexpr UDesc dj = S::at(wrap ? J - S::N : J);
-  if (ESR_ABL & 1) return;
-  if (4 * i >= dj.nf) return;
-  if (wrap && !s.wnext) return;
-  const int q = t.wave + 4 * i;
-  if (4 * i + 3 < dj.nf || q < dj.nf) {
-    const char* src = (wrap ? s.wnext : s.w) + (dj.off + q) * 1024 + lane16;
-    char* dst = smem + WOFF + ((s.ring + J) & (WR - 1)) * WSLOT + q * 1024;
-    dma16(src, dst);
+  const int start = (t.wave * dj.nf) >> 2;
+  Ahead a;
+  a.cnt = (((t.wave + 1) * dj.nf) >> 2) - start;
+  if ((wrap && !s.wnext) || (ESR_ABL & 1)) a.cnt = 0;
+  a.src = (wrap ? s.wnext : s.w) + (dj.off + start) * 1024 + (size_t)lane16;
+  a.dst = smem + WOFF + ((s.ring + J) & (WR - 1)) * WSLOT + start * 1024;
+  return a;
+}
+// SURE = requests every wave issues unconditionally (nf >> 2 of a unit of this block; none when the unit may
+// belong to a next block that does not exist)
+template <int I_, int SURE = 0> __device__ __forceinline__ void issue_one(const Ahead& a) {
+  if constexpr (I_ < 4) {
+    if (I_ < SURE || I_ < a.cnt)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a.src,
+                                       (__attribute__((address_space(3))) void*)a.dst, 16, I_ * 1024, 0);
   }
+}
+template <typename T, int I> constexpr int sure_ahead() {
+  using S = Sched<T>;
+  return (I + 3 >= S::N || (ESR_ABL & 1)) ? 0 : (S::at(I + 3).nf >> 2);
 }
 // units [I0, I1) of the schedule, back to back.  `hook(I)` runs inside unit I after the barrier that opens
 // unit I+1 (every wave has waited for everything older than unit I+2's requests by then).
@@ -673,7 +680,8 @@ __device__ __forceinline__ void run_units(Acc24& acc, const WStream& s, char* sm
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
   UFrags f;
-  const int lane = t.lane(), lane16 = lane * 16;
+  const int lane = t.lane();
+  const uint32_t lane16 = (uint32_t)lane * 16u;
   const int colofs[3] = {Tile::colofs(lane, 0), Tile::colofs(lane, 1), Tile::colofs(lane, 2)};
   wait_units<T, S::wait_top(I0, true), S::wait_top(I0, false)>(s);      // the first unit's weights
   __builtin_amdgcn_s_barrier();
@@ -687,7 +695,8 @@ __device__ __forceinline__ void run_units(Acc24& acc, const WStream& s, char* sm
     const uint32_t lw = lds0 + WOFF + ((s.ring + I) & (WR - 1)) * WSLOT + lane16;
     const uint32_t lbn = lds_rows + S::slot(dn) * ASLOT + colofs[S::nkw(dn) == 3 ? 0 : dn.kw];
     const uint32_t lwn = lds0 + WOFF + ((s.ring + I + 1) & (WR - 1)) * WSLOT + lane16;
-    auto issue = [&](int i) __attribute__((always_inline)) { issue_ahead<T, I>(s, t, smem, i, lane16); };
+    const Ahead ah = ahead_of<T, I>(s, t, smem, lane16);
+    auto issue = [&](auto SI) __attribute__((always_inline)) { issue_one<decltype(SI)::value, sure_ahead<T, I>()>(ah); };
     auto mid = [&]() __attribute__((always_inline)) {
       if constexpr (STRICT0 && I == I0) wait_units<T, S::wait_mid_strict(I, true), S::wait_mid_strict(I, false)>(s);
       else wait_units<T, S::wait_mid(I, true), S::wait_mid(I, false)>(s);   // the next unit's weights
@@ -714,8 +723,8 @@ __device__ __forceinline__ void run_1x1_res(Acc24& acc, const WStream& s, char* 
   const uint32_t lw = lds0 + WOFF + ((s.ring + I) & (WR - 1)) * WSLOT + lane * 16;
   wait_units<T, S::wait_top(I, true), S::wait_top(I, false)>(s);
   __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int i = 0; i < 5; ++i) issue_ahead<T, I>(s, t, smem, i, lane * 16);
+  { const Ahead ah = ahead_of<T, I>(s, t, smem, (uint32_t)lane * 16u);
+    sfor<4>([&](auto X) __attribute__((always_inline)) { issue_one<decltype(X)::value>(ah); }); }
   sfor<K>([&](auto CI) __attribute__((always_inline)) {
     constexpr int c = decltype(CI)::value;
     u32x4 a, b0, b1, b2, b3;
@@ -1147,14 +1156,8 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
           // the chain's input comes from another launch: stage all of x (with halo) by DMA, and start
           // the weight stream (its first three units)
           sfor<3>([&](auto UI) __attribute__((always_inline)) {
-            constexpr UDesc d = S::at(decltype(UI)::value);
-            const char* src = w + d.off * 1024 + t.lane() * 16;
-            char* dst = smem + WOFF + ((ws_.ring + decltype(UI)::value) & (WR - 1)) * WSLOT;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-              const int q = t.wave + 4 * j;
-              if (q < d.nf) dma16(src + q * 1024, dst + q * 1024);
-            }
+            const Ahead ah = ahead_of<T, decltype(UI)::value - 3>(ws_, t, smem, (uint32_t)t.lane() * 16u);
+            sfor<4>([&](auto X) __attribute__((always_inline)) { issue_one<decltype(X)::value>(ah); });
           });
           sfor<CF::KX>([&](auto CI) __attribute__((always_inline)) {
             issue_a(xin_b + decltype(CI)::value * blk.x_in.group_stride, decltype(CI)::value, smem, t);
