@@ -61,8 +61,12 @@ def describe_plan(net, plan):
             name += '_ups'
         if c.w1x1:
             name += '_1x1'
-        out.append((name, conv_flops(dict(B=c.B, H=c.H, W=c.W, cout=e.cout, cin=e.cin, ks=e.ks,
-                                          extra_mac=extra))))
+        fl = conv_flops(dict(B=c.B, H=c.H, W=c.W, cout=e.cout, cin=e.cin, ks=e.ks, extra_mac=extra))
+        if c.upsample == 3:
+            # nearest-x2 + 3x3 in its 4-phase 2x2 form: the kernel line counts the MACs it executes (16 of the
+            # reference op's 36 per 4 outputs); the whole-net figure keeps the reference's count
+            name, fl = 'upconv_subpix_c%d' % (32 if cbk == 1 else 64), fl * 4.0 / 9.0
+        out.append((name, fl))
     return out
 
 

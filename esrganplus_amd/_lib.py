@@ -55,7 +55,7 @@ class esr_pack(C.Structure):
                 ('ups_dgrad', C.c_int32),
                 ('gather', C.c_int32), ('dst_cout', C.c_int32), ('dst_chunk0', C.c_int32),
                 ('dst_nchunks', C.c_int32), ('src_co0', C.c_int32), ('src_ks', C.c_int32),
-                ('scale', C.c_float), ('_pad', C.c_int32)]
+                ('scale', C.c_float), ('ups_fwd', C.c_int32)]
 
 
 class esr_wgrad(C.Structure):

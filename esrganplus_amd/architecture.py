@@ -4,6 +4,7 @@
 (SURVEY.md Appendix B); ``forward`` replays a fused HIP launch plan instead of walking the
 ``nn.Sequential``.  Generators outside the path (SRResNet, pixelshuffle) raise NotImplementedError.
 """
+import os
 import math
 
 import torch.nn as nn
@@ -52,6 +53,10 @@ class _RRDBNetBase(B._PlannedModule):
         for idx in (3, 6, 8, 10):
             out.append(('model.%d' % idx, m[idx].weight, m[idx].bias))
         return out
+
+    def _subpix_keys(self):
+        # upconv_blcok (block.py:315-322) in its 4-phase 2x2 form: 16 instead of 36 MACs per 4 outputs
+        return () if os.environ.get('ESR_SUBPIX', '1') == '0' else ('model.3', 'model.6')
 
     def _dgrad_special(self):
         return {'model.3': {'ups': True}, 'model.6': {'ups': True}}

@@ -237,11 +237,15 @@ class _PlannedModule(nn.Module):
             self._wp[key] = dp
         return dp
 
+    def _subpix_keys(self):
+        """Keys of up-convs to run in the sub-pixel form (engine.WeightPack)."""
+        return ()
+
     def _weights(self, device):
         key = (self.precision, str(device))
         wp = self._wp.get(key)
         if wp is None:
-            wp = E.WeightPack(self._conv_list(), self.precision, device)
+            wp = E.WeightPack(self._conv_list(), self.precision, device, self._subpix_keys())
             self._wp[key] = wp
         wp.ensure(E.current_stream(), force=self._force_repack or self.training)
         self._force_repack = False

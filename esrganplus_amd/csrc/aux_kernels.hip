@@ -36,6 +36,35 @@ __device__ __forceinline__ void pack_piece(const esr_pack& p, int64_t idx) {
     for (int e = 0; e < EPL; ++e) dst[e] = v[e];
     return;
   }
+  if (p.ups_fwd) {
+    // sub-pixel form of nearest-x2 + conv3x3: phase (dy, dx), 2x2 taps (a, b); tap a of phase dy collects the
+    // forward rows {0} / {1,2} (dy = 0) or {0,1} / {2} (dy = 1), same for columns
+    const int nchunks = (p.cin + CPG - 1) / CPG, cbs = (p.cout + 31) / 32;
+    const int lane = idx & 63;
+    int64_t rest = idx >> 6;
+    const int tap = rest % 4; rest /= 4;
+    const int chunk = rest % nchunks; rest /= nchunks;
+    const int cb = rest % cbs, phase = rest / cbs;
+    const int dy = phase >> 1, dx = phase & 1, ta = tap >> 1, tb = tap & 1;
+    const int r0 = dy == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), r1 = dy == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
+    const int c0 = dx == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), c1 = dx == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
+    const int i = lane & 31, h = lane >> 5;
+    const int co = cb * 32 + esr_pi(i);
+    T v[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int ci = chunk * CPG + EPL * h + e;
+      float x = 0.f;
+      if (co < p.cout && ci < p.cin)
+        for (int r = r0; r <= r1; ++r)
+          for (int c = c0; c <= c1; ++c) x += p.src[(((int64_t)co * p.cin + ci) * 3 + r) * 3 + c];
+      v[e] = (T)x;
+    }
+    T* dst = (T*)p.dst + idx * EPL;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) dst[e] = v[e];
+    return;
+  }
   const int kdim = p.transpose_flip ? p.cout : p.cin;
   const int nchunks = (kdim + CPG - 1) / CPG;
   const int lane = idx & 63;
@@ -174,7 +203,7 @@ extern "C" size_t esr_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ks,
 
 extern "C" int esr_pack_conv_weights(const esr_pack* p, esr_stream_t stream) {
   if (!p || !p->src || !p->dst || p->cout <= 0 || p->cin <= 0 || (p->ks != 1 && p->ks != 3 && p->ks != 4) ||
-      (p->ups_dgrad && !(p->transpose_flip && p->ks == 4))) {
+      (p->ups_dgrad && !(p->transpose_flip && p->ks == 4)) || (p->ups_fwd && (p->transpose_flip || p->gather || p->ks != 3))) {
     esr_set_error("esr_pack_conv_weights: invalid arguments");
     return ESR_ERR_INVALID;
   }
@@ -183,7 +212,7 @@ extern "C" int esr_pack_conv_weights(const esr_pack* p, esr_stream_t stream) {
   const int rows = p->transpose_flip ? p->cin : p->cout;
   const int kdim = p->transpose_flip ? p->cout : p->cin;
   const int nchunks = (kdim + cpg - 1) / cpg;
-  const int64_t total = (int64_t)((rows + 31) / 32) * nchunks * p->ks * p->ks * 64;
+  const int64_t total = p->ups_fwd ? (int64_t)((rows + 31) / 32) * 4 * nchunks * 4 * 64 : (int64_t)((rows + 31) / 32) * nchunks * p->ks * p->ks * 64;
   const int blocks = (int)((total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
   if (p->dtype == ESR_F16) hipLaunchKernelGGL(pack_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, *p, nchunks, total);
@@ -195,6 +224,7 @@ extern "C" int esr_pack_conv_weights(const esr_pack* p, esr_stream_t stream) {
 extern "C" int64_t esr_pack_pieces(const esr_pack* p) {
   const int cpg = p->dtype == ESR_F16 ? 16 : 8;
   if (p->gather) return (int64_t)((p->dst_cout + 31) / 32) * ((p->cout + cpg - 1) / cpg) * 9 * 64;
+  if (p->ups_fwd) return (int64_t)((p->cout + 31) / 32) * 4 * ((p->cin + cpg - 1) / cpg) * 4 * 64;
   const int rows = p->transpose_flip ? p->cin : p->cout;
   const int kdim = p->transpose_flip ? p->cout : p->cin;
   return (int64_t)((rows + 31) / 32) * ((kdim + cpg - 1) / cpg) * p->ks * p->ks * 64;

@@ -36,7 +36,7 @@ namespace {
 // as documented on esr_conv in esrgan_hip.h.  Two phases: (1) issue EVERY global load of all R rows
 // (bias, residuals, explicit z, mask) back to back, (2) compute and store.  With one or two waves
 // per SIMD a load->use->store chain per row would expose R full memory latencies.
-template <typename T, int R, int NCW, int CW, bool HAS1X1, bool BWD>
+template <typename T, int R, int NCW, int CW, bool HAS1X1, bool BWD, int RS = 1>
 __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc8& acc1, int b, int cb, int h,
                                                int oyb, int ox) {
   const bool n1 = (p.noise_mode == ESR_NOISE_PHILOX && p.layer1 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z1.ptr);
@@ -49,13 +49,13 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
   Raw16<T> r1[R], r2[R];   // prefetched; explicit-z / mask operands (test & dgrad modes) load in phase 2
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int oy = oyb + r < p.H ? oyb + r : p.H - 1;     // clamp: rows past the image are not stored
+    const int oy = oyb + RS * r < p.H ? oyb + RS * r : p.H - 1;     // clamp: rows past the image are not stored
     if (p.res1.ptr) r1[r].load(p.res1, b, cb, h, (int64_t)(oy + 1) * p.res1.wp + ox + 1);
     if (p.res2.ptr) r2[r].load(p.res2, b, cb, h, (int64_t)(oy + 1) * p.res2.wp + ox + 1);
   }
   sfor<R>([&](auto RR) __attribute__((always_inline)) {
     constexpr int r = decltype(RR)::value;
-    const int oy = oyb + r;
+    const int oy = oyb + RS * r;
     if (oy >= p.H) return;
     const f32x16 a = accsel<r * NCW + CW>(acc);
     float v[16], tmp[16];
@@ -159,9 +159,11 @@ struct Geo {
   static constexpr int NW = WR * WC * NCG;                               // waves per workgroup
   static constexpr int NT = NW * 64;
   static constexpr int TH = R * WR, TW = 32 * WC;                        // output tile
-  static constexpr int IH = UPS ? TH / 2 + 2 : (TH - 1) * S + KS;       // staged input tile
-  static constexpr int IW = UPS ? TW / 2 + 2 : (TW - 1) * S + KS;
-  static constexpr int WIH = UPS ? R / 2 + 2 : (R - 1) * S + KS;        // input rows one wave reads
+  // UPS == 3 (sub-pixel up-conv, KS == 2): the tile is counted in INPUT pixels; the 4 cout groups are the 4
+  // output phases (dy, dx), each a 2x2 conv on the input shifted by (dy, dx)
+  static constexpr int IH = UPS == 3 ? TH + 2 : UPS ? TH / 2 + 2 : (TH - 1) * S + KS;       // staged input tile
+  static constexpr int IW = UPS == 3 ? TW + 2 : UPS ? TW / 2 + 2 : (TW - 1) * S + KS;
+  static constexpr int WIH = UPS == 3 ? R + 1 : UPS ? R / 2 + 2 : (R - 1) * S + KS;        // input rows one wave reads
   static constexpr int NSLOT = IH * IW * 2;                              // 16-byte slots (activations)
   static constexpr int NLD = (NSLOT + NT - 1) / NT;                      // activation DMA rounds
   static constexpr int ACT = NLD * NT * 16;                              // bytes (tail lanes -> padding)
@@ -185,6 +187,7 @@ struct Geo {
   static constexpr int LDS_BYTES = NSA * ACT + NSW * WBYTES;
   static constexpr int PAD = (KS - 1) / 2;
   static_assert(NW == 8 || NW == 4, "4 or 8 waves per workgroup");
+  static_assert(UPS != 3 || (KS == 2 && S == 1 && NCG == 4 && WLDS && !HAS1X1), "sub-pixel up-conv: 2x2 taps, one cout group per phase");
   static_assert(R * NCW <= 8, "accumulator budget");
   static_assert(LDS_BYTES <= LDS_BUDGET, "LDS budget");
 };
@@ -221,22 +224,24 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
 
   // ---- XCD-aware tile mapping: block b runs on XCD b%8; give every XCD a contiguous run of tiles
   // (= whole images) so the activations it wrote in the previous launch are in ITS L2 / nearby MALL.
-  const int tiles_x = (p.W + G::TW - 1) / G::TW, tiles_y = (p.H + G::TH - 1) / G::TH;
+  const int tw_ = UPS == 3 ? p.W / 2 : p.W, th_ = UPS == 3 ? p.H / 2 : p.H;   // extent the tiles cover
+  const int tiles_x = (tw_ + G::TW - 1) / G::TW, tiles_y = (th_ + G::TH - 1) / G::TH;
   int t;
   {
     const int nwg = grid_x, bid = block_x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
-  const int cb0 = (block_y * NCG + cg) * NCW;     // first 32-cout block of this wave
+  const int cb0 = UPS == 3 ? block_y * NCW : (block_y * NCG + cg) * NCW;     // first 32-cout block of this wave
+  const int pdy = UPS == 3 ? cg >> 1 : 0, pdx = UPS == 3 ? cg & 1 : 0;           // sub-pixel phase of this wave
   const int oy0 = ty * G::TH, ox0 = tx * G::TW;      // output tile origin (logical)
 
   // ---- activation staging map: LDS slot s = tid + NT*i (16 bytes) <- input tile, by LDS-DMA.
   // LDS image [row][col][2 halves]; the two 16-byte halves of pixel `col` are swapped when
   // (col>>3)&1 so the 16 lanes of a ds_read_b128 group cover 16 distinct bank slots.  The DMA
   // destination is lane-linear, so the swizzle is applied to the SOURCE address.
-  const int iy0 = UPS ? oy0 / 2 : oy0 * S + 1 - G::PAD;   // padded coords of the tile origin
-  const int ix0 = UPS ? ox0 / 2 : ox0 * S + 1 - G::PAD;
+  const int iy0 = UPS == 3 ? oy0 : UPS ? oy0 / 2 : oy0 * S + 1 - G::PAD;   // padded coords of the tile origin
+  const int ix0 = UPS == 3 ? ox0 : UPS ? ox0 / 2 : ox0 * S + 1 - G::PAD;
   int goff[G::NLD];
 #pragma unroll
   for (int i = 0; i < G::NLD; ++i) {
@@ -258,8 +263,9 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
     // of parity wc, tap kw contributes iff (wc+1-kw) is even and then reads g column j+(wc+1-kw)/2
     const int col = UPS == 1 ? (((wc * 32 + j + kw - 1) >> 1) + 1)
                   : UPS == 2 ? (j + ((wc + 1 - kw) >> 1) + 1)
+                  : UPS == 3 ? (wc * 32 + j + pdx + kw)
                              : ((wc * 32 + j) * S + kw);
-    colofs[kw] = col * 32 + ((h ^ ((col >> 3) & 1)) << 4) + (UPS ? wr * (R / 2) : wr * R * S) * G::IW * 32;
+    colofs[kw] = col * 32 + ((h ^ ((col >> 3) & 1)) << 4) + (UPS == 3 ? wr * R + pdy : UPS ? wr * (R / 2) : wr * R * S) * G::IW * 32;
   }
 
   // ---- weights: packed [cout_block][chunk][tap][lane][16 B]
@@ -282,7 +288,11 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
       } else {
         const int blk = q / G::NTAP;                  // cout block within the workgroup
         int cb = block_y * NCG * NCW + blk;
-        if (cb >= p.cout_blocks) cb = 0;
+        if constexpr (UPS == 3) {                     // packed phase-major: [phase][cout_block]
+          int rcb = block_y * NCW + blk % NCW;
+          if (rcb >= p.cout_blocks) rcb = 0;
+          cb = (blk / NCW) * p.cout_blocks + rcb;
+        } else if (cb >= p.cout_blocks) cb = 0;
         wsrc[i] = wbase + cb * w_cb_stride + ((q - blk * G::NTAP) * 64 + lane) * 16;
         wstep[i] = (int64_t)G::NTAP * 1024;
       }
@@ -590,14 +600,14 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
   }
 
   // ---------------------------------------------------------------- epilogue
-  const int ox = UPS == 2 ? ox0 + 2 * j + wc : ox0 + wc * 32 + j;
+  const int ox = UPS == 2 ? ox0 + 2 * j + wc : UPS == 3 ? 2 * (ox0 + wc * 32 + j) + pdx : ox0 + wc * 32 + j;
   if (ox >= p.W || (dbg & 1)) return;
-  const int oyb = oy0 + wr * R;
+  const int oyb = UPS == 3 ? 2 * (oy0 + wr * R) + pdy : oy0 + wr * R;
   sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
     constexpr int cw = decltype(CW)::value;
     const int cb = cb0 + cw;
     if (cb >= p.cout_blocks) return;
-    epilogue_block<T, R, NCW, cw, HAS1X1, BWD>(p, acc, acc1, b, cb, h, oyb, ox);
+    epilogue_block<T, R, NCW, cw, HAS1X1, BWD, (UPS == 3 ? 2 : 1)>(p, acc, acc1, b, cb, h, oyb, ox);
   });
 }
 
@@ -611,8 +621,9 @@ __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_c
 template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool PIPE = false>
 int launch(const esr_conv& p, hipStream_t st) {
   using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>;
-  const int tiles = ((p.W + G::TW - 1) / G::TW) * ((p.H + G::TH - 1) / G::TH) * p.B;
-  dim3 grid(tiles, (p.cout_blocks + NCG * NCW - 1) / (NCG * NCW));
+  const int tw_ = UPS == 3 ? p.W / 2 : p.W, th_ = UPS == 3 ? p.H / 2 : p.H;
+  const int tiles = ((tw_ + G::TW - 1) / G::TW) * ((th_ + G::TH - 1) / G::TH) * p.B;
+  dim3 grid(tiles, UPS == 3 ? (p.cout_blocks + NCW - 1) / NCW : (p.cout_blocks + NCG * NCW - 1) / (NCG * NCW));
   // the backward-chain epilogue stages (always-on alpha, partial residual views, mask/out2, out3)
   // live in their own instantiation so the forward kernels stay lean
   constexpr int GPB = DT<T>::GPB;
@@ -663,6 +674,12 @@ int dispatch(const esr_conv& p, hipStream_t st) {
   if (p.ks == 3 && p.stride == 1 && p.upsample == 1) {
     if ((p.H | p.W) & 1) { esr_set_error("conv: upsample needs even output size"); return ESR_ERR_INVALID; }
     return cbk == 1 ? launch<T, 3, 1, 1, 4, 1, 1, 1, true, false>(p, st) : launch<T, 3, 1, 1, 4, 1, 1, 2, true, false>(p, st);
+  }
+  if (p.ks == 2 && p.stride == 1 && p.upsample == 3) {
+    // sub-pixel form of nearest-x2 + 3x3 (weights packed with esr_pack.ups_fwd): 8 waves = 2 row groups x 4 phases
+    if ((p.H | p.W) & 1) { esr_set_error("conv: upsample needs even output size"); return ESR_ERR_INVALID; }
+    // (one cout block per wave with two workgroups per CU measured slower: 0.49 vs 0.43 ms for both up-convs)
+    return cbk == 1 ? launch<T, 2, 1, 3, 2, 1, 4, 1, true, false>(p, st) : launch<T, 2, 1, 3, 2, 1, 4, 2, true, false>(p, st);
   }
   if (p.ks == 4 && p.stride == 2 && !p.upsample) return launch<T, 4, 2, 0, 2, 1, 4, 1, false, false>(p, st);
   if (p.ks == 1 && p.stride == 1 && !p.upsample) {

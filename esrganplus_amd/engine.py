@@ -66,7 +66,7 @@ class G32:
 
 class ConvW:
     """Packed weights of one conv (a slice of a WeightPack arena)."""
-    __slots__ = ('key', 'cout', 'cin', 'ks', 'w_ptr', 'bias_ptr', 'has_bias')
+    __slots__ = ('key', 'cout', 'cin', 'ks', 'w_ptr', 'bias_ptr', 'has_bias', 'subpix')
 
 
 class WeightPack:
@@ -75,9 +75,11 @@ class WeightPack:
     ``ensure()`` re-packs (one launch per tensor, recorded once) whenever a parameter's storage
     or version changed, or unconditionally when ``force``."""
 
-    def __init__(self, convs, dtype, device):
-        # convs: list of (key, weight_param, bias_param_or_None)
+    def __init__(self, convs, dtype, device, subpix=()):
+        # convs: list of (key, weight_param, bias_param_or_None); subpix: keys of up-convs (nearest x2 + 3x3,
+        # block.py:315-322) packed in the 4-phase 2x2 form (esr_pack.ups_fwd, run with esr_conv.upsample = 3)
         self.esr_dtype, self.tdtype, self.cpg = _dt(dtype)
+        self.subpix = frozenset(subpix)
         self.device = device
         self.convs = convs
         self.entries = {}
@@ -86,7 +88,10 @@ class WeightPack:
         for key, w, b in convs:
             cout, cin, ks, _ = w.shape
             offs.append(total)
-            total += L.packed_weight_bytes(cout, cin, ks, self.esr_dtype)
+            if key in self.subpix:      # 4 phases x cout blocks, 2x2 taps
+                total += L.packed_weight_bytes(4 * 32 * ((cout + 31) // 32), cin, 2, self.esr_dtype)
+            else:
+                total += L.packed_weight_bytes(cout, cin, ks, self.esr_dtype)
         self.arena = torch.zeros(total, dtype=torch.uint8, device=device)
         nb_pad = sum(((w.shape[0] + 31) // 32) * 32 for _, w, b in convs if b is not None and w.shape[0] % 32)
         self.bias_arena = torch.zeros(max(nb_pad, 1), dtype=torch.float32, device=device)
@@ -95,6 +100,7 @@ class WeightPack:
         for (key, w, b), off in zip(convs, offs):
             e = ConvW()
             e.key, (e.cout, e.cin, e.ks) = key, w.shape[:3]
+            e.subpix = key in self.subpix
             e.w_ptr = self.arena.data_ptr() + off
             e.has_bias = b is not None
             e.bias_ptr = None
@@ -133,6 +139,7 @@ class WeightPack:
             pk.cout, pk.cin, pk.ks = e.cout, e.cin, e.ks
             pk.dtype = self.esr_dtype
             pk.transpose_flip = 0
+            pk.ups_fwd = 1 if e.subpix else 0
             packs.append(pk)
             if b is not None and e.cout % 32 == 0:
                 e.bias_ptr = b.data_ptr()
@@ -261,6 +268,8 @@ def _conv(dtype_e, B, H, W, src, src_ch, dst, cw, act=L.ACT_NONE, ks=None, strid
     c.ks = cw.ks if ks is None else ks
     c.stride = stride
     c.upsample = upsample
+    if upsample == 1 and getattr(cw, 'subpix', False):    # same function, 4-phase 2x2 form
+        c.ks, c.upsample = 2, 3
     c.B, c.H, c.W = B, H, W
     cpg = 16 if dtype_e == L.ESR_F16 else 8
     c.cin_groups = (src_ch + cpg - 1) // cpg

@@ -7,9 +7,10 @@ from . import _lib as L
 
 
 def conv2d(x, weight, bias=None, stride=1, act=None, upsample=False, precision='fp32',
-           residual=None, alpha=1.0):
+           residual=None, alpha=1.0, subpix=False):
     """act(conv2d(x, weight, bias, stride, padding=(k-1)//2)) [* alpha + residual] — the
-    conv_block of block.py:125-151 (optionally on a nearest-x2 upsampled input, block.py:315-322)."""
+    conv_block of block.py:125-151 (optionally on a nearest-x2 upsampled input, block.py:315-322;
+    subpix: that up-conv in its 4-phase 2x2 form, esr_conv.upsample == 3)."""
     E.require_cuda(x, 'input')
     x = x.detach().contiguous().float()
     B, Cin, H, W = x.shape
@@ -21,7 +22,7 @@ def conv2d(x, weight, bias=None, stride=1, act=None, upsample=False, precision='
     Ho, Wo = (Hi + 2 * pad - ks) // stride + 1, (Wi + 2 * pad - ks) // stride + 1
     w = weight.detach().contiguous().float()
     b = bias.detach().contiguous().float() if bias is not None else None
-    wp = E.WeightPack([('c', w, b)], precision, dev)
+    wp = E.WeightPack([('c', w, b)], precision, dev, ('c',) if (subpix and upsample) else ())
     st = E.current_stream()
     wp.ensure(st, force=True)
     dt_e = wp.esr_dtype

@@ -62,11 +62,14 @@ typedef struct esr_g32 {
  * of block.py:262-268,291 without extra elementwise passes.                                    */
 typedef struct esr_conv {
   int32_t dtype;       /* esr_dtype: storage type of every G32 tensor here (accumulate fp32) */
-  int32_t ks;          /* 1, 3 or 4 */
+  int32_t ks;          /* 1, 3 or 4 (2: upsample == 3) */
   int32_t stride;      /* 1, or 2 (ks==4) */
   int32_t upsample;    /* 1: input is nearest-x2 upsampled on load (ks==3 only);
                           2: TRANSPOSED 4x4/stride-2 conv (adjoint of ks==4,stride==2): the input is at
-                             half the output resolution; weights packed with transpose_flip=2 */
+                             half the output resolution; weights packed with transpose_flip=2;
+                          3: the same function as 1 in its 4-phase 2x2 ("sub-pixel") form, ks == 2, weights
+                             packed with esr_pack.ups_fwd (2.25x fewer MACs; results differ from 1 only by the
+                             rounding of the pre-summed taps) */
   int32_t B, H, W;     /* OUTPUT logical size */
   int32_t cin_groups;  /* K loop length: input channel groups read from `in` */
   int32_t cout_blocks; /* ceil(Cout/32) */
@@ -130,7 +133,12 @@ typedef struct esr_pack {
    * weights are multiplied by `scale`; src_ks == 1 embeds a 1x1 kernel as the centre tap. */
   int32_t gather, dst_cout, dst_chunk0, dst_nchunks, src_co0, src_ks;
   float scale;
-  int32_t _pad;
+  int32_t ups_fwd;     /* 1 (ks == 3, no transpose_flip): emit the 4-phase 2x2 ("sub-pixel") form of
+                          nearest-x2-upsample + 3x3 conv (block.py:315-322), the operand of esr_conv.upsample == 3:
+                          output pixel (2y+dy, 2x+dx) only ever sees the 2x2 input pixels (y-1+dy .., x-1+dx ..),
+                          each weighted by the SUM of the 3x3 taps that land on it — 16 instead of 36 MACs per
+                          4 outputs.  Packed as a 2x2 conv with 4*cout_blocks blocks, phase-major:
+                          [phase = 2 dy + dx][cout_block][chunk][2 a + b] */
 } esr_pack;
 
 /* All weight packs of a network in ONE launch: `table` is a DEVICE array of n esr_pack entries,

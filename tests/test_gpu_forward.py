@@ -59,6 +59,38 @@ def test_single_conv(dev, case, precision):
     assert (y - ref).abs().max().item() <= tol
 
 
+SUBPIX_CASES = [
+    # cin, cout, act, (B, H_in, W_in): upconv_blcok (block.py:315-322) in its 4-phase 2x2 form
+    (64, 64, 'leakyrelu', (1, 12, 20)),      # ragged: 12x20 input is not a multiple of the 8x32 tile
+    (64, 64, 'leakyrelu', (2, 16, 64)),
+    (64, 32, None, (1, 9, 33)),              # one cout block, odd input size
+    (32, 96, 'leakyrelu', (1, 8, 32)),       # 3 cout blocks: the second workgroup row has one live block
+    (64, 64, 'leakyrelu', (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16'])
+@pytest.mark.parametrize('case', SUBPIX_CASES)
+def test_subpixel_upconv(dev, case, precision):
+    """esr_conv.upsample == 3 against F.conv2d(F.interpolate(x, 2, 'nearest')) and against the gather-on-load
+    form (upsample == 1) of the same op."""
+    from esrganplus_amd import ops
+    cin, cout, act, (B, H, W) = case
+    g = np.random.default_rng(hash(case) % 1000)
+    x = torch.from_numpy(g.standard_normal((B, cin, H, W), dtype=np.float32))
+    w = torch.from_numpy(g.standard_normal((cout, cin, 3, 3), dtype=np.float32)) / np.sqrt(cin * 9)
+    b = torch.from_numpy(g.standard_normal(cout, dtype=np.float32))
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x, scale_factor=2, mode='nearest'), w, b, padding=1)
+    if act == 'leakyrelu':
+        ref = torch.nn.functional.leaky_relu(ref, 0.2)
+    y = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), act=act, upsample=True, precision=precision, subpix=True).cpu()
+    y1 = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), act=act, upsample=True, precision=precision).cpu()
+    assert y.shape == ref.shape
+    tol = 2e-5 if precision == 'fp32' else 3e-2
+    assert (y - ref).abs().max().item() <= tol
+    assert (y - y1).abs().max().item() <= tol
+
+
 @pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('fp16', 5e-2)])
 def test_rdb_golden(dev, golden, precision, tol):
     from esrganplus_amd import block as B
