@@ -302,6 +302,14 @@ class OpList:
         check(lib().esr_run_ops(C.cast(arr, C.c_void_p), len(self.ops), C.c_void_p(stream)),
               'esr_run_ops')
 
+    def run_range(self, stream, i0, i1):
+        """Ops [i0, i1) of the list (segmented backward: the gradient exchange starts between segments)."""
+        if i1 <= i0:
+            return
+        arr = self.array()
+        check(lib().esr_run_ops(C.c_void_p(C.addressof(arr) + i0 * C.sizeof(esr_op)), i1 - i0, C.c_void_p(stream)),
+              'esr_run_ops')
+
     def graph_launch(self, stream):
         """Replay the list as a captured hipGraph (one host call).  The graph is captured on first use
         from the CURRENT contents of the op array: every pointer / scalar is baked in, so callers must

@@ -54,6 +54,11 @@ class _RRDBNetBase(B._PlannedModule):
             out.append(('model.%d' % idx, m[idx].weight, m[idx].bias))
         return out
 
+    def attach_grad_sync(self, sync):
+        """Data-parallel hook (dp.GradExchange): `sync(flat_slice)` starts the mean all-reduce of a finished
+        slice of the backward's flat gradient buffer; the backward then runs segmented (no graph replay)."""
+        self._grad_sync = sync
+
     def _subpix_keys(self):
         # upconv_blcok (block.py:315-322) in its 4-phase 2x2 form: 16 instead of 36 MACs per 4 outputs
         return () if os.environ.get('ESR_SUBPIX', '1') == '0' else ('model.3', 'model.6')

@@ -8,9 +8,12 @@ the mean all-reduce of that network's gradients.
 
 * ``RRDBNet`` / ``Discriminator`` backward are single autograd nodes that emit ALL parameter
   gradients as views of one flat fp32 tensor, so the exchange all-reduces slices ("buckets") of that
-  tensor in place — no gather/scatter copies.  Buckets are issued asynchronously on RCCL's stream
-  (largest-first = reverse execution order) and only waited for right before ``optimizer.step()``,
-  so the G-gradient exchange overlaps the discriminator's forward/backward and vice versa.
+  tensor in place — no gather/scatter copies.
+* ``RRDBNet``'s node runs its backward list in SEGMENTS (tail, RRDB 22 .. 0, first conv) and hands every
+  finished slice to the exchange while the remaining segments are still being enqueued: the all-reduce of
+  the deep layers' gradients runs under the backward of the shallow ones (``GradExchange(overlap=True)``,
+  ``functional._train_backward``).  Other modules' buckets are issued right after ``backward()`` and only
+  waited for before ``optimizer.step()``, overlapping the other network's pass.
 * xGMI is point-to-point (7 links x ~153 GB/s per GPU): bucket size defaults to 32 MiB so each
   ring/tree step moves >= 4 MiB per link — large enough to be bandwidth- rather than latency-bound.
 * The relativistic-average GAN terms use the mean of D's logits over the GLOBAL batch
@@ -80,11 +83,31 @@ def flat_grad_spans(params):
 class GradExchange:
     """Mean all-reduce of a module's gradients, bucketed, asynchronous."""
 
-    def __init__(self, module, bucket_bytes=32 << 20):
+    def __init__(self, module, bucket_bytes=32 << 20, overlap=True):
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.bucket_bytes = bucket_bytes
         self.handles = []
         self._staged = []
+        # In-backward exchange (networks.py:105-107 reduces implicitly inside DataParallel's backward): a module
+        # whose backward is one fused node (RRDBNet) runs it in segments and calls `reduce_slice` on every
+        # finished span of its flat gradient buffer, so the all-reduce of the last layers' gradients runs
+        # under the backward of the first ones.  The gradients that reach `.grad` are then already averaged:
+        # start() / wait() skip them.
+        self.inline = False
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        if overlap and world_size() > 1 and hasattr(module, 'attach_grad_sync'):
+            module.attach_grad_sync(self)
+            self.inline = True
+
+    def __call__(self, flat_slice):
+        """Mean all-reduce of one finished slice (called from inside the backward node, stream-ordered after
+        the kernels that wrote it).  Returns the work handle (None on one rank)."""
+        if world_size() == 1:
+            return None
+        if dist.get_backend() == 'nccl':
+            return dist.all_reduce(flat_slice, op=dist.ReduceOp.AVG, async_op=True)
+        flat_slice.div_(float(world_size()))            # gloo has no AVG
+        return dist.all_reduce(flat_slice, async_op=True)
 
     def _flat_groups(self):
         """Group parameter grads by underlying storage: grads that are views of one flat tensor
@@ -100,7 +123,7 @@ class GradExchange:
     def start(self):
         """Issue the all-reduces (async).  Call right after ``loss.backward()``."""
         self.handles, self._staged = [], []
-        if world_size() == 1:
+        if world_size() == 1 or self.inline:
             return
         ws = float(world_size())
         for _, ps in self._flat_groups().items():

@@ -680,24 +680,29 @@ class TapMajorGrads:
         self.tm = torch.zeros_like(grad_flat)
         self.rows = []
         self.total = 0
-        self.table = None
 
     def slot(self, off_elems, cout, cin, ntap=9):
         self.rows.append((off_elems, off_elems, self.total, cout, cin, ntap))
         self.total += cout * cin * ntap
         return self.tm.data_ptr() + 4 * off_elems
 
-    def op(self):
-        if not self.rows:
+    def op(self, lo=None, hi=None):
+        """The unpermute of every slot (default) or of the slots inside flat elements [lo, hi) — the segmented
+        backward rewrites each finished span before its all-reduce starts."""
+        rows = [r for r in self.rows if lo is None or lo <= r[0] < hi]
+        if not rows:
             return None
-        arr = (L.esr_unperm_entry * len(self.rows))()
-        for i, r in enumerate(self.rows):
-            arr[i].src_off, arr[i].dst_off, arr[i].elem_begin = r[0], r[1], r[2]
+        arr = (L.esr_unperm_entry * len(rows))()
+        begin = 0
+        for i, r in enumerate(rows):
+            arr[i].src_off, arr[i].dst_off, arr[i].elem_begin = r[0], r[1], begin
             arr[i].cout, arr[i].cin, arr[i].ntap = r[3], r[4], r[5]
+            begin += r[3] * r[4] * r[5]
         raw = bytes(arr)
-        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.flat.device)
+        table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.flat.device)
+        self.tables = getattr(self, 'tables', []) + [table]
         up = L.esr_unpermute()
-        up.table, up.n, up.total = self.table.data_ptr(), len(self.rows), self.total
+        up.table, up.n, up.total = table.data_ptr(), len(rows), begin
         up.src, up.dst = self.tm.data_ptr(), self.flat.data_ptr()
         return up
 
@@ -716,6 +721,8 @@ class TrainPlan:
         self.grad_views = None
         self.tapmajor = None
         self.gx_op = None            # stand-alone blocks: layout op exporting dL/dx (NCHW fp32)
+        self.segments = None         # segmented backward: [(op_end, elem_lo, elem_hi)] — after ops [.., op_end) the
+                                     # gradients in flat[elem_lo:elem_hi] are final (see build_rrdbnet_train_plan)
         self.graph = False           # hipGraph replay with I/O bound to the static tensors below
 
     def enable_graph(self, in_shape, device):
@@ -752,14 +759,17 @@ class TrainPlan:
 
 
 def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, device, noise, variant,
-                             explicit_z, kind='net'):
+                             explicit_z, kind='net', segmented=False):
     """RRDBNet forward keeping every RDB concat buffer (+ pre-residual activations of conv2/conv4,
     whose signs are the LeakyReLU masks) and the backward pass:
       * input gradients = the same fused conv kernel over transposed/rotated weights, with the
         LeakyReLU-mask / noise / residual-scale backward applied in its epilogue;
       * weight/bias gradients = esr_conv_wgrad.
     kind 'net' = the whole generator; 'rrdb' / 'rdb' = a stand-alone RRDB / ResidualDenseBlock_5C
-    (64-channel NCHW in and out, gradient w.r.t. the input returned): same block code, no head/tail."""
+    (64-channel NCHW in and out, gradient w.r.t. the input returned): same block code, no head/tail.
+    segmented ('net' only): the backward list records, per RRDB (and for the tail / the first conv), the op
+    index after which that slice of the flat gradient buffer is final — data-parallel runs start its
+    all-reduce there, under the rest of the backward (TrainPlan.segments, functional._train_backward)."""
     dt_e, tdtype, cpg = _dt(dtype)
     block = kind != 'net'
     nj = 1 if kind == 'rdb' else 3                 # dense blocks per RRDB
@@ -883,6 +893,25 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         views.append((gw, gb))
         gptr[k] = (gw.data_ptr(), gb.data_ptr() if gb is not None else None)
     TP.grad_views = views
+    segmented = bool(segmented) and not block
+    gend = {}
+    for k, w, b_ in plist:
+        gend[k] = goff[k] + w.numel() + (b_.numel() if b_ is not None else 0)
+    segs = []
+
+    def close_segment(prefixes):
+        """Everything the ops so far produce for the parameters whose key starts with one of `prefixes` is
+        final: rewrite the tap-major pieces of that span, record the boundary."""
+        if not segmented:
+            return
+        ks_ = [k for k, _, _ in plist if any(k == p_ or k.startswith(p_ + '.') for p_ in prefixes)]
+        lo, hi = min(goff[k] for k in ks_), max(gend[k] for k in ks_)
+        assert hi - lo == sum(gend[k] - goff[k] for k in ks_), 'segment parameters must tile one span'
+        if TP.tapmajor is not None:
+            up = TP.tapmajor.op(lo, hi)
+            if up is not None:
+                Bk.add(L.OP_UNPERMUTE, 'unpermute', up)
+        segs.append((len(Bk.ops), lo, hi))
 
     # ------------------------------------------------------------------ backward
     Bk = TP.bwd
@@ -991,6 +1020,7 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         else:
             c.res1 = GTt.view(0, 64)                    # fea feeds both the trunk and the shortcut
         add_b(c, noisy=bool(nb))
+        close_segment(['model.1.sub.%d' % nb, 'model.3', 'model.6', 'model.8', 'model.10'])
     ca, ct = 0, 0
     GX = buf(64) if block else None                 # dL/dx of a stand-alone block
     for i in range(nb - 1, -1, -1):
@@ -1053,6 +1083,8 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             for wg in deferred:
                 Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE)
             deferred = None
+        if not block:
+            close_segment(['model.1.sub.%d' % i])
     if block:
         lo = L.esr_layout()
         lo.dtype, lo.to_g32 = dt_e, 0
@@ -1070,10 +1102,14 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             GF = GF2
         # fea_conv (model.0): weight gradient only (the LR input image needs no gradient)
         wgrad('model.0', GF.view(0, 64), xin.view(0, in_nc), H, W, 64, in_nc)
-    if TP.tapmajor is not None:
+        close_segment(['model.0'])
+    if TP.tapmajor is not None and not segmented:
         up = TP.tapmajor.op()
         if up is not None:
             Bk.add(L.OP_UNPERMUTE, 'unpermute', up)
+    if segmented:
+        assert sorted((lo, hi) for _, lo, hi in segs)[0][0] == 0 and sum(hi - lo for _, lo, hi in segs) == TP.grad_flat.numel()
+        TP.segments = segs
     if block:
         TP.gx_op = Bk.add(L.OP_LAYOUT, 'layout', gx_layout)
     return TP

@@ -95,7 +95,7 @@ def _train_forward(tp, xin, st, seed, zs):
     return out
 
 
-def _train_backward(tp, gy, st, noise, explicit, seed, want_gx):
+def _train_backward(tp, gy, st, noise, explicit, seed, want_gx, sync=None):
     """Runs the backward launch list; returns dL/dx (stand-alone blocks) or None."""
     tp.grad_flat.zero_()
     if tp.tapmajor is not None:
@@ -117,7 +117,31 @@ def _train_backward(tp, gy, st, noise, explicit, seed, want_gx):
     for i in tp.bwd_noise_ops:
         arr[i].u.conv.noise_mode = mode
         arr[i].u.conv.seed = seed
-    tp.bwd.run(st)
+    if tp.segments is None or sync is None:
+        tp.bwd.run(st)
+        return gx
+    # data-parallel: hand every finished slice of the flat gradient buffer to `sync` (an asynchronous
+    # all-reduce, dp.GradExchange) as soon as the ops that produce it are enqueued — slices are merged up to
+    # sync.bucket_elems so that a collective moves enough bytes per xGMI link — and wait for all of them
+    # (stream-side) before the gradients leave the node
+    i0, pend_lo, pend_hi, handles = 0, None, None, []
+    limit = getattr(sync, 'bucket_elems', 0)
+    for op_end, lo, hi in tp.segments:
+        tp.bwd.run_range(st, i0, op_end)
+        i0 = op_end
+        if pend_lo is not None and (hi != pend_lo and lo != pend_hi):
+            handles.append(sync(tp.grad_flat[pend_lo:pend_hi]))
+            pend_lo = None
+        pend_lo, pend_hi = (lo, hi) if pend_lo is None else (min(lo, pend_lo), max(hi, pend_hi))
+        if pend_hi - pend_lo >= limit:
+            handles.append(sync(tp.grad_flat[pend_lo:pend_hi]))
+            pend_lo = None
+    tp.bwd.run_range(st, i0, len(tp.bwd.ops))
+    if pend_lo is not None:
+        handles.append(sync(tp.grad_flat[pend_lo:pend_hi]))
+    for h in handles:
+        if h is not None:
+            h.wait()
     return gx
 
 
@@ -159,7 +183,8 @@ class _PlanLease:
 
 
 def _train_plan(net, wp, dp, B, H, W, dev, noise, explicit):
-    key = ('train', B, H, W, net.precision, noise, explicit, wp.generation, str(dev))
+    sync = getattr(net, '_grad_sync', None)      # dp.GradExchange attached: segmented backward, no graph replay
+    key = ('train', B, H, W, net.precision, noise, explicit, wp.generation, str(dev), sync is not None)
     pool = net._plans.get(key)
     if pool is None:
         # every shape keeps a full set of saved activations alive: bound the number of shapes (LRU over the
@@ -179,8 +204,8 @@ def _train_plan(net, wp, dp, B, H, W, dev, noise, explicit):
         if not tp.busy:
             return tp
     tp = E.build_rrdbnet_train_plan(net, wp, dp, net.nb, net.in_nc, net.out_nc, B, H, W,
-                                    net.precision, dev, noise, net.variant, explicit)
-    if not explicit and E.use_graphs():
+                                    net.precision, dev, noise, net.variant, explicit, segmented=sync is not None)
+    if not explicit and E.use_graphs() and sync is None:
         tp.enable_graph((B, net.in_nc, H, W), dev)
     pool.append(tp)
     return tp
@@ -206,6 +231,7 @@ class _RRDBNetFn(torch.autograd.Function):
         ctx.explicit = zs is not None
         ctx.noise = noise
         ctx.n_params = len(params)
+        ctx.sync = getattr(net, '_grad_sync', None)
         return _train_forward(tp, xin, st, ctx.seed, zs)
 
     @staticmethod
@@ -217,7 +243,7 @@ class _RRDBNetFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise NotImplementedError('gradient w.r.t. the LR input image is not provided')
         gy = gy.detach().contiguous().float()
-        _train_backward(tp, gy, E.current_stream(), ctx.noise, ctx.explicit, ctx.seed, False)
+        _train_backward(tp, gy, E.current_stream(), ctx.noise, ctx.explicit, ctx.seed, False, ctx.sync)
         grads = _grad_views(tp)
         ctx.lease.release()
         assert len(grads) == ctx.n_params

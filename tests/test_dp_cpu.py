@@ -61,6 +61,27 @@ def _worker(rank, world, port, q):
         assert torch.allclose(m, xa.mean().detach())
         # per-rank grads are later averaged over ranks: local grad == world * d(la)/dx_local
         assert torch.allclose(x.grad, world * xa.grad[3 * rank:3 * rank + 3], atol=1e-6), 'global_mean grad'
+        # (d) in-backward exchange: a module whose backward hands finished slices of its flat gradient
+        # buffer to the exchange (what RRDBNet's segmented backward does on the GPU)
+        class Seg(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.w = torch.nn.Parameter(torch.zeros(6))
+                self.sync = None
+
+            def attach_grad_sync(self, sync):
+                self.sync = sync
+        seg = Seg()
+        ex2 = dp.GradExchange(seg, bucket_bytes=8)
+        assert ex2.inline and seg.sync is ex2 and ex2.bucket_elems == 2
+        buf = torch.arange(6, dtype=torch.float32) * (rank + 1)
+        hs = [seg.sync(buf[4:6]), seg.sync(buf[0:4])]        # last layers first
+        for h in hs:
+            h.wait()
+        assert torch.allclose(buf, torch.arange(6, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
+        seg.w.grad = buf
+        ex2.start(); ex2.wait()                              # already averaged: must not reduce again
+        assert torch.allclose(seg.w.grad, torch.arange(6, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
         q.put((rank, 'ok'))
     except Exception as e:   # noqa: BLE001
         q.put((rank, repr(e)))
