@@ -186,29 +186,31 @@ class _SeqNet(B._PlannedModule):
         return CN.SeqNetFn.apply(x, self, *[t for _, t in self._pspec()])
 
 
-class Discriminator_VGG_128(_SeqNet):
-    """codes/models/modules/architecture.py:87-129 — VGG-style discriminator for 128x128 inputs:
-    10 convs (3x3/s1 and 4x4/s2, 64..512 ch), 9 BatchNorm2d (batch statistics in train mode),
-    LeakyReLU(0.2), flatten, Linear(8192,100), LeakyReLU, Linear(100,1).  State-dict keys as the
-    reference."""
+class _DiscriminatorVGG(_SeqNet):
+    """The reference's VGG-style discriminators (architecture.py:87-129, 178-270): 3x3/s1 and 4x4/s2 conv pairs
+    (64..512 ch) with BatchNorm2d (batch statistics in train mode) and LeakyReLU(0.2), flatten,
+    Linear(F,100), LeakyReLU, Linear(100,1).  State-dict keys as the reference."""
 
     _has_bn = True
+    _pairs = 5          # conv pairs (128 / 96: 5, 192: 6)
+    _final = 4          # side of the final feature map at the nominal input size
 
     def __init__(self, in_nc, base_nf, norm_type='batch', act_type='leakyrelu', mode='CNA'):
         super().__init__()
         if (base_nf, norm_type, act_type.lower(), mode) != (64, 'batch', 'leakyrelu', 'CNA'):
-            raise NotImplementedError('HIP Discriminator_VGG_128 supports base_nf=64, batch norm, '
-                                      'leakyrelu, CNA (train_ESRGANplus.json:46-53)')
+            raise NotImplementedError('HIP %s supports base_nf=64, batch norm, leakyrelu, CNA '
+                                      '(train_ESRGANplus.json:46-53)' % type(self).__name__)
         nf = base_nf
-        chans = [(in_nc, nf, 3, 1, None), (nf, nf, 4, 2, norm_type), (nf, 2 * nf, 3, 1, norm_type),
-                 (2 * nf, 2 * nf, 4, 2, norm_type), (2 * nf, 4 * nf, 3, 1, norm_type),
-                 (4 * nf, 4 * nf, 4, 2, norm_type), (4 * nf, 8 * nf, 3, 1, norm_type),
-                 (8 * nf, 8 * nf, 4, 2, norm_type), (8 * nf, 8 * nf, 3, 1, norm_type),
-                 (8 * nf, 8 * nf, 4, 2, norm_type)]
+        widths = [nf, 2 * nf, 4 * nf, 8 * nf, 8 * nf, 8 * nf][:self._pairs]
+        chans, cin = [], in_nc
+        for i, w in enumerate(widths):
+            chans.append((cin, w, 3, 1, None if i == 0 else norm_type))
+            chans.append((w, w, 4, 2, norm_type))
+            cin = w
         self.features = B.sequential(*[B.conv_block(ci, co, kernel_size=k, stride=s, norm_type=nt,
                                                     act_type=act_type, mode=mode)
                                        for ci, co, k, s, nt in chans])
-        self.classifier = nn.Sequential(nn.Linear(512 * 4 * 4, 100), nn.LeakyReLU(0.2, True),
+        self.classifier = nn.Sequential(nn.Linear(512 * self._final * self._final, 100), nn.LeakyReLU(0.2, True),
                                         nn.Linear(100, 1))
         self.in_nc = in_nc
         self._init_planned()
@@ -251,6 +253,21 @@ class Discriminator_VGG_128(_SeqNet):
         ps += [('head1.weight', c[0].weight), ('head1.bias', c[0].bias),
                ('head2.weight', c[2].weight), ('head2.bias', c[2].bias)]
         return ps
+
+
+class Discriminator_VGG_128(_DiscriminatorVGG):
+    """codes/models/modules/architecture.py:87-129 — 128x128 inputs: 10 convs, Linear(512*4*4, 100)."""
+    _pairs, _final = 5, 4
+
+
+class Discriminator_VGG_96(_DiscriminatorVGG):
+    """architecture.py:178-221 — 96x96 inputs: the same 10 convs, Linear(512*3*3, 100)."""
+    _pairs, _final = 5, 3
+
+
+class Discriminator_VGG_192(_DiscriminatorVGG):
+    """architecture.py:224-270 — 192x192 inputs: 12 convs (one more 512-channel pair), Linear(512*3*3, 100)."""
+    _pairs, _final = 6, 3
 
 
 VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M',

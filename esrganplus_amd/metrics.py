@@ -1,6 +1,9 @@
 """Image conversion + PSNR exactly as the reference's validation does it
 (codes/utils/util.py:71-95 ``tensor2img``, 107-114 ``calculate_psnr``; codes/train.py:131-148: crop
-``scale`` pixels, compare uint8 images).  numpy only — host-side harness code, not on the hot path."""
+``scale`` pixels, compare uint8 images).  The numpy functions are the host restatement (pinned by
+tests/golden/psnr.npz, metrics.npz); ``device_tensor2img`` / ``device_psnr_ssim`` run the same arithmetic in
+csrc/metrics.hip on the tensors' GPU, so that a validation pass over many images reads back four doubles per
+image pair instead of two images."""
 import math
 
 import numpy as np
@@ -93,3 +96,60 @@ def calculate_ssim(img1, img2):
         if img1.shape[2] == 1:
             return _ssim_plane(np.squeeze(img1), np.squeeze(img2))
     raise ValueError('Wrong input image dimensions.')
+
+
+# ---- the same on the device (csrc/metrics.hip, esr_image_metrics) -------------------------------------
+def _metrics_call(sr, hr, crop, y_only, min_max):
+    import torch
+    from . import _lib as L
+    from . import engine as E
+    E.require_cuda(sr, 'sr')
+    a = sr.detach().squeeze().float().contiguous()
+    if a.dim() == 2:
+        a = a[None]
+    C_, H, W = a.shape
+    dev = a.device
+    p = L.esr_img_metrics()
+    p.sr, p.C, p.H, p.W, p.crop, p.y_only = a.data_ptr(), C_, H, W, int(crop), 1 if y_only else 0
+    p.lo, p.hi = float(min_max[0]), float(min_max[1])
+    keep = [a]
+    img_sr = torch.empty((H, W, C_) if C_ == 3 else (H, W), dtype=torch.uint8, device=dev)
+    p.img_sr = img_sr.data_ptr()
+    img_hr = out = None
+    if hr is not None:
+        b = hr.detach().squeeze().float().contiguous()
+        if b.dim() == 2:
+            b = b[None]
+        if b.shape != a.shape or b.device != dev:
+            raise ValueError('Input images must have the same dimensions.')
+        img_hr = torch.empty_like(img_sr)
+        out = torch.empty(4, dtype=torch.float64, device=dev)
+        p.hr, p.img_hr, p.out = b.data_ptr(), img_hr.data_ptr(), out.data_ptr()
+        keep.append(b)
+    if y_only:
+        ys = torch.empty((2, H, W), dtype=torch.uint8, device=dev)
+        p.y_sr, p.y_hr = ys[0].data_ptr(), ys[1].data_ptr()
+        keep.append(ys)
+    k1 = gaussian_window()[5] / gaussian_window()[5].sum()       # the normalised 1-D kernel (outer(k, k) == window)
+    for i in range(11):
+        p.win[i] = float(k1[i])
+    L.check(L.lib().esr_image_metrics(p, E.current_stream()), 'esr_image_metrics')
+    return img_sr, img_hr, out, (C_, H, W), keep
+
+
+def device_tensor2img(t, min_max=(0, 1)):
+    """tensor2img on the tensor's GPU: uint8 HWC BGR (or HW) tensor, bit-identical with ``tensor2img``."""
+    return _metrics_call(t, None, 0, False, min_max)[0]
+
+
+def device_psnr_ssim(sr, hr, crop=4, y_only=False, min_max=(0, 1)):
+    """(PSNR, SSIM) of two (C,H,W) tensors exactly as the validation loops compute them (tensor2img both, crop
+    `crop` pixels per side, optionally MATLAB-style Y only), evaluated on the device; one small read-back."""
+    _, _, out, (C_, H, W), keep = _metrics_call(sr, hr, crop, y_only, min_max)
+    o = out.cpu().numpy()                       # synchronises with the metric kernels
+    planes = 1 if (y_only or C_ == 1) else C_
+    ch, cw = H - 2 * crop, W - 2 * crop
+    mse = o[0] / (ch * cw * planes)
+    psnr = float('inf') if mse == 0 else 20 * math.log10(255.0 / math.sqrt(mse))
+    ssim = float(o[2] / ((ch - 10) * (cw - 10) * planes)) if (ch > 10 and cw > 10) else float('nan')
+    return psnr, ssim

@@ -76,11 +76,22 @@ D_BNS = [(3, 64), (6, 128), (9, 128), (12, 256), (15, 256), (18, 512), (21, 512)
          (27, 512)]
 
 
-def discriminator_state_dict(seed=0):
-    """Discriminator_VGG_128(in_nc=3, base_nf=64) — keys per SURVEY.md Appendix C."""
+def discriminator_layout(size=128):
+    """(convs [(idx, cin, cout, ks)], bns [(idx, channels)], flattened features) of Discriminator_VGG_<size>
+    (architecture.py:87-129 / 178-270): 96 = the 128 net on a 3x3 final map, 192 = one more 512-channel pair."""
+    convs, bns = list(D_CONVS), list(D_BNS)
+    if size == 192:
+        convs += [(29, 512, 512, 3), (32, 512, 512, 4)]
+        bns += [(30, 512), (33, 512)]
+    return convs, bns, 512 * (16 if size == 128 else 9)
+
+
+def discriminator_state_dict(seed=0, size=128):
+    """Discriminator_VGG_128/96/192(in_nc=3, base_nf=64) — keys per SURVEY.md Appendix C."""
     sd = OrderedDict()
-    bn = dict(D_BNS)
-    for idx, cin, cout, k in D_CONVS:
+    convs, bns, nfeat = discriminator_layout(size)
+    bn = dict(bns)
+    for idx, cin, cout, k in convs:
         _conv(sd, seed, 'features.%d' % idx, cout, cin, k, True, gain=np.sqrt(3.0))
         if idx + 1 in bn:
             c = bn[idx + 1]
@@ -90,7 +101,7 @@ def discriminator_state_dict(seed=0):
             sd[p + '.running_mean'] = _uniform(seed, p + '.running_mean', (c,), 0.1)
             sd[p + '.running_var'] = 1.0 + _uniform(seed, p + '.running_var', (c,), 0.3)
             sd[p + '.num_batches_tracked'] = torch.tensor(0, dtype=torch.long)
-    for name, cout, cin in (('classifier.0', 100, 8192), ('classifier.2', 1, 100)):
+    for name, cout, cin in (('classifier.0', 100, nfeat), ('classifier.2', 1, 100)):
         b = 1.0 / np.sqrt(cin)
         sd[name + '.weight'] = _uniform(seed, name + '.weight', (cout, cin), b)
         sd[name + '.bias'] = _uniform(seed, name + '.bias', (cout,), b)

@@ -296,6 +296,27 @@ typedef struct esr_amp {
   float growth, backoff;
 } esr_amp;
 
+/* ---- validation metrics on the device (metrics.hip) -------------------------------------------------
+ * tensor2img (codes/utils/util.py:71-95: clamp, scale, x255, round, RGB -> BGR, HWC uint8) of one image or of
+ * an (sr, hr) pair, and on the pair, cropped by `crop` pixels per side (codes/train.py:131-148):
+ *   out[0] = sum of squared uint8 differences, out[1] unused, out[2] = sum of the SSIM map (util.py:117-158;
+ *   over all compared planes), out[3] unused;   PSNR = 20 log10(255 / sqrt(out[0] / n)),  SSIM = out[2] / n_ssim
+ * with n = (H-2crop)(W-2crop) planes, n_ssim = (H-2crop-10)(W-2crop-10) planes (the caller divides).
+ * y_only (C == 3): compare the MATLAB-style Y planes of the uint8 BGR images (data/util.py:150-168). */
+typedef struct esr_img_metrics {
+  const float* sr;           /* [C][H][W] fp32 */
+  const float* hr;           /* same shape, or NULL: conversion only */
+  int32_t C, H, W, crop;
+  int32_t y_only, _pad;
+  float lo, hi;              /* tensor2img's min_max */
+  uint8_t* img_sr;           /* [H][W][C] uint8 BGR */
+  uint8_t* img_hr;
+  uint8_t* y_sr;             /* [H][W] uint8 (y_only) */
+  uint8_t* y_hr;
+  double* out;               /* 4 doubles (device) */
+  double win[11];            /* 1-D Gaussian window (cv2.getGaussianKernel(11, 1.5)); the 2-D one is its outer product */
+} esr_img_metrics;
+
 /* ---- fused ResidualDenseBlock_5C chain (rdb_fused.hip) -------------------------------------------
  * ONE persistent launch runs n_blocks dense blocks (block.py:260-268) back to back on every 16x32
  * tile, the fp32 accumulators of all 192 output channels of the block in flight held in registers
@@ -419,6 +440,7 @@ size_t esr_rdb_workspace_bytes(int32_t B, int32_t H, int32_t W);
 size_t esr_rdb_weight_stream_bytes(int32_t dtype);
 int esr_rdb_max_tiles_per_image(void);   /* 16x32 tiles of ONE image must not exceed this (= CUs) */
 int esr_gather_fragments(const esr_frag_gather* g, esr_stream_t stream);
+int esr_image_metrics(const esr_img_metrics* p, esr_stream_t stream);   /* replaces util.py:71-158 on the device */
 
 /* Run a recorded list of ops back to back on `stream` (one host call per network pass; this is
  * what RRDBNet.forward — architecture.py:76-78 — becomes). */

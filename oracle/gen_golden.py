@@ -256,6 +256,43 @@ def gen_disc():
     np.savez_compressed(os.path.join(OUT, 'disc.npz'), **res)
 
 
+def gen_disc_variants():
+    """Discriminator_VGG_96 / _192 (architecture.py:178-270): eval + train forward, gradient checksums."""
+    for size, batch in ((96, 3), (192, 2)):
+        sd = synth.discriminator_state_dict(seed=40 + size, size=size)
+        net = RI.build_discriminator(size)
+        net.load_state_dict(sd, strict=True)
+        x = synth.image_batch(size, batch, 3, size, size, name='disc%d.x' % size)
+        gy = synth.normal_like(size, 'disc%d.gy' % size, (batch, 1))
+        res = {}
+        net.eval()
+        with torch.no_grad():
+            ye = net(x)
+            yo = RT.discriminator_forward(x, {k: v.clone() for k, v in sd.items()}, training=False, size=size)
+        assert_close(ye, yo, 1e-4, 'D%d eval fwd' % size)
+        res['y_eval'] = npy(ye)
+        net.train()
+        xr = x.clone().requires_grad_(True)
+        y = net(xr)
+        (y * gy).sum().backward()
+        sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k
+                   else v.clone()) for k, v in sd.items()}
+        xo = x.clone().requires_grad_(True)
+        yo = RT.discriminator_forward(xo, sdr, training=True, size=size)
+        (yo * gy).sum().backward()
+        assert_close(y, yo, 1e-4, 'D%d train fwd' % size)
+        assert_close(xr.grad, xo.grad, 1e-4, 'D%d train grad_x' % size)
+        params = dict(net.named_parameters())
+        res['y_train'] = npy(y)
+        res['gx_chk'] = checks(xr.grad)
+        res['gchk'] = np.stack([checks(params[k].grad) for k in params])
+        last = [k for k in params if k.startswith('features.') and k.endswith('.weight')][-1]
+        res['g_last_bn_weight'] = npy(params[last].grad)
+        res['g_classifier.0.bias'] = npy(params['classifier.0.bias'].grad)
+        res['g_features.0.weight'] = npy(params['features.0.weight'].grad)
+        np.savez_compressed(os.path.join(OUT, 'disc%d.npz' % size), **res)
+
+
 def _vgg19_features():
     layers, cin = [], 3
     for v in synth.VGG19_CFG:
@@ -428,7 +465,7 @@ if __name__ == '__main__':
     assert RI.available(), 'reference tree not found — fixtures can only be generated in the build container'
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['rdb', 'rrdbnet_small', 'rrdbnet_full', 'disc', 'vgg', 'train_step',
+    which = sys.argv[1:] or ['rdb', 'rrdbnet_small', 'rrdbnet_full', 'disc', 'disc_variants', 'vgg', 'train_step',
                              'psnr', 'imresize', 'metrics']
     for w in which:
         print('[gen_golden]', w)

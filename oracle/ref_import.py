@@ -95,10 +95,10 @@ def build_rrdbnet(nb=23, variant='codes'):
                              upsample_mode='upconv')
 
 
-def build_discriminator():
+def build_discriminator(size=128):
     arch, _ = codes_arch()
-    return arch.Discriminator_VGG_128(in_nc=3, base_nf=64, norm_type='batch',
-                                      mode='CNA', act_type='leakyrelu')
+    cls = getattr(arch, 'Discriminator_VGG_%d' % size)
+    return cls(in_nc=3, base_nf=64, norm_type='batch', mode='CNA', act_type='leakyrelu')
 
 
 def data_util():

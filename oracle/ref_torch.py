@@ -105,13 +105,15 @@ D_LAYOUT = [(0, None, 1), (2, 3, 2), (5, 6, 1), (8, 9, 2), (11, 12, 1), (14, 15,
             (17, 18, 1), (20, 21, 2), (23, 24, 1), (26, 27, 2)]   # (conv idx, bn idx, stride)
 
 
-def discriminator_forward(x, sd, training=True, momentum=0.1, eps=1e-5, update_stats=True):
-    """Discriminator_VGG_128.forward — architecture.py:87-129.  BatchNorm2d(affine) in train mode
+def discriminator_forward(x, sd, training=True, momentum=0.1, eps=1e-5, update_stats=True, size=128):
+    """Discriminator_VGG_128.forward — architecture.py:87-129 (size 96 / 192: architecture.py:178-270, the same
+    stack on a 3x3 final map / with one more 512-channel conv pair).  BatchNorm2d(affine) in train mode
     uses biased batch variance for normalisation and updates running stats with the unbiased
     one (torch.nn.BatchNorm2d semantics, block.py:28-32).  ``sd`` running stats are updated
     in place when ``training and update_stats`` (num_batches_tracked += 1 per call)."""
     t = x
-    for ci, bi, stride in D_LAYOUT:
+    layout = D_LAYOUT + ([(29, 30, 1), (32, 33, 2)] if size == 192 else [])
+    for ci, bi, stride in layout:
         t = _conv(t, sd, 'features.%d' % ci, stride)
         if bi is not None:
             p = 'features.%d' % bi

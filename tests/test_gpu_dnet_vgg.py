@@ -89,6 +89,35 @@ def test_discriminator_golden(dev, golden):
     assert int(bufs['features.3.num_batches_tracked']) == 4
 
 
+@pytest.mark.parametrize('size,batch', [(96, 3), (192, 2)])
+def test_discriminator_variants_golden(dev, golden, size, batch):
+    """Discriminator_VGG_96 / _192 (architecture.py:178-270) on the HIP kernels against the reference's outputs."""
+    from esrganplus_amd import architecture as arch
+    g = golden('disc%d' % size)
+    sd = synth.discriminator_state_dict(seed=40 + size, size=size)
+    net = getattr(arch, 'Discriminator_VGG_%d' % size)(3, 64).to(dev)
+    net.load_state_dict(sd, strict=True)
+    x = synth.image_batch(size, batch, 3, size, size, name='disc%d.x' % size).to(dev)
+    gy = synth.normal_like(size, 'disc%d.gy' % size, (batch, 1)).to(dev)
+    net.eval()
+    with torch.no_grad():
+        assert np.abs(net(x).cpu().numpy() - g['y_eval']).max() <= 2e-4
+    net.train()
+    xr = x.clone().requires_grad_(True)
+    y = net(xr)
+    assert np.abs(y.detach().cpu().numpy() - g['y_train']).max() <= 2e-4
+    (y * gy).sum().backward()
+    params = dict(net.named_parameters())
+    for k in ('classifier.0.bias', 'features.0.weight'):
+        ref = g['g_' + k]
+        assert np.abs(params[k].grad.cpu().numpy() - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max()), k
+    chk = np.stack([checks(p.grad) for p in params.values()])
+    rel = np.abs(chk - g['gchk']) / np.maximum(1.0, np.abs(g['gchk'][:, 1:2]))
+    assert rel.max() <= 2e-3, rel.max()
+    gchk = checks(xr.grad)
+    assert np.abs(gchk - g['gx_chk']).max() <= 2e-3 * max(1.0, np.abs(g['gx_chk'][1]))
+
+
 def test_discriminator_frozen_params_still_give_input_grad(dev):
     """SRRaGAN_model.py:115-116: D's parameters are frozen during the G step."""
     from esrganplus_amd import architecture as arch

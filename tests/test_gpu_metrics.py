@@ -1,0 +1,58 @@
+"""Device-side validation metrics (csrc/metrics.hip) against the reference's own outputs
+(tests/golden/psnr.npz: tensor2img images and PSNR values produced by the imported codes/utils/util.py) and
+against the host restatement in esrganplus_amd.metrics (itself pinned by tests/test_host.py / test_metrics.py)."""
+import numpy as np
+import pytest
+import torch
+
+from esrganplus_amd import metrics as M
+from esrganplus_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def test_device_tensor2img_and_psnr_match_reference_goldens(dev):
+    g = dict(np.load('tests/golden/psnr.npz'))
+    n = sum(1 for k in g if k.startswith('img_a'))
+    assert n > 0
+    for i in range(n):
+        a, b = torch.from_numpy(g['a%d' % i]).to(dev), torch.from_numpy(g['b%d' % i]).to(dev)
+        assert np.array_equal(M.device_tensor2img(a).cpu().numpy(), g['img_a%d' % i])     # bit-exact uint8 BGR
+        psnr, _ = M.device_psnr_ssim(a, b, crop=4)
+        assert abs(psnr - float(g['psnr%d' % i])) < 1e-9
+
+
+@pytest.mark.parametrize('shape,crop', [((3, 40, 52), 4), ((3, 33, 47), 0), ((1, 24, 30), 2), ((3, 128, 96), 4)])
+@pytest.mark.parametrize('y_only', [False, True])
+def test_device_psnr_ssim_match_host_metrics(dev, shape, crop, y_only):
+    if y_only and shape[0] != 3:
+        pytest.skip('Y channel needs 3 channels')
+    hr = synth.image_batch(21, 1, *shape, name='met.hr')[0]
+    # out-of-range values exercise the clamp; .5/255 steps exercise round-half-to-even
+    sr = (hr + 0.08 * synth.normal_like(22, 'met.n', shape)).mul(255).round().div(255) + 0.5 / 255
+    sr[0, 0, :3] = torch.tensor([-0.2, 1.3, 0.5])
+    a, b = M.tensor2img(sr), M.tensor2img(hr)
+    assert np.array_equal(M.device_tensor2img(sr.to(dev)).cpu().numpy(), a)
+    if a.ndim == 2:
+        a, b = a[..., None], b[..., None]
+    ca = a[crop:a.shape[0] - crop, crop:a.shape[1] - crop]
+    cb = b[crop:b.shape[0] - crop, crop:b.shape[1] - crop]
+    if y_only:
+        ca, cb = M.bgr2ycbcr(ca, only_y=True), M.bgr2ycbcr(cb, only_y=True)
+    want_psnr = M.calculate_psnr(ca, cb)
+    want_ssim = M.calculate_ssim(np.squeeze(ca) if ca.shape[-1] == 1 else ca, np.squeeze(cb) if cb.shape[-1] == 1 else cb)
+    psnr, ssim = M.device_psnr_ssim(sr.to(dev), hr.to(dev), crop=crop, y_only=y_only)
+    assert abs(psnr - want_psnr) < 1e-9
+    assert abs(ssim - want_ssim) < 1e-9
+
+
+def test_identical_images_give_inf_psnr_and_unit_ssim(dev):
+    x = synth.image_batch(23, 1, 3, 32, 32, name='met.same')[0].to(dev)
+    psnr, ssim = M.device_psnr_ssim(x, x.clone(), crop=4)
+    assert psnr == float('inf') and abs(ssim - 1.0) < 1e-12

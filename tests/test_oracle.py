@@ -117,6 +117,25 @@ def test_discriminator(golden):
     assert int(sdr['features.3.num_batches_tracked']) == int(g['nbt']) == 4
 
 
+@pytest.mark.parametrize('size,batch', [(96, 3), (192, 2)])
+def test_discriminator_variants(golden, size, batch):
+    """Discriminator_VGG_96 / _192 restatement against the imported reference's outputs."""
+    g = golden('disc%d' % size)
+    sd = synth.discriminator_state_dict(seed=40 + size, size=size)
+    x = synth.image_batch(size, batch, 3, size, size, name='disc%d.x' % size)
+    gy = synth.normal_like(size, 'disc%d.gy' % size, (batch, 1))
+    with torch.no_grad():
+        ye = RT.discriminator_forward(x, {k: v.clone() for k, v in sd.items()}, training=False, size=size)
+    assert np.abs(ye.numpy() - g['y_eval']).max() <= 1e-4
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k
+               else v.clone()) for k, v in sd.items()}
+    y = RT.discriminator_forward(x, sdr, training=True, size=size)
+    (y * gy).sum().backward()
+    assert np.abs(y.detach().numpy() - g['y_train']).max() <= 1e-4
+    assert np.abs(sdr['classifier.0.bias'].grad.numpy() - g['g_classifier.0.bias']).max() <= 1e-4
+    assert np.abs(sdr['features.0.weight'].grad.numpy() - g['g_features.0.weight']).max() <= 1e-3
+
+
 def test_vgg(golden):
     g = golden('vgg')
     sd = synth.vgg19_state_dict(6, 34)
