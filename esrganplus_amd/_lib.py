@@ -62,7 +62,8 @@ class esr_wgrad(C.Structure):
     _fields_ = [('dtype', C.c_int32), ('ks', C.c_int32), ('stride', C.c_int32),
                 ('upsample', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
                 ('cout', C.c_int32), ('cin', C.c_int32), ('g', esr_g32), ('in_', esr_g32),
-                ('dw', C.c_void_p), ('dbias', C.c_void_p), ('scale', C.c_float), ('tap_major', C.c_int32)]
+                ('dw', C.c_void_p), ('dbias', C.c_void_p), ('scale', C.c_float), ('tap_major', C.c_int32),
+                ('partial', C.c_void_p), ('partial_elems', C.c_int64)]
 
 
 class esr_layout(C.Structure):
@@ -185,7 +186,7 @@ EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_p
            'esr_linear_op', 'esr_grad_unpermute', 'esr_adam_step', 'esr_amp_step', 'esr_resample_axis', 'esr_pack_conv_weights_batch', 'esr_pack_pieces',
            'esr_run_ops', 'esr_run_ops_timed', 'esr_graph_create', 'esr_graph_launch', 'esr_graph_destroy', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op', 'esr_rdb_forward', 'esr_rdb_workspace_bytes', 'esr_rdb_weight_stream_bytes',
-           'esr_rdb_max_tiles_per_image', 'esr_gather_fragments', 'esr_image_metrics']
+           'esr_rdb_max_tiles_per_image', 'esr_gather_fragments', 'esr_image_metrics', 'esr_wgrad_workspace_elems']
 
 _lib = None
 _lock = threading.Lock()
@@ -225,6 +226,8 @@ def lib():
         L.esr_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
         L.esr_graph_destroy.argtypes = [C.c_void_p]
         L.esr_conv_wgrad_multi.argtypes = [C.POINTER(esr_wgrad), C.c_int32, C.c_void_p]
+        L.esr_wgrad_workspace_elems.restype = C.c_int64
+        L.esr_wgrad_workspace_elems.argtypes = [C.c_void_p, C.c_int32]
         L.esr_rdb_workspace_bytes.restype = C.c_size_t
         L.esr_rdb_workspace_bytes.argtypes = [C.c_int32] * 3
         L.esr_rdb_weight_stream_bytes.restype = C.c_size_t

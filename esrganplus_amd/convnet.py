@@ -283,6 +283,7 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
     if input_affine is not None:
         aff = (input_affine[0], input_affine[1])
     _layout(bk, dt_e, 0, B, cin0, gcur, nchw_ptr=P.gx_tensor.data_ptr(), affine=aff)
+    P.wgrad_arena = E.attach_wgrad_arena(bk, dev)
     return P
 
 

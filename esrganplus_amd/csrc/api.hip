@@ -130,6 +130,24 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
   return ESR_OK;
 }
 
+extern "C" int64_t esr_wgrad_run_partial_elems(const esr_wgrad* items, int32_t n);
+extern "C" int64_t esr_wgrad_workspace_elems(const esr_op* ops, int32_t n) {
+  // the same runs esr_run_ops forms: consecutive wgrad ops with one side flag, at most 16
+  int64_t need = 0;
+  for (int i = 0; ops && i < n; ++i) {
+    if (ops[i].kind != ESR_OP_WGRAD) continue;
+    const int side = ops[i].flags & ESR_OPF_SIDE;
+    int m = 1;
+    while (i + m < n && m < 16 && ops[i + m].kind == ESR_OP_WGRAD && (ops[i + m].flags & ESR_OPF_SIDE) == side) ++m;
+    esr_wgrad run[16];
+    for (int k = 0; k < m; ++k) run[k] = ops[i + k].u.wgrad;
+    const int64_t e = esr_wgrad_run_partial_elems(run, m);
+    if (e > need) need = e;
+    i += m - 1;
+  }
+  return need;
+}
+
 // ------------------------------------------------------------------------------------------------
 // hipGraph replay
 // ------------------------------------------------------------------------------------------------

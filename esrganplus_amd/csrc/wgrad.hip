@@ -298,8 +298,30 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
     }
   }
   if (!active) return;
-  // ---- fp32 atomics into dW[co][ci][kh][kw] / dbias[co]
   const int n = lane & 31, ci = cib * 32 + n;
+  if (p.partial) {
+    // ---- deterministic form: this workgroup's own slot (spatial split bx) of the partial arena, tap-major,
+    // plain stores; wgrad_reduce_kernel adds the slots up in a fixed order.  `partial_elems` carries the slot
+    // stride here (set by the launcher): [NTAP][cout][cin] floats + [cout] bias sums.
+    float* const slot = p.partial + (int64_t)bx * p.partial_elems;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const int t = T0 + tt;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+        if (co < p.cout && ci < p.cin) slot[((int64_t)t * p.cout + co) * p.cin + ci] = acc.a[tt][e] * p.scale;
+      }
+    }
+    if (T0 == 0 && cib == 0 && p.dbias) {
+      // lanes l and l+32 hold the two k halves of row l%32: fold them here, one store per row
+      const float other = __shfl_xor(bsum, 32);
+      const int co = cb * 32 + (lane & 31);
+      if (lane < 32 && co < p.cout) slot[(int64_t)NTAP * p.cout * p.cin + co] = (bsum + other) * p.scale;
+    }
+    return;
+  }
+  // ---- fp32 atomics into dW[co][ci][kh][kw] / dbias[co]
 #pragma unroll
   for (int tt = 0; tt < NT; ++tt) {
     const int t = T0 + tt;
@@ -326,10 +348,10 @@ __global__ __launch_bounds__((Wg16Mode<S, UPS>::NWV * 64), 2) void wgrad16_kerne
   wgrad16_body<KS, S, UPS, NCO, T0, NT>(p, rows_per_wg, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+constexpr int WG_BATCH_MAX = 8;
 // ---- several independent 3x3/s1 and 1x1 wgrads in ONE launch.  At training sizes (16 x 32x32) one
 // conv's wgrad is ~64 workgroups of mostly idle waves and ~25 us of pure latency; the six convs of a
 // residual dense block (same saved input, six gradient slices) fill the chip together.
-constexpr int WG_BATCH_MAX = 8;
 struct WgradBatch {
   int32_t n;
   int32_t start[WG_BATCH_MAX + 1];   // first linear workgroup of entry i
@@ -355,6 +377,56 @@ __global__ __launch_bounds__(256, 2) void wgrad16_batch_kernel(const WgradBatch 
     case 2: wgrad16_body<1, 1, false, 1, 0, 1>(p, pb.rows[i], smem, bx, by, bz); break;
     default: wgrad16_body<1, 1, false, 2, 0, 1>(p, pb.rows[i], smem, bx, by, bz); break;
   }
+}
+
+// ---- stage 2 of the deterministic form: dw[elem] += sum over the spatial splits, in split order
+struct WgradReduce {
+  int32_t n;
+  int64_t begin[WG_BATCH_MAX + 1];     // first linear element of entry i
+  const float* partial[WG_BATCH_MAX];
+  int64_t stride[WG_BATCH_MAX];
+  int32_t nsplit[WG_BATCH_MAX], cout[WG_BATCH_MAX], cin[WG_BATCH_MAX], ntap[WG_BATCH_MAX], tap_major[WG_BATCH_MAX];
+  float* dw[WG_BATCH_MAX];
+  float* dbias[WG_BATCH_MAX];
+};
+__global__ void wgrad_reduce_kernel(const WgradReduce r) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= r.begin[r.n]) return;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < WG_BATCH_MAX; ++k)
+    if (k < r.n && idx >= r.begin[k]) i = k;
+  const int64_t k = idx - r.begin[i];                 // element of the slot: tap-major weights, then bias sums
+  const float* src = r.partial[i] + k;
+  float s = 0.f;
+  for (int sp = 0; sp < r.nsplit[i]; ++sp) s += src[(int64_t)sp * r.stride[i]];
+  const int64_t nw = (int64_t)r.ntap[i] * r.cout[i] * r.cin[i];
+  if (k >= nw) { r.dbias[i][k - nw] += s; return; }
+  if (r.tap_major[i]) { r.dw[i][k] += s; return; }
+  const int ci = (int)(k % r.cin[i]);
+  const int64_t q = k / r.cin[i];
+  const int co = (int)(q % r.cout[i]), t = (int)(q / r.cout[i]);
+  r.dw[i][((int64_t)co * r.cin[i] + ci) * r.ntap[i] + t] += s;
+}
+static int64_t slot_elems(const esr_wgrad& p) {
+  const int64_t n = (int64_t)p.ks * p.ks * p.cout * p.cin + (p.dbias ? p.cout : 0);
+  return (n + 3) & ~(int64_t)3;
+}
+static void reduce_entry(WgradReduce& r, int i, const esr_wgrad& p, const float* partial, int nsplit) {
+  r.partial[i] = partial; r.stride[i] = slot_elems(p); r.nsplit[i] = nsplit;
+  r.cout[i] = p.cout; r.cin[i] = p.cin; r.ntap[i] = p.ks * p.ks; r.tap_major[i] = p.tap_major;
+  r.dw[i] = p.dw; r.dbias[i] = p.dbias;
+  r.begin[i + 1] = r.begin[i] + (int64_t)p.ks * p.ks * p.cout * p.cin + (p.dbias ? p.cout : 0);
+}
+static int launch_reduce(WgradReduce& r, int n, hipStream_t st) {
+  r.n = n;
+  for (int k = n; k < WG_BATCH_MAX; ++k) {
+    r.begin[k + 1] = r.begin[n]; r.partial[k] = r.partial[0]; r.stride[k] = 0; r.nsplit[k] = 0; r.cout[k] = r.cin[k] = r.ntap[k] = 1;
+    r.tap_major[k] = 1; r.dw[k] = r.dw[0]; r.dbias[k] = r.dbias[0];
+  }
+  const int64_t total = r.begin[n];
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
+  return esr_check_launch("wgrad_reduce_kernel");
 }
 
 // grid shape of one conv's fp16 wgrad (shared by the single and the batched launch)
@@ -388,16 +460,39 @@ Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs, int min_rows, int cap
 }
 
 template <int KS, int S, bool UPS, int T0, int NT>
-int launch_wgrad16(const esr_wgrad& p, hipStream_t st) {
-  const Wg16Grid g = wgrad16_grid<S, UPS>(p, 64, 8, max_rows());
+int launch_wgrad16(const esr_wgrad& p_in, hipStream_t st, bool reduce = true) {
+  const Wg16Grid g = wgrad16_grid<S, UPS>(p_in, 64, 8, max_rows());
   dim3 grid(g.gx, g.gy, g.gz);
+  esr_wgrad p = p_in;
+  if (p.partial) {
+    if ((int64_t)g.gx * slot_elems(p) > p.partial_elems) {
+      esr_set_error("wgrad: partial arena too small (%lld floats, need %lld: esr_wgrad_workspace_elems)",
+                    (long long)p.partial_elems, (long long)((int64_t)g.gx * slot_elems(p)));
+      return ESR_ERR_INVALID;
+    }
+    p.partial_elems = slot_elems(p);              // the kernel reads the slot stride here
+  }
   if constexpr (S == 2) {
     hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(Wg16Mode<S, UPS>::NWV * 64), 0, st, p, g.rows);
   } else {
     if (g.nco == 2) hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(Wg16Mode<S, UPS>::NWV * 64), 0, st, p, g.rows);
     else hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 1, T0, NT>), grid, dim3(Wg16Mode<S, UPS>::NWV * 64), 0, st, p, g.rows);
   }
-  return esr_check_launch("wgrad16_kernel");
+  const int rc = esr_check_launch("wgrad16_kernel");
+  if (rc || !p.partial || !reduce) return rc;
+  WgradReduce r;
+  r.begin[0] = 0;
+  reduce_entry(r, 0, p_in, p.partial, g.gx);
+  return launch_reduce(r, 1, st);
+}
+// spatial splits (= partial slots) the single launch of this conv uses
+template <int S, bool UPS> static int single_splits(const esr_wgrad& p) { return wgrad16_grid<S, UPS>(p, 64, 8, max_rows()).gx; }
+static int64_t single_partial_elems(const esr_wgrad& p) {
+  if (p.dtype != ESR_F16) return 0;
+  int gx = 0;
+  if (p.ks == 4 && p.stride == 2 && !p.upsample) gx = single_splits<2, false>(p);
+  else if (p.stride == 1 && (p.ks == 3 || p.ks == 1)) gx = p.upsample ? single_splits<1, true>(p) : single_splits<1, false>(p);
+  return (int64_t)gx * slot_elems(p);
 }
 
 template <typename T, int KS, int S, bool UPS>
@@ -461,9 +556,9 @@ extern "C" int esr_conv_wgrad(const esr_wgrad* p, esr_stream_t stream) {
     if (p->ks == 3 && p->stride == 1 && !p->upsample) return launch_wgrad16<3, 1, false, 0, 9>(*p, st);
     if (p->ks == 3 && p->stride == 1 && p->upsample) return launch_wgrad16<3, 1, true, 0, 9>(*p, st);
     if (p->ks == 1 && p->stride == 1 && !p->upsample) return launch_wgrad16<1, 1, false, 0, 1>(*p, st);
-    if (p->ks == 4 && p->stride == 2 && !p->upsample) {   // discriminator: two launches of 8 taps
-      const int rc = launch_wgrad16<4, 2, false, 0, 8>(*p, st);
-      return rc ? rc : launch_wgrad16<4, 2, false, 8, 8>(*p, st);
+    if (p->ks == 4 && p->stride == 2 && !p->upsample) {   // discriminator: two launches of 8 taps (one reduce)
+      const int rc = launch_wgrad16<4, 2, false, 0, 8>(*p, st, false);
+      return rc ? rc : launch_wgrad16<4, 2, false, 8, 8>(*p, st, true);
     }
     return dispatch_wgrad<_Float16>(*p, st);
   }
@@ -504,10 +599,18 @@ extern "C" int esr_conv_wgrad_multi(const esr_wgrad* items, int32_t n, esr_strea
       continue;
     }
     WgradBatch pb;
+    WgradReduce red;
+    red.begin[0] = 0;
+    const bool det = items[i].partial != nullptr;
+    int64_t used = 0;                                  // floats of the partial arena handed out
     pb.n = m;
     int total = 0;
     for (int k = 0; k < m; ++k) {
       const esr_wgrad& p = items[i + k];
+      if ((p.partial != nullptr) != det || (det && p.partial != items[i].partial)) {
+        esr_set_error("esr_conv_wgrad_multi: the wgrads of one run must share one partial arena (or none)");
+        return ESR_ERR_INVALID;
+      }
       // batched launch: every spatial split costs a full set of dW atomics (~5 us per million), so take
       // the LARGEST row chunk that still gives each conv ~64 workgroups (6 convs fill the chip once),
       // and never less than 32 rows
@@ -516,14 +619,48 @@ extern "C" int esr_conv_wgrad_multi(const esr_wgrad* items, int32_t n, esr_strea
       pb.gx[k] = g.gx; pb.gy[k] = g.gy; pb.rows[k] = g.rows;
       pb.kind[k] = (p.ks == 3 ? 0 : 2) + (g.nco == 2 ? 1 : 0);
       pb.w[k] = p;
+      if (det) {
+        pb.w[k].partial = p.partial + used;
+        pb.w[k].partial_elems = slot_elems(p);
+        reduce_entry(red, k, p, pb.w[k].partial, g.gx);
+        used += (int64_t)g.gx * slot_elems(p);
+        if (used > p.partial_elems) {
+          esr_set_error("wgrad: partial arena too small (%lld floats, need >= %lld: esr_wgrad_workspace_elems)",
+                        (long long)p.partial_elems, (long long)used);
+          return ESR_ERR_INVALID;
+        }
+      }
       total += g.gx * g.gy * g.gz;
     }
     for (int k = m; k <= WG_BATCH_MAX; ++k) pb.start[k] = total;
     for (int k = m; k < WG_BATCH_MAX; ++k) { pb.gx[k] = pb.gy[k] = 1; pb.rows[k] = 8; pb.kind[k] = 0; pb.w[k] = items[i]; }
     hipLaunchKernelGGL(wgrad16_batch_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, pb);
-    const int rc = esr_check_launch("wgrad16_batch_kernel");
+    int rc = esr_check_launch("wgrad16_batch_kernel");
+    if (rc == ESR_OK && det) rc = launch_reduce(red, m, (hipStream_t)stream);
     if (rc) return rc;
     i += m;
   }
   return ESR_OK;
+}
+
+// floats of partial arena one esr_conv_wgrad_multi call on these items needs (same grouping as above)
+extern "C" int64_t esr_wgrad_run_partial_elems(const esr_wgrad* items, int32_t n) {
+  int64_t need = 0;
+  int i = 0;
+  while (items && i < n) {
+    int m = 0;
+    if (wgrad_batchable(items[i]))
+      while (i + m < n && m < WG_BATCH_MAX && wgrad_batchable(items[i + m])) ++m;
+    if (m <= 1) {
+      const int64_t e = single_partial_elems(items[i]);
+      if (e > need) need = e;
+      ++i;
+      continue;
+    }
+    int64_t used = 0;
+    for (int k = 0; k < m; ++k) used += (int64_t)wgrad16_grid<1, false>(items[i + k], batch_min_wgs(), 32, 1 << 30).gx * slot_elems(items[i + k]);
+    if (used > need) need = used;
+    i += m;
+  }
+  return need;
 }

@@ -546,6 +546,31 @@ def use_graphs():
     return os.environ.get('ESR_GRAPH', '0') == '1'
 
 
+def deterministic_wgrad():
+    """Two-stage weight-gradient reduction (esr_wgrad.partial): bit-identical gradients run to run instead of
+    fp32 atomics (ESR_WGRAD_DET=0 restores the atomics)."""
+    return os.environ.get('ESR_WGRAD_DET', '1') != '0'
+
+
+def attach_wgrad_arena(oplist, device):
+    """Give every fp16 weight-gradient op of a backward list the partial arena of the deterministic reduction
+    (one arena per list: a slot only lives inside one esr_run_ops launch group, and the list's wgrad runs are
+    ordered on one stream).  Returns the arena tensor (keep it alive with the plan) or None."""
+    if not deterministic_wgrad():
+        return None
+    wops = [o for o in oplist.ops if o.kind == L.OP_WGRAD and o.u.wgrad.dtype == L.ESR_F16]
+    if not wops:
+        return None
+    need = L.lib().esr_wgrad_workspace_elems(C.cast(oplist.array(), C.c_void_p), len(oplist.ops))
+    if need <= 0:
+        return None
+    arena = torch.empty(need, dtype=torch.float32, device=device)
+    for o in wops:
+        o.u.wgrad.partial, o.u.wgrad.partial_elems = arena.data_ptr(), need
+    oplist._arr = None
+    return arena
+
+
 def current_stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -1112,4 +1137,5 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         TP.segments = segs
     if block:
         TP.gx_op = Bk.add(L.OP_LAYOUT, 'layout', gx_layout)
+    TP.wgrad_arena = attach_wgrad_arena(Bk, device)
     return TP

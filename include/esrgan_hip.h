@@ -186,6 +186,14 @@ typedef struct esr_wgrad {
   float scale;
   int32_t tap_major;   /* 1: dw is laid out [tap][cout][cin] (lane-contiguous atomics: 2 cache lines per
                           wave instruction instead of ~36); esr_grad_unpermute restores OIHW */
+  /* Deterministic two-stage reduction (ESR_F16 kernels): with `partial` set every workgroup stores its
+   * 32x32xtaps partial with plain stores into its own slot of this arena and a second launch of the same
+   * call adds the slots of a conv up in a fixed order into dw / dbias (+=, no atomics): bit-identical
+   * gradients run to run.  `partial_elems` = floats available; esr_wgrad_workspace_elems() returns what an
+   * op list needs (the arena is shared by all wgrad ops of a stream: a slot lives only inside one call).
+   * NULL: fp32 atomicAdd (results vary in the last bits with the arrival order). */
+  float* partial;
+  int64_t partial_elems;
 } esr_wgrad;
 
 /* One launch that rewrites every tap-major gradient block into its OIHW slot.  `table` is a DEVICE
@@ -445,6 +453,8 @@ int esr_image_metrics(const esr_img_metrics* p, esr_stream_t stream);   /* repla
 /* Run a recorded list of ops back to back on `stream` (one host call per network pass; this is
  * what RRDBNet.forward — architecture.py:76-78 — becomes). */
 int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream);
+/* floats of esr_wgrad.partial arena the wgrad ops of an op list need (max over the launches esr_run_ops forms) */
+int64_t esr_wgrad_workspace_elems(const esr_op* ops, int32_t n);
 
 /* hipGraph replay of an op list (training plans are ~1 000 launches of 10-100 us: per-launch host cost
  * is what bounds the step).  esr_graph_create captures `esr_run_ops(ops, n)` — including its

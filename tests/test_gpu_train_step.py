@@ -285,3 +285,30 @@ def test_eval_after_fused_adam_uses_updated_weights(dev):
             fresh.load_state_dict(net.state_dict())
             y2 = fresh(x)
         assert torch.equal(y, y2), prec
+
+
+def test_fp16_weight_gradients_are_bit_identical_run_to_run(dev):
+    """Deterministic two-stage wgrad reduction (esr_wgrad.partial): G and D gradients of two identical
+    backward passes are equal bit for bit (the fp32-atomics form, ESR_WGRAD_DET=0, is not)."""
+    from esrganplus_amd import architecture as arch
+    sd = synth.rrdbnet_state_dict(nb=2, seed=13)
+    x = synth.image_batch(13, 4, 3, 32, 32, name='det.x').to(dev)
+    gy = synth.normal_like(13, 'det.gy', (4, 3, 128, 128)).to(dev)
+    runs = []
+    for _ in range(2):
+        net = arch.RRDBNet(3, 3, 64, 2).to(dev).eval().set_precision('fp16')
+        net.load_state_dict(sd)
+        (net(x) * gy).sum().backward()
+        runs.append(torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone())
+    assert torch.equal(runs[0], runs[1])
+    assert torch.isfinite(runs[0]).all() and runs[0].abs().sum() > 0
+    dsd = synth.discriminator_state_dict(seed=14)
+    xd = synth.image_batch(14, 4, 3, 128, 128, name='det.xd').to(dev)
+    gd = synth.normal_like(14, 'det.gd', (4, 1)).to(dev)
+    runs = []
+    for _ in range(2):
+        netD = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision('fp16')
+        netD.load_state_dict(dsd)
+        (netD(xd) * gd).sum().backward()
+        runs.append(torch.cat([p.grad.reshape(-1) for p in netD.parameters()]).clone())
+    assert torch.equal(runs[0], runs[1])
