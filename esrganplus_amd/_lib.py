@@ -144,7 +144,7 @@ class esr_pack_batch(C.Structure):
 class esr_rdb_block(C.Structure):
     _fields_ = [('w', C.c_void_p), ('bias', C.c_void_p), ('x_in', esr_g32), ('x_out', esr_g32),
                 ('res2', esr_g32), ('layer1', C.c_uint32), ('layer2', C.c_uint32), ('flags', C.c_uint32),
-                ('_pad', C.c_uint32), ('dense', esr_g32), ('aux', esr_g32)]
+                ('_pad', C.c_uint32)]
 
 
 RDB_FULL_OUT = 1

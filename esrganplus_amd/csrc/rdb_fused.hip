@@ -930,7 +930,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
                                          const ImgView& out, int out_cb, int ch_cb, const RowsRaw<T>* ex,
                                          const RowsRaw<T>* r2, bool has_res2, const Tile& t, char* smem = nullptr,
                                          int slot0 = 0, RowsRaw<T>* keep = nullptr, float carry_scale = 0.f,
-                                         bool full_store = true, const ImgView* aux = nullptr, int aux_cb = 0) {
+                                         bool full_store = true) {
   using C16 = Ch16<T>;
   const int lane = t.lane(), tj = lane & 31, th = lane >> 5;
   int own_px = 0, own_swz = 0;
@@ -954,10 +954,6 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
       float x = a[e] + bq[e >> 2][e & 3];
       if constexpr (MODE != 3) x = __builtin_fmaxf(x, x * ESR_LRELU_SLOPE);     // LeakyReLU(0.2) = max(x, 0.2 x)
       v[e] = x;
-    }
-    if constexpr (MODE == 1 || MODE == 2) {
-      // training: the pre-residual activation (its sign is the backward's LeakyReLU mask)
-      if (aux) C16::store(*aux, (oy < p.H && ox < p.W) ? aux_cb : 0, th, (oy < p.H && ox < p.W) ? (oy + 1) * wp32 + (ox + 1) * 32 : (int)0x80000000u, v);
     }
     if constexpr (MODE == 1) {
       const f32x16 a1 = acc_br<0, r>(acc);
@@ -1060,6 +1056,9 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       t.halo(hsrc, hdst);
       *(volatile int*)(smem + LDS_HALO + t.tid() * 8) = hsrc;
     }
+    const ImgView dense = img_view(p.dense, t.b);
+    const char* const dense_b = (const char*)p.dense.ptr + (int64_t)t.b * p.dense.batch_stride;
+    const int64_t d_gs = p.dense.group_stride;
 
 
     unsigned epoch = 0;      // phases this tile has published
@@ -1100,13 +1099,6 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       // block-table fields are wave-uniform, but only readfirstlane makes that provable: without it every
       // test on them becomes an exec-masked region and every use a fresh vector load
       const bool noisy = p.noise_mode != ESR_NOISE_OFF;
-      // the block's own x1..x4 buffer (training) or the chain's shared scratch
-      const esr_g32& dg = blk.dense.ptr ? blk.dense : p.dense;
-      const ImgView dense = img_view(dg, t.b);
-      const char* const dense_b = (const char*)uniform_ptr(dg.ptr) + (int64_t)t.b * __builtin_amdgcn_readfirstlane((int)dg.batch_stride);
-      const int64_t d_gs = __builtin_amdgcn_readfirstlane((int)dg.group_stride);
-      const bool has_aux = __builtin_amdgcn_readfirstlane((int)(blk.aux.ptr != nullptr)) != 0;
-      const ImgView auxv = img_view(has_aux ? blk.aux : dg, t.b);
       BlkS bs;
       bs.bias = (const float*)uniform_ptr(blk.bias);
       bs.layer1 = __builtin_amdgcn_readfirstlane(blk.layer1);
@@ -1204,8 +1196,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         trace_ev(p, tile, ev);
         lds_bias(smem, 32, t, bb);
         mfma_drain();
-        if (has_aux) epilogue<T, 1, 1, 1>(acc, p, bs, bb, dense, 1, 0, nullptr, nullptr, false, t, smem, 2, nullptr, 0.f, true, &auxv, 0);
-        else epilogue<T, 1, 1, 1>(acc, p, bs, bb, dense, 1, 0, nullptr, nullptr, false, t, smem, 2);       // x2
+        epilogue<T, 1, 1, 1>(acc, p, bs, bb, dense, 1, 0, nullptr, nullptr, false, t, smem, 2);       // x2
         ++epoch;
         trace_ev(p, tile, ev);
         run_units<T, S::first(U_BULK, 2), S::end(U_BULK, 2), true>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 2)>{}, std::integral_constant<int, S::end(U_BULK, 2)>{}, CF::KD); });
@@ -1230,8 +1221,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         lds_bias(smem, 96, t, bb);
         lds_get_rows(smem, 2, x2.q, t);   // x2's own pixels still sit in the slots x4 is about to take
         mfma_drain();
-        if (has_aux) epilogue<T, 3, 2, 1>(acc, p, bs, bb, dense, 3, 0, &x2, nullptr, false, t, smem, 2, nullptr, 0.f, true, &auxv, 1);
-        else epilogue<T, 3, 2, 1>(acc, p, bs, bb, dense, 3, 0, &x2, nullptr, false, t, smem, 2);           // x4 (+ x2)
+        epilogue<T, 3, 2, 1>(acc, p, bs, bb, dense, 3, 0, &x2, nullptr, false, t, smem, 2);           // x4 (+ x2)
         RowsRaw<T> tx0, tx1, tr0, tr1;
         ++epoch;
         trace_ev(p, tile, ev);
@@ -1284,7 +1274,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       run_phase<T, 2>(acc, w + CF::phase_off(2), dense_b, d_gs, CF::KD, smem, t);
       trace_ev(p, tile, ev);
       mfma_drain();
-      epilogue<T, 1, 1>(acc, p, bs, fb[1], dense, 1, 0, nullptr, nullptr, false, t, nullptr, 0, nullptr, 0.f, true, has_aux ? &auxv : nullptr, 0);     // x2
+      epilogue<T, 1, 1>(acc, p, bs, fb[1], dense, 1, 0, nullptr, nullptr, false, t);     // x2
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- phase 3: x2 -> conv3..conv5
@@ -1305,7 +1295,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       trace_ev(p, tile, ev);
       mfma_drain();
       { RowsRaw<T> x2r; load_rows<T>(dense, 1, p, t, x2r);
-        epilogue<T, 3, 2>(acc, p, bs, fb[3], dense, 3, 0, &x2r, nullptr, false, t, nullptr, 0, nullptr, 0.f, true, has_aux ? &auxv : nullptr, 1); }     // x4 (+ x2)
+        epilogue<T, 3, 2>(acc, p, bs, fb[3], dense, 3, 0, &x2r, nullptr, false, t); }     // x4 (+ x2)
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- phase 5: x4 -> conv5; block tail (+ RRDB tail)

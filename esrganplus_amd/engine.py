@@ -773,9 +773,6 @@ class TrainPlan:
         for i in P.noise_ops:
             arr[i].u.conv.noise_mode = L.NOISE_PHILOX
             arr[i].u.conv.seed_dev = self.seed_t.data_ptr()
-        for i in P.chain_ops:
-            arr[i].u.rdb_chain.noise_mode = L.NOISE_PHILOX if P.chain_noise else L.NOISE_OFF
-            arr[i].u.rdb_chain.seed_dev = self.seed_t.data_ptr()
         barr = self.bwd.array()
         barr[self.gy_op].u.layout.nchw = self.gy_static.data_ptr()
         if self.gx_op is not None:
@@ -854,47 +851,7 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         c = _conv(d, B, H, W, xin.view(0), in_nc, (S[0][0] if nb else XF).view(0, 64), e['model.0'])
         c.aux_out = fea.view(0, 64)
         P.ops.add_conv(c)
-    # ESR_RDB_FUSED_TRAIN=1: fp16 'net' plans run the whole trunk as ONE fused chain launch (rdb_fused.hip) that also
-    # leaves what the backward needs in memory (off by default: with every slice stored in full, the AUX stores and
-    # the Philox layers in its serial epilogues the launch is 5 ms slower than the per-conv forward at gtrain sizes
-    # and equal at 32x32 tiles — profiles/r02_experiments.md): every block's x1..x4 in its own concat buffer (save_dense) and the pre-residual
-    # activations of conv2 / conv4 in AUX (esr_rdb_block.dense / .aux).  fp32 (the golden-parity path), explicit
-    # z and stand-alone blocks keep the five fused-conv launches per block.
-    use_chain = (not block and nb > 0 and dt_e == L.ESR_F16 and rdb_chain_ok(B, H, W, noise, explicit_z) and
-                 os.environ.get('ESR_RDB_FUSED_TRAIN', '0') == '1')
-    if use_chain:
-        prefixes = [pkey(i, j) for i in range(nb) for j in range(nj)]
-        P.streams = RdbStreams(wp, prefixes)
-        blocks = (L.esr_rdb_block * len(prefixes))()
-        for i in range(nb):
-            for j in range(nj):
-                bf, ax = S[i][j], AUX[i][j]
-                bn = S[i][j + 1] if j < nj - 1 else (S[i + 1][0] if i + 1 < nb else XF)
-                b_ = blocks[i * nj + j]
-                b_.w, b_.bias = P.streams.w_ptr(i * nj + j), P.streams.bias_ptr(i * nj + j)
-                b_.x_in, b_.x_out = bf.view(0, 64), bn.view(0, 64)
-                b_.dense, b_.aux = bf.view(64, 128), ax.view(0, 64)
-                b_.flags = L.RDB_FULL_OUT
-                b_.layer1 = b_.layer2 = L.NO_LAYER
-                if noise:
-                    b_.layer1 = per * i + j
-                if j == 2:
-                    b_.res2 = S[i][0].view(0, 64)
-                    if noise and variant == 'test_image':
-                        b_.layer2 = per * i + 3
-        blk_t = torch.frombuffer(bytearray(bytes(blocks)), dtype=torch.uint8).to(device)
-        ws_bytes = L.lib().esr_rdb_workspace_bytes(B, H, W)
-        ws = torch.zeros((ws_bytes + 3) // 4, dtype=torch.int32, device=device)
-        P.bufs.extend([blk_t, ws])
-        ch = L.esr_rdb_chain()
-        ch.dtype, ch.B, ch.H, ch.W = dt_e, B, H, W
-        ch.n_blocks, ch.noise_mode, ch.sigma, ch.save_dense = len(prefixes), L.NOISE_OFF, SIGMA, 1
-        ch.dense = S[0][0].view(64, 128)             # unused: every block brings its own
-        ch.blocks, ch.workspace, ch.workspace_bytes = blk_t.data_ptr(), ws.data_ptr(), ws_bytes
-        P.chain_ops.append(P.ops.add(L.OP_RDB_CHAIN, 'rdb_chain', ch))
-        P.chain_noise = bool(noise)
-        P.chain_ws = ws
-    for i in range(nb if not use_chain else 0):
+    for i in range(nb):
         for j in range(nj):
             bf, ax = S[i][j], AUX[i][j]
             bn = S[i][j + 1] if j < nj - 1 else (S[i + 1][0] if i + 1 < nb else XF)

@@ -357,11 +357,6 @@ typedef struct esr_rdb_block {
                                tiles' border pixels are stored: the next block takes its input from the LDS and its
                                `+ x` residual from the accumulators this block's epilogue primes with 5 x */
   uint32_t _pad;
-  /* Training forward (autograd keeps every block's activations): */
-  esr_g32 dense;            /* ptr != NULL: this block's own 128-channel x1..x4 buffer instead of the chain's shared
-                               scratch (use with esr_rdb_chain.save_dense = 1: whole slices reach memory) */
-  esr_g32 aux;              /* ptr != NULL: 64 channels receiving lrelu(conv2(..)) [0:32] and lrelu(conv4(..)) [32:64]
-                               BEFORE the `+ conv1x1(x)` / `+ x2` — their signs are the LeakyReLU masks of the backward */
 } esr_rdb_block;
 #define ESR_RDB_FULL_OUT 1u
 
@@ -374,7 +369,7 @@ typedef struct esr_rdb_chain {
                                re-reads); 1: the whole slices reach `dense` (e.g. to inspect / save activations) */
   uint64_t seed;
   const uint64_t* seed_dev; /* as esr_conv.seed_dev */
-  esr_g32 dense;            /* 128-channel scratch: x1..x4 of the block in flight (blocks without their own) */
+  esr_g32 dense;            /* 128-channel scratch: x1..x4 of the block in flight */
   const esr_rdb_block* blocks;  /* DEVICE array of n_blocks entries */
   void* workspace;          /* esr_rdb_workspace_bytes(B,H,W) bytes of device memory; word 1 != 0 after the
                                launch = a bounded spin timed out (results invalid) */
