@@ -238,3 +238,18 @@ def test_philox_backward_stand_alone_blocks(dev, kind):
     for k, g in gp.items():
         ref = sdr[pre + k].grad
         assert (g.cpu() - ref).abs().max().item() <= 1e-2 * max(1.0, ref.abs().max().item()), k    # see the mask-flip note above
+
+
+@pytest.mark.parametrize('shape,nb', [((1, 3, 16, 32), 2), ((4, 3, 64, 96), 2), ((16, 3, 128, 128), 1)])
+def test_fused_chain_is_deterministic_run_to_run(dev, shape, nb):
+    """No atomics and no timing-dependent reads in the chain launch: repeated forwards of one input are equal bit
+    for bit (one tile without neighbours, a few tiles, and the bench's two rounds of 256 tiles)."""
+    from esrganplus_amd import architecture as arch
+    net = arch.RRDBNet(3, 3, 64, nb).to(dev).eval().set_precision('fp16')
+    net.load_state_dict(synth.rrdbnet_state_dict(nb=nb, seed=3))
+    x = synth.image_batch(5, *shape, name='det.x').to(dev)
+    with torch.no_grad():
+        ref = net(x).clone()
+        assert _chain_plans(net)
+        for _ in range(5):
+            assert torch.equal(net(x), ref)
