@@ -939,6 +939,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
   const int oyb = t.oy0 + t.wave * R;
   const f32x4 (&bq)[4] = bias.q;
   const int wp32 = p.dense.wp * 32;
+  const bool ragged = t.oy0 + TH > p.H || t.ox0 + TW > p.W;      // wave-uniform
   const uint32_t layer1 = blk.layer1, layer2 = blk.layer2;
   const bool n1 = MODE == 3 && NOISE && p.noise_mode == ESR_NOISE_PHILOX && layer1 != ESR_NO_LAYER;
   const bool n2 = MODE == 3 && NOISE && p.noise_mode == ESR_NOISE_PHILOX && layer2 != ESR_NO_LAYER && has_res2;
@@ -949,11 +950,20 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
     const int oy = oyb + r;
     const f32x16 a = acc_br<BLK, r>(acc);
     float v[16], tmp[16];
+    // pairs: v_pk_add_f32 / v_pk_mul_f32 do two elements per instruction (same IEEE results as the scalar forms)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      float x = a[e] + bq[e >> 2][e & 3];
-      if constexpr (MODE != 3) x = __builtin_fmaxf(x, x * ESR_LRELU_SLOPE);     // LeakyReLU(0.2) = max(x, 0.2 x)
-      v[e] = x;
+    for (int e = 0; e < 16; e += 2) {
+      const f32x2 av = {a[e], a[e + 1]}, bv = {bq[e >> 2][e & 3], bq[e >> 2][(e & 3) + 1]};
+      const f32x2 x = av + bv;
+      if constexpr (MODE != 3) {
+        const f32x2 y = x * ESR_LRELU_SLOPE;                                     // LeakyReLU(0.2) = max(x, 0.2 x)
+        v[e] = __builtin_fmaxf(x[0], y[0]);
+        v[e + 1] = __builtin_fmaxf(x[1], y[1]);
+      } else {
+        v[e] = x[0];
+        v[e + 1] = x[1];
+      }
     }
     if constexpr (MODE == 1) {
       const f32x16 a1 = acc_br<0, r>(acc);
@@ -1007,7 +1017,8 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, con
       const bool edge = (MODE == 3 && full_store) || p.save_dense || tj == 0 || tj == TW - 1 || (t.wave == 0 && r == 0) ||
                         (t.wave == NT / 64 - 1 && r == R - 1);
       C16::store_packed(out, (inside && edge) ? out_cb : 0, th, (inside && edge) ? po : (int)0x80000000u, q.q);
-      if (!inside) { q.q[0] = u32x4{0, 0, 0, 0}; q.q[1] = u32x4{0, 0, 0, 0}; }   // beyond the image: the zero padding
+      // beyond the image: the zero padding (only tiles that stick out of the image have such pixels: one scalar test)
+      if (ragged && !inside) { q.q[0] = u32x4{0, 0, 0, 0}; q.q[1] = u32x4{0, 0, 0, 0}; }
       if constexpr (LW & 1) lds_put_row(smem, slot0 + th, r, q.q, own_px, own_swz);
       if constexpr (LW & 2) keep->q[r] = q;
       if constexpr (MODE == 3) {
