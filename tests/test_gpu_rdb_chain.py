@@ -253,3 +253,22 @@ def test_fused_chain_is_deterministic_run_to_run(dev, shape, nb):
         assert _chain_plans(net)
         for _ in range(5):
             assert torch.equal(net(x), ref)
+
+
+def test_chain_image_straddling_the_first_round_of_workgroups(dev, monkeypatch):
+    """6 images of 55 tiles = 330 tiles on 256 CUs: image 4's tiles 220..274 start partly in the first round of
+    workgroups and partly after the first chains have finished; the early ones spin (bounded) on their
+    neighbours' flags until those tiles are claimed.  Result must equal the per-conv path."""
+    from esrganplus_amd import architecture as arch
+    sd = synth.rrdbnet_state_dict(nb=1, seed=19)
+    x = synth.image_batch(19, 6, 3, 176, 160, name='straddle.x').to(dev)
+    ys = {}
+    for fused in ('1', '0'):
+        monkeypatch.setenv('ESR_RDB_FUSED', fused)
+        net = arch.RRDBNet(3, 3, 64, 1).to(dev).eval().set_precision('fp16')
+        net.load_state_dict(sd)
+        with torch.no_grad():
+            ys[fused] = net(x).clone()
+        assert bool(_chain_plans(net)) == (fused == '1')
+    assert torch.isfinite(ys['1']).all()
+    assert (ys['1'] - ys['0']).abs().max().item() <= 2e-3
