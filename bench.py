@@ -390,7 +390,9 @@ def main():
             desc = describe_plan(net, plan)
             st = E.current_stream()
             agg = {}
-            reps = 3
+            reps = 8
+            for _ in range(2):                       # untimed: the clocks settle again after the host-side gap above
+                plan.ops.run_timed(st)
             for _ in range(reps):
                 ms = plan.ops.run_timed(st)
                 for (name, fl), t in zip(desc, ms):
