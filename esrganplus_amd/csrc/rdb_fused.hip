@@ -342,8 +342,8 @@ template <int K> __device__ __forceinline__ void halo_put(char* smem, int slot0,
 }
 template <int K> __device__ __forceinline__ void halo_fetch(const ImgView& v, int g0, char* smem, const Tile& t, int slot0 = 0) {
   HaloRegs<K> h;
-  int hsrc, hdst;
-  t.halo(hsrc, hdst);
+  // the thread's slot as the tile set-up cached it (LDS_HALO)
+  const int hsrc = *(volatile int*)(smem + LDS_HALO + t.tid() * 8), hdst = *(volatile int*)(smem + LDS_HALO + t.tid() * 8 + 4);
   halo_issue<K>(v, g0, hsrc, h);
   halo_put<K>(smem, slot0, hsrc, hdst, h);
 }
@@ -1066,6 +1066,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       int hsrc, hdst;
       t.halo(hsrc, hdst);
       *(volatile int*)(smem + LDS_HALO + t.tid() * 8) = hsrc;
+      *(volatile int*)(smem + LDS_HALO + t.tid() * 8 + 4) = hdst;
     }
     const ImgView dense = img_view(p.dense, t.b);
     const char* const dense_b = (const char*)p.dense.ptr + (int64_t)t.b * p.dense.batch_stride;
@@ -1150,8 +1151,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         };
         // after the bulk: the halo of stage g0 into slots slot0..
         auto finish_halo = [&](int g0, int slot0) __attribute__((always_inline)) -> bool {
-          int hsrc, hdst;
-          t.halo(hsrc, hdst);
+          const int hsrc = *(volatile int*)(smem + LDS_HALO + t.tid() * 8), hdst = *(volatile int*)(smem + LDS_HALO + t.tid() * 8 + 4);
           if (!early) {
             if (!wait_neighbours(ws, epoch, smem, t, &p, &ev, tile)) return false;
             halo_issue<CF::KD>(dense, g0, hsrc, hq);
