@@ -725,19 +725,25 @@ __device__ __forceinline__ void run_1x1_res(Acc24& acc, const WStream& s, char* 
   __builtin_amdgcn_s_barrier();
   { const Ahead ah = ahead_of<T, I>(s, t, smem, (uint32_t)lane * 16u);
     sfor<4>([&](auto X) __attribute__((always_inline)) { issue_one<decltype(X)::value>(ah); }); }
+  // two fragment sets: K step c+1 is requested before the MFMAs of step c (one exposed LDS round trip, not K)
+  u32x4 fa[2], fb[2][R];
+  auto rd = [&](auto CI, auto SET) __attribute__((always_inline)) {
+    constexpr int c = decltype(CI)::value, st = decltype(SET)::value;
+    lds_read16<c * 1024>(fa[st], lw);
+    sfor<R>([&](auto RR) __attribute__((always_inline)) { lds_read16<c * ASLOT + decltype(RR)::value * IW * 32>(fb[st][decltype(RR)::value], lb); });
+  };
+  rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
   sfor<K>([&](auto CI) __attribute__((always_inline)) {
-    constexpr int c = decltype(CI)::value;
-    u32x4 a, b0, b1, b2, b3;
-    lds_read16<c * 1024>(a, lw);
-    lds_read16<c * ASLOT>(b0, lb);
-    lds_read16<c * ASLOT + IW * 32>(b1, lb);
-    lds_read16<c * ASLOT + 2 * IW * 32>(b2, lb);
-    lds_read16<c * ASLOT + 3 * IW * 32>(b3, lb);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
-    mma_cls<T, acc_in_agpr(0), c == 0>(acc_br<0, 0>(acc), a, b0);
-    mma_cls<T, acc_in_agpr(0), c == 0>(acc_br<0, 1>(acc), a, b1);
-    mma_cls<T, acc_in_agpr(0), c == 0>(acc_br<0, 2>(acc), a, b2);
-    mma_cls<T, acc_in_agpr(0), c == 0>(acc_br<0, 3>(acc), a, b3);
+    constexpr int c = decltype(CI)::value, st = c & 1;
+    if constexpr (c + 1 < K) {
+      rd(std::integral_constant<int, c + 1>{}, std::integral_constant<int, st ^ 1>{});
+      asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fa[st]), "+v"(fb[st][0]), "+v"(fb[st][1]), "+v"(fb[st][2]), "+v"(fb[st][3]));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[st]), "+v"(fb[st][0]), "+v"(fb[st][1]), "+v"(fb[st][2]), "+v"(fb[st][3]));
+    }
+    sfor<R>([&](auto RR) __attribute__((always_inline)) {
+      mma_cls<T, acc_in_agpr(0), c == 0>(acc_br<0, decltype(RR)::value>(acc), fa[st], fb[st][decltype(RR)::value]);
+    });
   });
 }
 
