@@ -674,7 +674,10 @@ template <typename T, int I> constexpr int sure_ahead() {
 // units [I0, I1) of the schedule, back to back.  `hook(I)` runs inside unit I after the barrier that opens
 // unit I+1 (every wave has waited for everything older than unit I+2's requests by then).
 struct NoHook { template <typename X> __device__ __forceinline__ void operator()(X) const {} };
-template <typename T, int I0, int I1, bool STRICT0 = false, typename HOOK = NoHook>
+// TRAIL: barrier after the last unit.  The slot of a segment's last unit is next written by the request of a unit
+// that runs behind the NEXT segment's opening barrier, so the barrier is only needed where the code that follows
+// writes LDS the last unit reads (the block tail's own-pixel writes over x4's slots).
+template <typename T, int I0, int I1, bool STRICT0 = false, bool TRAIL = true, typename HOOK = NoHook>
 __device__ __forceinline__ void run_units(Acc24& acc, const WStream& s, char* smem, const Tile& t, HOOK&& hook = NoHook{}) {
   using S = Sched<T>;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -706,7 +709,7 @@ __device__ __forceinline__ void run_units(Acc24& acc, const WStream& s, char* sm
     unit_steps<T, S::blk0(d), S::nblk(d), NKW, (d.P == 1 && d.c == 0 && d.kw == 0), (I > I0), (I + 1 < I1), S::parity(I0, I)>(
         acc, f, lb, lw, lbn, lwn, issue, mid);
   });
-  __builtin_amdgcn_s_barrier();            // every wave done with the last unit's slots
+  if constexpr (TRAIL) __builtin_amdgcn_s_barrier();            // every wave done with the last unit's slots
 }
 
 // P = conv1x1(x) from the resident x stages (slots 0..KX-1); its fragments are one unit of the weight
@@ -1189,7 +1192,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         Bias16 bb;
         trace_ev(p, tile, ev);
         // ---------------- conv1
-        run_units<T, S::first(U_CRIT, 1), S::end(U_CRIT, 1)>(acc, ws_, smem, t);
+        run_units<T, S::first(U_CRIT, 1), S::end(U_CRIT, 1), false, false>(acc, ws_, smem, t);
         trace_ev(p, tile, ev);
         lds_bias(smem, 0, t, bb);
         mfma_drain();
@@ -1197,7 +1200,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         epilogue<T, 0, 0, 2>(acc, p, bs, bb, dense, 0, 0, nullptr, nullptr, false, t, smem, 0, &x1);     // x1 (kept: x still occupies its slots)
         ++epoch;
         trace_ev(p, tile, ev);
-        run_units<T, S::first(U_BULK, 1), S::end(U_BULK, 1), true>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 1)>{}, std::integral_constant<int, S::end(U_BULK, 1)>{}, 0); });
+        run_units<T, S::first(U_BULK, 1), S::end(U_BULK, 1), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 1)>{}, std::integral_constant<int, S::end(U_BULK, 1)>{}, 0); });
         trace_ev(p, tile, ev);
         // ---------------- P = conv1x1(x) from the resident x; then x1 may take x's slots
         run_1x1_res<T>(acc, ws_, smem, t);
@@ -1209,31 +1212,31 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         if (!finish_halo(0, 0)) return;
         trace_ev(p, tile, ev);
         // ---------------- conv2
-        run_units<T, S::first(U_CRIT, 2), S::end(U_CRIT, 2)>(acc, ws_, smem, t);
+        run_units<T, S::first(U_CRIT, 2), S::end(U_CRIT, 2), false, false>(acc, ws_, smem, t);
         trace_ev(p, tile, ev);
         lds_bias(smem, 32, t, bb);
         mfma_drain();
         epilogue<T, 1, 1, 1>(acc, p, bs, bb, dense, 1, 0, nullptr, nullptr, false, t, smem, 2);       // x2
         ++epoch;
         trace_ev(p, tile, ev);
-        run_units<T, S::first(U_BULK, 2), S::end(U_BULK, 2), true>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 2)>{}, std::integral_constant<int, S::end(U_BULK, 2)>{}, CF::KD); });
+        run_units<T, S::first(U_BULK, 2), S::end(U_BULK, 2), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 2)>{}, std::integral_constant<int, S::end(U_BULK, 2)>{}, CF::KD); });
         trace_ev(p, tile, ev);
         if (!finish_halo(CF::KD, 2)) return;
         trace_ev(p, tile, ev);
         // ---------------- conv3
-        run_units<T, S::first(U_CRIT, 3), S::end(U_CRIT, 3)>(acc, ws_, smem, t);
+        run_units<T, S::first(U_CRIT, 3), S::end(U_CRIT, 3), false, false>(acc, ws_, smem, t);
         trace_ev(p, tile, ev);
         lds_bias(smem, 64, t, bb);
         mfma_drain();
         epilogue<T, 2, 0, 1>(acc, p, bs, bb, dense, 2, 0, nullptr, nullptr, false, t, smem, 0);       // x3
         ++epoch;
         trace_ev(p, tile, ev);
-        run_units<T, S::first(U_BULK, 3), S::end(U_BULK, 3), true>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD); });
+        run_units<T, S::first(U_BULK, 3), S::end(U_BULK, 3), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD); });
         trace_ev(p, tile, ev);
         if (!finish_halo(2 * CF::KD, 0)) return;
         trace_ev(p, tile, ev);
         // ---------------- conv4
-        run_units<T, S::first(U_CRIT, 4), S::end(U_CRIT, 4)>(acc, ws_, smem, t);
+        run_units<T, S::first(U_CRIT, 4), S::end(U_CRIT, 4), false, false>(acc, ws_, smem, t);
         trace_ev(p, tile, ev);
         lds_bias(smem, 96, t, bb);
         lds_get_rows(smem, 2, x2.q, t);   // x2's own pixels still sit in the slots x4 is about to take
@@ -1242,7 +1245,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
         RowsRaw<T> tx0, tx1, tr0, tr1;
         ++epoch;
         trace_ev(p, tile, ev);
-        run_units<T, S::first(U_BULK, 4), S::end(U_BULK, 4), true>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD); });
+        run_units<T, S::first(U_BULK, 4), S::end(U_BULK, 4), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD); });
         trace_ev(p, tile, ev);
         if (!finish_halo(3 * CF::KD, 2)) return;
         // the block tail's residual (every third block): requested here, used after conv5
