@@ -40,9 +40,12 @@
 //
 // GEMM view per unit (K step c, column tap kw):  D[cout][pixel] += W[cout][(kh, cin16)] X[(kh, cin16)][pixel]
 //   A fragments: NB x 3 (kh) x 1 KB per unit, streamed (LDS-DMA, L2 resident) through a 4-slot ring;
-//   B fragments: one 18x34 halo tile of a 32-byte channel group per K step, 3-slot ring (2 steps ahead).
-// The accumulation order per output element (chunk, kw, kh) equals conv_mfma.hip's, so fp16 results are
-// bit-identical with the per-conv path.
+//   B fragments: one 18x34 halo tile of a 32-byte channel group per K step — fp32: 3-slot ring (2 steps ahead);
+//   fp16: resident in the LDS (the epilogues write the tile's own pixels, only the halo ring is fetched).
+// The fp16 path runs every phase as crit_p (conv_p alone) -> epilogue -> bulk_p (the remaining convs, with the
+// halo hand-off hidden under them): see `Sched` below.  The accumulation order per output element (chunk, kw, kh)
+// equals conv_mfma.hip's in both orders, so fp32 results are bit-identical with the per-conv path and fp16
+// results differ from it only through the folded block residual (conv5's accumulators start at 5 x).
 #include <cstdlib>
 #include <mutex>
 
