@@ -43,9 +43,10 @@
 //   B fragments: one 18x34 halo tile of a 32-byte channel group per K step — fp32: 3-slot ring (2 steps ahead);
 //   fp16: resident in the LDS (the epilogues write the tile's own pixels, only the halo ring is fetched).
 // The fp16 path runs every phase as crit_p (conv_p alone) -> epilogue -> bulk_p (the remaining convs, with the
-// halo hand-off hidden under them): see `Sched` below.  The accumulation order per output element (chunk, kw, kh)
-// equals conv_mfma.hip's in both orders, so fp32 results are bit-identical with the per-conv path and fp16
-// results differ from it only through the folded block residual (conv5's accumulators start at 5 x).
+// halo hand-off hidden under them): see `Sched` below.  The accumulation order per output element is (chunk, kw,
+// kh) as in conv_mfma.hip; the fp16 path folds the block residual (conv5's accumulators start at 5 x) and keeps
+// x1..x4 as fp16 in the LDS.  tests/test_gpu_rdb_chain.py holds it to 1e-5 (fp32) / 2e-3 (fp16) of the per-conv
+// launches and requires bit-equal results run to run.
 #include <cstdlib>
 #include <mutex>
 
