@@ -84,7 +84,8 @@ class esr_bn(C.Structure):
                 ('x', esr_g32), ('y', esr_g32), ('g', esr_g32), ('gx', esr_g32),
                 ('sums', C.c_void_p), ('mean', C.c_void_p), ('invstd', C.c_void_p),
                 ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p),
-                ('running_var', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p)]
+                ('running_var', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p),
+                ('groups', C.c_int32), ('_pad', C.c_int32), ('num_batches_tracked', C.c_void_p)]
 
 
 class esr_pool(C.Structure):

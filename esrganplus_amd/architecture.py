@@ -136,7 +136,7 @@ class _SeqNet(B._PlannedModule):
     def _dgrad_special(self):
         return {s['conv']: {'ts2': True} for s in self._spec() if 'conv' in s and s['stride'] == 2}
 
-    def _run_forward(self, x, need_bwd):
+    def _run_forward(self, x, need_bwd, groups=1, bwd_B=None):
         E.require_cuda(x, 'input')
         xin = x.detach().contiguous().float()
         Bn, C_, H, W = xin.shape
@@ -149,12 +149,14 @@ class _SeqNet(B._PlannedModule):
             dp = self._dgrad_weights(dev)
             dp.ensure(st)
         training = bool(self.training) and self._has_bn
-        key = ('seq', Bn, H, W, self.precision, training, need_bwd, want_w, wp.generation, str(dev))
+        groups = groups if training else 1
+        key = ('seq', Bn, H, W, self.precision, training, need_bwd, want_w, wp.generation, str(dev), groups, bwd_B)
         pool = self._plans.setdefault(key, [])
         plan = next((p for p in pool if not p.busy), None)
         if plan is None:
             plan = CN.build_seq_plan(self._spec(), wp, dp, self._pspec(), want_w, Bn, H, W, self.precision,
-                                     dev, training, need_bwd, self._input_affine(), self._head())
+                                     dev, training, need_bwd, self._input_affine(), self._head(),
+                                     groups=groups, bwd_B=bwd_B if need_bwd else None)
             if E.use_graphs():
                 # hipGraph replay: the input lands in a fixed staging tensor (everything else these
                 # plans touch — outputs, upstream gradients, BN sums — already lives in fixed buffers)
@@ -171,12 +173,7 @@ class _SeqNet(B._PlannedModule):
         else:
             plan.fwd.array()[plan.in_op].u.layout.nchw = xin.data_ptr()
             plan.fwd.run(st)
-        if training:
-            with torch.no_grad():
-                for m in self.modules():
-                    if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None:
-                        m.num_batches_tracked += 1
-        plan.keep_x = xin
+        plan.keep_x = xin       # (num_batches_tracked is advanced by the BN finalize launches)
         return plan.out_tensor.clone(), lease
 
     def forward(self, x):
@@ -184,6 +181,31 @@ class _SeqNet(B._PlannedModule):
         if not need:
             return self._run_forward(x, need_bwd=False)[0]
         return CN.SeqNetFn.apply(x, self, *[t for _, t in self._pspec()])
+
+    def forward_pair(self, a, b):
+        """``(self(a), self(b))`` as ONE pass over the concatenated batch — the two calls the train step makes on
+        every network (SRRaGAN_model.py:128-129 netF, 133-134 and 150-151 netD).  BatchNorm layers in train mode
+        keep the two calls' semantics: batch statistics per half, running statistics updated once per half in call
+        order (esr_bn.groups).  When no parameter requires a gradient and ``b`` does not either (the detached
+        ``real`` operand of the G step), the backward runs on ``a``'s half only and ``self(b)`` comes back
+        detached."""
+        if a.shape != b.shape:
+            raise ValueError('forward_pair: the two batches must have one shape')
+        n = a.shape[0]
+        x = torch.cat([a, b])
+        wantp = any(p.requires_grad for p in self.parameters())
+        need = torch.is_grad_enabled() and (x.requires_grad or wantp)
+        groups = 2 if self._has_bn else 1
+        if not need:
+            y = self._run_forward(x, need_bwd=False, groups=groups)[0]
+            return y[:n], y[n:]
+        half = not wantp and not b.requires_grad
+        self._pair_opts = dict(groups=groups, bwd_B=n if half else None)
+        try:
+            y = CN.SeqNetFn.apply(x, self, *[t for _, t in self._pspec()])
+        finally:
+            self._pair_opts = {}
+        return y[:n], (y[n:].detach() if half else y[n:])
 
 
 class _DiscriminatorVGG(_SeqNet):
@@ -234,7 +256,8 @@ class _DiscriminatorVGG(_SeqNet):
                  'ks': c.kernel_size[0], 'stride': c.stride[0], 'act': L.ACT_LRELU, 'bn': None}
             if bn is not None:
                 m = bn[1]
-                d['bn'] = dict(weight=m.weight, bias=m.bias, rm=m.running_mean, rv=m.running_var)
+                d['bn'] = dict(weight=m.weight, bias=m.bias, rm=m.running_mean, rv=m.running_var,
+                               nbt=m.num_batches_tracked)
             spec.append(d)
         return spec
 

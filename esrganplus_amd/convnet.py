@@ -75,8 +75,13 @@ def _layout(ops, dt_e, to_g32, B, C_, buf, nchw_ptr=None, affine=None):
 
 
 def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, training, need_bwd,
-                   input_affine=None, head=None):
-    """spec: list of dicts, in execution order:
+                   input_affine=None, head=None, groups=1, bwd_B=None):
+    """groups: BatchNorm statistics groups of the batch (``forward_pair``: two reference forward calls as one
+    pass; esr_bn.groups).  bwd_B: the backward covers only the first ``bwd_B`` images (the second half of a pair
+    that is detached: its saved activations are the batch suffix of every buffer, so the backward launches simply
+    run on the prefix) — with groups == 2 that prefix is statistics group 0.
+
+       spec: list of dicts, in execution order:
          {'conv': key, 'cin', 'cout', 'ks', 'stride', 'act': ACT_*, 'bn': None | dict(weight,bias,rm,rv)}
          {'pool': True}
        head: None | dict(w1,b1,w2,b2) — flatten + Linear(.,100) + LeakyReLU + Linear(100,1)
@@ -110,9 +115,12 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
     P.in_op = _layout(f, dt_e, 1, B, cin0, xin, affine=input_affine)
     nbn = sum(1 for s in spec if s.get('bn'))
     maxc = max([s['cout'] for s in spec if 'conv' in s] + [1])
-    P.sums_f = torch.zeros(max(nbn, 1) * 2 * maxc, dtype=torch.float64, device=dev)
-    P.sums_b = torch.zeros(max(nbn, 1) * 2 * maxc, dtype=torch.float64, device=dev)
-    stats = torch.zeros(max(nbn, 1) * 2 * maxc, dtype=torch.float32, device=dev)   # mean | invstd
+    Bb = B if bwd_B is None else bwd_B
+    gb = groups if Bb == B else 1           # statistics groups the backward sees
+    assert B % groups == 0 and (Bb == B or (groups > 1 and Bb == B // groups) or groups == 1)
+    P.sums_f = torch.zeros(max(nbn, 1) * 2 * maxc * groups, dtype=torch.float64, device=dev)
+    P.sums_b = torch.zeros(max(nbn, 1) * 2 * maxc * groups, dtype=torch.float64, device=dev)
+    stats = torch.zeros(max(nbn, 1) * 2 * maxc * groups, dtype=torch.float32, device=dev)   # mean | invstd, [groups][C] each
     P.keep += [stats]
     cur, ch, h, w = xin, cin0, H, W
     recs = []          # per layer record for the backward
@@ -141,14 +149,18 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
         else:
             cb = _g32(P, B, cpad, ho, wo, dtype, dev)
             f.add_conv(E._conv(dt_e, B, ho, wo, cur.view(0), ch, cb.view(0), e[key], L.ACT_NONE, stride=st))
-            base = ibn * 2 * maxc
+            base = ibn * 2 * maxc * groups
             mk = dict(sums_f=P.sums_f.data_ptr() + 8 * base, sums_b=P.sums_b.data_ptr() + 8 * base,
-                      mean=stats.data_ptr() + 4 * base, invstd=stats.data_ptr() + 4 * (base + maxc))
+                      mean=stats.data_ptr() + 4 * base, invstd=stats.data_ptr() + 4 * (base + maxc * groups))
 
             def bnop(mode, x=cb, y=yb, g=None, gx=None, sums=mk['sums_f'], act=s['act'], bn=bn, mk=mk,
                      cout=cout, ho=ho, wo=wo):
                 o = L.esr_bn()
-                o.dtype, o.mode, o.B, o.C, o.H, o.W = dt_e, mode, B, cout, ho, wo
+                fwd_op = mode in (L.BN_STATS, L.BN_FINALIZE, L.BN_APPLY)
+                o.dtype, o.mode, o.B, o.C, o.H, o.W = dt_e, mode, (B if fwd_op else Bb), cout, ho, wo
+                o.groups = groups if fwd_op else gb
+                if mode == L.BN_FINALIZE and training and bn.get('nbt') is not None:
+                    o.num_batches_tracked = bn['nbt'].data_ptr()
                 o.training, o.act, o.momentum, o.eps = int(training), act, BN_MOMENTUM, BN_EPS
                 o.x, o.y = x.view(0, cout), y.view(0, cout)
                 if g is not None:
@@ -190,38 +202,38 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
     de = dp.entries
     gcur = None      # G32 gradient w.r.t. the current layer's OUTPUT (post-activation)
     if head is None:
-        P.gy_tensor = torch.empty(B, ch, h, w, dtype=torch.float32, device=dev)
-        gcur = _g32(P, B, ch, h, w, dtype, dev)
-        _layout(bk, dt_e, 1, B, ch, gcur, nchw_ptr=P.gy_tensor.data_ptr())
+        P.gy_tensor = torch.empty(Bb, ch, h, w, dtype=torch.float32, device=dev)
+        gcur = _g32(P, Bb, ch, h, w, dtype, dev)
+        _layout(bk, dt_e, 1, Bb, ch, gcur, nchw_ptr=P.gy_tensor.data_ptr())
     else:
-        P.gy_tensor = torch.empty(B, O2, dtype=torch.float32, device=dev)
-        gH1 = torch.empty(B, O1, dtype=torch.float32, device=dev)
-        gF = torch.empty(B, I1, dtype=torch.float32, device=dev)
+        P.gy_tensor = torch.empty(Bb, O2, dtype=torch.float32, device=dev)
+        gH1 = torch.empty(Bb, O1, dtype=torch.float32, device=dev)
+        gF = torch.empty(Bb, I1, dtype=torch.float32, device=dev)
         P.keep += [gH1, gF]
         lin = _lin
         g2 = params_grad.get('head2')
         g1 = params_grad.get('head1')
         if g2 is not None:
-            bk.add(L.OP_LINEAR, 'linear', lin(2, B, O1, O2, L.ACT_NONE, x=H1.data_ptr(), g=P.gy_tensor.data_ptr(),
+            bk.add(L.OP_LINEAR, 'linear', lin(2, Bb, O1, O2, L.ACT_NONE, x=H1.data_ptr(), g=P.gy_tensor.data_ptr(),
                                               dw=g2[0], db=g2[1], w=head['w2'].data_ptr()))
-        bk.add(L.OP_LINEAR, 'linear', lin(1, B, O1, O2, L.ACT_NONE, g=P.gy_tensor.data_ptr(),
+        bk.add(L.OP_LINEAR, 'linear', lin(1, Bb, O1, O2, L.ACT_NONE, g=P.gy_tensor.data_ptr(),
                                           w=head['w2'].data_ptr(), gx=gH1.data_ptr()))
         if g1 is not None:
-            bk.add(L.OP_LINEAR, 'linear', lin(2, B, I1, O1, L.ACT_LRELU, x=F_.data_ptr(), g=gH1.data_ptr(),
+            bk.add(L.OP_LINEAR, 'linear', lin(2, Bb, I1, O1, L.ACT_LRELU, x=F_.data_ptr(), g=gH1.data_ptr(),
                                               ysaved=H1.data_ptr(), dw=g1[0], db=g1[1], w=head['w1'].data_ptr()))
-        bk.add(L.OP_LINEAR, 'linear', lin(1, B, I1, O1, L.ACT_LRELU, g=gH1.data_ptr(), ysaved=H1.data_ptr(),
+        bk.add(L.OP_LINEAR, 'linear', lin(1, Bb, I1, O1, L.ACT_LRELU, g=gH1.data_ptr(), ysaved=H1.data_ptr(),
                                           w=head['w1'].data_ptr(), gx=gF.data_ptr()))
-        gcur = _g32(P, B, ch, h, w, dtype, dev)
-        _layout(bk, dt_e, 1, B, ch, gcur, nchw_ptr=gF.data_ptr())
+        gcur = _g32(P, Bb, ch, h, w, dtype, dev)
+        _layout(bk, dt_e, 1, Bb, ch, gcur, nchw_ptr=gF.data_ptr())
 
     # gcur_masked: True when gcur already is the gradient w.r.t. the producing conv's pre-activation
     masked = False
     for li in range(len(recs) - 1, -1, -1):
         r = recs[li]
         if r['kind'] == 'pool':
-            gx = _g32(P, B, r['ch'], r['h'] * 2, r['w'] * 2, dtype, dev)
+            gx = _g32(P, Bb, r['ch'], r['h'] * 2, r['w'] * 2, dtype, dev)
             pl = L.esr_pool()
-            pl.dtype, pl.mode, pl.B, pl.C, pl.H, pl.W = dt_e, 1, B, r['ch'], r['h'], r['w']
+            pl.dtype, pl.mode, pl.B, pl.C, pl.H, pl.W = dt_e, 1, Bb, r['ch'], r['h'], r['w']
             pl.x, pl.y, pl.g, pl.gx = r['x'].view(0, r['ch']), r['y'].view(0, r['ch']), gcur.view(0, r['ch']), gx.view(0, r['ch'])
             prev = recs[li - 1] if li > 0 else None
             pl.relu_mask = 1 if (prev and prev['kind'] == 'conv' and prev['act'] == L.ACT_RELU and prev['bn'] is None) else 0
@@ -230,7 +242,7 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
             continue
         cout, cin_ = r['cout'], r['cin']
         if r['bn'] is not None:
-            gconv = _g32(P, B, ((cout + 31) // 32) * 32, r['h'], r['w'], dtype, dev)
+            gconv = _g32(P, Bb, ((cout + 31) // 32) * 32, r['h'], r['w'], dtype, dev)
             bnop = r['bnop']
             bk.add(L.OP_BN, 'bn', bnop(L.BN_BWD_REDUCE, g=gcur, sums=r['mk']['sums_b']))
             gbn = params_grad.get('bn%d' % r['ibn'])
@@ -249,7 +261,7 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
         if gw is not None:
             wg = L.esr_wgrad()
             wg.dtype, wg.ks, wg.stride, wg.upsample = dt_e, r['ks'], r['st'], 0
-            wg.B, wg.H, wg.W, wg.cout, wg.cin = B, r['h'], r['w'], cout, cin_
+            wg.B, wg.H, wg.W, wg.cout, wg.cin = Bb, r['h'], r['w'], cout, cin_
             wg.g, wg.in_ = gpre.view(0, cout), r['x'].view(0, cin_)
             wg.dw, wg.dbias, wg.scale = gw[0], gw[1], 1.0
             if P.tapmajor is not None and r['ks'] in (3, 4):
@@ -259,11 +271,11 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
             bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE)
         # input gradient
         prev = recs[li - 1] if li > 0 else None
-        gx = _g32(P, B, ((cin_ + cpg - 1) // cpg) * cpg, r['hin'], r['win'], dtype, dev)
+        gx = _g32(P, Bb, ((cin_ + cpg - 1) // cpg) * cpg, r['hin'], r['win'], dtype, dev)
         if r['st'] == 1:
-            c = E._conv(dt_e, B, r['hin'], r['win'], gpre.view(0), cout, None, de[r['key']], L.ACT_NONE)
+            c = E._conv(dt_e, Bb, r['hin'], r['win'], gpre.view(0), cout, None, de[r['key']], L.ACT_NONE)
         else:
-            c = E._conv(dt_e, B, r['hin'], r['win'], gpre.view(0), cout, None, de[r['key']], L.ACT_NONE,
+            c = E._conv(dt_e, Bb, r['hin'], r['win'], gpre.view(0), cout, None, de[r['key']], L.ACT_NONE,
                         ks=4, stride=1, upsample=2)
         c.bias = None
         need_mask = prev is not None and prev['kind'] == 'conv' and prev['bn'] is None and prev['act'] != L.ACT_NONE
@@ -278,11 +290,11 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
         up = P.tapmajor.op()
         if up is not None:
             bk.add(L.OP_UNPERMUTE, 'unpermute', up)
-    P.gx_tensor = torch.empty(B, cin0, H, W, dtype=torch.float32, device=dev)
+    P.gx_tensor = torch.empty(Bb, cin0, H, W, dtype=torch.float32, device=dev)
     aff = None
     if input_affine is not None:
         aff = (input_affine[0], input_affine[1])
-    _layout(bk, dt_e, 0, B, cin0, gcur, nchw_ptr=P.gx_tensor.data_ptr(), affine=aff)
+    _layout(bk, dt_e, 0, Bb, cin0, gcur, nchw_ptr=P.gx_tensor.data_ptr(), affine=aff)
     P.wgrad_arena = E.attach_wgrad_arena(bk, dev)
     return P
 
@@ -292,7 +304,7 @@ class SeqNetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, *params):
-        out, lease = mod._run_forward(x, need_bwd=True)
+        out, lease = mod._run_forward(x, need_bwd=True, **getattr(mod, '_pair_opts', {}))
         ctx.mod, ctx.lease, ctx.n = mod, lease, len(params)
         return out
 
@@ -303,7 +315,8 @@ class SeqNetFn(torch.autograd.Function):
             raise RuntimeError('backward called twice on the same forward (retain_graph unsupported)')
         mod = ctx.mod
         st = E.current_stream()
-        P.gy_tensor.copy_(gy.detach().reshape(P.gy_tensor.shape))
+        nb_ = P.gy_tensor.shape[0]              # images the backward covers (a pair's first half, or all)
+        P.gy_tensor.copy_(gy.detach()[:nb_].reshape(P.gy_tensor.shape))
         P.sums_b.zero_()
         if P.grad_flat is not None:
             P.grad_flat.zero_()
@@ -313,7 +326,11 @@ class SeqNetFn(torch.autograd.Function):
             P.bwd.graph_launch(st)
         else:
             P.bwd.run(st)
-        gx = P.gx_tensor.clone() if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = P.gx_tensor.clone()
+            if nb_ < gy.shape[0]:                # detached second half: zero gradient
+                gx = torch.cat([gx, gx.new_zeros((gy.shape[0] - nb_,) + tuple(gx.shape[1:]))])
         grads = [None] * ctx.n
         if P.grad_flat is not None:
             flat = P.grad_flat.clone()

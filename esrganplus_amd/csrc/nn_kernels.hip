@@ -59,7 +59,13 @@ __global__ __launch_bounds__(256) void bn_pass_kernel(const esr_bn p, const int 
   float s0[CPG], s1[CPG];
 #pragma unroll
   for (int e = 0; e < CPG; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
-  const double N = (double)p.B * p.H * p.W;
+  // statistics groups: images [grp*B/groups, (grp+1)*B/groups) are one BatchNorm batch (two forward calls of the
+  // reference run as one launch); every per-channel array carries one [C] row per group
+  const int ngrp = p.groups > 1 ? p.groups : 1, bpg = p.B / ngrp, grp = b / bpg;
+  const double N = (double)bpg * p.H * p.W;
+  const float* const mean = p.mean + grp * p.C;
+  const float* const invstd = p.invstd + grp * p.C;
+  double* const sums = p.sums + (int64_t)grp * 2 * p.C;
   for (int k = 0; k < ppt; ++k) {
   const int pix = (blockIdx.x * ppt + k) * 256 + threadIdx.x;
   const bool ok = pix < p.H * p.W;
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256) void bn_pass_kernel(const esr_bn p, const int 
       for (int e = 0; e < CPG; ++e) {
         const int c = g * CPG + e;
         float v = 0.f;
-        if (c < p.C) v = act_fwd((xv[e] - p.mean[c]) * p.invstd[c] * p.gamma[c] + p.beta[c], p.act);
+        if (c < p.C) v = act_fwd((xv[e] - mean[c]) * invstd[c] * p.gamma[c] + p.beta[c], p.act);
         yv[e] = v;
       }
       st16<T>((char*)p.y.ptr + pix_off(p.y, b, g, y, x), yv);
@@ -86,12 +92,12 @@ __global__ __launch_bounds__(256) void bn_pass_kernel(const esr_bn p, const int 
         const int c = g * CPG + e;
         if (c >= p.C) { gv[e] = 0.f; continue; }
         const float gp = gv[e] * act_bwd(yv[e], p.act);
-        const float xh = (xv[e] - p.mean[c]) * p.invstd[c];
+        const float xh = (xv[e] - mean[c]) * invstd[c];
         if (MODE == ESR_BN_BWD_REDUCE) { s0[e] += gp; s1[e] += gp * xh; }
         else {
           float r = gp;
-          if (p.training) r = gp - (float)(p.sums[c] / N) - xh * (float)(p.sums[p.C + c] / N);
-          gv[e] = r * p.gamma[c] * p.invstd[c];
+          if (p.training) r = gp - (float)(sums[c] / N) - xh * (float)(sums[p.C + c] / N);
+          gv[e] = r * p.gamma[c] * invstd[c];
         }
       }
       if (MODE == ESR_BN_BWD_APPLY) st16<T>((char*)p.gx.ptr + pix_off(p.gx, b, g, y, x), gv);
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(256) void bn_pass_kernel(const esr_bn p, const int 
       const int k = threadIdx.x / CPG, e = threadIdx.x % CPG, c = g * CPG + e;
       if (c < p.C) {
         const double v = (double)red[0][k][e] + red[1][k][e] + red[2][k][e] + red[3][k][e];
-        atomicAdd(p.sums + k * p.C + c, v);
+        atomicAdd(sums + k * p.C + c, v);
       }
     }
   }
@@ -124,25 +130,39 @@ __global__ __launch_bounds__(256) void bn_pass_kernel(const esr_bn p, const int 
 __global__ void bn_small_kernel(const esr_bn p) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= p.C) return;
-  const double N = (double)p.B * p.H * p.W;
+  const int ngrp = p.groups > 1 ? p.groups : 1;
+  const double N = (double)(p.B / ngrp) * p.H * p.W;
   if (p.mode == ESR_BN_FINALIZE) {
     if (p.training) {
-      const double m = p.sums[c] / N;
-      double var = p.sums[p.C + c] / N - m * m;
-      if (var < 0) var = 0;
-      p.mean[c] = (float)m;
-      p.invstd[c] = (float)(1.0 / sqrt(var + (double)p.eps));
-      if (p.running_mean) {
-        p.running_mean[c] = (float)((1.0 - p.momentum) * p.running_mean[c] + p.momentum * m);
-        p.running_var[c] = (float)((1.0 - p.momentum) * p.running_var[c] + p.momentum * var * (N / (N - 1.0)));
+      // groups in order: the running statistics see the same sequence of momentum updates as one forward call
+      // per group would give them
+      float rm = p.running_mean ? p.running_mean[c] : 0.f, rv = p.running_mean ? p.running_var[c] : 0.f;
+      for (int q = 0; q < ngrp; ++q) {
+        const double* s = p.sums + (int64_t)q * 2 * p.C;
+        const double m = s[c] / N;
+        double var = s[p.C + c] / N - m * m;
+        if (var < 0) var = 0;
+        p.mean[q * p.C + c] = (float)m;
+        p.invstd[q * p.C + c] = (float)(1.0 / sqrt(var + (double)p.eps));
+        rm = (float)((1.0 - p.momentum) * rm + p.momentum * m);
+        rv = (float)((1.0 - p.momentum) * rv + p.momentum * var * (N / (N - 1.0)));
       }
+      if (p.running_mean) { p.running_mean[c] = rm; p.running_var[c] = rv; }
+      if (p.num_batches_tracked && c == 0) *p.num_batches_tracked += ngrp;
     } else {
-      p.mean[c] = p.running_mean[c];
-      p.invstd[c] = 1.0f / sqrtf(p.running_var[c] + p.eps);
+      for (int q = 0; q < ngrp; ++q) {
+        p.mean[q * p.C + c] = p.running_mean[c];
+        p.invstd[q * p.C + c] = 1.0f / sqrtf(p.running_var[c] + p.eps);
+      }
     }
   } else {   // BWD_FINAL
-    if (p.dgamma) p.dgamma[c] += (float)p.sums[p.C + c];
-    if (p.dbeta) p.dbeta[c] += (float)p.sums[c];
+    double sg = 0, sb = 0;
+    for (int q = 0; q < ngrp; ++q) {
+      const double* s = p.sums + (int64_t)q * 2 * p.C;
+      sg += s[p.C + c]; sb += s[c];
+    }
+    if (p.dgamma) p.dgamma[c] += (float)sg;
+    if (p.dbeta) p.dbeta[c] += (float)sb;
   }
 }
 
@@ -245,6 +265,10 @@ int bn_dispatch(const esr_bn& p, hipStream_t st) {
 extern "C" int esr_batchnorm(const esr_bn* p, esr_stream_t stream) {
   if (!p || p->B <= 0 || p->C <= 0 || p->H <= 0 || p->W <= 0 || !p->mean || !p->invstd) {
     esr_set_error("esr_batchnorm: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  if (p->groups > 1 && p->B % p->groups) {
+    esr_set_error("esr_batchnorm: batch %d does not split into %d statistics groups", p->B, p->groups);
     return ESR_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;

@@ -55,13 +55,11 @@ class ESRGANPlusStep:
         fake_H = netG(var_L, z=z) if z is not None else netG(var_L)
         self.fake_H = fake_H
         l_g_pix = self.l_pix_w * F.l1_loss(fake_H, var_H)
-        with torch.no_grad():
-            real_fea = netF(var_H)
-        fake_fea = netF(fake_H)
+        # both operands of each network in ONE pass (forward_pair: per-half BatchNorm statistics, the detached
+        # ``real`` half costs no backward) — the reference's call order fake, real is the group order
+        fake_fea, real_fea = netF.forward_pair(fake_H, var_H)
         l_g_fea = self.l_fea_w * F.l1_loss(fake_fea, real_fea)
-        pred_g_fake = netD(fake_H)
-        with torch.no_grad():
-            pred_d_real = netD(var_ref)
+        pred_g_fake, pred_d_real = netD.forward_pair(fake_H, var_ref)
         l_g_gan = self.l_gan_w * (bce_logits(pred_d_real - mean(pred_g_fake), False) +
                                   bce_logits(pred_g_fake - mean(pred_d_real), True)) / 2
         l_g_total = l_g_pix + l_g_fea + l_g_gan
@@ -71,8 +69,7 @@ class ESRGANPlusStep:
         for p in netD.parameters():
             p.requires_grad = True
         self.optimizer_D.zero_grad(set_to_none=True)
-        pred_d_real = netD(var_ref)
-        pred_d_fake = netD(fake_H.detach())
+        pred_d_real, pred_d_fake = netD.forward_pair(var_ref, fake_H.detach())
         l_d_real = bce_logits(pred_d_real - mean(pred_d_fake), True)
         l_d_fake = bce_logits(pred_d_fake - mean(pred_d_real), False)
         l_d_total = (l_d_real + l_d_fake) / 2

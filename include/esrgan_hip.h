@@ -233,6 +233,12 @@ typedef struct esr_bn {
   const float* gamma; const float* beta;
   float* running_mean; float* running_var;
   float* dgamma; float* dbeta;
+  /* groups > 1: the batch is `groups` independent BatchNorm batches of B/groups images each (the reference's
+   * netD(real) and netD(fake) calls, SRRaGAN_model.py:133-134,150-151, as ONE launch per layer): sums is
+   * [groups][2*C], mean / invstd are [groups][C]; FINALIZE applies the running-statistics update once per group,
+   * in group order; BWD_FINAL adds the groups' sums into dgamma / dbeta.  0 or 1 = one batch. */
+  int32_t groups, _pad;
+  int64_t* num_batches_tracked; /* FINALIZE (training): += groups (NULL: caller counts) */
 } esr_bn;
 
 /* MaxPool2d(2,2) (torchvision VGG19 cfg 'E', architecture.py:287-298).  mode 0: y = pool(x);

@@ -199,3 +199,75 @@ def test_discriminator_fp16_grads_track_fp32(dev):
     assert not bad, bad
     a, b = gxs['fp32'].flatten(), gxs['fp16'].flatten()
     assert torch.nn.functional.cosine_similarity(a, b, dim=0).item() >= 0.97
+
+
+def _ragan(ya, yb):
+    f = torch.nn.functional.binary_cross_entropy_with_logits
+    return (f(ya - yb.mean(), torch.ones_like(ya)) + f(yb - ya.mean(), torch.zeros_like(yb))) / 2
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', 2e-4), ('fp16', 3e-2)])
+@pytest.mark.parametrize('mode', ['d_step', 'g_step'])
+def test_discriminator_forward_pair_matches_two_calls(dev, mode, prec, tol):
+    """``forward_pair(a, b)`` (one pass over the concatenated batch, BatchNorm statistics per half) against the
+    two calls of the reference's train step (SRRaGAN_model.py:133-134 G step: D frozen, ``real`` detached;
+    150-151 D step): logits, input / parameter gradients, running statistics and num_batches_tracked."""
+    from esrganplus_amd import architecture as arch
+    sd = synth.discriminator_state_dict(5)
+    a0 = synth.image_batch(61, 3, 3, 128, 128, name='pair.a').to(dev)
+    b0 = synth.image_batch(62, 3, 3, 128, 128, name='pair.b').to(dev)
+    res = {}
+    for how in ('two', 'pair'):
+        net = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision(prec)
+        net.load_state_dict(sd)
+        a, b = a0.clone(), b0.clone()
+        if mode == 'g_step':
+            for p in net.parameters():
+                p.requires_grad = False
+            a.requires_grad_(True)
+        if how == 'two':
+            ya = net(a)
+            yb = net(b).detach() if mode == 'g_step' else net(b)
+        else:
+            ya, yb = net.forward_pair(a, b)
+            assert yb.requires_grad == (mode == 'd_step')
+        _ragan(ya, yb).backward()
+        bn = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        res[how] = dict(ya=ya.detach(), yb=yb.detach(), ga=a.grad,
+                        gp=[p.grad for p in net.parameters()] if mode == 'd_step' else [],
+                        rm=[m.running_mean.clone() for m in bn], rv=[m.running_var.clone() for m in bn],
+                        nbt=[int(m.num_batches_tracked) for m in bn])
+    two, pair = res['two'], res['pair']
+    assert pair['nbt'] == two['nbt'] == [2] * len(two['nbt'])
+    rel = lambda x, y: ((x - y).abs().max() / y.abs().max().clamp_min(1e-12)).item()
+    assert rel(pair['ya'], two['ya']) <= tol and rel(pair['yb'], two['yb']) <= tol
+    for x, y in zip(pair['rm'] + pair['rv'], two['rm'] + two['rv']):
+        assert rel(x, y) <= max(tol * 0.1, 1e-5)
+    if mode == 'g_step':
+        assert rel(pair['ga'], two['ga']) <= tol
+    else:
+        assert pair['ga'] is None
+        gmax = max(y.abs().max().item() for y in two['gp'])
+        for x, y in zip(pair['gp'], two['gp']):       # (conv biases in front of a BatchNorm: exact gradient 0, noise)
+            assert (x - y).abs().max().item() <= tol * max(y.abs().max().item(), 1e-3 * gmax)
+
+
+def test_vgg_forward_pair_matches_two_calls(dev):
+    """netF(fake) / netF(real).detach() (SRRaGAN_model.py:128-129) as one batch: features and d/d fake."""
+    from esrganplus_amd import architecture as arch
+    net = arch.VGGFeatureExtractor(34, False, True, dev).to(dev).eval().set_precision('fp32')
+    net.load_state_dict(synth.vgg19_state_dict(3, 34), strict=False)
+    a0 = synth.image_batch(71, 2, 3, 64, 64, name='vpair.a').to(dev)
+    b0 = synth.image_batch(72, 2, 3, 64, 64, name='vpair.b').to(dev)
+    out = {}
+    for how in ('two', 'pair'):
+        a = a0.clone().requires_grad_(True)
+        if how == 'two':
+            fa, fb = net(a), net(b0).detach()
+        else:
+            fa, fb = net.forward_pair(a, b0)
+            assert not fb.requires_grad
+        torch.nn.functional.l1_loss(fa, fb).backward()
+        out[how] = (fa.detach(), fb, a.grad)
+    for x, y in zip(out['pair'], out['two']):
+        assert torch.equal(x, y)
