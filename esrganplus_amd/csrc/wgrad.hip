@@ -171,11 +171,17 @@ template <int S, bool UPS> struct Wg16Mode {
   static constexpr int NWV = 4;                        // waves per workgroup
 };
 
-template <int KS, int S, bool UPS, int NCO>
+// log2 of the column count one image gets in a packed tile (stride 2: at least 8, the 64 KB static LDS bound)
+template <int S> __host__ __device__ constexpr int pack_wl(int W) { return (W <= 4 && S == 1) ? 2 : (W <= 8 ? 3 : 4); }
+// PACK (feature maps at most 16 pixels wide — the discriminator's deep layers): the 32 tile columns are 2, 4 or 8
+// IMAGES of width Wt = 16, 8, 4 side by side, each with its own halo columns in the input tile, instead of one
+// image's mostly empty row; IW is then the widest such pitch (8 images of width 4; stride 2: 4 of width 8).
+template <int KS, int S, bool UPS, int NCO, bool PACK = false>
 struct Wg16Geo {
   static constexpr int TR = S == 2 ? 2 : 4, TC = 32;
   static constexpr int NCI = Wg16Mode<S, UPS>::NWV / NCO;
-  static constexpr int IH = UPS ? TR / 2 + 2 : (TR - 1) * S + KS, IW = UPS ? TC / 2 + 2 : (TC - 1) * S + KS;
+  static constexpr int IH = UPS ? TR / 2 + 2 : (TR - 1) * S + KS;
+  static constexpr int IW = PACK ? (S == 2 ? 4 * (7 * S + KS) : 8 * (3 * S + KS)) : UPS ? TC / 2 + 2 : (TC - 1) * S + KS;
   static constexpr int G_BYTES = NCO * 2 * TR * TC * 32;
   static constexpr int IN_GROUP = IH * IW * 32;
   static constexpr int LDS_BYTES = G_BYTES + NCI * 2 * IN_GROUP;
@@ -183,18 +189,24 @@ struct Wg16Geo {
 
 // (bx, by, bz) = the workgroup's coordinates in THIS conv's grid (the batched launch packs the grids
 // of several convs into one 1-D grid)
-template <int KS, int S, bool UPS, int NCO, int T0, int NT>
+template <int KS, int S, bool UPS, int NCO, int T0, int NT, bool PACK = false>
 __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_arg, char* const smem,
                                              const int bx, const int by, const int bz) {
+  static_assert(!PACK || !UPS, "packed tiles: plain and stride-2 convs");
   // taps [T0, T0+NT) of the KSxKS kernel are accumulated by this launch (4x4 kernels: two launches
   // of 8 taps, keeping the accumulators within the register file)
   constexpr int TR = S == 2 ? 2 : 4, TC = 32, NTAP = KS * KS, PAD = (KS - 1) / 2;
   constexpr int NWV = Wg16Mode<S, UPS>::NWV, NTH = NWV * 64;
   constexpr int NCI = NWV / NCO;                      // cin blocks (of 32 channels) per workgroup
-  constexpr int IH = UPS ? TR / 2 + 2 : (TR - 1) * S + KS, IW = UPS ? TC / 2 + 2 : (TC - 1) * S + KS;
+  constexpr int IH = UPS ? TR / 2 + 2 : (TR - 1) * S + KS, IWMAX = Wg16Geo<KS, S, UPS, NCO, PACK>::IW;
   static_assert(NT <= 9 && T0 + NT <= NTAP, "tap range");
   constexpr int G_BYTES = NCO * 2 * TR * TC * 32;     // [cout group][row][col][32 B]
-  constexpr int IN_GROUP = IH * IW * 32;
+  // packed tiles: wl = log2 of the per-image column count, ipt images per tile, iwimg input columns per image;
+  // the input tile's pitch IW is then a run-time (wave-uniform) number, at most IWMAX
+  const int wl = !PACK ? 5 : pack_wl<S>(p.W);
+  const int ipt = 32 >> wl, iwimg = ((1 << wl) - 1) * S + KS;
+  const int IW = PACK ? ipt * iwimg : IWMAX;
+  const int IN_GROUP = IH * IW * 32;
   char* const lg = smem;
   char* const li = smem + G_BYTES;
 
@@ -236,8 +248,46 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
   // LDS-DMA staging: slot s (16 bytes) of the linear [g tile | input tile] image comes straight from
   // global memory; no bounds tests — the G32 invariant (zero ring, nothing ever written outside the
   // image) supplies the padding, lanes past the last existing group are masked off.
-  constexpr int NP = (GS + NCI * 2 * IH * IW * 2 + NTH - 1) / NTH;
-  auto dma_tile = [&](int oy0) __attribute__((always_inline)) {
+  constexpr int NP = (GS + NCI * 2 * IH * IWMAX * 2 + NTH - 1) / NTH;
+  // packed tiles: the slot -> source map (image of the tile, row, column) costs integer divisions by run-time
+  // numbers, so it is built once: poff = byte offset from the first image of the tile at tile row 0 (-1: no
+  // slot), pzero = offset of a zero pixel of the same plane (for images past the batch) | image-in-tile
+  int poff[PACK ? NP : 1], pzero[PACK ? NP : 1];
+  if constexpr (PACK) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int s = tid + NTH * k;
+      poff[k] = -1; pzero[k] = 0;
+      if (s < GS) {
+        const int half = s & 1, px = (s >> 1) % (TR * TC), g = (s >> 1) / (TR * TC);
+        const int gg = (bz * NCO) * 2 + g, c = px % TC, bi = c >> wl, x = c & ((1 << wl) - 1);
+        if (gg < p.g.ngroups) {
+          pzero[k] = (int)(gg * p.g.group_stride) + half * 16 + bi;       // padded (0, 0): ring corner
+          poff[k] = (int)(bi * p.g.batch_stride + gg * p.g.group_stride) + ((px / TC + 1) * p.g.wp + x + 1) * 32 + half * 16;
+        }
+      } else if (s - GS < IS) {
+        const int t = s - GS;
+        const int half = t & 1, px = (t >> 1) % (IH * IW), g = (t >> 1) / (IH * IW);
+        const int gg = by * NCI * 2 + g, colp = px % IW, bi = colp / iwimg, xi = colp - bi * iwimg;
+        pzero[k] = (int)(gg * p.in.group_stride) + half * 16 + bi;
+        poff[k] = (int)(bi * p.in.batch_stride + gg * p.in.group_stride) + ((px / IW + 1 - PAD) * p.in.wp + 1 - PAD + xi) * 32 + half * 16;
+      }
+    }
+  }
+  auto dma_tile = [&](int oy0, int b) __attribute__((always_inline)) {
+    if constexpr (PACK) {
+      const int grow = oy0 * p.g.wp * 32, irow = oy0 * S * p.in.wp * 32;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        if (poff[k] < 0) continue;
+        char* const dst = smem + (wave * 64 + NTH * k) * 16;
+        const bool isg = tid + NTH * k < GS;
+        const bool inb = b + (pzero[k] & 15) < bend;
+        const char* src = (isg ? gbase : ibase) + (inb ? poff[k] + (isg ? grow : irow) : (pzero[k] & ~15));
+        dma16(src, dst);
+      }
+      return;
+    }
     const int iy0 = UPS ? oy0 / 2 : oy0 * S + 1 - PAD, ix0 = UPS ? ox0 / 2 : ox0 * S + 1 - PAD;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -256,10 +306,20 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
       }
     }
   };
-  for (int b = b0; b < bend; ++b, gbase += p.g.batch_stride, ibase += p.in.batch_stride)
+  // packed: per-lane column terms of the two transposed reads of each 16-pixel half run
+  int cm[PACK ? 4 : 1];
+  if constexpr (PACK) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = 16 * (u >> 1) + pk + 4 * (u & 1);
+      cm[u] = ((c >> wl) * iwimg + (c & ((1 << wl) - 1)) * S) * 32;
+    }
+  }
+  const int bstep = PACK ? ipt : 1;
+  for (int b = b0; b < bend; b += bstep, gbase += bstep * p.g.batch_stride, ibase += bstep * p.in.batch_stride)
   for (int oy0 = y_begin; oy0 < y_end; oy0 += TR) {
     __syncthreads();                 // every wave is done reading the previous tile
-    dma_tile(oy0);
+    dma_tile(oy0, b);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                 // (the CU's other workgroup computes meanwhile)
     if (!active) continue;
@@ -279,6 +339,9 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
             const int rr = ((r + kh - 1) >> 1) + 1;
             o0 = (rr * IW + ((c0 + kw - 1) >> 1) + 1) * 32;
             o1 = (rr * IW + ((c0 + 4 + kw - 1) >> 1) + 1) * 32;
+          } else if (PACK) {
+            o0 = ((r * S + kh) * IW + kw) * 32 + cm[2 * hf];
+            o1 = ((r * S + kh) * IW + kw) * 32 + cm[2 * hf + 1];
           } else {
             o0 = ((r * S + kh) * IW + c0 * S + kw) * 32;
             o1 = o0 + 4 * S * 32;
@@ -342,10 +405,10 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
 }
 
 
-template <int KS, int S, bool UPS, int NCO, int T0, int NT>
+template <int KS, int S, bool UPS, int NCO, int T0, int NT, bool PACK = false>
 __global__ __launch_bounds__((Wg16Mode<S, UPS>::NWV * 64), 2) void wgrad16_kernel(const esr_wgrad p, int rows_per_wg) {
-  __shared__ __attribute__((aligned(16))) char smem[Wg16Geo<KS, S, UPS, NCO>::LDS_BYTES];
-  wgrad16_body<KS, S, UPS, NCO, T0, NT>(p, rows_per_wg, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+  __shared__ __attribute__((aligned(16))) char smem[Wg16Geo<KS, S, UPS, NCO, PACK>::LDS_BYTES];
+  wgrad16_body<KS, S, UPS, NCO, T0, NT, PACK>(p, rows_per_wg, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 constexpr int WG_BATCH_MAX = 8;
@@ -434,7 +497,12 @@ static int max_rows() {
   static const int v = [] { const char* e = getenv("ESR_WGRAD_MAX_ROWS"); return e ? atoi(e) : 32; }();
   return v;
 }
-struct Wg16Grid { int nco, gx, gy, gz, rows; };   // rows = rows per workgroup | images per workgroup << 16
+struct Wg16Grid { int nco, gx, gy, gz, rows; };
+// packed tiles (Wg16Geo): maps of at most 16 columns, more than one image (ESR_WGRAD_PACK=0 switches it off)
+template <int S, bool UPS> static bool wgrad16_packed(const esr_wgrad& p) {
+  static const bool on = [] { const char* e = getenv("ESR_WGRAD_PACK"); return !e || atoi(e) != 0; }();
+  return on && !UPS && p.W <= 16 && p.B > 1 && (S == 2 || (p.ks == 3 && p.cout > 32));   // (two cout blocks per workgroup: LDS)
+}   // rows = rows per workgroup | images per workgroup << 16
 template <int S, bool UPS>
 Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs, int min_rows, int cap_rows) {
   const int strips = (p.W + 31) / 32;
@@ -451,7 +519,8 @@ Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs, int min_rows, int cap
   if (rows > cap_rows) rows = cap_rows;       // bound the serial load->LDS->MFMA iterations of one workgroup
   while (rows > min_rows && (int64_t)p.B * strips * ((p.H + rows - 1) / rows) * g.gy * g.gz < min_wgs) rows = ((rows / 2 + 3) / 4) * 4;
   const int rchunks = (p.H + rows - 1) / rows;
-  int ipw = 1;                                            // images per workgroup
+  int ipw = wgrad16_packed<S, UPS>(p) ? 32 >> pack_wl<S>(p.W) : 1;   // images per workgroup (packed: >= one tile of them)
+  if (ipw > p.B) ipw = p.B;
   while (ipw < p.B && ipw < 0x7FFF &&
          (int64_t)((p.B + 2 * ipw - 1) / (2 * ipw)) * strips * rchunks * g.gy * g.gz >= min_wgs) ipw *= 2;
   g.rows = rows | (ipw << 16);
@@ -471,6 +540,17 @@ int launch_wgrad16(const esr_wgrad& p_in, hipStream_t st, bool reduce = true) {
       return ESR_ERR_INVALID;
     }
     p.partial_elems = slot_elems(p);              // the kernel reads the slot stride here
+  }
+  if constexpr (!UPS && (S == 2 || KS == 3)) {
+    if (wgrad16_packed<S, UPS>(p_in)) {
+      hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT, true>), grid, dim3(Wg16Mode<S, UPS>::NWV * 64), 0, st, p, g.rows);
+      const int rc = esr_check_launch("wgrad16_kernel");
+      if (rc || !p.partial || !reduce) return rc;
+      WgradReduce r;
+      r.begin[0] = 0;
+      reduce_entry(r, 0, p_in, p.partial, g.gx);
+      return launch_reduce(r, 1, st);
+    }
   }
   if constexpr (S == 2) {
     hipLaunchKernelGGL((wgrad16_kernel<KS, S, UPS, 2, T0, NT>), grid, dim3(Wg16Mode<S, UPS>::NWV * 64), 0, st, p, g.rows);
