@@ -153,9 +153,10 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
 // rounds re-copy an earlier window), weights before activations, so a counted
 // `s_waitcnt vmcnt(NLD)` leaves exactly the newest activation stage in flight.
 // ------------------------------------------------------------------------------------------------
-template <int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool PIPE_ = false>
+template <int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool PIPE_ = false, int RW = 4>
 struct Geo {
-  static constexpr int R = 4;
+  static constexpr int R = RW;      // output rows per wave (2: half-height tiles, twice the workgroups, for grids
+                                    // far below one workgroup per CU — the LR-size training launches)
   static constexpr int NW = WR * WC * NCG;                               // waves per workgroup
   static constexpr int NT = NW * 64;
   static constexpr int TH = R * WR, TW = 32 * WC;                        // output tile
@@ -205,10 +206,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD, bool PIPE = false>
+template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD, bool PIPE = false, int RW = 4>
 __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, const int block_x, const int grid_x,
                                           const int block_y) {
-  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, PIPE>;
+  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, PIPE, RW>;
+  static_assert(RW == 4 || (KS == 3 && S == 1 && UPS == 0), "half-height tiles: plain 3x3");
   static_assert(!PIPE || (KS == 3 && S == 1 && UPS == 0 && WLDS && NCG == 1), "pipelined K loop: 3x3/s1, LDS weights");
   constexpr int R = G::R;
   constexpr int NSA = G::NSA;
@@ -611,16 +613,16 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
   });
 }
 
-template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD, bool PIPE = false>
+template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD, bool PIPE = false, int RW = 4>
 __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_conv p) {
-  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, PIPE>;
+  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, PIPE, RW>;
   __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
-  conv_body<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, BWD, PIPE>(p, smem, blockIdx.x, gridDim.x, blockIdx.y);
+  conv_body<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, BWD, PIPE, RW>(p, smem, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
-template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool PIPE = false>
+template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool PIPE = false, int RW = 4>
 int launch(const esr_conv& p, hipStream_t st) {
-  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1>;
+  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, PIPE, RW>;
   const int tw_ = UPS == 3 ? p.W / 2 : p.W, th_ = UPS == 3 ? p.H / 2 : p.H;
   const int tiles = ((tw_ + G::TW - 1) / G::TW) * ((th_ + G::TH - 1) / G::TH) * p.B;
   dim3 grid(tiles, UPS == 3 ? (p.cout_blocks + NCW - 1) / NCW : (p.cout_blocks + NCG * NCW - 1) / (NCG * NCW));
@@ -630,8 +632,8 @@ int launch(const esr_conv& p, hipStream_t st) {
   const bool bwd = p.mask.ptr || p.out3.ptr || (!p.res1.ptr && p.alpha != 1.0f) ||
                    (p.res1.ptr && p.res1.ngroups < p.cout_blocks * GPB && p.res1.ngroups < p.out.ngroups) ||
                    (p.res2.ptr && p.res2.ngroups < p.cout_blocks * GPB && p.res2.ngroups < p.out.ngroups);
-  if (bwd) hipLaunchKernelGGL((conv_kernel<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, true, PIPE>), grid, dim3(G::NT), 0, st, p);
-  else hipLaunchKernelGGL((conv_kernel<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, false, PIPE>), grid, dim3(G::NT), 0, st, p);
+  if (bwd) hipLaunchKernelGGL((conv_kernel<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, true, PIPE, RW>), grid, dim3(G::NT), 0, st, p);
+  else hipLaunchKernelGGL((conv_kernel<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, false, PIPE, RW>), grid, dim3(G::NT), 0, st, p);
   return esr_check_launch("conv_kernel");
 }
 
@@ -644,11 +646,20 @@ int dispatch(const esr_conv& p, hipStream_t st) {
   // the workgroup count on small images).  Wider convs (discriminator, VGG): 8 waves = 2 spatial x 4
   // cout groups with register-resident weights.
   if (p.ks == 3 && p.stride == 1 && !p.upsample) {
-    if (has1) {
-      if (cbk != 1) { esr_set_error("conv: fused 1x1 needs cout_blocks==1"); return ESR_ERR_UNSUPPORTED; }
-      return launch<T, 3, 1, 0, 4, 1, 1, 1, true, true>(p, st);
-    }
     const int64_t tiles = (int64_t)((p.W + 31) / 32) * ((p.H + 15) / 16) * p.B;
+    // Grids of at most 64 workgroups (16 LR crops of 32x32: 32 tiles): half-height tiles — twice the workgroups,
+    // half the MFMA chain per wave and K step (ESR_HALF_TILES=0 / debug_flags bit 8 switch it off)
+    static const bool half_on = [] { const char* e = getenv("ESR_HALF_TILES"); return !e || atoi(e) != 0; }();
+    const bool half = half_on && !(p.debug_flags & 256) && tiles * cbk <= 64 && sizeof(T) == 2;
+    if (has1 && cbk != 1) { esr_set_error("conv: fused 1x1 needs cout_blocks==1"); return ESR_ERR_UNSUPPORTED; }
+    if constexpr (sizeof(T) == 2) {
+      if (half) {
+        if (has1) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, true, false, 2>(p, st);
+        if (cbk == 1) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false, true, 2>(p, st);
+        return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false, false, 2>(p, st);
+      }
+    }
+    if (has1) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, true>(p, st);
     if (cbk == 1) {
       // Few workgroups (training tiles: at most one per CU): nothing else hides a wave's barrier / LDS
       // round trip / DMA issue, so the hand-pipelined K loop pays (0.87 -> ~0.55 us per K step);
