@@ -647,13 +647,23 @@ int dispatch(const esr_conv& p, hipStream_t st) {
   // cout groups with register-resident weights.
   if (p.ks == 3 && p.stride == 1 && !p.upsample) {
     const int64_t tiles = (int64_t)((p.W + 31) / 32) * ((p.H + 15) / 16) * p.B;
-    // Grids of at most 64 workgroups (16 LR crops of 32x32: 32 tiles): half-height tiles — twice the workgroups,
-    // half the MFMA chain per wave and K step (ESR_HALF_TILES=0 / debug_flags bit 8 switch it off)
-    static const bool half_on = [] { const char* e = getenv("ESR_HALF_TILES"); return !e || atoi(e) != 0; }();
-    const bool half = half_on && !(p.debug_flags & 256) && tiles * cbk <= 64 && sizeof(T) == 2;
+    // Grids far below one workgroup per CU (16 LR crops of 32x32 = 32 tiles of 16x32: the training launches):
+    // tiles of 4 or 8 rows instead of 16 — 4x / 2x the workgroups, a quarter / half of the MFMA chain per wave and
+    // K step.  Thresholds on the 16-row grid size; ESR_TILE_ROWS=4 (or debug_flags bit 8) keeps 16-row tiles.
+    static const int q1 = [] { const char* e = getenv("ESR_TILE_Q1"); return e ? atoi(e) : 128; }();
+    static const int q2 = [] { const char* e = getenv("ESR_TILE_Q2"); return e ? atoi(e) : 384; }();
+    static const int rows_forced = [] { const char* e = getenv("ESR_TILE_ROWS"); return e ? atoi(e) : 0; }();
+    int rw = tiles * cbk <= q1 ? 1 : (tiles * cbk <= q2 ? 2 : 4);
+    if (rows_forced) rw = rows_forced;
+    if ((p.debug_flags & 256) || sizeof(T) != 2) rw = 4;
     if (has1 && cbk != 1) { esr_set_error("conv: fused 1x1 needs cout_blocks==1"); return ESR_ERR_UNSUPPORTED; }
     if constexpr (sizeof(T) == 2) {
-      if (half) {
+      if (rw == 1) {
+        if (has1) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, true, false, 1>(p, st);
+        if (cbk == 1) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false, true, 1>(p, st);
+        return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false, false, 1>(p, st);
+      }
+      if (rw == 2) {
         if (has1) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, true, false, 2>(p, st);
         if (cbk == 1) return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false, true, 2>(p, st);
         return launch<T, 3, 1, 0, 4, 1, 1, 1, true, false, false, 2>(p, st);

@@ -17,8 +17,9 @@ netG.load_state_dict(synth.rrdbnet_state_dict(NB, 0, gain=0.5))
 netD.load_state_dict(synth.discriminator_state_dict(0))
 netF.load_state_dict(synth.vgg19_state_dict(0, 34), strict=False)
 st = train.ESRGANPlusStep(netG, netD, netF, loss_scale=1024.0)
-lr = synth.image_batch(200, 16, 3, 32, 32, name='bench.lr').to(dev)
-hr = synth.image_batch(300, 16, 3, 128, 128, name='bench.hr').to(dev)
+NBATCH = int(os.environ.get('TP_BATCH', '16'))
+lr = synth.image_batch(200, NBATCH, 3, 32, 32, name='bench.lr').to(dev)
+hr = synth.image_batch(300, NBATCH, 3, 128, 128, name='bench.hr').to(dev)
 bce = train.bce_logits
 mean = DP.global_mean
 
