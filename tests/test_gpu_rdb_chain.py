@@ -272,3 +272,27 @@ def test_chain_image_straddling_the_first_round_of_workgroups(dev, monkeypatch):
         assert bool(_chain_plans(net)) == (fused == '1')
     assert torch.isfinite(ys['1']).all()
     assert (ys['1'] - ys['0']).abs().max().item() <= 2e-3
+
+
+@pytest.mark.parametrize('shape,rows', [((2, 3, 32, 32), 4), ((3, 3, 57, 86), 4), ((9, 3, 64, 128), 8)])
+def test_short_tiles_equal_sixteen_row_tiles(dev, monkeypatch, shape, rows):
+    """Small grids run the 3x3 convs on tiles of 4 or 8 rows (conv_mfma.hip dispatch); esr_conv.debug_flags bit 8
+    keeps the 16-row tiles.  Same K order per output element -> forward, input-side and parameter gradients of a
+    train-mode fp16 RRDBNet (per-conv launches, Philox noise) must be bit-identical, ragged bottom rows included."""
+    from esrganplus_amd import architecture as arch
+    monkeypatch.setenv('ESR_RDB_FUSED', '0')
+    sd = synth.rrdbnet_state_dict(nb=2, seed=41)
+    x = synth.image_batch(41, *shape, name='short.x').to(dev)
+    res = {}
+    for flag in ('0', '256'):
+        monkeypatch.setenv('ESR_DBG', flag)
+        net = arch.RRDBNet(3, 3, 64, 2).to(dev).train().set_precision('fp16')
+        net.load_state_dict(sd)
+        torch.manual_seed(7)
+        y = net(x)
+        y.square().mean().backward()
+        res[flag] = [y.detach()] + [p.grad for p in net.parameters()]
+    tiles = ((shape[3] + 31) // 32) * ((shape[2] + 15) // 16) * shape[0]
+    assert (tiles <= 128) == (rows == 4) and tiles <= 384
+    for a, b in zip(res['0'], res['256']):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
