@@ -68,6 +68,9 @@ SideState* side_state() {
 }
 }  // namespace
 
+// consecutive weight-gradient ops handed to one esr_conv_wgrad_multi call (an RRDB: 3 x 6)
+constexpr int ESR_WGRAD_RUN_MAX = 24;
+
 extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
   if (!ops || n < 0) { esr_set_error("esr_run_ops: invalid arguments"); return ESR_ERR_INVALID; }
   int nside = 0;        // side runs launched by this call
@@ -84,8 +87,8 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
         // only g / saved inputs): hand the run to the batched launcher
         const int side = ops[i].flags & ESR_OPF_SIDE;
         int m = 1;
-        while (i + m < n && m < 16 && ops[i + m].kind == ESR_OP_WGRAD && (ops[i + m].flags & ESR_OPF_SIDE) == side) ++m;
-        esr_wgrad run[16];
+        while (i + m < n && m < ESR_WGRAD_RUN_MAX && ops[i + m].kind == ESR_OP_WGRAD && (ops[i + m].flags & ESR_OPF_SIDE) == side) ++m;
+        esr_wgrad run[ESR_WGRAD_RUN_MAX];
         for (int k = 0; k < m; ++k) run[k] = ops[i + k].u.wgrad;
         if (!side) {
           rc = m == 1 ? esr_conv_wgrad(&run[0], stream) : esr_conv_wgrad_multi(run, m, stream);
@@ -138,8 +141,8 @@ extern "C" int64_t esr_wgrad_workspace_elems(const esr_op* ops, int32_t n) {
     if (ops[i].kind != ESR_OP_WGRAD) continue;
     const int side = ops[i].flags & ESR_OPF_SIDE;
     int m = 1;
-    while (i + m < n && m < 16 && ops[i + m].kind == ESR_OP_WGRAD && (ops[i + m].flags & ESR_OPF_SIDE) == side) ++m;
-    esr_wgrad run[16];
+    while (i + m < n && m < ESR_WGRAD_RUN_MAX && ops[i + m].kind == ESR_OP_WGRAD && (ops[i + m].flags & ESR_OPF_SIDE) == side) ++m;
+    esr_wgrad run[ESR_WGRAD_RUN_MAX];
     for (int k = 0; k < m; ++k) run[k] = ops[i + k].u.wgrad;
     const int64_t e = esr_wgrad_run_partial_elems(run, m);
     if (e > need) need = e;

@@ -993,7 +993,11 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
     # connectivity mirrored, no read-modify-write of an accumulator.  Q rotates through 3 buffers: the
     # block's weight gradients read it on the side stream while the next block runs, and the block
     # after that is the first to overwrite it (its predecessor already writes ITS g_t into slot 0).
-    Qs = [buf(224), buf(224), buf(224)]
+    # The side runs are forked once per RRDB (its three blocks' 18 weight gradients in one run: every fork costs the
+    # main stream an event record + wait, ~11 us of idle chip at LR sizes) and joined at the next fork, so a block's
+    # Q has to survive two groups: 2 * nj + 1 buffers.
+    NQ = 2 * nj + 1
+    Qs = [buf(224) for _ in range(NQ)]
     gT = [q for q in Qs]                            # g_t of a block = channels [0,64) of its Q
     X4 = buf(32)                                    # raw g_x4 (identity path x4 = lrelu(a4) + x2)
     GF = buf(64)                                    # dL/dfea
@@ -1053,9 +1057,10 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             bf, ax = S[i][j], AUX[i][j]
             p = pkey(i, j)
             Q = Qs[ct]                              # Q[0:64] already holds this block's g_t
-            # the block's six weight gradients read Q and the saved input, intact until the block after
-            # next starts -> emit them together after the dgrad chain (one batched side-stream launch)
-            deferred = []
+            # the block's six weight gradients read Q and the saved input, intact until the group after next
+            # starts -> emitted together with the rest of the RRDB's after its last dgrad chain (one side run)
+            if deferred is None:
+                deferred = []
             wgrad(p + '.conv5.0', Q.view(0, 64), bf.view(0, 192), H, W, 64, 192, scale=0.2)
             wgrad(p + '.conv4.0', Q.view(64, 32), bf.view(0, 160), H, W, 32, 160)
             wgrad(p + '.conv3.0', Q.view(96, 32), bf.view(0, 128), H, W, 32, 128)
@@ -1085,9 +1090,9 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             c.res1 = Q.view(0, 64)
             if j > 0:
                 # g_x = g_y of RDB j (previous in forward order) -> its g_t = g_y * n
-                c.out = gT[(ct + 1) % 3].view(0, 64)
+                c.out = gT[(ct + 1) % NQ].view(0, 64)
                 set_noise(c, 2, per * i + j - 1)
-                ct = (ct + 1) % 3
+                ct = (ct + 1) % NQ
             elif kind == 'rdb':
                 c.out = GX.view(0, 64)
             else:
@@ -1098,16 +1103,16 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
                     c.out = gA[ca ^ 1].view(0, 64)
                     if variant == 'test_image':
                         set_noise(c, 2, per * (i - 1) + 3)
-                    c.out3, c.gamma = gT[(ct + 1) % 3].view(0, 64), 0.2
+                    c.out3, c.gamma = gT[(ct + 1) % NQ].view(0, 64), 0.2
                     set_noise(c, 3, per * (i - 1) + 2)
                     ca ^= 1
-                    ct = (ct + 1) % 3
+                    ct = (ct + 1) % NQ
                 else:
                     c.out = GF.view(0, 64)
             add_b(c, noisy=True)
-            for wg in deferred:
-                Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE)
-            deferred = None
+        for wg in deferred:
+            Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE)
+        deferred = None
         if not block:
             close_segment(['model.1.sub.%d' % i])
     if block:
