@@ -657,7 +657,9 @@ class DgradPack:
         self._ptrs = None
         self.ops = None
 
-    def ensure(self, stream):
+    def ensure(self, stream, force=True):
+        """force=False (a frozen eval-mode net, the VGG feature extractor): re-pack only when a parameter's
+        storage or version changed, like WeightPack.ensure."""
         ptrs = tuple(w.data_ptr() for _, w in self.convs) + tuple(
             w.data_ptr() for _, _, pieces in self.gathers for w, _, _ in pieces)
         if ptrs != self._ptrs:
@@ -692,7 +694,11 @@ class DgradPack:
             bp, self._pack_keep = L.batch_pack_op(packs, self.arena.device)
             ops.add(L.OP_PACK_BATCH, 'pack_batch', bp)
             self.ops, self._ptrs = ops, ptrs
-        self.ops.run(stream)      # weights change every optimizer step: always re-pack
+            self._sig = None
+        sig = tuple(w._version for _, w in self.convs) + tuple(w._version for _, _, pieces in self.gathers for w, _, _ in pieces)
+        if force or sig != getattr(self, '_sig', None):
+            self.ops.run(stream)  # (training nets: weights change every optimizer step, always re-pack)
+            self._sig = sig
 
 
 class TapMajorGrads:
