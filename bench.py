@@ -294,8 +294,8 @@ def fwd_bwd_probe(args, dev, steps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--lr', type=int, default=LR)
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -158,6 +158,18 @@ class esr_rdb_chain(C.Structure):
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('trace', C.c_void_p)]
 
 
+class esr_l1_loss(C.Structure):
+    _fields_ = [('a', C.c_void_p), ('b', C.c_void_p), ('grad_a', C.c_void_p), ('loss', C.c_void_p),
+                ('scratch', C.c_void_p), ('n', C.c_int64), ('weight', C.c_float), ('_pad', C.c_int32)]
+
+
+class esr_ragan_loss(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('grad_x', C.c_void_p), ('grad_y', C.c_void_p),
+                ('loss', C.c_void_p), ('mean_x', C.c_void_p), ('mean_y', C.c_void_p),
+                ('bce_x', C.c_void_p), ('bce_y', C.c_void_p), ('n', C.c_int32),
+                ('tx', C.c_float), ('ty', C.c_float), ('weight', C.c_float)]
+
+
 class esr_img_metrics(C.Structure):
     _fields_ = [('sr', C.c_void_p), ('hr', C.c_void_p), ('C', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
                 ('crop', C.c_int32), ('y_only', C.c_int32), ('_pad', C.c_int32), ('lo', C.c_float), ('hi', C.c_float),
@@ -187,7 +199,8 @@ EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_p
            'esr_linear_op', 'esr_grad_unpermute', 'esr_adam_step', 'esr_amp_step', 'esr_resample_axis', 'esr_pack_conv_weights_batch', 'esr_pack_pieces',
            'esr_run_ops', 'esr_run_ops_timed', 'esr_graph_create', 'esr_graph_launch', 'esr_graph_destroy', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op', 'esr_rdb_forward', 'esr_rdb_workspace_bytes', 'esr_rdb_weight_stream_bytes',
-           'esr_rdb_max_tiles_per_image', 'esr_gather_fragments', 'esr_image_metrics', 'esr_wgrad_workspace_elems']
+           'esr_rdb_max_tiles_per_image', 'esr_gather_fragments', 'esr_image_metrics', 'esr_wgrad_workspace_elems',
+           'esr_l1_loss_forward', 'esr_ragan_loss_forward']
 
 _lib = None
 _lock = threading.Lock()
@@ -239,7 +252,8 @@ def lib():
                          ('esr_maxpool2', esr_pool), ('esr_linear_op', esr_linear),
                          ('esr_grad_unpermute', esr_unpermute), ('esr_adam_step', esr_adam), ('esr_amp_step', esr_amp), ('esr_resample_axis', esr_resample),
                          ('esr_pack_conv_weights_batch', esr_pack_batch), ('esr_rdb_forward', esr_rdb_chain),
-                         ('esr_gather_fragments', esr_frag_gather), ('esr_image_metrics', esr_img_metrics)):
+                         ('esr_gather_fragments', esr_frag_gather), ('esr_image_metrics', esr_img_metrics),
+                         ('esr_l1_loss_forward', esr_l1_loss), ('esr_ragan_loss_forward', esr_ragan_loss)):
             getattr(L, name).argtypes = [C.POINTER(st), C.c_void_p]
         if L.esr_sizeof_op() != C.sizeof(esr_op):
             raise HipExtensionError('ABI mismatch: sizeof(esr_op) C=%d ctypes=%d'

@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from . import dp as DP
+from . import losses as LS
 from .optim import FusedAdam, DynamicLossScaler
 
 
@@ -43,37 +44,44 @@ class ESRGANPlusStep:
         self.log = {}
         self.fake_H = None
 
+    def _scale_t(self, dev):
+        t = self.__dict__.get('_scale_tensor')
+        if t is None or t.device != dev or float(self._scale_value) != float(self.loss_scale):
+            t = self._scale_tensor = torch.full((), float(self.loss_scale), dtype=torch.float32, device=dev)
+            self._scale_value = float(self.loss_scale)
+        return t
+
     def step(self, var_L, var_H, var_ref=None, z=None, sync_log=True):
         """One optimisation step (SRRaGAN_model.py:113-168)."""
         netG, netD, netF = self.netG, self.netD, self.netF
         var_ref = var_H if var_ref is None else var_ref
-        mean = DP.global_mean
+        # batch means of the relativistic terms: over ALL ranks when data-parallel (torch formulas), else inside the
+        # fused loss launch
+        mean = DP.global_mean if DP.world_size() > 1 else None
         # ---------------- G ----------------
         for p in netD.parameters():
             p.requires_grad = False
         self.optimizer_G.zero_grad(set_to_none=True)
         fake_H = netG(var_L, z=z) if z is not None else netG(var_L)
         self.fake_H = fake_H
-        l_g_pix = self.l_pix_w * F.l1_loss(fake_H, var_H)
+        l_g_pix = LS.l1_loss(fake_H, var_H, self.l_pix_w)
         # both operands of each network in ONE pass (forward_pair: per-half BatchNorm statistics, the detached
         # ``real`` half costs no backward) — the reference's call order fake, real is the group order
         fake_fea, real_fea = netF.forward_pair(fake_H, var_H)
-        l_g_fea = self.l_fea_w * F.l1_loss(fake_fea, real_fea)
+        l_g_fea = LS.l1_loss(fake_fea, real_fea, self.l_fea_w)
         pred_g_fake, pred_d_real = netD.forward_pair(fake_H, var_ref)
-        l_g_gan = self.l_gan_w * (bce_logits(pred_d_real - mean(pred_g_fake), False) +
-                                  bce_logits(pred_g_fake - mean(pred_d_real), True)) / 2
-        l_g_total = l_g_pix + l_g_fea + l_g_gan
-        (l_g_total * (self.scaler.scale if self.scaler else self.loss_scale)).backward()
+        l_g_gan, _ = LS.ragan_loss(pred_d_real, pred_g_fake, False, True, self.l_gan_w, mean)
+        scale = self.scaler.scale if self.scaler else self._scale_t(fake_H.device)
+        # d(scale * (pix + fea + gan)): one backward over the three terms, no sum / multiply launches
+        torch.autograd.backward([l_g_pix, l_g_fea, l_g_gan], [scale, scale, scale])
         self.exG.start()                      # RCCL all-reduce of G grads overlaps the D pass below
         # ---------------- D ----------------
         for p in netD.parameters():
             p.requires_grad = True
         self.optimizer_D.zero_grad(set_to_none=True)
         pred_d_real, pred_d_fake = netD.forward_pair(var_ref, fake_H.detach())
-        l_d_real = bce_logits(pred_d_real - mean(pred_d_fake), True)
-        l_d_fake = bce_logits(pred_d_fake - mean(pred_d_real), False)
-        l_d_total = (l_d_real + l_d_fake) / 2
-        (l_d_total * (self.scaler.scale if self.scaler else self.loss_scale)).backward()
+        l_d_total, aux = LS.ragan_loss(pred_d_real, pred_d_fake, True, False, 1.0, mean)
+        torch.autograd.backward([l_d_total], [scale])
         self.exD.start()
         inv = 1.0 / self.loss_scale          # the loss-scale division rides inside the Adam kernel
         self.exG.wait()
@@ -82,8 +90,8 @@ class ESRGANPlusStep:
         self.optimizer_D.step(grad_scale=inv, scaler=self.scaler)
         if self.scaler:
             self.scaler.update()
-        logs = dict(l_g_pix=l_g_pix, l_g_fea=l_g_fea, l_g_gan=l_g_gan, l_d_real=l_d_real,
-                    l_d_fake=l_d_fake, D_real=pred_d_real.detach().mean(), D_fake=pred_d_fake.detach().mean())
+        logs = dict(l_g_pix=l_g_pix, l_g_fea=l_g_fea, l_g_gan=l_g_gan, l_d_real=aux[2], l_d_fake=aux[3],
+                    D_real=aux[0], D_fake=aux[1])
         if sync_log:      # the reference calls .item() on every loss each step (SRRaGAN_model.py:171-186)
             self.log = {k: float(v.detach()) for k, v in logs.items()}
         else:

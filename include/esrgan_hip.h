@@ -317,6 +317,24 @@ typedef struct esr_amp {
  *   over all compared planes), out[3] unused;   PSNR = 20 log10(255 / sqrt(out[0] / n)),  SSIM = out[2] / n_ssim
  * with n = (H-2crop)(W-2crop) planes, n_ssim = (H-2crop-10)(W-2crop-10) planes (the caller divides).
  * y_only (C == 3): compare the MATLAB-style Y planes of the uint8 BGR images (data/util.py:150-168). */
+typedef struct esr_l1_loss {
+  const float* a; const float* b;
+  float* grad_a;               /* may be NULL */
+  float* loss;                 /* 1 float */
+  double* scratch;             /* 2 doubles, zero */
+  int64_t n;
+  float weight; int32_t _pad;
+} esr_l1_loss;
+
+typedef struct esr_ragan_loss {
+  const float* x; const float* y;      /* n logits each */
+  float* grad_x; float* grad_y;        /* may be NULL */
+  float* loss; float* mean_x; float* mean_y;
+  float* bce_x; float* bce_y;          /* optional: the two BCE terms, unweighted (the reference logs them) */
+  int32_t n;
+  float tx, ty, weight;                /* targets (1 = real, 0 = fake) of the x / y terms */
+} esr_ragan_loss;
+
 typedef struct esr_img_metrics {
   const float* sr;           /* [C][H][W] fp32 */
   const float* hr;           /* same shape, or NULL: conversion only */
@@ -455,6 +473,16 @@ size_t esr_rdb_weight_stream_bytes(int32_t dtype);
 int esr_rdb_max_tiles_per_image(void);   /* 16x32 tiles of ONE image must not exceed this (= CUs) */
 int esr_gather_fragments(const esr_frag_gather* g, esr_stream_t stream);
 int esr_image_metrics(const esr_img_metrics* p, esr_stream_t stream);   /* replaces util.py:71-158 on the device */
+
+/* The train step's losses with their gradients, one launch each (SRRaGAN_model.py:124-137,150-156).
+ * esr_l1_loss_forward: *loss = weight * mean|a - b| (nn.L1Loss, loss.py cri_pix / cri_fea);
+ *   grad_a (optional) = weight * sign(a - b) / n.  scratch: 2 doubles of device memory, zero before the first
+ *   call (the kernel leaves them zero).
+ * esr_ragan_loss_forward: *loss = weight/2 * ( BCEWithLogits(x - mean(y), tx) + BCEWithLogits(y - mean(x), ty) )
+ *   (GANLoss 'vanilla' on the relativistic-average logits, loss.py:6-38); grad_x / grad_y optional (the means'
+ *   dependence on the other side included); mean_x / mean_y optional outputs (the D_real / D_fake log values). */
+int esr_l1_loss_forward(const esr_l1_loss* p, esr_stream_t stream);
+int esr_ragan_loss_forward(const esr_ragan_loss* p, esr_stream_t stream);
 
 /* Run a recorded list of ops back to back on `stream` (one host call per network pass; this is
  * what RRDBNet.forward — architecture.py:76-78 — becomes). */

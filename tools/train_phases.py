@@ -6,7 +6,7 @@ import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
-from esrganplus_amd import architecture as arch, synth, train, dp as DP
+from esrganplus_amd import architecture as arch, synth, train, dp as DP, losses as LS
 
 dev = torch.device('cuda:0')
 NB = 23
@@ -20,8 +20,7 @@ st = train.ESRGANPlusStep(netG, netD, netF, loss_scale=1024.0)
 NBATCH = int(os.environ.get('TP_BATCH', '16'))
 lr = synth.image_batch(200, NBATCH, 3, 32, 32, name='bench.lr').to(dev)
 hr = synth.image_batch(300, NBATCH, 3, 128, 128, name='bench.hr').to(dev)
-bce = train.bce_logits
-mean = DP.global_mean
+SCALE = torch.full((), 1024.0, device=dev)
 
 def step(marks):
     def mark(name):
@@ -30,17 +29,16 @@ def step(marks):
     for p in netD.parameters(): p.requires_grad = False
     st.optimizer_G.zero_grad(set_to_none=True)
     fake = netG(lr); mark('G fwd')
-    l_pix = 1e-2 * F.l1_loss(fake, hr)
-    ff, rf = netF.forward_pair(fake, hr); l_fea = F.l1_loss(ff, rf); mark('VGG fwd x2')
+    l_pix = LS.l1_loss(fake, hr, 1e-2)
+    ff, rf = netF.forward_pair(fake, hr); l_fea = LS.l1_loss(ff, rf, 1.0); mark('VGG fwd x2')
     pg, pr = netD.forward_pair(fake, hr)
-    l_gan = 5e-3 * (bce(pr - mean(pg), False) + bce(pg - mean(pr), True)) / 2
-    tot = l_pix + l_fea + l_gan; mark('D fwd x2 + losses')
-    (tot * 1024.0).backward(); mark('backward (D, VGG, G)')
+    l_gan, _ = LS.ragan_loss(pr, pg, False, True, 5e-3); mark('D fwd x2 + losses')
+    torch.autograd.backward([l_pix, l_fea, l_gan], [SCALE, SCALE, SCALE]); mark('backward (D, VGG, G)')
     for p in netD.parameters(): p.requires_grad = True
     st.optimizer_D.zero_grad(set_to_none=True)
     pr, pf = netD.forward_pair(hr, fake.detach())
-    ld = (bce(pr - mean(pf), True) + bce(pf - mean(pr), False)) / 2; mark('D fwd x2 (D step)')
-    (ld * 1024.0).backward(); mark('D backward x2')
+    ld, _ = LS.ragan_loss(pr, pf, True, False, 1.0); mark('D fwd x2 (D step)')
+    torch.autograd.backward([ld], [SCALE]); mark('D backward x2')
     st.optimizer_G.step(grad_scale=1 / 1024.0); st.optimizer_D.step(grad_scale=1 / 1024.0); mark('Adam x2')
 
 for _ in range(3): step([])
