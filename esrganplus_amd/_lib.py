@@ -279,6 +279,7 @@ def packed_weight_bytes(cout, cin, ks, dtype):
 
 
 OPF_SIDE = 1   # esr_op.flags: run of wgrad ops on the library's side stream (include/esrgan_hip.h)
+OPF_SIDE_FREE = 2   # with OPF_SIDE: independent run (own partial region, inputs never overwritten): no waits between runs
 
 
 class OpList:

@@ -268,7 +268,8 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
                 wg.dw, wg.tap_major = P.tapmajor.slot(poff[r['key'] + '.weight'], cout, cin_, r['ks'] ** 2), 1
             # every layer owns its gradient buffers, so the weight gradient can run on the side stream
             # next to the dgrad chain (joined before the unpermute / at the end of the plan)
-            bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE)
+            # (no waits between these runs, several in flight: ESR_OPF_SIDE_FREE; each gets its own partial region)
+            bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE | L.OPF_SIDE_FREE)
         # input gradient
         prev = recs[li - 1] if li > 0 else None
         gx = _g32(P, Bb, ((cin_ + cpg - 1) // cpg) * cpg, r['hin'], r['win'], dtype, dev)
@@ -295,7 +296,7 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
     if input_affine is not None:
         aff = (input_affine[0], input_affine[1])
     _layout(bk, dt_e, 0, Bb, cin0, gcur, nchw_ptr=P.gx_tensor.data_ptr(), affine=aff)
-    P.wgrad_arena = E.attach_wgrad_arena(bk, dev)
+    P.wgrad_arena = E.attach_wgrad_arena(bk, dev, exclusive=True)
     return P
 
 

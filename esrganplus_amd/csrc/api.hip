@@ -48,7 +48,8 @@ extern "C" void esr_g32_dims(int32_t H, int32_t W, int32_t* Hp, int32_t* Wp) {
 // Side stream for ESR_OPF_SIDE runs: one non-blocking stream + two fork/join event pairs per device,
 // created on first use (the only resources the library ever owns).
 namespace {
-struct SideState { hipStream_t stream; hipEvent_t fork[2], join[2]; };
+constexpr int NFREE = 3;   // streams for ESR_OPF_SIDE_FREE runs (independent weight gradients, several at once)
+struct SideState { hipStream_t stream; hipEvent_t fork[2], join[2]; hipStream_t xs[NFREE]; hipEvent_t xfork, xjoin[NFREE]; };
 SideState* side_state() {
   static std::mutex mu;
   static SideState* per_dev[64] = {};
@@ -61,6 +62,10 @@ SideState* side_state() {
     for (int k = 0; k < 2 && ok; ++k)
       ok = hipEventCreateWithFlags(&s->fork[k], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&s->join[k], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&s->xfork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < NFREE && ok; ++k)
+      ok = hipStreamCreateWithFlags(&s->xs[k], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&s->xjoin[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) { esr_set_error("side stream: creation failed"); delete s; return nullptr; }
     per_dev[dev] = s;
   }
@@ -75,6 +80,15 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
   if (!ops || n < 0) { esr_set_error("esr_run_ops: invalid arguments"); return ESR_ERR_INVALID; }
   int nside = 0;        // side runs launched by this call
   bool joined = true;   // main stream already waits for the last side run
+  int nfree = 0;        // ESR_OPF_SIDE_FREE runs launched by this call (joined at the unpermute / the end)
+  auto join_free = [&]() -> int {
+    if (nfree > 0) {
+      SideState* ss = side_state();
+      for (int q = 0; q < NFREE && q < nfree; ++q) ESR_HIP(hipStreamWaitEvent((hipStream_t)stream, ss->xjoin[q], 0));
+      nfree = 0;
+    }
+    return ESR_OK;
+  };
   for (int i = 0; i < n; ++i) {
     int rc;
     switch (ops[i].kind) {
@@ -92,6 +106,17 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
         for (int k = 0; k < m; ++k) run[k] = ops[i + k].u.wgrad;
         if (!side) {
           rc = m == 1 ? esr_conv_wgrad(&run[0], stream) : esr_conv_wgrad_multi(run, m, stream);
+        } else if (ops[i].flags & ESR_OPF_SIDE_FREE) {
+          // what this run reads is never overwritten inside the list and its partial arena is its own: no wait
+          // for earlier runs, round-robin over NFREE streams (latency-bound launches overlap each other)
+          SideState* ss = side_state();
+          if (!ss) return ESR_ERR_LAUNCH;
+          const int q = nfree % NFREE;
+          ESR_HIP(hipEventRecord(ss->xfork, (hipStream_t)stream));
+          ESR_HIP(hipStreamWaitEvent(ss->xs[q], ss->xfork, 0));
+          rc = esr_conv_wgrad_multi(run, m, (esr_stream_t)ss->xs[q]);
+          ESR_HIP(hipEventRecord(ss->xjoin[q], ss->xs[q]));
+          ++nfree;
         } else {
           // fork: side stream waits for everything enqueued so far; the previous side run must be done
           // before anything after this point (its inputs may be overwritten from here on)
@@ -113,6 +138,7 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       case ESR_OP_POOL: rc = esr_maxpool2(&ops[i].u.pool, stream); break;
       case ESR_OP_LINEAR: rc = esr_linear_op(&ops[i].u.linear, stream); break;
       case ESR_OP_UNPERMUTE:
+        if ((rc = join_free()) != ESR_OK) break;
         if (nside > 0 && !joined) { ESR_HIP(hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0)); joined = true; }
         rc = esr_grad_unpermute(&ops[i].u.unpermute, stream);
         break;
@@ -126,11 +152,12 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       snprintf(tmp, sizeof(tmp), "%s", esr_last_error());
       esr_set_error("op %d (kind %d): %s", i, ops[i].kind, tmp);
       if (nside > 0 && !joined) (void)hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0);
+      (void)join_free();
       return rc;
     }
   }
   if (nside > 0 && !joined) ESR_HIP(hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0));
-  return ESR_OK;
+  return join_free();
 }
 
 extern "C" int64_t esr_wgrad_run_partial_elems(const esr_wgrad* items, int32_t n);
@@ -148,7 +175,7 @@ extern "C" int64_t esr_wgrad_workspace_elems(const esr_op* ops, int32_t n) {
     if (e > need) need = e;
     i += m - 1;
   }
-  return need;
+  return need;     // (ESR_OPF_SIDE_FREE runs: the caller gives each its own region of this size or of its own need)
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -552,15 +552,33 @@ def deterministic_wgrad():
     return os.environ.get('ESR_WGRAD_DET', '1') != '0'
 
 
-def attach_wgrad_arena(oplist, device):
+def attach_wgrad_arena(oplist, device, exclusive=False):
     """Give every fp16 weight-gradient op of a backward list the partial arena of the deterministic reduction
     (one arena per list: a slot only lives inside one esr_run_ops launch group, and the list's wgrad runs are
-    ordered on one stream).  Returns the arena tensor (keep it alive with the plan) or None."""
+    ordered on one stream).  exclusive: every op gets a region of its own (ESR_OPF_SIDE_FREE runs are in flight
+    together).  Returns the arena tensor (keep it alive with the plan) or None."""
     if not deterministic_wgrad():
         return None
     wops = [o for o in oplist.ops if o.kind == L.OP_WGRAD and o.u.wgrad.dtype == L.ESR_F16]
     if not wops:
         return None
+    if exclusive:
+        arr = oplist.array()
+        needs = []
+        for i, o in enumerate(oplist.ops):
+            if o.kind == L.OP_WGRAD and o.u.wgrad.dtype == L.ESR_F16:
+                n = L.lib().esr_wgrad_workspace_elems(C.cast(C.byref(arr[i]), C.c_void_p), 1)
+                needs.append((o, (int(n) + 63) // 64 * 64))
+        total = sum(n for _, n in needs)
+        if total <= 0:
+            return None
+        arena = torch.empty(total, dtype=torch.float32, device=device)
+        off = 0
+        for o, n in needs:
+            o.u.wgrad.partial, o.u.wgrad.partial_elems = (arena.data_ptr() + 4 * off, n) if n else (None, 0)
+            off += n
+        oplist._arr = None
+        return arena
     need = L.lib().esr_wgrad_workspace_elems(C.cast(oplist.array(), C.c_void_p), len(oplist.ops))
     if need <= 0:
         return None

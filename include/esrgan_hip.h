@@ -424,6 +424,12 @@ enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_N
                             esr_run_ops enqueued on `stream` completes.  The caller guarantees that nothing
                             up to the end of the next side run writes the run's inputs or reads its outputs
                             (the train plan double-buffers the gradient slices it reads). */
+#define ESR_OPF_SIDE_FREE 2   /* with ESR_OPF_SIDE: the run's inputs are never overwritten and its outputs never read
+                            inside this list, and its esr_wgrad.partial region belongs to this run alone — it is
+                            launched without waiting for earlier side runs, on one of three library-owned streams
+                            (round robin), complete before any ESR_OP_UNPERMUTE and when the list's work on `stream`
+                            completes.  (The discriminator's backward: ten independent, latency-bound weight
+                            gradients next to the dgrad chain.) */
 
 typedef struct esr_op {
   int32_t kind;
