@@ -147,7 +147,7 @@ class _SeqNet(B._PlannedModule):
         want_w = any(p.requires_grad for p in self.parameters())
         if need_bwd:
             dp = self._dgrad_weights(dev)
-            dp.ensure(st, force=bool(self.training) or want_w)
+            dp.ensure(st, force=(bool(self.training) or want_w) and not self.__dict__.get('_weights_clean', False))
         training = bool(self.training) and self._has_bn
         groups = groups if training else 1
         key = ('seq', Bn, H, W, self.precision, training, need_bwd, want_w, wp.generation, str(dev), groups, bwd_B)

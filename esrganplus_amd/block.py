@@ -143,6 +143,20 @@ class _PlannedModule(nn.Module):
         self.precision = 'fp32'       # 'fp32' (exact path, reference numerics) or 'fp16'
         self._force_repack = True
 
+    def weights_unchanged(self):
+        """Context manager: the caller vouches that no parameter changed since this module's last forward (the D step
+        of the train loop runs right after the G step's D pass, before any optimizer step) — the forced re-pack of
+        training-mode modules is skipped; a changed storage or version still re-packs."""
+        mod = self
+
+        class _Ctx(object):
+            def __enter__(self):
+                object.__setattr__(mod, '_weights_clean', True)
+
+            def __exit__(self, *a):
+                object.__setattr__(mod, '_weights_clean', False)
+        return _Ctx()
+
     def set_precision(self, precision):
         """'fp32': v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain) — the <=1e-3 parity path.
         'fp16': fp16 storage + v_mfma_f32_32x32x16_f16 with fp32 accumulation — the fast path."""
@@ -247,7 +261,8 @@ class _PlannedModule(nn.Module):
         if wp is None:
             wp = E.WeightPack(self._conv_list(), self.precision, device, self._subpix_keys())
             self._wp[key] = wp
-        wp.ensure(E.current_stream(), force=self._force_repack or self.training)
+        clean = self.__dict__.get('_weights_clean', False)
+        wp.ensure(E.current_stream(), force=self._force_repack or (self.training and not clean))
         self._force_repack = False
         return wp
 

@@ -43,6 +43,15 @@ class ESRGANPlusStep:
         self.exG, self.exD = DP.GradExchange(netG), DP.GradExchange(netD)
         self.log = {}
         self.fake_H = None
+        # single-GPU: enqueue the D step on a second stream under the G backward (ESR_TRAIN_OVERLAP=0: in sequence)
+        import os
+        self.overlap_d_step = os.environ.get('ESR_TRAIN_OVERLAP', '1') != '0'
+
+    def _side(self, dev):
+        s = self.__dict__.get('_side_stream')
+        if s is None or s.device != dev:
+            s = self._side_stream = torch.cuda.Stream(device=dev)
+        return s
 
     def _scale_t(self, dev):
         t = self.__dict__.get('_scale_tensor')
@@ -72,17 +81,38 @@ class ESRGANPlusStep:
         pred_g_fake, pred_d_real = netD.forward_pair(fake_H, var_ref)
         l_g_gan, _ = LS.ragan_loss(pred_d_real, pred_g_fake, False, True, self.l_gan_w, mean)
         scale = self.scaler.scale if self.scaler else self._scale_t(fake_H.device)
-        # d(scale * (pix + fea + gan)): one backward over the three terms, no sum / multiply launches
-        torch.autograd.backward([l_g_pix, l_g_fea, l_g_gan], [scale, scale, scale])
-        self.exG.start()                      # RCCL all-reduce of G grads overlaps the D pass below
-        # ---------------- D ----------------
-        for p in netD.parameters():
-            p.requires_grad = True
-        self.optimizer_D.zero_grad(set_to_none=True)
-        pred_d_real, pred_d_fake = netD.forward_pair(var_ref, fake_H.detach())
-        l_d_total, aux = LS.ragan_loss(pred_d_real, pred_d_fake, True, False, 1.0, mean)
-        torch.autograd.backward([l_d_total], [scale])
-        self.exD.start()
+
+        def d_step():
+            # ---------------- D ---------------- (SRRaGAN_model.py:143-168; only needs fake_H's VALUES and D as it is)
+            for p in netD.parameters():
+                p.requires_grad = True
+            self.optimizer_D.zero_grad(set_to_none=True)
+            with netD.weights_unchanged():        # no optimizer step since the G step's D pass
+                pred_d_real, pred_d_fake = netD.forward_pair(var_ref, fake_H.detach())
+            l_d_total, aux = LS.ragan_loss(pred_d_real, pred_d_fake, True, False, 1.0, mean)
+            torch.autograd.backward([l_d_total], [scale])
+            return aux
+
+        def g_backward():
+            # d(scale * (pix + fea + gan)): one backward over the three terms, no sum / multiply launches
+            torch.autograd.backward([l_g_pix, l_g_fea, l_g_gan], [scale, scale, scale])
+
+        if self.overlap_d_step and DP.world_size() == 1 and fake_H.is_cuda:
+            # The D step does not depend on the G backward: it runs on a second stream UNDER it (both are chains of
+            # small launches).  Same arithmetic, same order of BatchNorm running-statistics updates (its forward
+            # still follows the G step's D pass); the autograd graphs are disjoint.
+            main = torch.cuda.current_stream()
+            side = self._side(fake_H.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                aux = d_step()
+            g_backward()
+            main.wait_stream(side)
+        else:
+            g_backward()
+            self.exG.start()                  # RCCL all-reduce of G grads overlaps the D pass below
+            aux = d_step()
+            self.exD.start()
         inv = 1.0 / self.loss_scale          # the loss-scale division rides inside the Adam kernel
         self.exG.wait()
         self.optimizer_G.step(grad_scale=inv, scaler=self.scaler)
