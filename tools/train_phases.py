@@ -33,12 +33,17 @@ def step(marks):
     ff, rf = netF.forward_pair(fake, hr); l_fea = LS.l1_loss(ff, rf, 1.0); mark('VGG fwd x2')
     pg, pr = netD.forward_pair(fake, hr)
     l_gan, _ = LS.ragan_loss(pr, pg, False, True, 5e-3); mark('D fwd x2 + losses')
-    torch.autograd.backward([l_pix, l_fea, l_gan], [SCALE, SCALE, SCALE]); mark('backward (D, VGG, G)')
-    for p in netD.parameters(): p.requires_grad = True
-    st.optimizer_D.zero_grad(set_to_none=True)
-    pr, pf = netD.forward_pair(hr, fake.detach())
-    ld, _ = LS.ragan_loss(pr, pf, True, False, 1.0); mark('D fwd x2 (D step)')
-    torch.autograd.backward([ld], [SCALE]); mark('D backward x2')
+    main = torch.cuda.current_stream(); side = st._side(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for p in netD.parameters(): p.requires_grad = True
+        st.optimizer_D.zero_grad(set_to_none=True)
+        with netD.weights_unchanged():
+            pr, pf = netD.forward_pair(hr, fake.detach())
+        ld, _ = LS.ragan_loss(pr, pf, True, False, 1.0)
+        torch.autograd.backward([ld], [SCALE])
+    mark('D step enqueued on side stream')
+    torch.autograd.backward([l_pix, l_fea, l_gan], [SCALE, SCALE, SCALE]); main.wait_stream(side); mark('backward (D, VGG, G) || D step')
     st.optimizer_G.step(grad_scale=1 / 1024.0); st.optimizer_D.step(grad_scale=1 / 1024.0); mark('Adam x2')
 
 for _ in range(3): step([])
