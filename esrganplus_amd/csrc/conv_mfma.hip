@@ -654,6 +654,11 @@ int dispatch(const esr_conv& p, hipStream_t st) {
     static const int q2 = [] { const char* e = getenv("ESR_TILE_Q2"); return e ? atoi(e) : 384; }();
     static const int rows_forced = [] { const char* e = getenv("ESR_TILE_ROWS"); return e ? atoi(e) : 0; }();
     int rw = tiles * cbk <= q1 ? 1 : (tiles * cbk <= q2 ? 2 : 4);
+    // maps of at most 8 (4) rows: the lower half (three quarters) of a 16-row tile is padding whatever the grid
+    // size — the VGG / discriminator layers behind four or five poolings (ESR_TILE_HCLAMP=0 switches it off)
+    static const bool hclamp = [] { const char* e = getenv("ESR_TILE_HCLAMP"); return !e || atoi(e) != 0; }();
+    if (hclamp && p.H <= 4) rw = 1;
+    else if (hclamp && p.H <= 8 && rw > 2) rw = 2;
     if (rows_forced) rw = rows_forced;
     if ((p.debug_flags & 256) || sizeof(T) != 2) rw = 4;
     if (has1 && cbk != 1) { esr_set_error("conv: fused 1x1 needs cout_blocks==1"); return ESR_ERR_UNSUPPORTED; }
