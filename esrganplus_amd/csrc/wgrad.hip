@@ -274,6 +274,26 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
       }
     }
   }
+  int soff[PACK ? 1 : NP];
+  if constexpr (!PACK) {
+    const int ix0 = UPS ? ox0 / 2 : ox0 * S + 1 - PAD;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int s = tid + NTH * k;
+      soff[k] = -1;
+      if (s < GS) {
+        const int half = s & 1, px = (s >> 1) % (TR * TC), g = (s >> 1) / (TR * TC);
+        const int gg = (bz * NCO) * 2 + g;
+        if (gg < p.g.ngroups)
+          soff[k] = (int)(gg * p.g.group_stride) + ((px / TC + 1) * p.g.wp + ox0 + px % TC + 1) * 32 + half * 16;
+      } else if (s - GS < IS) {
+        const int t = s - GS;
+        const int half = t & 1, px = (t >> 1) % (IH * IW), g = (t >> 1) / (IH * IW);
+        const int gg = by * NCI * 2 + g;
+        soff[k] = (int)(gg * p.in.group_stride) + ((px / IW + (UPS ? 0 : 1 - PAD)) * p.in.wp + ix0 + px % IW) * 32 + half * 16;
+      }
+    }
+  }
   auto dma_tile = [&](int oy0, int b) __attribute__((always_inline)) {
     if constexpr (PACK) {
       const int grow = oy0 * p.g.wp * 32, irow = oy0 * S * p.in.wp * 32;
@@ -288,22 +308,15 @@ __device__ __forceinline__ void wgrad16_body(const esr_wgrad& p, const int rows_
       }
       return;
     }
-    const int iy0 = UPS ? oy0 / 2 : oy0 * S + 1 - PAD, ix0 = UPS ? ox0 / 2 : ox0 * S + 1 - PAD;
+    // the slot -> source map is the same for every tile of the workgroup (soff, built once below): per tile only
+    // the row base moves — the per-slot divisions and 64-bit multiplies used to cost as many issue cycles per
+    // tile as its MFMAs
+    const char* const grow = gbase + (int64_t)oy0 * p.g.wp * 32;
+    const char* const irow = ibase + (int64_t)(UPS ? oy0 / 2 : oy0 * S) * p.in.wp * 32;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const int s = tid + NTH * k;
       char* const dst = smem + (wave * 64 + NTH * k) * 16;         // wave-uniform; lane*16 is implicit
-      if (s < GS) {
-        const int half = s & 1, px = (s >> 1) % (TR * TC), g = (s >> 1) / (TR * TC);
-        const int gg = (bz * NCO) * 2 + g;
-        if (gg < p.g.ngroups)
-          dma16(gbase + (int64_t)gg * p.g.group_stride + ((int64_t)(oy0 + px / TC + 1) * p.g.wp + ox0 + px % TC + 1) * 32 + half * 16, dst);
-      } else if (s - GS < IS) {
-        const int t = s - GS;
-        const int half = t & 1, px = (t >> 1) % (IH * IW), g = (t >> 1) / (IH * IW);
-        const int gg = by * NCI * 2 + g;
-        dma16(ibase + (int64_t)gg * p.in.group_stride + ((int64_t)(iy0 + px / IW) * p.in.wp + ix0 + px % IW) * 32 + half * 16, dst);
-      }
+      if (soff[k] >= 0) dma16((tid + NTH * k < GS ? grow : irow) + soff[k], dst);
     }
   };
   // packed: per-lane column terms of the two transposed reads of each 16-pixel half run
