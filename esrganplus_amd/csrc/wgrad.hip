@@ -115,7 +115,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const esr_wgrad p) {
     }
   }
 
-  // ---- accumulate into the fp32 OIHW gradient (and bias gradient) with atomics
+  // ---- deterministic form (esr_wgrad.partial): this workgroup's (image, column strip) slot of the partial arena,
+  // tap-major like the fp16 kernels', plain stores; wgrad_reduce_kernel adds the slots up in slot order.
+  // Otherwise: fp32 atomics into the OIHW gradient (and bias gradient).
+  float* const slot = p.partial ? p.partial + (int64_t)blockIdx.x * p.partial_elems : nullptr;
 #pragma unroll
   for (int t = 0; t < W::TPW; ++t) {
     if ((wave + 4 * t) >= W::NTILE || bkind[t] == 2) continue;
@@ -126,6 +129,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const esr_wgrad p) {
       const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;     // MFMA C/D row map
       if (co >= p.cout) continue;
       const float v = acc[t][e] * p.scale;
+      if (slot) {
+        if (bkind[t] == 1) { if (p.dbias && cg == 0) slot[(int64_t)KS * KS * p.cout * p.cin + co] = v; }
+        else if (ci < p.cin) slot[((int64_t)tap * p.cout + co) * p.cin + ci] = v;
+        continue;
+      }
       if (bkind[t] == 1) {
         if (p.dbias && cg == 0) atomicAdd(p.dbias + co, v);
       } else if (ci < p.cin) {
@@ -581,6 +589,7 @@ int launch_wgrad16(const esr_wgrad& p_in, hipStream_t st, bool reduce = true) {
 // spatial splits (= partial slots) the single launch of this conv uses
 template <int S, bool UPS> static int single_splits(const esr_wgrad& p) { return wgrad16_grid<S, UPS>(p, 64, 8, max_rows()).gx; }
 static int64_t single_partial_elems(const esr_wgrad& p) {
+  if (p.dtype == ESR_F32) return (int64_t)p.B * ((p.W + 31) / 32) * slot_elems(p);   // wgrad_kernel: one slot per (image, strip)
   if (p.dtype != ESR_F16) return 0;
   int gx = 0;
   if (p.ks == 4 && p.stride == 2 && !p.upsample) gx = single_splits<2, false>(p);
@@ -592,8 +601,17 @@ template <typename T, int KS, int S, bool UPS>
 int launch_wgrad(const esr_wgrad& p, hipStream_t st) {
   const int strips = (p.W + 31) / 32;
   dim3 grid(p.B * strips, p.in.ngroups, (p.cout + 31) / 32);
-  hipLaunchKernelGGL((wgrad_kernel<T, KS, S, UPS>), grid, dim3(256), 0, st, p);
-  return esr_check_launch("wgrad_kernel");
+  esr_wgrad q = p;
+  // two-stage reduction when the caller gave a partial arena that holds one slot per (image, strip); else atomics
+  const bool det = q.partial && (int64_t)grid.x * slot_elems(p) <= q.partial_elems && !q.tap_major;
+  if (det) q.partial_elems = slot_elems(p); else q.partial = nullptr;
+  hipLaunchKernelGGL((wgrad_kernel<T, KS, S, UPS>), grid, dim3(256), 0, st, q);
+  const int rc = esr_check_launch("wgrad_kernel");
+  if (rc || !det) return rc;
+  WgradReduce r;
+  r.begin[0] = 0;
+  reduce_entry(r, 0, p, q.partial, (int)grid.x);
+  return launch_reduce(r, 1, st);
 }
 
 template <typename T>

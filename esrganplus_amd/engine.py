@@ -559,14 +559,14 @@ def attach_wgrad_arena(oplist, device, exclusive=False):
     together).  Returns the arena tensor (keep it alive with the plan) or None."""
     if not deterministic_wgrad():
         return None
-    wops = [o for o in oplist.ops if o.kind == L.OP_WGRAD and o.u.wgrad.dtype == L.ESR_F16]
+    wops = [o for o in oplist.ops if o.kind == L.OP_WGRAD]      # fp16 kernels and the fp32 parity kernel alike
     if not wops:
         return None
     if exclusive:
         arr = oplist.array()
         needs = []
         for i, o in enumerate(oplist.ops):
-            if o.kind == L.OP_WGRAD and o.u.wgrad.dtype == L.ESR_F16:
+            if o.kind == L.OP_WGRAD:
                 n = L.lib().esr_wgrad_workspace_elems(C.cast(C.byref(arr[i]), C.c_void_p), 1)
                 needs.append((o, (int(n) + 63) // 64 * 64))
         total = sum(n for _, n in needs)

@@ -287,16 +287,17 @@ def test_eval_after_fused_adam_uses_updated_weights(dev):
         assert torch.equal(y, y2), prec
 
 
-def test_fp16_weight_gradients_are_bit_identical_run_to_run(dev):
-    """Deterministic two-stage wgrad reduction (esr_wgrad.partial): G and D gradients of two identical
-    backward passes are equal bit for bit (the fp32-atomics form, ESR_WGRAD_DET=0, is not)."""
+@pytest.mark.parametrize('prec', ['fp16', 'fp32'])
+def test_weight_gradients_are_bit_identical_run_to_run(dev, prec):
+    """Deterministic two-stage wgrad reduction (esr_wgrad.partial; fp16 kernels and the fp32 parity kernel): G and D
+    gradients of two identical backward passes are equal bit for bit (the atomics form, ESR_WGRAD_DET=0, is not)."""
     from esrganplus_amd import architecture as arch
     sd = synth.rrdbnet_state_dict(nb=2, seed=13)
     x = synth.image_batch(13, 4, 3, 32, 32, name='det.x').to(dev)
     gy = synth.normal_like(13, 'det.gy', (4, 3, 128, 128)).to(dev)
     runs = []
     for _ in range(2):
-        net = arch.RRDBNet(3, 3, 64, 2).to(dev).eval().set_precision('fp16')
+        net = arch.RRDBNet(3, 3, 64, 2).to(dev).eval().set_precision(prec)
         net.load_state_dict(sd)
         (net(x) * gy).sum().backward()
         runs.append(torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone())
@@ -307,7 +308,7 @@ def test_fp16_weight_gradients_are_bit_identical_run_to_run(dev):
     gd = synth.normal_like(14, 'det.gd', (4, 1)).to(dev)
     runs = []
     for _ in range(2):
-        netD = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision('fp16')
+        netD = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision(prec)
         netD.load_state_dict(dsd)
         (netD(xd) * gd).sum().backward()
         runs.append(torch.cat([p.grad.reshape(-1) for p in netD.parameters()]).clone())
