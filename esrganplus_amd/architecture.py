@@ -2,7 +2,7 @@
 ``RRDBNet`` (codes/models/modules/architecture.py:47-78) and ``RRDB_Net``
 (test_image/architecture.py:7-38).  Same constructor signatures, module tree and state-dict keys
 (SURVEY.md Appendix B); ``forward`` replays a fused HIP launch plan instead of walking the
-``nn.Sequential``.  Generators outside the path (SRResNet, pixelshuffle) raise NotImplementedError.
+``nn.Sequential``.  ``SRResNet`` (architecture.py:13-44) is a chain of per-conv HIP modules (``Conv2dHIP``).
 """
 import os
 import math
@@ -17,7 +17,8 @@ class _RRDBNetBase(B._PlannedModule):
     def _build(self, in_nc, out_nc, nf, nb, upscale, norm_type, act_type, mode, upsample_mode,
                extra_noise):
         if upsample_mode == 'pixelshuffle':
-            B.pixelshuffle_block()
+            raise NotImplementedError('the planned RRDBNet uses upconv (networks.py:99); pixelshuffle_block itself '
+                                      'is available (block.pixelshuffle_block, SRResNet)')
         if upsample_mode != 'upconv':
             raise NotImplementedError('upsample mode [{:s}] is not found'.format(upsample_mode))
         if (nf, upscale, norm_type, act_type.lower(), mode) != (64, 4, None, 'leakyrelu', 'CNA'):
@@ -104,8 +105,46 @@ class RRDB_Net(_RRDBNetBase):
 
 
 class SRResNet(nn.Module):
-    def __init__(self, *a, **k):
-        raise NotImplementedError('SRResNet is outside the ESRGAN+ hot path (SURVEY.md §2.1 row 2)')
+    """architecture.py:13-44 of the reference (networks.py:88-91 builds it with act 'relu', upsample_mode
+    'pixelshuffle'; train_SRResNet.json:39-43: norm_type null, mode CNA, nb 16).  Not planned as a whole like
+    RRDBNet: a chain of ``Conv2dHIP`` modules (every conv, forward and backward, on the HIP kernels) with torch glue
+    for ReLU, the residual adds and nn.PixelShuffle / nn.Upsample.  Same state-dict keys as the reference."""
+
+    def __init__(self, in_nc, out_nc, nf, nb, upscale=4, norm_type=None, act_type='relu', mode='CNA', res_scale=1,
+                 upsample_mode='upconv'):
+        super().__init__()
+        if norm_type or mode != 'CNA':
+            raise NotImplementedError('HIP SRResNet: norm_type null, mode CNA (train_SRResNet.json:40-41)')
+        n_upscale = 1 if upscale == 3 else int(math.log(upscale, 2))
+        fea_conv = B.conv_block(in_nc, nf, kernel_size=3, norm_type=None, act_type=None, hip=True)
+        blocks = [B.ResNetBlock(nf, nf, nf, norm_type=None, act_type=act_type, mode=mode, res_scale=res_scale)
+                  for _ in range(nb)]
+        LR_conv = B.conv_block(nf, nf, kernel_size=3, norm_type=None, act_type=None, mode=mode, hip=True)
+        if upsample_mode == 'upconv':
+            up = lambda *a, **k: B.upconv_blcok(*a, hip=True, **k)
+        elif upsample_mode == 'pixelshuffle':
+            up = B.pixelshuffle_block
+        else:
+            raise NotImplementedError('upsample mode [{:s}] is not found'.format(upsample_mode))
+        if upscale == 3:
+            if upsample_mode == 'upconv':
+                raise NotImplementedError('x3 upconv is outside the kernels (nearest x2 only)')
+            upsampler = [up(nf, nf, 3, act_type=act_type)]
+        else:
+            upsampler = [up(nf, nf, act_type=act_type) for _ in range(n_upscale)]
+        HR_conv0 = B.conv_block(nf, nf, kernel_size=3, norm_type=None, act_type=act_type, hip=True)
+        HR_conv1 = B.conv_block(nf, out_nc, kernel_size=3, norm_type=None, act_type=None, hip=True)
+        self.model = B.sequential(fea_conv, B.ShortcutBlock(B.sequential(*blocks, LR_conv)), *upsampler,
+                                  HR_conv0, HR_conv1)
+
+    def set_precision(self, precision):
+        for m in self.modules():
+            if isinstance(m, Conv2dHIP):
+                m.set_precision(precision)
+        return self
+
+    def forward(self, x):
+        return self.model(x)
 
 
 # =================================================================================================
@@ -351,4 +390,35 @@ class VGGFeatureExtractor(_SeqNet):
         ps = []
         for k, w, b in self._conv_list():
             ps += [(k + '.weight', w), (k + '.bias', b)]
+        return ps
+
+
+class Conv2dHIP(_SeqNet, nn.Conv2d):
+    """An nn.Conv2d (same parameters, same state-dict keys) whose forward AND backward run on the HIP kernels as a
+    one-layer plan (convnet.build_seq_plan: layout in, fused conv, layout out; dgrad + wgrad + layout back) — the
+    building block of the module families that are not planned as a whole.  3x3 / 1x1 stride 1 and 4x4 stride 2,
+    zero padding (k-1)//2, like every conv of the reference's generators and discriminators."""
+
+    _has_bn = False
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        nn.Conv2d.__init__(self, in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                           padding=padding, dilation=1, groups=1, bias=bias)
+        ks, st = self.kernel_size[0], self.stride[0]
+        if (self.kernel_size[0] != self.kernel_size[1] or (ks, st) not in ((3, 1), (1, 1), (4, 2))
+                or self.padding != ((ks - 1) // 2,) * 2):
+            raise NotImplementedError('Conv2dHIP: 3x3/s1, 1x1/s1 or 4x4/s2 with padding (k-1)//2')
+        self._init_planned()
+
+    def _conv_list(self):
+        return [('conv', self.weight, self.bias)]
+
+    def _spec(self):
+        return [{'conv': 'conv', 'cin': self.in_channels, 'cout': self.out_channels, 'ks': self.kernel_size[0],
+                 'stride': self.stride[0], 'act': L.ACT_NONE, 'bn': None}]
+
+    def _pspec(self):
+        ps = [('conv.weight', self.weight)]
+        if self.bias is not None:
+            ps.append(('conv.bias', self.bias))
         return ps

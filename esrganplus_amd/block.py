@@ -67,15 +67,23 @@ def sequential(*args):
 
 
 def conv_block(in_nc, out_nc, kernel_size, stride=1, dilation=1, groups=1, bias=True,
-               pad_type='zero', norm_type=None, act_type='relu', mode='CNA'):
-    """block.py:125-151 — Conv(zero pad (k-1)//2) -> Norm -> Act holder chain ('CNA' only)."""
+               pad_type='zero', norm_type=None, act_type='relu', mode='CNA', hip=False):
+    """block.py:125-151 — Conv(zero pad (k-1)//2) -> Norm -> Act holder chain ('CNA' only).
+    hip=True: the conv is a ``Conv2dHIP`` (runs by itself on the HIP kernels, forward and backward) — what the
+    module families that are NOT planned as a whole (SRResNet, pixelshuffle_block) are built from; the planned
+    networks (RRDBNet, the discriminators) only read ``.weight`` / ``.bias`` of plain nn.Conv2d holders."""
     if mode != 'CNA':
         raise NotImplementedError('conv mode [{:s}] is outside the ESRGAN+ hot path'.format(mode))
     if dilation != 1 or groups != 1:
         raise NotImplementedError('dilation/groups are outside the ESRGAN+ hot path')
     p = pad(pad_type, get_valid_padding(kernel_size, dilation)) if pad_type else None
-    c = nn.Conv2d(in_nc, out_nc, kernel_size=kernel_size, stride=stride,
-                  padding=get_valid_padding(kernel_size, dilation), dilation=1, bias=bias, groups=1)
+    if hip:
+        from .architecture import Conv2dHIP
+        c = Conv2dHIP(in_nc, out_nc, kernel_size=kernel_size, stride=stride,
+                      padding=get_valid_padding(kernel_size, dilation), bias=bias)
+    else:
+        c = nn.Conv2d(in_nc, out_nc, kernel_size=kernel_size, stride=stride,
+                      padding=get_valid_padding(kernel_size, dilation), dilation=1, bias=bias, groups=1)
     a = act(act_type) if act_type else None
     n = norm(norm_type, out_nc) if norm_type else None
     return sequential(p, c, n, a)
@@ -87,18 +95,44 @@ def conv1x1(in_planes, out_planes, stride=1):
 
 
 def upconv_blcok(in_nc, out_nc, upscale_factor=2, kernel_size=3, stride=1, bias=True,
-                 pad_type='zero', norm_type=None, act_type='relu', mode='nearest'):
+                 pad_type='zero', norm_type=None, act_type='relu', mode='nearest', hip=False):
     """block.py:315-322 (sic: reference spelling)."""
     if upscale_factor != 2 or mode != 'nearest':
         raise NotImplementedError('only nearest x2 upconv is on the ESRGAN+ hot path')
     up = nn.Upsample(scale_factor=upscale_factor, mode=mode)
-    return sequential(up, conv_block(in_nc, out_nc, kernel_size, stride, bias=bias,
-                                     pad_type=pad_type, norm_type=norm_type, act_type=act_type))
+    return sequential(up, conv_block(in_nc, out_nc, kernel_size, stride, bias=bias, pad_type=pad_type,
+                                     norm_type=norm_type, act_type=act_type, hip=hip))
 
 
-def pixelshuffle_block(*a, **k):
-    raise NotImplementedError('pixelshuffle upsampling is outside the ESRGAN+ hot path '
-                              '(RRDBNet uses upconv, networks.py:99)')
+def pixelshuffle_block(in_nc, out_nc, upscale_factor=2, kernel_size=3, stride=1, bias=True,
+                       pad_type='zero', norm_type=None, act_type='relu'):
+    """block.py:299-312: conv to out_nc * r^2 channels (HIP conv, ``Conv2dHIP``) -> nn.PixelShuffle(r) -> act.
+    Keys as the reference: ``0.weight`` / ``0.bias`` (the shuffle and the activation hold no parameters)."""
+    if norm_type:
+        raise NotImplementedError('pixelshuffle_block with a norm layer is not used by the reference configs')
+    conv = conv_block(in_nc, out_nc * (upscale_factor ** 2), kernel_size, stride, bias=bias, pad_type=pad_type,
+                      norm_type=None, act_type=None, hip=True)
+    return sequential(conv, nn.PixelShuffle(upscale_factor), act(act_type) if act_type else None)
+
+
+class ResNetBlock(nn.Module):
+    """block.py:199-232: x + res_scale * conv1(act(conv0(x))) ('CNA', no norm: train_SRResNet.json:39-41), both
+    convs on the HIP kernels (``Conv2dHIP``)."""
+
+    def __init__(self, in_nc, mid_nc, out_nc, kernel_size=3, stride=1, dilation=1, groups=1, bias=True,
+                 pad_type='zero', norm_type=None, act_type='relu', mode='CNA', res_scale=1):
+        super().__init__()
+        if norm_type or mode != 'CNA':
+            raise NotImplementedError('HIP ResNetBlock: mode CNA without a norm layer (train_SRResNet.json:40-41)')
+        conv0 = conv_block(in_nc, mid_nc, kernel_size, stride, dilation, groups, bias, pad_type, None, act_type,
+                           mode, hip=True)
+        conv1 = conv_block(mid_nc, out_nc, kernel_size, stride, dilation, groups, bias, pad_type, None, None,
+                           mode, hip=True)
+        self.res = sequential(conv0, conv1)
+        self.res_scale = res_scale
+
+    def forward(self, x):
+        return x + self.res(x).mul(self.res_scale)
 
 
 class GaussianNoise(nn.Module):
@@ -126,7 +160,17 @@ class ShortcutBlock(nn.Module):
         self.sub = submodule
 
     def forward(self, x):
-        raise L.HipExtensionError('ShortcutBlock is fused into RRDBNet.forward; call the network')
+        # inside RRDBNet this module is never called (the skip is LR_conv's epilogue).  Called directly it runs
+        # x + sub(x) only when every conv below is a HIP module (SRResNet); plain nn.Conv2d holders would fall back
+        # to torch's convolution silently — refused.
+        ok = self.__dict__.get('_hip_only')
+        if ok is None:
+            from .architecture import Conv2dHIP
+            ok = all(isinstance(m, Conv2dHIP) for m in self.sub.modules() if isinstance(m, nn.Conv2d))
+            self.__dict__['_hip_only'] = ok
+        if not ok:
+            raise L.HipExtensionError('ShortcutBlock is fused into RRDBNet.forward; call the network')
+        return x + self.sub(x)
 
     def __repr__(self):
         return 'Identity + \n|' + self.sub.__repr__().replace('\n', '\n|')

@@ -69,6 +69,27 @@ def rrdbnet_state_dict(nb=23, seed=0, gain=1.0):
     return sd
 
 
+def srresnet_keys(nb, upsample_mode='pixelshuffle'):
+    """(key-prefix, cout, cin, k) of SRResNet x4 (architecture.py:13-44 of the reference, networks.py:88-91)."""
+    out = [('model.0', 64, 3, 3)]
+    for i in range(nb):
+        out += [('model.1.sub.%d.res.0' % i, 64, 64, 3), ('model.1.sub.%d.res.2' % i, 64, 64, 3)]
+    out.append(('model.1.sub.%d' % nb, 64, 64, 3))
+    if upsample_mode == 'pixelshuffle':       # [conv, PixelShuffle, ReLU] x 2, then HR_conv0, ReLU, HR_conv1
+        out += [('model.2', 256, 64, 3), ('model.5', 256, 64, 3)]
+    else:                                     # [Upsample, conv, ReLU] x 2
+        out += [('model.3', 64, 64, 3), ('model.6', 64, 64, 3)]
+    out += [('model.8', 64, 64, 3), ('model.10', 3, 64, 3)]
+    return out
+
+
+def srresnet_state_dict(nb=16, seed=0, upsample_mode='pixelshuffle'):
+    sd = OrderedDict()
+    for key, cout, cin, k in srresnet_keys(nb, upsample_mode):
+        _conv(sd, seed, key, cout, cin, k, True)
+    return sd
+
+
 D_CONVS = [(0, 3, 64, 3), (2, 64, 64, 4), (5, 64, 128, 3), (8, 128, 128, 4), (11, 128, 256, 3),
            (14, 256, 256, 4), (17, 256, 512, 3), (20, 512, 512, 4), (23, 512, 512, 3),
            (26, 512, 512, 4)]

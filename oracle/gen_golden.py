@@ -293,6 +293,28 @@ def gen_disc_variants():
         np.savez_compressed(os.path.join(OUT, 'disc%d.npz' % size), **res)
 
 
+def gen_srresnet():
+    """SRResNet x4 (architecture.py:13-44; nb=3 here) with both upsamplers: forward, input gradient, every
+    parameter gradient's checksum and three full ones — straight from the imported reference."""
+    for mode in ('pixelshuffle', 'upconv'):
+        nb = 3
+        sd = synth.srresnet_state_dict(nb=nb, seed=77, upsample_mode=mode)
+        net = RI.build_srresnet(nb, mode)
+        net.load_state_dict(sd, strict=True)
+        x = synth.image_batch(77, 2, 3, 20, 28, name='srresnet.x')
+        gy = synth.normal_like(77, 'srresnet.gy', (2, 3, 80, 112))
+        xr = x.clone().requires_grad_(True)
+        y = net(xr)
+        (y * gy).sum().backward()
+        params = dict(net.named_parameters())
+        res = dict(y=npy(y), gx=npy(xr.grad), gchk=np.stack([checks(params[k].grad) for k in params]))
+        for key in ('model.0.weight', 'model.1.sub.1.res.2.bias', 'model.10.weight'):
+            res['g_' + key] = npy(params[key].grad)
+        up = 'model.2.weight' if mode == 'pixelshuffle' else 'model.3.weight'
+        res['g_up'] = npy(params[up].grad)
+        np.savez_compressed(os.path.join(OUT, 'srresnet_%s.npz' % mode), **res)
+
+
 def _vgg19_features():
     layers, cin = [], 3
     for v in synth.VGG19_CFG:
@@ -466,7 +488,7 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['rdb', 'rrdbnet_small', 'rrdbnet_full', 'disc', 'disc_variants', 'vgg', 'train_step',
-                             'psnr', 'imresize', 'metrics']
+                             'psnr', 'imresize', 'metrics', 'srresnet']
     for w in which:
         print('[gen_golden]', w)
         globals()['gen_' + w]()

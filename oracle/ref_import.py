@@ -95,6 +95,14 @@ def build_rrdbnet(nb=23, variant='codes'):
                              upsample_mode='upconv')
 
 
+def build_srresnet(nb=16, upsample_mode='pixelshuffle'):
+    """networks.py:88-91 with train_SRResNet.json:39-43 (norm_type null, mode CNA)."""
+    with cuda_to_cpu():
+        arch, _ = codes_arch()
+        return arch.SRResNet(in_nc=3, out_nc=3, nf=64, nb=nb, upscale=4, norm_type=None, act_type='relu',
+                             mode='CNA', upsample_mode=upsample_mode)
+
+
 def build_discriminator(size=128):
     arch, _ = codes_arch()
     cls = getattr(arch, 'Discriminator_VGG_%d' % size)

@@ -190,3 +190,15 @@ def test_committed_bench_line_follows_the_contract():
     # consistency of the headline itself: value = HR megapixels of one step / time of one step
     hr_mpix = d['config']['global_batch'] * 512 * 512 / 1e6
     assert abs(d['value'] - hr_mpix / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-3
+
+
+def test_srresnet_state_dict_keys_match_the_reference_layout():
+    """SRResNet / pixelshuffle_block build on CPU with the reference's key names and shapes (synth.srresnet_keys
+    was accepted by the imported reference with strict=True when the fixtures were generated)."""
+    from esrganplus_amd import architecture as arch, synth
+    for mode in ('pixelshuffle', 'upconv'):
+        net = arch.SRResNet(3, 3, 64, 2, upsample_mode=mode)
+        sd = synth.srresnet_state_dict(nb=2, seed=1, upsample_mode=mode)
+        assert list(net.state_dict().keys()) == list(sd.keys())
+        assert all(tuple(net.state_dict()[k].shape) == tuple(v.shape) for k, v in sd.items())
+        net.load_state_dict(sd, strict=True)
