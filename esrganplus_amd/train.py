@@ -8,7 +8,13 @@ The three networks are the drop-in HIP modules; the losses are a handful of tiny
 exchanges are started right after each backward and waited for right before the matching
 ``optimizer.step()``, so the G exchange overlaps the whole D forward/backward (the D step only uses
 ``fake_H.detach()`` computed before the G update, exactly as in the reference).
+
+Launch economy (the step is a few thousand small launches): each network sees its two operands in ONE pass
+(``forward_pair``: per-operand BatchNorm statistics), the losses are single launches that also produce their
+gradients (``losses``), and on one GPU the D step is enqueued on a second stream under the G backward.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -44,7 +50,6 @@ class ESRGANPlusStep:
         self.log = {}
         self.fake_H = None
         # single-GPU: enqueue the D step on a second stream under the G backward (ESR_TRAIN_OVERLAP=0: in sequence)
-        import os
         self.overlap_d_step = os.environ.get('ESR_TRAIN_OVERLAP', '1') != '0'
 
     def _side(self, dev):
