@@ -513,7 +513,7 @@ int esr_graph_destroy(esr_graph_t g);
 int esr_run_ops_timed(const esr_op* ops, int32_t n, esr_stream_t stream, float* ms_out);
 
 const char* esr_last_error(void);
-int esr_abi_version(void);
+int esr_abi_version(void);   /* 2 (round 2: esr_bn.groups / num_batches_tracked, esr_l1_loss, esr_ragan_loss, ESR_OPF_SIDE_FREE) */
 size_t esr_sizeof_op(void);
 
 #ifdef __cplusplus
