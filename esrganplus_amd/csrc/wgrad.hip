@@ -432,7 +432,7 @@ __global__ __launch_bounds__((Wg16Mode<S, UPS>::NWV * 64), 2) void wgrad16_kerne
   wgrad16_body<KS, S, UPS, NCO, T0, NT, PACK>(p, rows_per_wg, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-constexpr int WG_BATCH_MAX = 8;
+constexpr int WG_BATCH_MAX = 18;   // an RRDB: 3 x 6 (kernel arguments: 3 KB of 4)
 // ---- several independent 3x3/s1 and 1x1 wgrads in ONE launch.  At training sizes (16 x 32x32) one
 // conv's wgrad is ~64 workgroups of mostly idle waves and ~25 us of pure latency; the six convs of a
 // residual dense block (same saved input, six gradient slices) fill the chip together.
