@@ -1,3 +1,5 @@
+"""bench.py's fwd_bwd probe on its own (batch 16 of 128x128 LR, fp16 train-mode forward + backward): the command
+the rocprofv3 kernel traces / PMC passes of the backward were taken with.  Usage (GPU box): python tools/fwd_bwd_probe.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench, argparse
