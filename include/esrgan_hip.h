@@ -94,7 +94,9 @@ typedef struct esr_conv {
   float* nchw_out;     /* [B][nchw_out_c][H][W] */
   int32_t debug_flags; /* measurement only: 1 = skip epilogue, 2 = skip MFMAs, 4 = skip activation DMA;
                           test hooks (results valid): 64 = force the plain K loop, 128 = force the hand-pipelined
-                          K loop of the 32-cout 3x3 conv (default: pipelined up to 256 tiles) */
+                          K loop of the 32-cout 3x3 conv (default: pipelined up to 256 tiles), 256 = keep 16-row
+                          tiles (default: fp16 3x3/s1 convs whose 16-row grid x cout blocks is <= 128 / <= 384
+                          workgroups, or whose map has <= 4 / <= 8 rows, run on 4- / 8-row tiles — same results) */
   int32_t mask_cb_begin; /* mask/out2 apply to cout blocks >= this one, indexed from it */
   float gamma;          /* third stage (backward chains): out3 = v * gamma * (1 + sigma*z3) */
   uint32_t layer3;      /* philox stream id of z3 (0xFFFFFFFF = no noise on out3) */
