@@ -76,12 +76,25 @@ class ESRGANPlusStep:
         for p in netD.parameters():
             p.requires_grad = False
         self.optimizer_G.zero_grad(set_to_none=True)
+        early_real = self.overlap_d_step and DP.world_size() == 1 and var_L.is_cuda
+        if early_real:
+            # netF(var_H) does not depend on G: on the second stream, under the generator's forward
+            main0 = torch.cuda.current_stream()
+            side0 = self._side(var_L.device)
+            side0.wait_stream(main0)
+            with torch.cuda.stream(side0), torch.no_grad():
+                real_fea = netF(var_H)
+            real_fea.record_stream(main0)
         fake_H = netG(var_L, z=z) if z is not None else netG(var_L)
         self.fake_H = fake_H
         l_g_pix = LS.l1_loss(fake_H, var_H, self.l_pix_w)
         # both operands of each network in ONE pass (forward_pair: per-half BatchNorm statistics, the detached
         # ``real`` half costs no backward) — the reference's call order fake, real is the group order
-        fake_fea, real_fea = netF.forward_pair(fake_H, var_H)
+        if early_real:
+            fake_fea = netF(fake_H)
+            main0.wait_stream(side0)
+        else:
+            fake_fea, real_fea = netF.forward_pair(fake_H, var_H)
         l_g_fea = LS.l1_loss(fake_fea, real_fea, self.l_fea_w)
         pred_g_fake, pred_d_real = netD.forward_pair(fake_H, var_ref)
         l_g_gan, _ = LS.ragan_loss(pred_d_real, pred_g_fake, False, True, self.l_gan_w, mean)
