@@ -707,7 +707,13 @@ int dispatch(const esr_conv& p, hipStream_t st) {
     // (one cout block per wave with two workgroups per CU measured slower: 0.49 vs 0.43 ms for both up-convs)
     return cbk == 1 ? launch<T, 2, 1, 3, 2, 1, 4, 1, true, false>(p, st) : launch<T, 2, 1, 3, 2, 1, 4, 2, true, false>(p, st);
   }
-  if (p.ks == 4 && p.stride == 2 && !p.upsample) return launch<T, 4, 2, 0, 2, 1, 4, 1, false, false>(p, st);
+  if (p.ks == 4 && p.stride == 2 && !p.upsample) {
+    // 8 waves = 2 row groups x 4 cout groups; with at most two cout blocks (the up-convs' adjoint, the
+    // discriminator's first stride-2 conv) half of those would idle: 2 row x 2 column x 2 cout groups on an 8x64 tile
+    static const bool wide = [] { const char* e = getenv("ESR_S2_WIDE"); return !e || atoi(e) != 0; }();
+    if (wide && cbk <= 2 && p.W > 32) return launch<T, 4, 2, 0, 2, 2, 2, 1, false, false>(p, st);
+    return launch<T, 4, 2, 0, 2, 1, 4, 1, false, false>(p, st);
+  }
   if (p.ks == 1 && p.stride == 1 && !p.upsample) {
     return cbk == 1 ? launch<T, 1, 1, 0, 4, 1, 1, 1, true, false>(p, st) : launch<T, 1, 1, 0, 4, 1, 1, 2, true, false>(p, st);
   }
