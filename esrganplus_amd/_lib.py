@@ -120,15 +120,17 @@ class esr_adam(C.Structure):
                 ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),
                 ('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
                 ('bc1', C.c_float), ('bc2', C.c_float), ('grad_scale', C.c_float), ('weight_decay', C.c_float),
-                ('amp_state', C.c_void_p)]
+                ('amp_state', C.c_void_p), ('amp_slot', C.c_int32), ('_pad2', C.c_int32), ('step_count', C.c_void_p),
+                ('beta1_d', C.c_double), ('beta2_d', C.c_double)]
 
 
-AMP_CHECK, AMP_UPDATE = 0, 1
+AMP_CHECK, AMP_UPDATE, AMP_COUNT = 0, 1, 2
 
 
 class esr_amp(C.Structure):
     _fields_ = [('mode', C.c_int32), ('interval', C.c_int32), ('state', C.c_void_p), ('grad', C.c_void_p),
-                ('n', C.c_int64), ('growth', C.c_float), ('backoff', C.c_float)]
+                ('n', C.c_int64), ('growth', C.c_float), ('backoff', C.c_float),
+                ('slot', C.c_int32), ('_pad', C.c_int32), ('step_count', C.c_void_p)]
 
 
 class esr_resample(C.Structure):
@@ -167,7 +169,8 @@ class esr_ragan_loss(C.Structure):
     _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('grad_x', C.c_void_p), ('grad_y', C.c_void_p),
                 ('loss', C.c_void_p), ('mean_x', C.c_void_p), ('mean_y', C.c_void_p),
                 ('bce_x', C.c_void_p), ('bce_y', C.c_void_p), ('n', C.c_int32),
-                ('tx', C.c_float), ('ty', C.c_float), ('weight', C.c_float)]
+                ('tx', C.c_float), ('ty', C.c_float), ('weight', C.c_float),
+                ('mode', C.c_int32), ('_pad', C.c_int32), ('sums', C.c_void_p), ('ext', C.c_void_p)]
 
 
 class esr_img_metrics(C.Structure):

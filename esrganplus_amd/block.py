@@ -8,8 +8,9 @@ Same factory names, constructor arguments, module tree and state-dict keys as th
 composite modules (``ResidualDenseBlock_5C``, ``RRDB``, and ``RRDBNet`` in architecture.py) execute
 as fused HIP launch plans (engine.py -> libesrgan_hip.so) and raise on CPU tensors.
 
-Out of scope here exactly as SURVEY.md §2.1 row 1 marks them: ResNetBlock, pixelshuffle_block,
-ConcatBlock, minibatch_std_concat_layer, reflect/replicate padding, prelu, instance norm, NAC mode.
+``ResNetBlock`` and ``pixelshuffle_block`` (the SRResNet siblings) are chains of ``Conv2dHIP``
+one-layer plans further down.  Out of scope exactly as SURVEY.md §2.1 row 1 marks them: ConcatBlock,
+minibatch_std_concat_layer, reflect/replicate padding, prelu, instance norm, NAC / CNAC modes.
 """
 from collections import OrderedDict
 

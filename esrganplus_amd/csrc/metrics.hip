@@ -13,9 +13,11 @@ __device__ __forceinline__ int quant8(float v, float lo, float hi) {
   v = (v - lo) / (hi - lo);
   return (int)rintf(v * 255.0f);
 }
-// MATLAB-style Y of a uint8 BGR pixel, rounded (data/util.py:150-168 bgr2ycbcr, only_y, uint8 branch)
-__device__ __forceinline__ int y_of_bgr(int b, int g, int r) {
-  return (int)rint(((double)b * 24.966 + (double)g * 128.553 + (double)r * 65.481) / 255.0 + 16.0);
+// MATLAB-style Y of a uint8 BGR pixel, NOT rounded: the validation script converts the FLOAT images
+// (codes/test.py:81-86: bgr2ycbcr(sr_img / 255., only_y=True) -> data/util.py:150-168, float branch), so PSNR_Y / SSIM_Y
+// compare unrounded luma values  (B 24.966 + G 128.553 + R 65.481) / 255 + 16  in [16, 235]
+__device__ __forceinline__ double y_of_bgr(int b, int g, int r) {
+  return ((double)b * 24.966 + (double)g * 128.553 + (double)r * 65.481) / 255.0 + 16.0;
 }
 
 // one thread per pixel: writes the HWC BGR uint8 image(s) and, when y_only, the Y planes
@@ -34,7 +36,7 @@ __global__ void tensor2img_kernel(const esr_img_metrics p) {
       img[pix * 3 + 0] = (uint8_t)q[2];   // BGR (util.py:86: img_np[[2, 1, 0], :, :])
       img[pix * 3 + 1] = (uint8_t)q[1];
       img[pix * 3 + 2] = (uint8_t)q[0];
-      if (p.y_only) (s == 0 ? p.y_sr : p.y_hr)[pix] = (uint8_t)y_of_bgr(q[2], q[1], q[0]);
+      if (p.y_only) (s == 0 ? p.y_sr : p.y_hr)[pix] = y_of_bgr(q[2], q[1], q[0]);
     } else {
       img[pix] = (uint8_t)q[0];
     }
@@ -55,17 +57,17 @@ __device__ __forceinline__ void block_add(double v, double* dst, double* red) {
 }
 
 // planes compared: the NP channels of the HWC images, or the single Y plane
-__device__ __forceinline__ int px(const uint8_t* img, int np, int c, int64_t pix) { return img[pix * np + c]; }
+template <typename E> __device__ __forceinline__ double px(const E* img, int np, int c, int64_t pix) { return (double)img[pix * np + c]; }
 
 // sum of squared differences over the cropped region (util.py:107-114 on the cropped uint8 images)
-__global__ void sse_kernel(const esr_img_metrics p, const uint8_t* a, const uint8_t* b, int np) {
+template <typename E> __global__ void sse_kernel(const esr_img_metrics p, const E* a, const E* b, int np) {
   __shared__ double red[8];
   const int x = blockIdx.x * blockDim.x + threadIdx.x + p.crop, y = blockIdx.y + p.crop;
   double s = 0.0;
   if (x < p.W - p.crop) {
     const int64_t pix = (int64_t)y * p.W + x;
     for (int c = 0; c < np; ++c) {
-      const double d = (double)(px(a, np, c, pix) - px(b, np, c, pix));
+      const double d = px(a, np, c, pix) - px(b, np, c, pix);
       s += d * d;
     }
   }
@@ -73,7 +75,7 @@ __global__ void sse_kernel(const esr_img_metrics p, const uint8_t* a, const uint
 }
 
 // SSIM (util.py:117-158): 11x11 Gaussian window (sigma 1.5), valid region of the cropped planes, fp64
-__global__ void ssim_kernel(const esr_img_metrics p, const uint8_t* a, const uint8_t* b, int np) {
+template <typename E> __global__ void ssim_kernel(const esr_img_metrics p, const E* a, const E* b, int np) {
   __shared__ double red[8];
   const int ow = p.W - 2 * p.crop - 10;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, c = blockIdx.z;
@@ -84,7 +86,7 @@ __global__ void ssim_kernel(const esr_img_metrics p, const uint8_t* a, const uin
       const int64_t row = (int64_t)(y + p.crop + i) * p.W + x + p.crop;
       for (int j = 0; j < 11; ++j) {
         const double w = p.win[i] * p.win[j];
-        const double u = (double)px(a, np, c, row + j), t = (double)px(b, np, c, row + j);
+        const double u = px(a, np, c, row + j), t = px(b, np, c, row + j);
         m1 += w * u; m2 += w * t; s11 += w * u * u; s22 += w * t * t; s12 += w * u * t;
       }
     }
@@ -109,12 +111,14 @@ extern "C" int esr_image_metrics(const esr_img_metrics* p, esr_stream_t stream) 
     const int ch = p->H - 2 * p->crop, cw = p->W - 2 * p->crop;
     if (ch <= 0 || cw <= 0) { esr_set_error("esr_image_metrics: crop leaves no pixels"); return ESR_ERR_INVALID; }
     if (hipMemsetAsync(p->out, 0, 4 * sizeof(double), st) != hipSuccess) { esr_set_error("esr_image_metrics: memset failed"); return ESR_ERR_LAUNCH; }
-    const uint8_t* a = p->y_only ? p->y_sr : p->img_sr;
-    const uint8_t* b = p->y_only ? p->y_hr : p->img_hr;
-    const int np = p->y_only ? 1 : p->C;
-    hipLaunchKernelGGL(sse_kernel, dim3((cw + 255) / 256, ch), dim3(256), 0, st, *p, a, b, np);
-    if (ch > 10 && cw > 10)
-      hipLaunchKernelGGL(ssim_kernel, dim3((cw - 10 + 255) / 256, ch - 10, np), dim3(256), 0, st, *p, a, b, np);
+    const bool ssim = ch > 10 && cw > 10;
+    if (p->y_only) {
+      hipLaunchKernelGGL(sse_kernel<double>, dim3((cw + 255) / 256, ch), dim3(256), 0, st, *p, (const double*)p->y_sr, (const double*)p->y_hr, 1);
+      if (ssim) hipLaunchKernelGGL(ssim_kernel<double>, dim3((cw - 10 + 255) / 256, ch - 10, 1), dim3(256), 0, st, *p, (const double*)p->y_sr, (const double*)p->y_hr, 1);
+    } else {
+      hipLaunchKernelGGL(sse_kernel<uint8_t>, dim3((cw + 255) / 256, ch), dim3(256), 0, st, *p, (const uint8_t*)p->img_sr, (const uint8_t*)p->img_hr, p->C);
+      if (ssim) hipLaunchKernelGGL(ssim_kernel<uint8_t>, dim3((cw - 10 + 255) / 256, ch - 10, p->C), dim3(256), 0, st, *p, (const uint8_t*)p->img_sr, (const uint8_t*)p->img_hr, p->C);
+    }
   }
   return esr_check_launch("esr_image_metrics");
 }

@@ -318,10 +318,16 @@ __global__ __launch_bounds__(256) void adam_kernel(const esr_adam a) {
   const esr_adam_block blk = a.blocks[blockIdx.x];
   const esr_adam_entry e = a.entries[blk.entry];
   const int64_t end = min((int64_t)blk.first + ESR_ADAM_BLOCK_ELEMS, e.n);
-  const float step = a.lr / a.bc1, rs2 = rsqrtf(a.bc2), omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
+  float bc1 = a.bc1, bc2 = a.bc2;
+  if (a.step_count) {                      // device step counter: only APPLIED steps age the bias correction
+    const double t = (double)a.step_count[0];
+    bc1 = (float)(1.0 - pow(a.beta1_d, t));
+    bc2 = (float)(1.0 - pow(a.beta2_d, t));
+  }
+  const float step = a.lr / bc1, rs2 = rsqrtf(bc2), omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
   float gs = a.grad_scale;
   if (a.amp_state) {                       // dynamic loss scaling: skip the step on overflow, else un-scale
-    if (a.amp_state[1] != 0.f) return;
+    if (a.amp_state[4 + a.amp_slot] != 0.f) return;
     gs /= a.amp_state[0];
   }
   for (int64_t i = blk.first + threadIdx.x; i < end; i += 256) {
@@ -344,18 +350,25 @@ __global__ __launch_bounds__(256) void amp_check_kernel(const esr_amp a) {
     const float g = a.grad[i];
     bad |= !(fabsf(g) <= 3.4028234e38f);        // inf or nan
   }
-  if (__any(bad) && (threadIdx.x & 63) == 0) a.state[1] = 1.f;   // benign race: every writer stores the same value
+  if (__any(bad) && (threadIdx.x & 63) == 0) a.state[4 + a.slot] = 1.f;   // benign race: every writer stores the same value
+}
+__global__ void amp_count_kernel(const esr_amp a) {
+  if (a.state[4 + a.slot] == 0.f) a.step_count[0] += 1.f;
 }
 __global__ void amp_update_kernel(const esr_amp a) {
   float s = a.state[0], good = a.state[2];
-  if (a.state[1] != 0.f) { s *= a.backoff; good = 0.f; }
+  const bool found = a.state[4] != 0.f || a.state[5] != 0.f || a.state[6] != 0.f || a.state[7] != 0.f;
+  if (found) { s *= a.backoff; good = 0.f; }
   else if (++good >= (float)a.interval) { s *= a.growth; good = 0.f; }
   a.state[0] = s; a.state[1] = 0.f; a.state[2] = good;
+  a.state[4] = a.state[5] = a.state[6] = a.state[7] = 0.f;
 }
 }  // namespace
 
 extern "C" int esr_amp_step(const esr_amp* p, esr_stream_t stream) {
   if (!p || !p->state || (p->mode == ESR_AMP_CHECK && (!p->grad || p->n <= 0)) ||
+      ((p->mode == ESR_AMP_CHECK || p->mode == ESR_AMP_COUNT) && (p->slot < 0 || p->slot > 3)) ||
+      (p->mode == ESR_AMP_COUNT && !p->step_count) ||
       (p->mode == ESR_AMP_UPDATE && (p->interval <= 0 || !(p->growth >= 1.f) || !(p->backoff > 0.f && p->backoff <= 1.f)))) {
     esr_set_error("esr_amp_step: invalid arguments");
     return ESR_ERR_INVALID;
@@ -365,13 +378,15 @@ extern "C" int esr_amp_step(const esr_amp* p, esr_stream_t stream) {
     hipLaunchKernelGGL(amp_check_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, *p);
   } else if (p->mode == ESR_AMP_UPDATE) {
     hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, *p);
+  } else if (p->mode == ESR_AMP_COUNT) {
+    hipLaunchKernelGGL(amp_count_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, *p);
   } else { esr_set_error("esr_amp_step: bad mode %d", p->mode); return ESR_ERR_INVALID; }
   return esr_check_launch("amp_kernel");
 }
 
 extern "C" int esr_adam_step(const esr_adam* p, esr_stream_t stream) {
   if (!p || !p->entries || !p->blocks || p->nblocks <= 0 || !p->grad || !p->exp_avg || !p->exp_avg_sq ||
-      !(p->bc1 > 0.f) || !(p->bc2 > 0.f)) {
+      (!p->step_count && (!(p->bc1 > 0.f) || !(p->bc2 > 0.f))) || (p->amp_state && (p->amp_slot < 0 || p->amp_slot > 3))) {
     esr_set_error("esr_adam_step: invalid arguments");
     return ESR_ERR_INVALID;
   }

@@ -5,10 +5,13 @@ device, so eight GPUs are not fed by eight Python processes looping over image r
 * ``imresize`` — MATLAB-compatible bicubic resize with antialiasing (util.py:276-343 /
   ``imresize_np`` 345-412): output size ceil(in*scale), cubic kernel of width 4 (4/scale when
   shrinking), weights normalised per output sample, symmetric border, H pass then W pass, float32.
-  The tiny weight / index tables are built on the host exactly as the reference builds them (same
-  float32 torch ops); the two gather passes are HIP launches (``esr_resample_axis``).
-* ``paired_random_crop`` / ``augment`` — the crop + flip/rot logic with the reference's use of
-  Python's ``random`` (same call order), applied to NCHW device tensors."""
+  The tiny weight / index tables are derived on the host in float64 from the definition of the resize
+  (``resample_tables``) and pinned to the reference's outputs by fixtures (<= 2e-6); the two gather passes are
+  HIP launches (``esr_resample_axis``).
+* ``paired_random_crop`` / ``augment`` — the crop + flip/rot logic on NCHW device tensors, one window / one
+  set of coin flips per sample.  ``crop_and_augment`` draws from Python's ``random`` in the reference's
+  per-item order (randint, randint, then the three coin flips, sample by sample: LRHR_dataset.py:96-110);
+  the two separate helpers draw all windows first, then all flips."""
 import ctypes as C
 import math
 import random
@@ -19,42 +22,49 @@ from . import _lib as L
 from . import engine as E
 
 
-def _cubic(x):
-    """util.py:213-218."""
-    ax = torch.abs(x)
-    ax2, ax3 = ax ** 2, ax ** 3
-    return ((1.5 * ax3 - 2.5 * ax2 + 1) * (ax <= 1).type_as(ax)
-            + (-0.5 * ax3 + 2.5 * ax2 - 4 * ax + 2) * ((ax > 1) * (ax <= 2)).type_as(ax))
+def _keys_kernel(t):
+    """Keys' piecewise-cubic interpolation kernel with a = -1/2 (what MATLAB's bicubic `imresize` and the
+    reference's `cubic`, util.py:213-218, evaluate): support [-2, 2], C1, reproduces quadratics.
+    Horner form on |t|, float64."""
+    import numpy as np
+    a = np.abs(np.asarray(t, dtype=np.float64))
+    near = (1.5 * a - 2.5) * a * a + 1.0                     # |t| <= 1
+    far = ((-0.5 * a + 2.5) * a - 4.0) * a + 2.0             # 1 < |t| <= 2
+    return np.where(a <= 1.0, near, np.where(a <= 2.0, far, 0.0))
 
 
 def resample_tables(in_length, scale, antialiasing=True):
-    """Weights and SOURCE indices of one axis (util.py:221-273 with the symmetric padding of
-    276-343 folded into the index table).  -> (weights [out, P] float32, src [out, P] int32, out_len)."""
-    out_length = math.ceil(in_length * scale)
-    kernel_width = 4.0
-    shrink = scale < 1 and antialiasing
-    if shrink:
-        kernel_width = kernel_width / scale
-    x = torch.linspace(1, out_length, out_length)
-    u = x / scale + 0.5 * (1 - 1 / scale)
-    left = torch.floor(u - kernel_width / 2)
-    P = math.ceil(kernel_width) + 2
-    indices = left.view(out_length, 1).expand(out_length, P) + torch.linspace(0, P - 1, P).view(1, P).expand(
-        out_length, P)
-    dist = u.view(out_length, 1).expand(out_length, P) - indices
-    weights = scale * _cubic(dist * scale) if shrink else _cubic(dist)
-    weights = weights / torch.sum(weights, 1).view(out_length, 1).expand(out_length, P)
-    zero_cols = torch.sum((weights == 0), 0)
-    if not math.isclose(zero_cols[0], 0, rel_tol=1e-6):
-        indices, weights = indices.narrow(1, 1, P - 2), weights.narrow(1, 1, P - 2)
-    if not math.isclose(zero_cols[-1], 0, rel_tol=1e-6):
-        indices, weights = indices.narrow(1, 0, P - 2), weights.narrow(1, 0, P - 2)
-    sym_s = int(-indices.min() + 1)
-    # 1-based input coordinate c (possibly < 1 or > in_length) -> mirrored 0-based source index
-    c = indices.long()
-    src = torch.where(c < 1, -c, torch.where(c > in_length, 2 * in_length - c + 1 - 1, c - 1))
-    assert sym_s >= 0 and int(src.min()) >= 0 and int(src.max()) < in_length
-    return weights.contiguous().float(), src.to(torch.int32).contiguous(), out_length
+    """Weights and SOURCE indices of one axis of the MATLAB-style resize (the function util.py:221-343
+    computes; derived here from its definition, in float64, not from the reference's float32 tensor code):
+
+      * output sample o (0-based) sits at input coordinate  c(o) = (o + 0.5) / scale - 0.5   (pixel centres
+        of the two grids coincide at the image borders);
+      * the footprint is Keys' kernel stretched by s = 1/scale when shrinking with antialiasing (a low-pass of
+        width 4/scale), unstretched otherwise:  w(o, i) = k((c(o) - i) / s) / s, then normalised per o;
+      * taps run over the integer positions within half a footprint of c(o); positions outside the image are
+        mirrored about the border pixel EDGES (period 2 n: -1 -> 0, n -> n - 1);
+      * columns that are zero for every output sample are dropped, so the table is [out, P] with P the
+        widest real support.
+    -> (weights [out, P] float32, src [out, P] int32, out_len)"""
+    import numpy as np
+    n = int(in_length)
+    out_length = math.ceil(n * scale)
+    stretch = 1.0 / scale if (scale < 1 and antialiasing) else 1.0
+    half = 2.0 * stretch                                          # half width of the footprint
+    o = np.arange(out_length, dtype=np.float64)
+    centre = (o + 0.5) / scale - 0.5
+    first = np.floor(centre - half).astype(np.int64) + 1          # first integer position that can fall inside
+    ntap = int(math.ceil(2.0 * half)) + 1
+    pos = first[:, None] + np.arange(ntap, dtype=np.int64)[None, :]
+    w = _keys_kernel((centre[:, None] - pos) / stretch) / stretch
+    w /= w.sum(axis=1, keepdims=True)
+    live = np.nonzero(np.any(w != 0.0, axis=0))[0]                # trim all-zero columns at either end
+    pos, w = pos[:, live[0]:live[-1] + 1], w[:, live[0]:live[-1] + 1]
+    m = np.mod(pos, 2 * n)                                        # mirror: period 2n
+    src = np.where(m < n, m, 2 * n - 1 - m)
+    assert src.min() >= 0 and src.max() < n
+    return (torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)),
+            torch.from_numpy(np.ascontiguousarray(src, dtype=np.int32)), out_length)
 
 
 def _axis_pass(x, axis, w, idx, out_len, stream):
@@ -96,8 +106,9 @@ def imresize(img, scale, antialiasing=True):
 
 def paired_random_crop(lr, hr, lr_size, scale):
     """LRHR_dataset.py:96-103 on NCHW batches.  The reference's ``__getitem__`` draws one window PER SAMPLE
-    (two ``random.randint`` calls each, in sample order); a batch does the same — B independent windows, the
-    same consumption of Python's ``random`` stream as B dataset items.  A 3-D tensor is one sample."""
+    (two ``random.randint`` calls each, in sample order); a batch does the same — B independent windows.  The
+    stream of Python's ``random`` is consumed as B consecutive crops would consume it; use ``crop_and_augment``
+    for the reference's interleaved crop / flip order.  A 3-D tensor is one sample."""
     single = lr.dim() == 3
     if single:
         lr, hr = lr[None], hr[None]
@@ -117,7 +128,8 @@ def paired_random_crop(lr, hr, lr_size, scale):
 
 def augment(img_list, hflip=True, rot=True):
     """util.py:94-106: horizontal flip, vertical flip, transpose.  For NCHW batches the three coin flips are
-    drawn per SAMPLE (as B dataset items would), applied to the same sample of every tensor in ``img_list``;
+    drawn per SAMPLE, applied to the same sample of every tensor in ``img_list`` (``crop_and_augment`` keeps the
+    reference's crop-then-flip draw order per item);
     [C,H,W] tensors are one sample.  Batches need square images when ``rot`` is on (a transposed sample must
     stack with an un-transposed one), which the reference's fixed-size crops guarantee."""
     if img_list[0].dim() == 3:
@@ -139,3 +151,22 @@ def augment(img_list, hflip=True, rot=True):
             t = t.transpose(-1, -2)
         return t
     return [torch.stack([_aug(t[b], flags[b]) for b in range(B)]) for t in img_list]
+
+
+def crop_and_augment(lr, hr, lr_size, scale, hflip=True, rot=True):
+    """One training batch exactly as B consecutive ``LRHRDataset.__getitem__`` calls would cut it
+    (LRHR_dataset.py:96-110): per sample, in order, the crop window (``randint`` for the row, ``randint`` for the
+    column) and then the flip / transpose coins (util.py:94-106; a disabled option draws nothing) — so a seeded
+    run picks the reference's windows and flips.  lr / hr: NCHW batches (or one CHW sample)."""
+    single = lr.dim() == 3
+    if single:
+        lr, hr = lr[None], hr[None]
+    outl, outh = [], []
+    for b in range(lr.shape[0]):
+        l, h = paired_random_crop(lr[b], hr[b], lr_size, scale)
+        l, h = augment([l, h], hflip, rot)
+        outl.append(l)
+        outh.append(h)
+    if single:
+        return outl[0], outh[0]
+    return torch.stack(outl), torch.stack(outh)

@@ -3,13 +3,15 @@ SRRaGAN_model.py:124-131) and the relativistic-average GAN term built from ``GAN
 (codes/models/modules/loss.py:6-38; SRRaGAN_model.py:133-137, 150-156).  Each forward launch also produces the
 gradient w.r.t. its differentiable operands; backward is one multiply by the upstream scalar.
 
-Same numbers as the torch formulas (tests/test_gpu_losses.py); anything the kernels do not cover (CPU tensors,
-non-fp32, misaligned views) takes the torch formulas.
+Same numbers as the torch formulas (tests/test_gpu_losses.py).  No fallback: operands the kernels do not cover (CPU
+tensors, non-fp32, shape mismatch, a target that needs a gradient) raise ``HipExtensionError``; non-contiguous or
+16-byte-misaligned views are handled (a contiguous copy / the kernel's scalar path).  Data-parallel runs keep the
+relativistic means GLOBAL: the same kernel in three modes with two scalar all-reduces in between
+(``ragan_loss(..., global_mean=True)``).
 """
 import ctypes as C
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib as L
 from . import engine as E
@@ -24,8 +26,16 @@ def _dev_scratch(dev):
     return t
 
 
-def _fusable(*ts):
-    return all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+def _require(ok, what):
+    if not ok:
+        raise L.HipExtensionError('esrganplus_amd.losses: ' + what + ' (the fused loss kernels take fp32 tensors on '
+                                  'the MI355X; there is no torch fallback)')
+
+
+def _check_operands(name, *ts):
+    for t in ts:
+        _require(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32,
+                 '%s: operand is %s / %s' % (name, getattr(t, 'device', type(t)), getattr(t, 'dtype', '')))
 
 
 class _L1Fn(torch.autograd.Function):
@@ -49,9 +59,9 @@ class _L1Fn(torch.autograd.Function):
 
 def l1_loss(a, b, weight=1.0):
     """``weight * F.l1_loss(a, b)``; the gradient flows to ``a`` only (``b`` is the target: var_H / real_fea)."""
-    if (not _fusable(a, b) or a.shape != b.shape or b.requires_grad or a.data_ptr() % 16 or b.data_ptr() % 16
-            or not a.is_contiguous() or not b.is_contiguous()):
-        return weight * F.l1_loss(a, b)
+    _check_operands('l1_loss', a, b)
+    _require(a.shape == b.shape, 'l1_loss: shapes %s vs %s' % (tuple(a.shape), tuple(b.shape)))
+    _require(not b.requires_grad, 'l1_loss: the target must not require a gradient')
     return _L1Fn.apply(a, b, float(weight))
 
 
@@ -82,15 +92,66 @@ class _RaGANFn(torch.autograd.Function):
                 None, None, None)
 
 
-def ragan_loss(x, y, x_is_real, y_is_real, weight=1.0, mean=None):
+class _RaGANGlobalFn(torch.autograd.Function):
+    """The same loss with the batch means taken over ALL ranks (SRRaGAN_model.py:136-137,151-152: under the
+    reference's DataParallel the loss is formed on the gathered outputs).  Three launches of the one
+    kernel; between them the rank-local scalar sums are all-reduced: [sum x, sum y, n] before the loss,
+    [sum (sigmoid(z1) - tx), sum (sigmoid(z2) - ty)] before the gradients (every rank's loss sees the means, and the
+    parameter gradients are averaged over ranks afterwards — GradExchange — which together reproduce the gradient of
+    the single global-batch loss)."""
+
+    @staticmethod
+    def forward(ctx, x, y, tx, ty, weight):
+        import torch.distributed as dist
+        x_, y_ = x.detach().contiguous().view(-1), y.detach().contiguous().view(-1)
+        dev = x.device
+        st = C.c_void_p(E.current_stream())
+        ext = torch.zeros(5, dtype=torch.float32, device=dev)       # sum x, sum y, n | D1, D2 (all ranks)
+        ext[2] = float(x_.numel())
+        p = L.esr_ragan_loss()
+        p.x, p.y, p.n = x_.data_ptr(), y_.data_ptr(), x_.numel()
+        p.tx, p.ty, p.weight = tx, ty, weight
+        p.mode, p.sums = 1, ext.data_ptr()
+        L.check(L.lib().esr_ragan_loss_forward(C.byref(p), st), 'esr_ragan_loss_forward')
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(ext[0:3])
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        dsum = torch.zeros(2, dtype=torch.float32, device=dev)
+        p.mode, p.sums, p.ext = 2, dsum.data_ptr(), ext.data_ptr()
+        p.loss, p.mean_x, p.mean_y = loss.data_ptr(), out.data_ptr(), out.data_ptr() + 4
+        p.bce_x, p.bce_y = out.data_ptr() + 8, out.data_ptr() + 12
+        L.check(L.lib().esr_ragan_loss_forward(C.byref(p), st), 'esr_ragan_loss_forward')
+        ctx.need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        ctx.keep = (x_, y_, ext, dsum, tx, ty, weight, x.shape, y.shape)
+        ctx.mark_non_differentiable(out)
+        return loss, out
+
+    @staticmethod
+    def backward(ctx, g, _unused):
+        import torch.distributed as dist
+        x_, y_, ext, dsum, tx, ty, weight, sx, sy = ctx.keep
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(dsum)
+        ext[3:5] = dsum
+        gx = torch.empty_like(x_) if ctx.need[0] else None
+        gy = torch.empty_like(y_) if ctx.need[1] else None
+        p = L.esr_ragan_loss()
+        p.x, p.y, p.n = x_.data_ptr(), y_.data_ptr(), x_.numel()
+        p.tx, p.ty, p.weight = tx, ty, weight
+        p.mode, p.ext = 3, ext.data_ptr()
+        p.grad_x = gx.data_ptr() if gx is not None else None
+        p.grad_y = gy.data_ptr() if gy is not None else None
+        L.check(L.lib().esr_ragan_loss_forward(C.byref(p), C.c_void_p(E.current_stream())), 'esr_ragan_loss_forward')
+        return ((gx * g).view(sx) if gx is not None else None, (gy * g).view(sy) if gy is not None else None,
+                None, None, None)
+
+
+def ragan_loss(x, y, x_is_real, y_is_real, weight=1.0, global_mean=False):
     """``weight * (BCE(x - mean(y), x_is_real) + BCE(y - mean(x), y_is_real)) / 2`` and the two means
-    (returned as ``(loss, aux)`` with ``aux = [mean_x, mean_y, BCE_x, BCE_y]``, detached).  ``mean``: a differentiable batch mean other than ``torch.mean``
-    (dp.global_mean over all ranks) — then the torch formulas run, the fused kernel only knows the local batch."""
-    if mean is not None or not _fusable(x, y) or x.numel() != y.numel():
-        m = mean if mean is not None else torch.mean
-        t = lambda v, real: torch.ones_like(v) if real else torch.zeros_like(v)
-        lx = F.binary_cross_entropy_with_logits(x - m(y), t(x, x_is_real))
-        ly = F.binary_cross_entropy_with_logits(y - m(x), t(y, y_is_real))
-        aux = torch.stack([x.detach().mean(), y.detach().mean(), lx.detach(), ly.detach()])
-        return weight * (lx + ly) / 2, aux
-    return _RaGANFn.apply(x, y, 1.0 if x_is_real else 0.0, 1.0 if y_is_real else 0.0, float(weight))
+    (returned as ``(loss, aux)`` with ``aux = [mean_x, mean_y, BCE_x, BCE_y]``, detached).  ``global_mean``: the means
+    run over the batch of ALL ranks (data-parallel training; == the local batch on one rank)."""
+    _check_operands('ragan_loss', x, y)
+    _require(x.numel() == y.numel(), 'ragan_loss: %d vs %d logits' % (x.numel(), y.numel()))
+    fn = _RaGANGlobalFn if global_mean else _RaGANFn
+    return fn.apply(x, y, 1.0 if x_is_real else 0.0, 1.0 if y_is_real else 0.0, float(weight))

@@ -127,7 +127,7 @@ def _metrics_call(sr, hr, crop, y_only, min_max):
         p.hr, p.img_hr, p.out = b.data_ptr(), img_hr.data_ptr(), out.data_ptr()
         keep.append(b)
     if y_only:
-        ys = torch.empty((2, H, W), dtype=torch.uint8, device=dev)
+        ys = torch.empty((2, H, W), dtype=torch.float64, device=dev)     # unrounded luma (codes/test.py:81-86)
         p.y_sr, p.y_hr = ys[0].data_ptr(), ys[1].data_ptr()
         keep.append(ys)
     k1 = gaussian_window()[5] / gaussian_window()[5].sum()       # the normalised 1-D kernel (outer(k, k) == window)
@@ -144,7 +144,8 @@ def device_tensor2img(t, min_max=(0, 1)):
 
 def device_psnr_ssim(sr, hr, crop=4, y_only=False, min_max=(0, 1)):
     """(PSNR, SSIM) of two (C,H,W) tensors exactly as the validation loops compute them (tensor2img both, crop
-    `crop` pixels per side, optionally MATLAB-style Y only), evaluated on the device; one small read-back."""
+    `crop` pixels per side), evaluated on the device; one small read-back.  y_only: PSNR_Y / SSIM_Y of
+    codes/test.py:81-90 — ``bgr2ycbcr(img / 255., only_y=True)`` on the FLOAT images, i.e. unrounded luma."""
     _, _, out, (C_, H, W), keep = _metrics_call(sr, hr, crop, y_only, min_max)
     o = out.cpu().numpy()                       # synchronises with the metric kernels
     planes = 1 if (y_only or C_ == 1) else C_

@@ -57,7 +57,8 @@ class FusedAdam(torch.optim.Optimizer):
                   nblocks=len(blocks),
                   exp_avg=old.get('exp_avg') if old.get('total') == total else torch.zeros(total, device=dev),
                   exp_avg_sq=old.get('exp_avg_sq') if old.get('total') == total else torch.zeros(total, device=dev),
-                  step=old.get('step', 0) if old.get('total') == total else 0, stage=None)
+                  step=old.get('step', 0) if old.get('total') == total else 0, stage=None,
+                  applied=old.get('applied') if old.get('total') == total else None)
         self._g[gi] = st
         return st
 
@@ -109,17 +110,26 @@ class FusedAdam(torch.optim.Optimizer):
                 continue
             st = self._group_state(gi, params)
             flat = self._flat_grad(st, params)
-            if scaler is not None:
-                scaler.check(flat, stream)
-            st['step'] += 1
+            st['step'] += 1                 # steps ATTEMPTED (== applied without a scaler)
             b1, b2 = group['betas']
+            slot = 0
+            if scaler is not None:
+                # per-optimizer overflow flag and a DEVICE count of the steps really applied (torch.amp.GradScaler:
+                # found_inf is tracked per optimizer, and a skipped step does not advance Adam's bias correction)
+                slot = scaler.slot_of((id(self), gi))
+                if st.get('applied') is None:
+                    st['applied'] = torch.full((1,), float(st['step'] - 1), dtype=torch.float32, device=flat.device)
+                scaler.check(flat, stream, slot)
+                scaler.count(st['applied'], stream, slot)
             a = L.esr_adam()
             a.entries, a.blocks, a.nblocks = st['entries'].data_ptr(), st['blocks'].data_ptr(), st['nblocks']
             a.grad, a.exp_avg, a.exp_avg_sq = flat.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
             a.lr, a.beta1, a.beta2, a.eps = group['lr'], b1, b2, group['eps']
             a.bc1, a.bc2 = 1.0 - math.pow(b1, st['step']), 1.0 - math.pow(b2, st['step'])
             a.grad_scale, a.weight_decay = grad_scale, group['weight_decay']
-            a.amp_state = scaler.state.data_ptr() if scaler is not None else None
+            if scaler is not None:
+                a.amp_state, a.amp_slot = scaler.state.data_ptr(), slot
+                a.step_count, a.beta1_d, a.beta2_d = st['applied'].data_ptr(), float(b1), float(b2)
             L.check(L.lib().esr_adam_step(C.byref(a), C.c_void_p(stream)), 'esr_adam_step')
         return loss
 
@@ -137,7 +147,9 @@ class FusedAdam(torch.optim.Optimizer):
                 if st is not None and id(p) in pos and st['step'] > 0:
                     k = pos[id(p)]
                     o, n = st['goff'][k], st['sizes'][k]
-                    state[idx] = {'step': torch.tensor(float(st['step'])),
+                    # under dynamic loss scaling only the APPLIED steps count (read back here, at checkpoint time)
+                    nstep = float(st['applied'].item()) if st.get('applied') is not None else float(st['step'])
+                    state[idx] = {'step': torch.tensor(nstep),
                                   'exp_avg': st['exp_avg'][o:o + n].view_as(p).clone(),
                                   'exp_avg_sq': st['exp_avg_sq'][o:o + n].view_as(p).clone()}
                 idx += 1
@@ -160,6 +172,7 @@ class FusedAdam(torch.optim.Optimizer):
                     st['exp_avg'][o:o + n].copy_(ent['exp_avg'].reshape(-1).to(st['exp_avg'].device, torch.float32))
                     st['exp_avg_sq'][o:o + n].copy_(ent['exp_avg_sq'].reshape(-1).to(st['exp_avg'].device, torch.float32))
                     st['step'] = int(float(ent['step']))
+                    st['applied'] = None           # re-seeded from `step` at the next scaled step
                 idx += 1
 
 
@@ -171,16 +184,32 @@ class DynamicLossScaler:
     overflow and doubles it after ``interval`` clean steps (the torch.amp.GradScaler policy)."""
 
     def __init__(self, device, init_scale=1024.0, growth=2.0, backoff=0.5, interval=2000):
-        self.state = torch.tensor([init_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+        # {scale, -, good steps, -, found[0..3]}: one overflow flag per optimizer (include/esrgan_hip.h, esr_amp)
+        self.state = torch.tensor([init_scale, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
         self.growth, self.backoff, self.interval = growth, backoff, interval
+        self._slots = {}
+
+    def slot_of(self, key):
+        s = self._slots.get(key)
+        if s is None:
+            if len(self._slots) >= 4:
+                raise L.HipExtensionError('DynamicLossScaler tracks at most 4 optimizers / parameter groups')
+            s = self._slots[key] = len(self._slots)
+        return s
 
     @property
     def scale(self):
         return self.state[0]            # a 0-dim DEVICE tensor: multiplying the loss by it needs no sync
 
-    def check(self, flat, stream=None):
+    def check(self, flat, stream=None, slot=0):
         a = L.esr_amp()
-        a.mode, a.state, a.grad, a.n = L.AMP_CHECK, self.state.data_ptr(), flat.data_ptr(), flat.numel()
+        a.mode, a.state, a.grad, a.n, a.slot = L.AMP_CHECK, self.state.data_ptr(), flat.data_ptr(), flat.numel(), slot
+        L.check(L.lib().esr_amp_step(C.byref(a), C.c_void_p(stream or E.current_stream())), 'esr_amp_step')
+
+    def count(self, step_count, stream=None, slot=0):
+        """step_count[0] += 1 unless this optimizer's gradients overflowed (the step esr_adam_step is about to apply)."""
+        a = L.esr_amp()
+        a.mode, a.state, a.slot, a.step_count = L.AMP_COUNT, self.state.data_ptr(), slot, step_count.data_ptr()
         L.check(L.lib().esr_amp_step(C.byref(a), C.c_void_p(stream or E.current_stream())), 'esr_amp_step')
 
     def update(self, stream=None):

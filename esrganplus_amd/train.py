@@ -11,22 +11,16 @@ exchanges are started right after each backward and waited for right before the 
 
 Launch economy (the step is a few thousand small launches): each network sees its two operands in ONE pass
 (``forward_pair``: per-operand BatchNorm statistics), the losses are single launches that also produce their
-gradients (``losses``), and on one GPU the D step is enqueued on a second stream under the G backward.
+gradients (``losses``), and the D step is enqueued on a second stream under the G backward (one GPU and
+data-parallel alike: the step that is measured on one GPU is the step that scales).
 """
 import os
 
 import torch
-import torch.nn.functional as F
 
 from . import dp as DP
 from . import losses as LS
 from .optim import FusedAdam, DynamicLossScaler
-
-
-def bce_logits(x, target_is_real):
-    """GANLoss('vanilla', 1.0, 0.0) — codes/models/modules/loss.py:6-38."""
-    t = torch.ones_like(x) if target_is_real else torch.zeros_like(x)
-    return F.binary_cross_entropy_with_logits(x, t)
 
 
 class ESRGANPlusStep:
@@ -69,14 +63,14 @@ class ESRGANPlusStep:
         """One optimisation step (SRRaGAN_model.py:113-168)."""
         netG, netD, netF = self.netG, self.netD, self.netF
         var_ref = var_H if var_ref is None else var_ref
-        # batch means of the relativistic terms: over ALL ranks when data-parallel (torch formulas), else inside the
-        # fused loss launch
-        mean = DP.global_mean if DP.world_size() > 1 else None
+        # batch means of the relativistic terms: over ALL ranks when data-parallel (losses._RaGANGlobalFn: the fused
+        # kernel + two scalar all-reduces), else inside the one fused loss launch
+        mean = DP.world_size() > 1
         # ---------------- G ----------------
         for p in netD.parameters():
             p.requires_grad = False
         self.optimizer_G.zero_grad(set_to_none=True)
-        early_real = self.overlap_d_step and DP.world_size() == 1 and var_L.is_cuda
+        early_real = self.overlap_d_step and var_L.is_cuda
         if early_real:
             # netF(var_H) does not depend on G: on the second stream, under the generator's forward
             main0 = torch.cuda.current_stream()
@@ -91,8 +85,10 @@ class ESRGANPlusStep:
         # both operands of each network in ONE pass (forward_pair: per-half BatchNorm statistics, the detached
         # ``real`` half costs no backward) — the reference's call order fake, real is the group order
         if early_real:
-            fake_fea = netF(fake_H)
+            # join BEFORE netF runs on the main stream: the first netF call of a process packs its weights on the
+            # side stream, and the side work finished under the generator's forward anyway
             main0.wait_stream(side0)
+            fake_fea = netF(fake_H)
         else:
             fake_fea, real_fea = netF.forward_pair(fake_H, var_H)
         l_g_fea = LS.l1_loss(fake_fea, real_fea, self.l_fea_w)
@@ -115,16 +111,21 @@ class ESRGANPlusStep:
             # d(scale * (pix + fea + gan)): one backward over the three terms, no sum / multiply launches
             torch.autograd.backward([l_g_pix, l_g_fea, l_g_gan], [scale, scale, scale])
 
-        if self.overlap_d_step and DP.world_size() == 1 and fake_H.is_cuda:
+        if self.overlap_d_step and fake_H.is_cuda:
             # The D step does not depend on the G backward: it runs on a second stream UNDER it (both are chains of
             # small launches).  Same arithmetic, same order of BatchNorm running-statistics updates (its forward
-            # still follows the G step's D pass); the autograd graphs are disjoint.
+            # still follows the G step's D pass); the autograd graphs are disjoint.  Data-parallel runs take the
+            # same route: every rank issues its collectives in the same program order (D's loss sums, D's gradient
+            # buckets on the side stream; G's in-backward buckets on the main stream), each stream-ordered after
+            # the kernels that feed it.
             main = torch.cuda.current_stream()
             side = self._side(fake_H.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 aux = d_step()
+                self.exD.start()
             g_backward()
+            self.exG.start()
             main.wait_stream(side)
         else:
             g_backward()

@@ -294,22 +294,33 @@ typedef struct esr_adam {
   float lr, beta1, beta2, eps, bc1, bc2, grad_scale, weight_decay;
   const float* amp_state; /* NULL, or the DEVICE state of dynamic loss scaling (esr_amp): gradients are additionally
                              divided by amp_state[0] (the loss scale), and the whole update is skipped — weights and
-                             moments untouched — while amp_state[1] != 0 (a non-finite gradient was found).  No host
-                             synchronisation anywhere: the fp16 train path's overflow handling */
+                             moments untouched — while amp_state[4 + amp_slot] != 0 (a non-finite gradient was found in
+                             THIS optimizer's gradients).  No host synchronisation anywhere: the fp16 train path's
+                             overflow handling */
+  int32_t amp_slot, _pad2;
+  const float* step_count; /* NULL: bc1 / bc2 above are used.  Else a DEVICE counter of the steps this optimizer has
+                             APPLIED including the current one (ESR_AMP_COUNT advances it only when the step is not
+                             skipped): bc = 1 - beta^step_count[0] is formed in the kernel from beta1_d / beta2_d, so a
+                             skipped step does not age Adam's bias correction (torch.amp.GradScaler semantics) */
+  double beta1_d, beta2_d;
 } esr_adam;
 
 /* Dynamic loss scaling for the fp16 training path (new capability; the reference trains in fp32 only).
- * state = DEVICE float[4] {scale, found_nonfinite, good_steps, -}.
- *   ESR_AMP_CHECK   found |= any(!isfinite(grad[0..n)))             (after the backward / gradient exchange)
- *   ESR_AMP_UPDATE  found ? (scale *= backoff, good = 0) : (++good == interval ? (scale *= growth, good = 0) : -);
- *                   found = 0                                         (once per step, after the optimizers)    */
-enum esr_amp_mode { ESR_AMP_CHECK = 0, ESR_AMP_UPDATE = 1 };
+ * state = DEVICE float[8] {scale, -, good_steps, -, found[0..3]}: one found-a-non-finite-gradient flag per optimizer
+ * (slot), as torch.amp.GradScaler tracks found_inf per optimizer — an overflow in G's gradients does not skip D's step.
+ *   ESR_AMP_CHECK   found[slot] |= any(!isfinite(grad[0..n)))       (after the backward / gradient exchange)
+ *   ESR_AMP_COUNT   if (!found[slot]) step_count[0] += 1            (before esr_adam_step: the step it will apply)
+ *   ESR_AMP_UPDATE  any(found) ? (scale *= backoff, good = 0) : (++good == interval ? (scale *= growth, good = 0) : -);
+ *                   found[*] = 0                                      (once per iteration, after the optimizers)  */
+enum esr_amp_mode { ESR_AMP_CHECK = 0, ESR_AMP_UPDATE = 1, ESR_AMP_COUNT = 2 };
 typedef struct esr_amp {
   int32_t mode, interval;
   float* state;
   const float* grad;
   int64_t n;
   float growth, backoff;
+  int32_t slot, _pad;         /* 0..3 (CHECK, COUNT) */
+  float* step_count;          /* COUNT */
 } esr_amp;
 
 /* ---- validation metrics on the device (metrics.hip) -------------------------------------------------
@@ -318,7 +329,8 @@ typedef struct esr_amp {
  *   out[0] = sum of squared uint8 differences, out[1] unused, out[2] = sum of the SSIM map (util.py:117-158;
  *   over all compared planes), out[3] unused;   PSNR = 20 log10(255 / sqrt(out[0] / n)),  SSIM = out[2] / n_ssim
  * with n = (H-2crop)(W-2crop) planes, n_ssim = (H-2crop-10)(W-2crop-10) planes (the caller divides).
- * y_only (C == 3): compare the MATLAB-style Y planes of the uint8 BGR images (data/util.py:150-168). */
+ * y_only (C == 3): compare the MATLAB-style Y planes of the BGR images as codes/test.py:81-90 forms them — bgr2ycbcr on
+ * the float images, data/util.py:150-168, i.e. luma NOT rounded to uint8. */
 typedef struct esr_l1_loss {
   const float* a; const float* b;
   float* grad_a;               /* may be NULL */
@@ -335,6 +347,16 @@ typedef struct esr_ragan_loss {
   float* bce_x; float* bce_y;          /* optional: the two BCE terms, unweighted (the reference logs them) */
   int32_t n;
   float tx, ty, weight;                /* targets (1 = real, 0 = fake) of the x / y terms */
+  /* Data-parallel form (round 3): the batch means stay GLOBAL (SRRaGAN_model.py:136-137,151-152) while every
+   * launch only sees the rank's own n logits — the two scalar sums cross the ranks (RCCL all-reduce) between launches:
+   *   mode 0  everything from the local batch (one GPU)
+   *   mode 1  sums[0..1] = {sum x, sum y}
+   *   mode 2  means = ext[0]/ext[2], ext[1]/ext[2] (global sums, global count): loss, mean_x/y, bce_x/y and
+   *           sums[0..1] = {sum_i sigmoid(x_i - mean y) - tx,  sum_i sigmoid(y_i - mean x) - ty}
+   *   mode 3  grad_x / grad_y from the global means and ext[3..4] = those two sums over all ranks         */
+  int32_t mode, _pad;
+  float* sums;                         /* 2 floats (modes 1, 2) */
+  const float* ext;                    /* 5 floats (modes 2, 3) */
 } esr_ragan_loss;
 
 typedef struct esr_img_metrics {
@@ -345,8 +367,8 @@ typedef struct esr_img_metrics {
   float lo, hi;              /* tensor2img's min_max */
   uint8_t* img_sr;           /* [H][W][C] uint8 BGR */
   uint8_t* img_hr;
-  uint8_t* y_sr;             /* [H][W] uint8 (y_only) */
-  uint8_t* y_hr;
+  double* y_sr;              /* [H][W] fp64 (y_only): UNROUNDED luma, codes/test.py:81-86 converts the float images */
+  double* y_hr;
   double* out;               /* 4 doubles (device) */
   double win[11];            /* 1-D Gaussian window (cv2.getGaussianKernel(11, 1.5)); the 2-D one is its outer product */
 } esr_img_metrics;
@@ -515,7 +537,8 @@ int esr_graph_destroy(esr_graph_t g);
 int esr_run_ops_timed(const esr_op* ops, int32_t n, esr_stream_t stream, float* ms_out);
 
 const char* esr_last_error(void);
-int esr_abi_version(void);   /* 2 (round 2: esr_bn.groups / num_batches_tracked, esr_l1_loss, esr_ragan_loss, ESR_OPF_SIDE_FREE) */
+int esr_abi_version(void);   /* 3 (round 3: esr_ragan_loss.mode / sums / ext, ...; 2 = round 2: esr_bn.groups / num_batches_tracked,
+                                esr_l1_loss, esr_ragan_loss, ESR_OPF_SIDE_FREE) */
 size_t esr_sizeof_op(void);
 
 #ifdef __cplusplus

@@ -451,6 +451,37 @@ def gen_metrics():
     np.savez_compressed(os.path.join(OUT, 'metrics.npz'), **res)
 
 
+def gen_metrics_y():
+    """PSNR on the Y channel exactly as the reference's test script forms it (codes/test.py:69-90): tensor2img both
+    images, /255 (float64), bgr2ycbcr(only_y) on the FLOAT images (the unrounded branch of data/util.py:150-168),
+    crop, x255, calculate_psnr.  (SSIM_Y needs cv2 — absent: pinned against the host restatement only.)"""
+    sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+    RI._stub_torchvision()
+    p = os.path.join(RI.REF, 'codes')
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import importlib
+    util = importlib.import_module('utils.util')
+    U = RI.data_util()
+    res = {}
+    for i, (h, w, crop) in enumerate(((40, 52, 4), (33, 47, 2), (128, 96, 4))):
+        hr = synth.image_batch(80 + i, 1, 3, h, w, name='mety.hr')[0]
+        sr = hr + 0.06 * synth.normal_like(80 + i, 'mety.n', (3, h, w))
+        sr_img = util.tensor2img(sr.clone()) / 255.
+        gt_img = util.tensor2img(hr.clone()) / 255.
+        c_sr, c_gt = sr_img[crop:-crop, crop:-crop, :], gt_img[crop:-crop, crop:-crop, :]
+        psnr = util.calculate_psnr(c_sr * 255, c_gt * 255)
+        sr_y, gt_y = U.bgr2ycbcr(sr_img, only_y=True), U.bgr2ycbcr(gt_img, only_y=True)     # (scales its input in place)
+        psnr_y = util.calculate_psnr(sr_y[crop:-crop, crop:-crop] * 255, gt_y[crop:-crop, crop:-crop] * 255)
+        # inputs are seeded (synth): the tests regenerate them; kept: sizes, results, one Y plane
+        res['shape%d' % i], res['crop%d' % i] = np.array([h, w]), np.array(crop)
+        res['psnr%d' % i], res['psnr_y%d' % i] = np.array(psnr), np.array(psnr_y)
+        if i == 0:
+            res['y_sr0'] = (sr_y * 255).astype(np.float64)
+        print('  metrics_y case %d: PSNR %.6f dB, PSNR_Y %.6f dB' % (i, psnr, psnr_y))
+    np.savez_compressed(os.path.join(OUT, 'metrics_y.npz'), **res)
+
+
 def gen_imresize():
     """MATLAB-style bicubic imresize (codes/data/util.py:276-412) and augment (94-106): outputs of
     the imported reference on seeded inputs."""
@@ -488,7 +519,7 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['rdb', 'rrdbnet_small', 'rrdbnet_full', 'disc', 'disc_variants', 'vgg', 'train_step',
-                             'psnr', 'imresize', 'metrics', 'srresnet']
+                             'psnr', 'imresize', 'metrics', 'metrics_y', 'srresnet']
     for w in which:
         print('[gen_golden]', w)
         globals()['gen_' + w]()

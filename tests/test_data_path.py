@@ -104,3 +104,24 @@ def test_crop_and_augment_draw_per_sample():
     random.seed(5)
     pa = [D.augment([lb[b], hb[b]], True, True) for b in range(B)]
     assert all(torch.equal(ab[0][b], pa[b][0]) and torch.equal(ab[1][b], pa[b][1]) for b in range(B))
+
+
+def test_crop_and_augment_interleaves_draws_like_dataset_items():
+    """crop_and_augment consumes `random` in the reference's per-item order (LRHR_dataset.py:96-110: randint,
+    randint, then util.augment's three coins, sample after sample) — restated here with plain slicing."""
+    from esrganplus_amd import data as D
+    B, S = 5, 4
+    lr = torch.arange(B * 2 * 20 * 24, dtype=torch.float32).reshape(B, 2, 20, 24)
+    hr = torch.arange(B * 2 * 80 * 96, dtype=torch.float32).reshape(B, 2, 80, 96)
+    random.seed(21)
+    gl, gh = D.crop_and_augment(lr, hr, 16, S)
+    random.seed(21)
+    for b in range(B):
+        rh, rw = random.randint(0, 20 - 16), random.randint(0, 24 - 16)
+        hf, vf, r9 = random.random() < 0.5, random.random() < 0.5, random.random() < 0.5
+        l = lr[b, :, rh:rh + 16, rw:rw + 16]
+        h = hr[b, :, S * rh:S * rh + 64, S * rw:S * rw + 64]
+        for flag, fn in ((hf, lambda t: t.flip(-1)), (vf, lambda t: t.flip(-2)), (r9, lambda t: t.transpose(-1, -2))):
+            if flag:
+                l, h = fn(l), fn(h)
+        assert torch.equal(gl[b], l) and torch.equal(gh[b], h), b

@@ -5,6 +5,7 @@ import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -120,3 +121,119 @@ def test_in_backward_exchange_two_ranks_rccl():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+
+
+# ---- the full ESRGAN+ step, data-parallel: 2 ranks sharing cuda:0 over gloo --------------------------------------
+def _make_nets(dev, precision='fp32'):
+    from esrganplus_amd import architecture as arch
+    netG = arch.RRDBNet(3, 3, 64, 1).to(dev).train().set_precision(precision)
+    netD = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision(precision)
+    netF = arch.VGGFeatureExtractor(34, False, True, dev).to(dev).eval().set_precision(precision)
+    netG.load_state_dict(synth.rrdbnet_state_dict(nb=1, seed=40), strict=True)
+    netD.load_state_dict(synth.discriminator_state_dict(seed=41), strict=True)
+    netF.load_state_dict(synth.vgg19_state_dict(6, 34), strict=False)
+    return netG, netD, netF
+
+
+def _shard(rank, dev):
+    lr = synth.image_batch(50 + rank, 2, 3, 32, 32, name='dpstep.lr').to(dev)
+    hr = synth.image_batch(60 + rank, 2, 3, 128, 128, name='dpstep.hr').to(dev)
+    return lr, hr
+
+
+def _noise_z(rank, dev):
+    from oracle import ref_torch as RT
+    return [synth.normal_like(70 + rank, 'dpstep.z.%d' % i, s).to(dev)
+            for i, s in enumerate(RT.noise_shapes((2, 3, 32, 32), 1, 'codes'))]
+
+
+def _step_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from esrganplus_amd import dp, train
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        dev = torch.device('cuda', 0)
+        netG, netD, netF = _make_nets(dev)
+        st = train.ESRGANPlusStep(netG, netD, netF)
+        assert st.exG.inline and dp.world_size() == 2
+        st.optimizer_G.step = lambda **kw: None            # keep the (averaged) gradients: they are what is compared
+        st.optimizer_D.step = lambda **kw: None
+        lr, hr = _shard(rank, dev)
+        log = st.step(lr, hr, z=_noise_z(rank, dev))
+        torch.cuda.synchronize()
+        gG = torch.cat([p.grad.reshape(-1) for p in netG.parameters()]).cpu()
+        gD = torch.cat([p.grad.reshape(-1) for p in netD.parameters()]).cpu()
+        q.put((rank, 'ok', gG.numpy(), gD.numpy(), {k: float(v) for k, v in log.items()}))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc(), None, None, None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_train_step_two_ranks_equals_global_batch_loss(dev):
+    """train.ESRGANPlusStep under torch.distributed (2 ranks on cuda:0, gloo): the gradients that reach the
+    optimizers are the rank-average of a loss whose relativistic means run over the GLOBAL batch
+    (SRRaGAN_model.py:136-137,151-152) with per-rank BatchNorm statistics — restated here in one
+    process with torch formulas over the two shards.  Exercises the fused global-mean RaGAN loss, the in-backward
+    G exchange, the D exchange and both stream overlaps."""
+    import torch.multiprocessing as mp
+    import torch.nn.functional as F
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == 'ok' for r in res), [r[1] for r in res]
+    # both ranks hold the same averaged gradients
+    assert np.abs(res[0][2] - res[1][2]).max() <= 1e-6 * np.abs(res[0][2]).max()
+    assert np.abs(res[0][3] - res[1][3]).max() <= 1e-6 * np.abs(res[0][3]).max()
+
+    # ---- single-process restatement
+    netG, netD, netF = _make_nets(dev)
+    shards = [_shard(r, dev) for r in range(2)]
+    bce = lambda v, real: F.binary_cross_entropy_with_logits(v, torch.ones_like(v) if real else torch.zeros_like(v))
+    for p in netD.parameters():
+        p.requires_grad = False
+    fakes, pix, fea, pg, pr = [], [], [], [], []
+    for r, (lr, hr) in enumerate(shards):
+        fake = netG(lr, z=_noise_z(r, dev))
+        fakes.append(fake)
+        pix.append(1e-2 * F.l1_loss(fake, hr))
+        ff, rf = netF.forward_pair(fake, hr)
+        fea.append(F.l1_loss(ff, rf.detach()))
+        a, b = netD.forward_pair(fake, hr)
+        pg.append(a); pr.append(b.detach())
+    m_fake, m_real = torch.cat(pg).mean(), torch.cat(pr).mean()
+    tot = 0
+    for r in range(2):
+        gan = 5e-3 * (bce(pr[r] - m_fake, False) + bce(pg[r] - m_real, True)) / 2
+        tot = tot + (pix[r] + fea[r] + gan) / 2
+    tot.backward()
+    wantG = torch.cat([p.grad.reshape(-1) for p in netG.parameters()]).cpu().numpy()
+    for p in netD.parameters():
+        p.requires_grad = True
+    netD.zero_grad(set_to_none=True)
+    dr, df = [], []
+    for r, (lr, hr) in enumerate(shards):
+        a, b = netD.forward_pair(hr, fakes[r].detach())
+        dr.append(a); df.append(b)
+    m_real, m_fake = torch.cat(dr).mean(), torch.cat(df).mean()
+    totd = 0
+    for r in range(2):
+        totd = totd + (bce(dr[r] - m_fake, True) + bce(df[r] - m_real, False)) / 2 / 2
+    totd.backward()
+    wantD = torch.cat([p.grad.reshape(-1) for p in netD.parameters()]).cpu().numpy()
+    eG = np.linalg.norm(res[0][2] - wantG) / np.linalg.norm(wantG)
+    eD = np.linalg.norm(res[0][3] - wantD) / np.linalg.norm(wantD)
+    print('relative gradient error  G %.3e  D %.3e' % (eG, eD))
+    assert eG <= 2e-4 and eD <= 2e-4

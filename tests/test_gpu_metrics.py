@@ -43,8 +43,8 @@ def test_device_psnr_ssim_match_host_metrics(dev, shape, crop, y_only):
         a, b = a[..., None], b[..., None]
     ca = a[crop:a.shape[0] - crop, crop:a.shape[1] - crop]
     cb = b[crop:b.shape[0] - crop, crop:b.shape[1] - crop]
-    if y_only:
-        ca, cb = M.bgr2ycbcr(ca, only_y=True), M.bgr2ycbcr(cb, only_y=True)
+    if y_only:      # codes/test.py:81-86: the conversion runs on the float images (/255.), luma stays unrounded
+        ca, cb = M.bgr2ycbcr(ca / 255., only_y=True) * 255, M.bgr2ycbcr(cb / 255., only_y=True) * 255
     want_psnr = M.calculate_psnr(ca, cb)
     want_ssim = M.calculate_ssim(np.squeeze(ca) if ca.shape[-1] == 1 else ca, np.squeeze(cb) if cb.shape[-1] == 1 else cb)
     psnr, ssim = M.device_psnr_ssim(sr.to(dev), hr.to(dev), crop=crop, y_only=y_only)
@@ -56,3 +56,20 @@ def test_identical_images_give_inf_psnr_and_unit_ssim(dev):
     x = synth.image_batch(23, 1, 3, 32, 32, name='met.same')[0].to(dev)
     psnr, ssim = M.device_psnr_ssim(x, x.clone(), crop=4)
     assert psnr == float('inf') and abs(ssim - 1.0) < 1e-12
+
+
+def test_device_psnr_y_matches_reference_test_script(dev):
+    """PSNR_Y under the golden captured from the reference's own flow (codes/test.py:69-90 with the imported
+    utils/util.py + data/util.py; oracle/gen_golden.py: gen_metrics_y): the Y conversion runs on the FLOAT images,
+    so the luma is not rounded to uint8."""
+    g = dict(np.load('tests/golden/metrics_y.npz'))
+    for i in range(3):
+        h, w = (int(v) for v in g['shape%d' % i])
+        crop = int(g['crop%d' % i])
+        hr = synth.image_batch(80 + i, 1, 3, h, w, name='mety.hr')[0]
+        sr = hr + 0.06 * synth.normal_like(80 + i, 'mety.n', (3, h, w))
+        psnr, _ = M.device_psnr_ssim(sr.to(dev), hr.to(dev), crop=crop)
+        psnr_y, ssim_y = M.device_psnr_ssim(sr.to(dev), hr.to(dev), crop=crop, y_only=True)
+        assert abs(psnr - float(g['psnr%d' % i])) < 1e-9
+        assert abs(psnr_y - float(g['psnr_y%d' % i])) < 1e-7, (psnr_y, float(g['psnr_y%d' % i]))
+        assert 0.0 < ssim_y <= 1.0

@@ -232,6 +232,46 @@ def test_dynamic_loss_scaler_skips_overflow_step(dev):
     assert float(sc.state[0]) == 256.0 and all(torch.isfinite(p).all() for p in ps)
 
 
+def test_dynamic_loss_scaler_is_per_optimizer_and_keeps_bias_correction(dev):
+    """torch.amp.GradScaler semantics: an overflow in ONE optimizer's gradients skips only that
+    optimizer's step, and a skipped step does not advance Adam's step count — after the skip the first applied
+    update equals torch.optim.Adam's FIRST step (bias correction with t = 1, not t = 2)."""
+    from esrganplus_amd.optim import FusedAdam, DynamicLossScaler
+    torch.manual_seed(2)
+    shapes = [(32, 3, 3, 3), (700,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    pb = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    ra, rb = [p.detach().clone() for p in pa], [p.detach().clone() for p in pb]
+    oa, ob = FusedAdam(pa, lr=1e-2), FusedAdam(pb, lr=1e-2)
+    sc = DynamicLossScaler(dev, init_scale=64.0, interval=1000)
+    ga = [torch.randn_like(p) for p in pa]
+    gb = [torch.randn_like(p) for p in pb]
+    for p, g in zip(pa, ga):
+        p.grad = g * 64.0
+    pa[1].grad[3] = float('nan')
+    for p, g in zip(pb, gb):
+        p.grad = g * 64.0
+    oa.step(scaler=sc)
+    ob.step(scaler=sc)
+    sc.update()
+    assert all(torch.equal(p.detach(), r) for p, r in zip(pa, ra))            # A skipped
+    assert all(not torch.equal(p.detach(), r) for p, r in zip(pb, rb))        # B stepped in the same iteration
+    assert float(sc.state[0]) == 32.0
+    # A's first APPLIED step (second attempt) == torch Adam's first step on the same gradients
+    pt = [torch.nn.Parameter(r.clone()) for r in ra]
+    ot = torch.optim.Adam(pt, lr=1e-2)
+    g2 = [torch.randn_like(p) for p in pa]
+    for p, q, g in zip(pa, pt, g2):
+        p.grad = g * 32.0
+        q.grad = g.clone()
+    oa.step(scaler=sc)
+    sc.update()
+    ot.step()
+    for p, q in zip(pa, pt):
+        assert (p - q).abs().max().item() <= 2e-6 * max(1.0, q.abs().max().item())
+    assert float(oa.state_dict()['state'][0]['step']) == 1.0 and float(ob.state_dict()['state'][0]['step']) == 1.0
+
+
 @pytest.mark.parametrize('size', [192, 256])
 def test_generator_training_tiles_192_256_vs_oracle(dev, size):
     """BASELINE configs[4] tile sizes (mixed 128/192/256 LR tiles; nb=2 here): noise-on generator forward +

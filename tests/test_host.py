@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_struct_mirror_sizes(built):
     L = built.lib()
     assert L.esr_sizeof_op() == ctypes.sizeof(built.esr_op)
-    assert L.esr_abi_version() == 2
+    assert L.esr_abi_version() == 3
     assert built.packed_weight_bytes(32, 64, 3, built.ESR_F16) == 1 * 4 * 9 * 1024
     assert built.packed_weight_bytes(64, 192, 3, built.ESR_F32) == 2 * 24 * 9 * 1024
     assert built.g32_dims(128, 128) == (134, 130)
@@ -202,3 +202,29 @@ def test_srresnet_state_dict_keys_match_the_reference_layout():
         assert list(net.state_dict().keys()) == list(sd.keys())
         assert all(tuple(net.state_dict()[k].shape) == tuple(v.shape) for k, v in sd.items())
         net.load_state_dict(sd, strict=True)
+
+
+def test_bare_name_architecture_and_block_shims():
+    """test_image/test.py:7-21 imports `architecture` by bare name (and test_image/architecture.py:4 `block`):
+    with dropin/ on sys.path instead of the reference's test_image/, the script's statements run unchanged."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, os
+sys.path.insert(0, os.path.join(%r, 'dropin'))
+import torch
+import architecture as arch
+import block as B
+model = arch.RRDB_Net(3, 3, 64, 23, gc=32, upscale=4, norm_type=None, act_type='leakyrelu', \
+                        mode='CNA', res_scale=1, upsample_mode='upconv')
+from esrganplus_amd import synth
+model.load_state_dict(synth.rrdbnet_state_dict(23, 0), strict=False)
+model.eval()
+for k, v in model.named_parameters():
+    v.requires_grad = False
+assert len(model.state_dict()) == 771 and arch.RRDB_Net.__module__ == 'esrganplus_amd.architecture'
+assert B.ResidualDenseBlock_5C.__module__ == 'esrganplus_amd.block' and callable(B.upconv_blcok)
+print('ok')
+''' % ROOT
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]

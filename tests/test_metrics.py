@@ -49,3 +49,21 @@ def test_gaussian_window_is_cv2_formula():
     assert w.shape == (11, 11) and abs(w.sum() - 1.0) < 1e-15
     k = w.sum(0)
     assert abs(k[5] / k[4] - np.exp(1.0 / (2 * 1.5 ** 2))) < 1e-12
+
+
+def test_host_psnr_y_flow_matches_reference_test_script():
+    """The host restatement of codes/test.py:69-90 (tensor2img, /255, bgr2ycbcr on the float image, crop, x255,
+    PSNR) against the golden produced by the imported reference (oracle/gen_golden.py: gen_metrics_y)."""
+    from esrganplus_amd import synth
+    g = dict(np.load('tests/golden/metrics_y.npz'))
+    for i in range(3):
+        h, w = (int(v) for v in g['shape%d' % i])
+        crop = int(g['crop%d' % i])
+        hr = synth.image_batch(80 + i, 1, 3, h, w, name='mety.hr')[0]
+        sr = hr + 0.06 * synth.normal_like(80 + i, 'mety.n', (3, h, w))
+        a, b = M.tensor2img(sr) / 255., M.tensor2img(hr) / 255.
+        ya, yb = M.bgr2ycbcr(a, only_y=True), M.bgr2ycbcr(b, only_y=True)
+        if i == 0:
+            assert np.abs(ya * 255 - g['y_sr0']).max() < 1e-9
+        got = M.calculate_psnr(ya[crop:-crop, crop:-crop] * 255, yb[crop:-crop, crop:-crop] * 255)
+        assert abs(got - float(g['psnr_y%d' % i])) < 1e-9
