@@ -19,7 +19,7 @@ ESR_F16, ESR_F32 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 NOISE_OFF, NOISE_PHILOX, NOISE_EXPLICIT = 0, 1, 2
 OP_CONV, OP_PACK, OP_LAYOUT, OP_NOISE_FILL, OP_WGRAD, OP_BN, OP_POOL, OP_LINEAR, OP_UNPERMUTE, OP_PACK_BATCH = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-OP_RDB_CHAIN, OP_FRAG_GATHER = 11, 12
+OP_RDB_CHAIN, OP_FRAG_GATHER, OP_RDB_WGRAD = 11, 12, 13
 BN_STATS, BN_FINALIZE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_FINAL, BN_BWD_APPLY = 0, 1, 2, 3, 4, 5
 NO_LAYER = 0xFFFFFFFF
 
@@ -185,11 +185,22 @@ class esr_frag_gather(C.Structure):
                 ('piece_bytes', C.c_int32), ('_pad', C.c_int32)]
 
 
+class esr_rdb_wgrad_block(C.Structure):
+    _fields_ = [('in_', esr_g32), ('q', esr_g32), ('dw', C.c_void_p * 6), ('db', C.c_void_p * 6)]
+
+
+class esr_rdb_wgrad(C.Structure):
+    _fields_ = [('dtype', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('n_blocks', C.c_int32), ('tap_major', C.c_int32), ('scale5', C.c_float), ('scale', C.c_float),
+                ('blocks', C.c_void_p), ('partial', C.c_void_p), ('partial_elems', C.c_int64)]
+
+
 class _op_union(C.Union):
     _fields_ = [('conv', esr_conv), ('pack', esr_pack), ('layout', esr_layout),
                 ('noise_fill', esr_noise_fill), ('wgrad', esr_wgrad), ('bn', esr_bn),
                 ('pool', esr_pool), ('linear', esr_linear), ('unpermute', esr_unpermute),
-                ('pack_batch', esr_pack_batch), ('rdb_chain', esr_rdb_chain), ('frag_gather', esr_frag_gather)]
+                ('pack_batch', esr_pack_batch), ('rdb_chain', esr_rdb_chain), ('frag_gather', esr_frag_gather),
+                ('rdb_wgrad', esr_rdb_wgrad)]
 
 
 class esr_op(C.Structure):
@@ -203,7 +214,7 @@ EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_p
            'esr_run_ops', 'esr_run_ops_timed', 'esr_graph_create', 'esr_graph_launch', 'esr_graph_destroy', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op', 'esr_rdb_forward', 'esr_rdb_workspace_bytes', 'esr_rdb_weight_stream_bytes',
            'esr_rdb_max_tiles_per_image', 'esr_gather_fragments', 'esr_image_metrics', 'esr_wgrad_workspace_elems',
-           'esr_l1_loss_forward', 'esr_ragan_loss_forward']
+           'esr_l1_loss_forward', 'esr_ragan_loss_forward', 'esr_rdb_wgrad_run', 'esr_rdb_wgrad_workspace_elems']
 
 _lib = None
 _lock = threading.Lock()
@@ -249,6 +260,8 @@ def lib():
         L.esr_rdb_workspace_bytes.argtypes = [C.c_int32] * 3
         L.esr_rdb_weight_stream_bytes.restype = C.c_size_t
         L.esr_rdb_weight_stream_bytes.argtypes = [C.c_int32]
+        L.esr_rdb_wgrad_workspace_elems.restype = C.c_int64
+        L.esr_rdb_wgrad_workspace_elems.argtypes = [C.c_int32] * 4
         for name, st in (('esr_conv_forward', esr_conv), ('esr_pack_conv_weights', esr_pack),
                          ('esr_convert_layout', esr_layout), ('esr_fill_noise', esr_noise_fill),
                          ('esr_conv_wgrad', esr_wgrad), ('esr_batchnorm', esr_bn),
@@ -256,7 +269,8 @@ def lib():
                          ('esr_grad_unpermute', esr_unpermute), ('esr_adam_step', esr_adam), ('esr_amp_step', esr_amp), ('esr_resample_axis', esr_resample),
                          ('esr_pack_conv_weights_batch', esr_pack_batch), ('esr_rdb_forward', esr_rdb_chain),
                          ('esr_gather_fragments', esr_frag_gather), ('esr_image_metrics', esr_img_metrics),
-                         ('esr_l1_loss_forward', esr_l1_loss), ('esr_ragan_loss_forward', esr_ragan_loss)):
+                         ('esr_l1_loss_forward', esr_l1_loss), ('esr_ragan_loss_forward', esr_ragan_loss),
+                         ('esr_rdb_wgrad_run', esr_rdb_wgrad)):
             getattr(L, name).argtypes = [C.POINTER(st), C.c_void_p]
         if L.esr_sizeof_op() != C.sizeof(esr_op):
             raise HipExtensionError('ABI mismatch: sizeof(esr_op) C=%d ctypes=%d'

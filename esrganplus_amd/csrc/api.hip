@@ -145,6 +145,21 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       case ESR_OP_PACK_BATCH: rc = esr_pack_conv_weights_batch(&ops[i].u.pack_batch, stream); break;
       case ESR_OP_RDB_CHAIN: rc = esr_rdb_forward(&ops[i].u.rdb_chain, stream); break;
       case ESR_OP_FRAG_GATHER: rc = esr_gather_fragments(&ops[i].u.frag_gather, stream); break;
+      case ESR_OP_RDB_WGRAD: {
+        // dense-block weight gradients: like a run of wgrad ops — on the side stream when flagged ESR_OPF_SIDE
+        if (!(ops[i].flags & ESR_OPF_SIDE)) { rc = esr_rdb_wgrad_run(&ops[i].u.rdb_wgrad, stream); break; }
+        SideState* ss = side_state();
+        if (!ss) return ESR_ERR_LAUNCH;
+        hipStream_t main_st = (hipStream_t)stream;
+        if (nside > 0) ESR_HIP(hipStreamWaitEvent(main_st, ss->join[(nside - 1) & 1], 0));
+        ESR_HIP(hipEventRecord(ss->fork[nside & 1], main_st));
+        ESR_HIP(hipStreamWaitEvent(ss->stream, ss->fork[nside & 1], 0));
+        rc = esr_rdb_wgrad_run(&ops[i].u.rdb_wgrad, (esr_stream_t)ss->stream);
+        ESR_HIP(hipEventRecord(ss->join[nside & 1], ss->stream));
+        ++nside;
+        joined = false;
+        break;
+      }
       default: esr_set_error("esr_run_ops: op %d has unknown kind %d", i, ops[i].kind); return ESR_ERR_INVALID;
     }
     if (rc != ESR_OK) {

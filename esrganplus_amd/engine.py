@@ -593,6 +593,13 @@ def current_stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def use_rdb_wgrad():
+    """fp16 training plans: the six weight gradients of a dense block as ONE esr_rdb_wgrad pass over its saved
+    concat buffer and gradient concat (csrc/rdb_wgrad.hip) instead of six esr_conv_wgrad problems
+    (ESR_RDB_WGRAD=0 restores those, for A/B runs)."""
+    return os.environ.get('ESR_RDB_WGRAD', '1') != '0'
+
+
 def build_block_plan(kind, wp, B, H, W, dtype, device, noise, variant, explicit_z):
     """Stand-alone ResidualDenseBlock_5C ('rdb') or RRDB ('rrdb') pass: NCHW in -> NCHW out."""
     bld = Builder(wp, B, H, W, dtype, device, noise, variant)
@@ -1075,6 +1082,12 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         add_b(c, noisy=bool(nb))
         close_segment(['model.1.sub.%d' % nb, 'model.3', 'model.6', 'model.8', 'model.10'])
     ca, ct = 0, 0
+    fused_wgrad = dt_e == L.ESR_F16 and use_rdb_wgrad() and nb > 0
+    if fused_wgrad:
+        # per-task partial sums of the deterministic two-stage reduction: one arena, reused by every RRDB's pass
+        # (the passes are ordered on the side stream; a slot only lives inside one pass)
+        rdbw_arena = torch.empty(int(L.lib().esr_rdb_wgrad_workspace_elems(B, H, W, nj)), dtype=torch.float32, device=device)
+        TP.bufs.append(rdbw_arena)
     GX = buf(64) if block else None                 # dL/dx of a stand-alone block
     for i in range(nb - 1, -1, -1):
         for j in range(nj - 1, -1, -1):
@@ -1085,12 +1098,23 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             # starts -> emitted together with the rest of the RRDB's after its last dgrad chain (one side run)
             if deferred is None:
                 deferred = []
-            wgrad(p + '.conv5.0', Q.view(0, 64), bf.view(0, 192), H, W, 64, 192, scale=0.2)
-            wgrad(p + '.conv4.0', Q.view(64, 32), bf.view(0, 160), H, W, 32, 160)
-            wgrad(p + '.conv3.0', Q.view(96, 32), bf.view(0, 128), H, W, 32, 128)
-            wgrad(p + '.conv2.0', Q.view(128, 32), bf.view(0, 96), H, W, 32, 96)
-            wgrad(p + '.conv1x1', Q.view(192, 32), bf.view(0, 64), H, W, 32, 64, ks=1)
-            wgrad(p + '.conv1.0', Q.view(160, 32), bf.view(0, 64), H, W, 32, 64)
+            if fused_wgrad:
+                # one esr_rdb_wgrad pass per RRDB over (saved concat buffer, Q) of its blocks (rdb_wgrad.hip)
+                wb = L.esr_rdb_wgrad_block()
+                wb.in_, wb.q = bf.view(0, 192), Q.view(0, 224)
+                for k in range(5):
+                    key = p + '.conv%d.0' % (k + 1)
+                    wb.dw[k] = TP.tapmajor.slot(goff[key], 64 if k == 4 else 32, 64 + 32 * k)
+                    wb.db[k] = gptr[key][1]
+                wb.dw[5] = gptr[p + '.conv1x1'][0]
+                deferred.append(wb)
+            else:
+                wgrad(p + '.conv5.0', Q.view(0, 64), bf.view(0, 192), H, W, 64, 192, scale=0.2)
+                wgrad(p + '.conv4.0', Q.view(64, 32), bf.view(0, 160), H, W, 32, 160)
+                wgrad(p + '.conv3.0', Q.view(96, 32), bf.view(0, 128), H, W, 32, 128)
+                wgrad(p + '.conv2.0', Q.view(128, 32), bf.view(0, 96), H, W, 32, 96)
+                wgrad(p + '.conv1x1', Q.view(192, 32), bf.view(0, 64), H, W, 32, 64, ks=1)
+                wgrad(p + '.conv1.0', Q.view(160, 32), bf.view(0, 64), H, W, 32, 64)
             # slice x4: g_x4 = conv5^T[x4](0.2 g_t)  -> raw to X4, masked (lrelu'(a4)) to Q[64:96]
             c = dconv(H, W, Q.view(0), 64, X4.view(0, 32), p + '.g4')
             c.mask, c.out2, c.mask_cb_begin = ax.view(32, 32), Q.view(64, 32), 0
@@ -1134,8 +1158,19 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
                 else:
                     c.out = GF.view(0, 64)
             add_b(c, noisy=True)
-        for wg in deferred:
-            Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE)
+        if fused_wgrad:
+            arr = (L.esr_rdb_wgrad_block * len(deferred))(*deferred)
+            blk_t = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+            TP.bufs.append(blk_t)
+            rw = L.esr_rdb_wgrad()
+            rw.dtype, rw.B, rw.H, rw.W = dt_e, B, H, W
+            rw.n_blocks, rw.tap_major, rw.scale5, rw.scale = len(deferred), 1, 0.2, 1.0
+            rw.blocks = blk_t.data_ptr()
+            rw.partial, rw.partial_elems = rdbw_arena.data_ptr(), rdbw_arena.numel()
+            Bk.add(L.OP_RDB_WGRAD, 'rdb_wgrad', rw, flags=L.OPF_SIDE)
+        else:
+            for wg in deferred:
+                Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE)
         deferred = None
         if not block:
             close_segment(['model.1.sub.%d' % i])

@@ -436,10 +436,35 @@ typedef struct esr_frag_gather {
   int32_t piece_bytes, _pad;
 } esr_frag_gather;
 
+/* ---- weight / bias gradients of a whole dense block in one pass (rdb_wgrad.hip) --------------------------------
+ * Replaces the six esr_conv_wgrad problems of a ResidualDenseBlock_5C (block.py:239-268; autograd's conv
+ * backward-weight, SRRaGAN_model.py:140) for n_blocks blocks in ONE launch (+ one deterministic reduce launch):
+ *   in = [x (64) | x1 | x2 | x3 | x4] (192 channels),   q = [g_t (64) | g_a4 | g_a3 | g_a2 | g_a1 | g_x2] (224 channels)
+ *   dW_convk += g_ak (x) in[0 : 32 (k + 1))  (3x3; conv5: g_a5 = scale5 * g_t),  dW_1x1 += g_x2 (x) x,  db_k += sum g_ak
+ * where g_x2 is the gradient of x2 BEFORE its LeakyReLU mask (it feeds the bias-free 1x1, block.py:263).
+ * Both views share one geometry (wp, H, W); one image of either must be < 4 GB.  dw[k]: k = 0..4 conv1..conv5 ([cout][cin][3][3] fp32, or tap-major
+ * [tap][cout][cin] when tap_major; accumulated: +=), k = 5 the 1x1 ([32][64]); db[k] k = 0..4 (NULL: skipped). */
+typedef struct esr_rdb_wgrad_block {
+  esr_g32 in;               /* the block's saved concat buffer (forward) */
+  esr_g32 q;                /* the block's gradient concat (backward chain) */
+  float* dw[6];
+  float* db[6];             /* db[5] unused (the 1x1 has no bias) */
+} esr_rdb_wgrad_block;
+typedef struct esr_rdb_wgrad {
+  int32_t dtype;            /* ESR_F16 */
+  int32_t B, H, W;
+  int32_t n_blocks, tap_major;
+  float scale5;             /* 0.2: g_a5 = 0.2 g_t (block.py:267) */
+  float scale;              /* applied to every gradient (1.0) */
+  const esr_rdb_wgrad_block* blocks;   /* DEVICE array */
+  float* partial;           /* esr_rdb_wgrad_workspace_elems() floats: per-task partial sums, reduced in a fixed order */
+  int64_t partial_elems;
+} esr_rdb_wgrad;
+
 enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_NOISE_FILL = 4,
                    ESR_OP_WGRAD = 5, ESR_OP_BN = 6, ESR_OP_POOL = 7, ESR_OP_LINEAR = 8,
                    ESR_OP_UNPERMUTE = 9, ESR_OP_PACK_BATCH = 10,
-                   ESR_OP_RDB_CHAIN = 11, ESR_OP_FRAG_GATHER = 12 };
+                   ESR_OP_RDB_CHAIN = 11, ESR_OP_FRAG_GATHER = 12, ESR_OP_RDB_WGRAD = 13 };
 
 /* esr_op.flags */
 #define ESR_OPF_SIDE 1   /* on a run of consecutive ESR_OP_WGRAD ops: launch the run on the library's side
@@ -471,6 +496,7 @@ typedef struct esr_op {
     esr_pack_batch pack_batch;
     esr_rdb_chain rdb_chain;
     esr_frag_gather frag_gather;
+    esr_rdb_wgrad rdb_wgrad;
   } u;
 } esr_op;
 
@@ -502,6 +528,9 @@ size_t esr_rdb_workspace_bytes(int32_t B, int32_t H, int32_t W);
 size_t esr_rdb_weight_stream_bytes(int32_t dtype);
 int esr_rdb_max_tiles_per_image(void);   /* 16x32 tiles of ONE image must not exceed this (= CUs) */
 int esr_gather_fragments(const esr_frag_gather* g, esr_stream_t stream);
+/* Dense-block weight gradients (replaces 6 x n_blocks esr_conv_wgrad calls). */
+int esr_rdb_wgrad_run(const esr_rdb_wgrad* p, esr_stream_t stream);
+int64_t esr_rdb_wgrad_workspace_elems(int32_t B, int32_t H, int32_t W, int32_t n_blocks);
 int esr_image_metrics(const esr_img_metrics* p, esr_stream_t stream);   /* replaces util.py:71-158 on the device */
 
 /* The train step's losses with their gradients, one launch each (SRRaGAN_model.py:124-137,150-156).
