@@ -19,7 +19,7 @@ ESR_F16, ESR_F32 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 NOISE_OFF, NOISE_PHILOX, NOISE_EXPLICIT = 0, 1, 2
 OP_CONV, OP_PACK, OP_LAYOUT, OP_NOISE_FILL, OP_WGRAD, OP_BN, OP_POOL, OP_LINEAR, OP_UNPERMUTE, OP_PACK_BATCH = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-OP_RDB_CHAIN, OP_FRAG_GATHER, OP_RDB_WGRAD = 11, 12, 13
+OP_RDB_CHAIN, OP_FRAG_GATHER, OP_RDB_WGRAD, OP_RDB_CHAIN_BWD = 11, 12, 13, 14
 BN_STATS, BN_FINALIZE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_FINAL, BN_BWD_APPLY = 0, 1, 2, 3, 4, 5
 NO_LAYER = 0xFFFFFFFF
 
@@ -55,7 +55,7 @@ class esr_pack(C.Structure):
                 ('ups_dgrad', C.c_int32),
                 ('gather', C.c_int32), ('dst_cout', C.c_int32), ('dst_chunk0', C.c_int32),
                 ('dst_nchunks', C.c_int32), ('src_co0', C.c_int32), ('src_ks', C.c_int32),
-                ('scale', C.c_float), ('ups_fwd', C.c_int32)]
+                ('scale', C.c_float), ('ups_fwd', C.c_int32), ('fold_co0', C.c_int32), ('one_t', C.c_int32)]
 
 
 class esr_wgrad(C.Structure):
@@ -147,7 +147,7 @@ class esr_pack_batch(C.Structure):
 class esr_rdb_block(C.Structure):
     _fields_ = [('w', C.c_void_p), ('bias', C.c_void_p), ('x_in', esr_g32), ('x_out', esr_g32),
                 ('res2', esr_g32), ('layer1', C.c_uint32), ('layer2', C.c_uint32), ('flags', C.c_uint32),
-                ('_pad', C.c_uint32)]
+                ('_pad', C.c_uint32), ('dense', esr_g32), ('mask', C.c_void_p), ('aux', esr_g32), ('out_a', esr_g32)]
 
 
 RDB_FULL_OUT = 1
@@ -157,7 +157,8 @@ class esr_rdb_chain(C.Structure):
     _fields_ = [('dtype', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
                 ('n_blocks', C.c_int32), ('noise_mode', C.c_int32), ('sigma', C.c_float), ('save_dense', C.c_int32),
                 ('seed', C.c_uint64), ('seed_dev', C.c_void_p), ('dense', esr_g32), ('blocks', C.c_void_p),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('trace', C.c_void_p)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('trace', C.c_void_p),
+                ('mode', C.c_int32), ('_pad2', C.c_int32)]
 
 
 class esr_l1_loss(C.Structure):
@@ -214,7 +215,8 @@ EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_p
            'esr_run_ops', 'esr_run_ops_timed', 'esr_graph_create', 'esr_graph_launch', 'esr_graph_destroy', 'esr_last_error',
            'esr_abi_version', 'esr_sizeof_op', 'esr_rdb_forward', 'esr_rdb_workspace_bytes', 'esr_rdb_weight_stream_bytes',
            'esr_rdb_max_tiles_per_image', 'esr_gather_fragments', 'esr_image_metrics', 'esr_wgrad_workspace_elems',
-           'esr_l1_loss_forward', 'esr_ragan_loss_forward', 'esr_rdb_wgrad_run', 'esr_rdb_wgrad_workspace_elems']
+           'esr_l1_loss_forward', 'esr_ragan_loss_forward', 'esr_rdb_wgrad_run', 'esr_rdb_wgrad_workspace_elems', 'esr_rdb_backward',
+           'esr_rdb_mask_bytes', 'esr_rdb_check_abort']
 
 _lib = None
 _lock = threading.Lock()
@@ -260,6 +262,8 @@ def lib():
         L.esr_rdb_workspace_bytes.argtypes = [C.c_int32] * 3
         L.esr_rdb_weight_stream_bytes.restype = C.c_size_t
         L.esr_rdb_weight_stream_bytes.argtypes = [C.c_int32]
+        L.esr_rdb_mask_bytes.restype = C.c_size_t
+        L.esr_rdb_mask_bytes.argtypes = [C.c_int32] * 3
         L.esr_rdb_wgrad_workspace_elems.restype = C.c_int64
         L.esr_rdb_wgrad_workspace_elems.argtypes = [C.c_int32] * 4
         for name, st in (('esr_conv_forward', esr_conv), ('esr_pack_conv_weights', esr_pack),
@@ -270,7 +274,7 @@ def lib():
                          ('esr_pack_conv_weights_batch', esr_pack_batch), ('esr_rdb_forward', esr_rdb_chain),
                          ('esr_gather_fragments', esr_frag_gather), ('esr_image_metrics', esr_img_metrics),
                          ('esr_l1_loss_forward', esr_l1_loss), ('esr_ragan_loss_forward', esr_ragan_loss),
-                         ('esr_rdb_wgrad_run', esr_rdb_wgrad)):
+                         ('esr_rdb_wgrad_run', esr_rdb_wgrad), ('esr_rdb_backward', esr_rdb_chain)):
             getattr(L, name).argtypes = [C.POINTER(st), C.c_void_p]
         if L.esr_sizeof_op() != C.sizeof(esr_op):
             raise HipExtensionError('ABI mismatch: sizeof(esr_op) C=%d ctypes=%d'

@@ -323,6 +323,13 @@ def _rdb_gathers(prefix, m):
     for j, co0 in ((4, 160), (3, 128), (2, 96), (1, 64)):
         out.append((prefix + '.g%d' % j, 32, [(t, co0, sc) for t, sc in later(j)]))
     out.append((prefix + '.g0', 64, [(t, 0, sc) for t, sc in later(0)] + [(m.conv1x1.weight, 0, 1.0)]))
+    # operands of the fused backward chain (esr_rdb_backward, csrc/rdb_chain_kernel.h) where they differ from the
+    # per-conv launches': the x2 slice with the identity path x4 = lrelu(a4) + x2 (block.py:266) folded into conv5's
+    # piece (its x4 columns added to its x2 columns: no residual read of g_x4), the x slice without the 1x1 (K = 192),
+    # and the transposed 1x1 in the K order of the chain's epilogue registers (esr_pack.one_t)
+    out.append((prefix + '.c2', 32, [(w[5], 96, 0.2, 160)] + [(w[k], 96, 1.0) for k in (4, 3)]))
+    out.append((prefix + '.c0', 64, [(t, 0, sc) for t, sc in later(0)]))
+    out.append((prefix + '.o1', 'one_t', m.conv1x1.weight))
     return out
 
 

@@ -78,6 +78,10 @@ constexpr int ESR_WGRAD_RUN_MAX = 24;
 
 extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
   if (!ops || n < 0) { esr_set_error("esr_run_ops: invalid arguments"); return ESR_ERR_INVALID; }
+  if (esr_rdb_check_abort()) {
+    esr_set_error("esr_run_ops: an earlier fused-chain launch aborted (a tile waited > 1 s for its neighbours: CUs held by other work?) — its results are invalid");
+    return ESR_ERR_LAUNCH;
+  }
   int nside = 0;        // side runs launched by this call
   bool joined = true;   // main stream already waits for the last side run
   int nfree = 0;        // ESR_OPF_SIDE_FREE runs launched by this call (joined at the unpermute / the end)
@@ -144,6 +148,7 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
         break;
       case ESR_OP_PACK_BATCH: rc = esr_pack_conv_weights_batch(&ops[i].u.pack_batch, stream); break;
       case ESR_OP_RDB_CHAIN: rc = esr_rdb_forward(&ops[i].u.rdb_chain, stream); break;
+      case ESR_OP_RDB_CHAIN_BWD: rc = esr_rdb_backward(&ops[i].u.rdb_chain, stream); break;
       case ESR_OP_FRAG_GATHER: rc = esr_gather_fragments(&ops[i].u.frag_gather, stream); break;
       case ESR_OP_RDB_WGRAD: {
         // dense-block weight gradients: like a run of wgrad ops — on the side stream when flagged ESR_OPF_SIDE

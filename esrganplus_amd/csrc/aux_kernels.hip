@@ -8,6 +8,19 @@ template <typename T>
 __device__ __forceinline__ void pack_piece(const esr_pack& p, int64_t idx) {
   constexpr int CPG = DT<T>::CPG;
   constexpr int EPL = CPG / 2;   // elements per lane (8 halves / 4 floats)
+  if (p.one_t) {
+    // transposed 1x1 of a dense block for the backward chain (esrgan_hip.h: esr_pack.one_t): fragment (cb, c), lane
+    // (row i, k half h), element e  <-  W1x1[g_x2 channel 16 h + 8 c + e][x channel cb * 32 + pi(i)]
+    if constexpr (CPG == 16) {
+      const int lane = idx & 63, c = (idx >> 6) & 1, cb = (int)(idx >> 7);
+      const int i = lane & 31, h = lane >> 5;
+      const int ci_f = cb * 32 + esr_pi(i);
+      T* dst = (T*)p.dst + idx * EPL;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) dst[e] = (T)(p.src[(int64_t)(16 * h + 8 * c + e) * p.cin + ci_f] * (p.scale == 0.f ? 1.f : p.scale));
+    }
+    return;
+  }
   if (p.gather) {
     // one K range of a gather-form dgrad operand (esrgan_hip.h): rows = slice channels, K = fwd couts
     const int nchunks = (p.cout + CPG - 1) / CPG;
@@ -28,6 +41,9 @@ __device__ __forceinline__ void pack_piece(const esr_pack& p, int64_t idx) {
         const int64_t base = (int64_t)ci * p.cin + p.src_co0 + co;
         if (p.src_ks == 3) x = p.src[(base * 3 + (2 - kh)) * 3 + (2 - kw)];
         else if (kh == 1 && kw == 1) x = p.src[base];
+        // identity path folded in (x4 = lrelu(a4) + x2: conv's x4 columns added to its x2 columns)
+        if (p.fold_co0 > 0 && p.src_ks == 3)
+          x += p.src[(((int64_t)ci * p.cin + p.fold_co0 + co) * 3 + (2 - kh)) * 3 + (2 - kw)];
       }
       v[e] = (T)(x * p.scale);
     }
@@ -223,6 +239,7 @@ extern "C" int esr_pack_conv_weights(const esr_pack* p, esr_stream_t stream) {
 
 extern "C" int64_t esr_pack_pieces(const esr_pack* p) {
   const int cpg = p->dtype == ESR_F16 ? 16 : 8;
+  if (p->one_t) return 4 * 64;
   if (p->gather) return (int64_t)((p->dst_cout + 31) / 32) * ((p->cout + cpg - 1) / cpg) * 9 * 64;
   if (p->ups_fwd) return (int64_t)((p->cout + 31) / 32) * 4 * ((p->cin + cpg - 1) / cpg) * 4 * 64;
   const int rows = p->transpose_flip ? p->cin : p->cout;

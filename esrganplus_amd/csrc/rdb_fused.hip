@@ -1,1361 +1,45 @@
-// rdb_fused.hip — input-stationary, persistent ResidualDenseBlock_5C chain on the gfx950 matrix cores.
-//
-// Replaces, for a CHAIN of dense blocks (the RRDB trunk of RRDBNet, architecture.py:57-59, i.e.
-// 3 x nb ResidualDenseBlock_5C, block.py:232-268, with the RRDB tails of block.py:287-291 /
-// test_image/block.py:252-256), what conv_mfma.hip runs as 5 launches per block.
-//
-// Why another kernel.  Layer by layer every conv of a block re-reads its whole concat prefix:
-// (64+96+128+160+192) = 640 channel-reads per pixel for 192 channels of new data, all of it from beyond
-// the 4 MB L2 (a block's working set is 12.6 MB per XCD).  profiles/r01_*: conv time = (time of the
-// memory side alone) + (MFMA time), i.e. the launch is paced by the bytes it moves.  Here the roles are
-// swapped: the OUTPUTS stay put.  A workgroup (4 waves, ONE per SIMD, 512 registers each) owns a
-// 16x32-pixel tile and keeps the fp32 accumulators of ALL 192 output channels of the block in registers:
-// a wave owns 4 rows x 32 pixels x 6 cout blocks = 24 MFMA accumulators = 384 registers.  hipcc only ever
-// emits the AGPR form of v_mfma (256 accumulator registers at most, anything beyond is shuttled through
-// v_accvgpr copies), so the MFMAs are issued through inline asm with explicit register classes: conv3,
-// conv4, conv5 accumulate in the 256 AGPRs ("+a"), conv1 / conv2 (the first to retire) in 128 VGPRs
-// ("+v"), which leaves 128 VGPRs for fragments and addresses.  The block then runs as five PHASES, one
-// per newly available input slice:
-//     phase 1  stage x   (64 ch)  -> accumulate into conv1..conv5        (6 cout blocks)
-//     phase 2  stage x1  (32 ch)  -> conv2..conv5                        (5)
-//     phase 3  stage x2           -> conv3..conv5                        (4)
-//     phase 4  stage x3           -> conv4, conv5                        (3)
-//     phase 5  stage x4           -> conv5                               (2)
-// so every input channel is staged ONCE (192 channel-reads per pixel instead of 640) and each staged
-// B fragment feeds 3 kh x NB MFMAs instead of 3.  After phase p the finished conv_p leaves through the
-// usual fused epilogue (bias, LeakyReLU, + conv1x1(x) for x2, + x2 for x4, *0.2 + x, noise, RRDB tail).
-// The bias-free 1x1 (block.py:263) is computed between phases 1 and 2 from the tile's own x pixels
-// (no halo, no neighbour needed) into the registers conv1 just vacated — it fills the wait for the
-// neighbours' x1.
-//
-// The 3x3 taps of phase p+1 need x_p on a 1-pixel halo, i.e. from the 8 neighbouring tiles.  All tiles
-// of an image are co-resident (one workgroup per CU, <= 256 tiles per image) and run in lock step; each
-// publishes "phase e done" through a per-tile flag and polls its neighbours' flags before staging the
-// next slice.  The hand-off is placement independent (agent scope; cdna guide, Guideline 16 R1): payload
-// = write-through (sc1) 16-byte stores, every storing wave drains vmcnt, one lane stores the flag (relaxed,
-// agent scope); the consumer polls relaxed and then reads the payload with sc1 loads (LDS-DMA, L1
-// bypassed).  Spins are bounded; a time-out raises the abort word of the workspace and every workgroup
-// leaves.  Overwrite hazards: a slot written in phase e is read by the neighbours in phase e+1 only, and
-// is next overwritten in phase e+5, which the owner cannot reach before every neighbour published e+1.
-//
-// GEMM view per unit (K step c, column tap kw):  D[cout][pixel] += W[cout][(kh, cin16)] X[(kh, cin16)][pixel]
-//   A fragments: NB x 3 (kh) x 1 KB per unit, streamed (LDS-DMA, L2 resident) through a 4-slot ring;
-//   B fragments: one 18x34 halo tile of a 32-byte channel group per K step — fp32: 3-slot ring (2 steps ahead);
-//   fp16: resident in the LDS (the epilogues write the tile's own pixels, only the halo ring is fetched).
-// The fp16 path runs every phase as crit_p (conv_p alone) -> epilogue -> bulk_p (the remaining convs, with the
-// halo hand-off hidden under them): see `Sched` below.  The accumulation order per output element is (chunk, kw,
-// kh) as in conv_mfma.hip; the fp16 path folds the block residual (conv5's accumulators start at 5 x) and keeps
-// x1..x4 as fp16 in the LDS.  tests/test_gpu_rdb_chain.py holds it to 1e-5 (fp32) / 2e-3 (fp16) of the per-conv
-// launches and requires bit-equal results run to run.
-#include <cstdlib>
-#include <mutex>
+// rdb_fused.hip — host entry points of the fused dense-block chain + the inference instantiations of its kernel
+// (csrc/rdb_chain_kernel.h; the training-forward and backward instantiations live in rdb_fused_train.hip /
+// rdb_fused_bwd.hip so that the three compile in parallel).
+#include "rdb_chain_kernel.h"
 
-#include "mfma_tile.h"
-
-#ifndef ESR_ABL
-#define ESR_ABL 0   // timing ablations (development only; results are wrong when non-zero)
-#endif
+// defined next to their kernels
+int esr_rdb_launch_train(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
+int esr_rdb_launch_bwd(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 
 namespace {
-
-constexpr int R = 4;                        // output rows per wave
-constexpr int TH = 16, TW = 32;             // tile of a workgroup (4 waves stacked vertically)
-constexpr int IH = TH + 2, IW = TW + 2;     // staged halo tile
-constexpr int NT = 256;                     // 4 waves, one per SIMD
-constexpr int NSLOT = IH * IW * 2;          // 16-byte slots of one activation stage
-constexpr int NLD = (NSLOT + NT - 1) / NT;  // DMA rounds per stage (5)
-constexpr int ASLOT = NLD * NT * 16;        // 20480
-constexpr int AR = 4;                       // activation slots: all stages of a 64-channel fp16 input are resident
-constexpr int WSLOT = 18 * 1024;            // weight unit (6 blocks x 3 kh fragments)
-constexpr int WR = 4;                       // weight ring depth (3 units ahead)
-constexpr int WOFF = AR * ASLOT;
-constexpr int LDS_CTRL = WOFF + WR * WSLOT;   // two control words behind the rings
-constexpr int LDS_BIAS = LDS_CTRL + 64;        // fp16 path: the block's 192 biases (fp32)
-constexpr int LDS_FLAGS = LDS_BIAS + 192 * 4;  // fp16 path: the neighbours' flags as wave 0 last fetched them (64 words)
-constexpr int LDS_HALO = LDS_FLAGS + 256;      // fp16 path: per thread {source, destination} offset of its halo slot
-constexpr int LDS_BYTES = LDS_HALO + NT * 8;   // 158784
-constexpr int NHALO = 2 * 2 * IW + 2 * 2 * TH;  // 16-byte slots of the 1-pixel halo ring of one stage (200)
-constexpr int WS_HDR = 16;                  // workspace words before the per-tile flags
-enum { WS_TICKET = 0, WS_ABORT = 1 };
-
-// ---- 24 named accumulators per wave: [cout block 0..5][row 0..3] --------------------------------------
-// cout blocks of a dense block: 0..3 = conv1..conv4, 4/5 = conv5[0:32]/[32:64].
-struct Acc24 {
-  f32x16 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15, v16, v17, v18, v19, v20, v21, v22, v23;
-};
-template <int I> __device__ __forceinline__ f32x16& acc_at(Acc24& s) {
-  static_assert(I >= 0 && I < 24, "acc index");
-#define ESR_ACC_CASE(n) if constexpr (I == n) return s.v##n; else
-  ESR_ACC_CASE(0) ESR_ACC_CASE(1) ESR_ACC_CASE(2) ESR_ACC_CASE(3) ESR_ACC_CASE(4) ESR_ACC_CASE(5)
-  ESR_ACC_CASE(6) ESR_ACC_CASE(7) ESR_ACC_CASE(8) ESR_ACC_CASE(9) ESR_ACC_CASE(10) ESR_ACC_CASE(11)
-  ESR_ACC_CASE(12) ESR_ACC_CASE(13) ESR_ACC_CASE(14) ESR_ACC_CASE(15) ESR_ACC_CASE(16) ESR_ACC_CASE(17)
-  ESR_ACC_CASE(18) ESR_ACC_CASE(19) ESR_ACC_CASE(20) ESR_ACC_CASE(21) ESR_ACC_CASE(22)
-  return s.v23;
-#undef ESR_ACC_CASE
+// pinned host word the kernels raise when a bounded spin times out (one per process; first use allocates it)
+unsigned* abort_word() {
+  static unsigned* w = [] {
+    unsigned* q = nullptr;
+    if (hipHostMalloc((void**)&q, 64, hipHostMallocMapped) != hipSuccess) return (unsigned*)nullptr;
+    *q = 0u;
+    return q;
+  }();
+  return w;
 }
-template <int BLK, int ROW> __device__ __forceinline__ f32x16& acc_br(Acc24& s) { return acc_at<BLK * R + ROW>(s); }
-
-// MFMA through inline asm with an explicit accumulator register class: AGPR (blocks 2..5) or VGPR
-// (blocks 0,1).  hipcc does not pad hazards of asm statements (cdna guide 5.7): accumulate chains
-// (same D as C) need none; before anything else reads or overwrites an accumulator the callers run
-// mfma_drain().  A/B come from ds_read (s_waitcnt is placed by the compiler through the operands).
-constexpr bool acc_in_agpr(int blk) { return blk >= 2; }
-// FIRST: the accumulator's first MFMA of a block takes the inline constant 0 as SrcC and a write-only
-// output, so accumulators are never zeroed by VALU code (hipcc materialises such zeros lazily with
-// v_mov copies BETWEEN the asm MFMAs, where nothing pads the VALU-write -> MFMA-read hazard).
-template <typename T, bool AGPR, bool FIRST = false>
-__device__ __forceinline__ void mma_cls(f32x16& acc, const u32x4& a, const u32x4& b) {
-  if constexpr (sizeof(T) == 2) {
-    if constexpr (FIRST) {
-      if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
-      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
-    } else {
-      if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-    }
-  } else {
-    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
-    if constexpr (FIRST) {
-      if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(fa[0]), "v"(fb[0]));
-      else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(fa[0]), "v"(fb[0]));
-    }
-#pragma unroll
-    for (int t = FIRST ? 1 : 0; t < 4; ++t) {
-      if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(fa[t]), "v"(fb[t]));
-      else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(fa[t]), "v"(fb[t]));
-    }
-  }
+// device-visible alias of the pinned word
+unsigned* abort_word_dev() {
+  static unsigned* d = [] {
+    unsigned* w = abort_word();
+    void* q = nullptr;
+    if (!w || hipHostGetDevicePointer(&q, w, 0) != hipSuccess) return (unsigned*)nullptr;
+    return (unsigned*)q;
+  }();
+  return d;
 }
-// >= 18 wait states: covers "XDL write VGPR -> VALU / VMEM read or write" for 8- and 16-pass MFMAs
-__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
-
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void wait_vm_dyn(int n) {   // n is wave-uniform; conservative above 47
-  if (n >= 16) {
-    if (n >= 32) { if (n >= 40) wait_vm<40>(); else wait_vm<32>(); }
-    else { if (n >= 24) wait_vm<24>(); else wait_vm<16>(); }
-    return;
-  }
-  switch (n) {
-    case 0: wait_vm<0>(); break;   case 1: wait_vm<1>(); break;   case 2: wait_vm<2>(); break;
-    case 3: wait_vm<3>(); break;   case 4: wait_vm<4>(); break;   case 5: wait_vm<5>(); break;
-    case 6: wait_vm<6>(); break;   case 7: wait_vm<7>(); break;   case 8: wait_vm<8>(); break;
-    case 9: wait_vm<9>(); break;   case 10: wait_vm<10>(); break; case 11: wait_vm<11>(); break;
-    case 12: wait_vm<12>(); break; case 13: wait_vm<13>(); break; case 14: wait_vm<14>(); break;
-    default: wait_vm<15>(); break;
-  }
-}
-
-// agent-scope (L1-bypassing) LDS-DMA: the activations another workgroup just published
-__device__ __forceinline__ void dma16_sc1(const char* g, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 16);
-}
-
-// One G32 view of ONE image as a buffer resource (wave-uniform): 16-byte sc1 loads / stores.
-struct ImgView {
-  __amdgpu_buffer_rsrc_t r;
-  int gs;        // group stride (bytes)
-  int ng;        // groups addressable
-};
-// hipcc wraps every buffer access whose descriptor it cannot PROVE wave-uniform in a waterfall loop
-// (readfirstlane x4 + compare + saveexec, cdna guide T20) — and anything that went through the LDS or a
-// block-table load counts as divergent.  Descriptor inputs therefore pass through readfirstlane once.
-__device__ __forceinline__ char* uniform_ptr(const void* p) {
-  const uint64_t v = (uint64_t)p;
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return (char*)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ ImgView img_view(const esr_g32& v, int b, int g0 = 0) {
-  ImgView o;
-  char* base = uniform_ptr((char*)v.ptr + (int64_t)b * v.batch_stride + (int64_t)g0 * v.group_stride);
-  o.r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
-  o.gs = __builtin_amdgcn_readfirstlane((int)v.group_stride);
-  o.ng = v.ngroups - g0;
-  return o;
-}
-
-// 16 consecutive channels (cout block cb, lane half h) of one pixel <-> float[16], through sc1 accesses
-template <typename T> struct Ch16;
-template <> struct Ch16<_Float16> {
-  static __device__ __forceinline__ void store(const ImgView& t, int cb, int h, int pixoff, const float v[16]) {
-    half8 x, y;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { x[i] = (_Float16)v[i]; y[i] = (_Float16)v[8 + i]; }
-    const int off = (2 * cb + h) * t.gs + pixoff;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), t.r, off, 0, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), t.r, off + 16, 0, 16);
-  }
-  // packed row: the lane's 16 channels as stored (2 x 16 bytes)
-  static __device__ __forceinline__ void pack(const float v[16], u32x4 (&q)[2]) {
-    half8 x, y;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { x[i] = (_Float16)v[i]; y[i] = (_Float16)v[8 + i]; }
-    q[0] = __builtin_bit_cast(u32x4, x); q[1] = __builtin_bit_cast(u32x4, y);
-  }
-  static __device__ __forceinline__ void store_packed(const ImgView& t, int cb, int h, int pixoff, const u32x4 (&q)[2]) {
-    const int off = (2 * cb + h) * t.gs + pixoff;
-    __builtin_amdgcn_raw_buffer_store_b128(q[0], t.r, off, 0, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(q[1], t.r, off + 16, 0, 16);
-  }
-  struct Raw { u32x4 q[2]; };
-  static __device__ __forceinline__ void load(const ImgView& t, int cb, int h, int pixoff, Raw& r) {
-    const int off = (2 * cb + h) * t.gs + pixoff;
-    r.q[0] = __builtin_amdgcn_raw_buffer_load_b128(t.r, off, 0, 16);
-    r.q[1] = __builtin_amdgcn_raw_buffer_load_b128(t.r, off + 16, 0, 16);
-  }
-  static __device__ __forceinline__ void get(const Raw& r, float v[16]) {
-    const half8 x = __builtin_bit_cast(half8, r.q[0]), y = __builtin_bit_cast(half8, r.q[1]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { v[i] = (float)x[i]; v[8 + i] = (float)y[i]; }
-  }
-};
-template <> struct Ch16<float> {
-  static __device__ __forceinline__ void store(const ImgView& t, int cb, int h, int pixoff, const float v[16]) {
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int off = (4 * cb + 2 * h + g) * t.gs + pixoff;
-      f32x4 a, c;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = v[8 * g + i]; c[i] = v[8 * g + 4 + i]; }
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), t.r, off, 0, 16);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, c), t.r, off + 16, 0, 16);
-    }
-  }
-  struct Raw { u32x4 q[4]; };
-  static __device__ __forceinline__ void load(const ImgView& t, int cb, int h, int pixoff, Raw& r) {
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int off = (4 * cb + 2 * h + g) * t.gs + pixoff;
-      r.q[2 * g] = __builtin_amdgcn_raw_buffer_load_b128(t.r, off, 0, 16);
-      r.q[2 * g + 1] = __builtin_amdgcn_raw_buffer_load_b128(t.r, off + 16, 0, 16);
-    }
-  }
-  static __device__ __forceinline__ void get(const Raw& r, float v[16]) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 a = __builtin_bit_cast(f32x4, r.q[g]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[4 * g + i] = a[i];
-    }
-  }
-};
-
-template <typename T> struct Cfg {
-  static constexpr int CPG = DT<T>::CPG, GPB = DT<T>::GPB;
-  static constexpr int KX = 64 / CPG;      // K steps of the 64-channel block input
-  static constexpr int KD = 32 / CPG;      // K steps of one 32-channel dense slice
-  static constexpr int ksteps(int p) { return p == 1 ? KX : KD; }
-  static constexpr int nblk(int p) { return 7 - p; }
-  // byte offset of phase p (1..5) in the block's fused weight stream; phase_off(6) = the 1x1 fragments
-  static constexpr int phase_off(int p) {
-    int o = 0;
-    for (int q = 1; q < p; ++q) o += ksteps(q) * 3 * nblk(q) * 3 * 1024;
-    return o;
-  }
-  static constexpr int STREAM_BYTES = phase_off(6) + KX * 1024;
-};
-
-// The tile in flight.  Only wave-uniform values live here (SGPRs).  Everything per lane is RE-DERIVED from the
-// lane id where it is used: a per-lane constant computed once per tile is a VGPR that lives across the whole
-// block loop, i.e. across the MFMA segments where all registers are taken — hipcc spills it and reloads it at
-// every use, and with weight DMAs in flight each scratch reload is a full `vmcnt(0)` drain.  The lane id itself
-// costs nothing to keep: v_mbcnt derives it from EXEC (volatile asm, so that the values derived from it are
-// not hoisted back out of the loops into long-lived registers).
-__device__ __forceinline__ int fresh_lane() {
-  int l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
-}
-struct Tile {
-  int b, oy0, ox0;
-  int ty, tx, tiles_y, tiles_x;
-  int wave;
-  int wp;            // row pitch (pixels) of every view
-  __device__ __forceinline__ int lane() const { return fresh_lane(); }
-  __device__ __forceinline__ int tid() const { return wave * 64 + fresh_lane(); }
-  // per-lane B-fragment offset of column tap kw (pixel j + kw, half h; halves swapped by (col >> 3) & 1)
-  static __device__ __forceinline__ int colofs(int lane, int kw) {
-    const int col = (lane & 31) + kw;
-    return col * 32 + (((lane >> 5) ^ ((col >> 3) & 1)) << 4);
-  }
-  // this lane's own pixel (row 4*wave, column j) inside an activation slot, half 0; swz = 16 if the two halves
-  // of that pixel are swapped in the LDS image
-  __device__ __forceinline__ void own(int lane, int& px, int& swz) const {
-    const int j = lane & 31;
-    px = ((wave * R + 1) * IW + j + 1) * 32;
-    swz = (((j + 1) >> 3) & 1) << 4;
-  }
-  // LDS-resident path (fp16): the 1-pixel halo ring of a stage = 200 16-byte slots, one per thread: rows 0 / 17
-  // (34 pixels each), then columns 0 / 33 of rows 1..16.  src: byte offset inside a group plane (-1: this
-  // thread has no slot); dst: byte offset inside an activation slot
-  __device__ __forceinline__ void halo(int& src, int& dst) const {
-    const int i = tid();
-    int row, col, hs;
-    if (i < 4 * IW) { const int s = i % (2 * IW); row = i < 2 * IW ? 0 : IH - 1; col = s >> 1; hs = s & 1; }
-    else { const int s = (i - 4 * IW) % (2 * TH); row = 1 + (s >> 1); col = i < 4 * IW + 2 * TH ? 0 : IW - 1; hs = s & 1; }
-    src = i < NHALO ? ((oy0 + row) * wp + ox0 + col) * 32 + ((hs ^ ((col >> 3) & 1)) << 4) : -1;
-    dst = (row * IW + col) * 32 + hs * 16;
-  }
-};
-
-// ---- weights of unit u of a phase -> ring slot (u & 3) ---------------------------------------------
-template <int NF> __device__ __forceinline__ void issue_w(const char* wsrc, int u, char* smem, const Tile& t) {
-  const char* src = wsrc + ((int64_t)u * NF) * 1024 + t.lane() * 16;
-  char* dst = smem + WOFF + (u & (WR - 1)) * WSLOT;
-#pragma unroll
-  for (int i = 0; i < (NF + 3) / 4; ++i) {
-    const int q = t.wave + 4 * i;
-    if (q < NF) dma16(src + q * 1024, dst + q * 1024);
-  }
-}
-// ---- activation stage (one 32-byte channel group, 18x34 halo tile) -> ring slot sa -----------------
-__device__ __forceinline__ void issue_a(const char* plane, int sa, char* smem, const Tile& t) {
-  // LDS slot s = tid + 256*i  <-  (row, col, 16-byte half), halves swapped by (col>>3)&1 on the SOURCE address
-  // so that ds_read_b128 B-fragment reads are bank-conflict free.  Offsets are recomputed per call: this
-  // path only stages a chain's first input (and the fp32 reference path), and 5 live registers cost more.
-  char* dst = smem + sa * ASLOT + t.wave * 1024;
-  const int tid = t.tid();
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    int s = tid + NT * i;
-    if (s >= NSLOT) s = NSLOT - 1;            // tail lanes: harmless re-copy into the padding
-    const int row = s / (2 * IW), r2 = s - row * 2 * IW;
-    const int col = r2 >> 1, hs = r2 & 1, half = hs ^ ((col >> 3) & 1);
-    dma16_sc1(plane + ((t.oy0 + row) * t.wp + t.ox0 + col) * 32 + half * 16, dst + NT * 16 * i);
-  }
-}
-
-// ---- LDS-resident activations (fp16 path) -----------------------------------------------------------
-// A tile's own 16x32 pixels of a slice never come back from memory: the epilogue that produces them also
-// writes them into the stage slots the next phase reads (slot = channel group of the slice).  Only the
-// 1-pixel ring around the tile is fetched (sc1 loads, after the neighbours published): one 16-byte load
-// + one ds_write per thread and stage.
-template <int K> struct HaloRegs { u32x4 q[K]; };
-template <int K> __device__ __forceinline__ void halo_issue(const ImgView& v, int g0, int hsrc, HaloRegs<K>& h) {
-  // threads without a slot read (and later drop) the view's first bytes: a branch around the loads would
-  // also fence them off from the MFMAs they are meant to hide under
-#pragma unroll
-  for (int c = 0; c < K; ++c) h.q[c] = __builtin_amdgcn_raw_buffer_load_b128(v.r, hsrc >= 0 ? (g0 + c) * v.gs + hsrc : 0, 0, 16);
-}
-template <int K> __device__ __forceinline__ void halo_put(char* smem, int slot0, int hsrc, int hdst, const HaloRegs<K>& h) {
-  if (hsrc >= 0) {
-#pragma unroll
-    for (int c = 0; c < K; ++c) *(u32x4*)(smem + (slot0 + c) * ASLOT + hdst) = h.q[c];
-  }
-}
-template <int K> __device__ __forceinline__ void halo_fetch(const ImgView& v, int g0, char* smem, const Tile& t, int slot0 = 0) {
-  HaloRegs<K> h;
-  // the thread's slot as the tile set-up cached it (LDS_HALO)
-  const int hsrc = *(volatile int*)(smem + LDS_HALO + t.tid() * 8), hdst = *(volatile int*)(smem + LDS_HALO + t.tid() * 8 + 4);
-  halo_issue<K>(v, g0, hsrc, h);
-  halo_put<K>(smem, slot0, hsrc, hdst, h);
-}
-// the lane's packed 16 channels of row r (own pixel) -> stage slot `slot`
-__device__ __forceinline__ void lds_put_row(char* smem, int slot, int r, const u32x4 (&q)[2], int own_px, int own_swz) {
-  char* px = smem + slot * ASLOT + own_px + r * (IW * 32);
-  *(u32x4*)(px + own_swz) = q[0];
-  *(u32x4*)(px + (own_swz ^ 16)) = q[1];
-}
-
-// .. and back (the lane's own pixel as the epilogue stored it)
-template <typename RAW> __device__ __forceinline__ void lds_get_rows(const char* smem, int slot0, RAW (&q)[R], const Tile& t) {
-  const int lane = t.lane();
-  int own_px, own_swz;
-  t.own(lane, own_px, own_swz);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const char* px = smem + (slot0 + (lane >> 5)) * ASLOT + own_px + r * (IW * 32);
-    q[r].q[0] = *(const u32x4*)(px + own_swz);
-    q[r].q[1] = *(const u32x4*)(px + (own_swz ^ 16));
-  }
-}
-
-// ---- the MFMAs of one unit of phase P: cout blocks P-1..5 x 3 kh taps x 4 rows ----------------------
-// Every LDS fragment read is inline asm as well: with a compiler-tracked ds_read outstanding hipcc puts
-// `s_waitcnt lgkmcnt(0)` in front of every asm MFMA.  A fragments are double buffered; block bi+1's
-// three fragments are requested after the 4th of block bi's 12 MFMAs (the buffer's previous readers,
-// block bi-1, are >= 4 MFMAs back; 8 MFMAs = 256 cycles cover the LDS latency) and waited for with
-// lgkmcnt(0) in front of block bi+1.
-template <int OFF> __device__ __forceinline__ void lds_read16(u32x4& d, uint32_t addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
-__device__ __forceinline__ void lds_wait3(u32x4& a, u32x4& b, u32x4& c) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
-}
-struct NoIssue { __device__ __forceinline__ void operator()(int) const {} };
-// `issue(i)`, i = 0..4: the wave's i-th weight DMA of the unit it prefetches; called BETWEEN the cout
-// blocks' MFMA groups so that the DMA issue time hides under the matrix pipe (one wave per SIMD: any
-// instruction that is not in an MFMA's shadow is lost time).
-template <typename T, int P, bool FIRST = false, bool CARRY45 = false, typename ISSUE = NoIssue>
-__device__ __forceinline__ void unit_mma(Acc24& acc, const uint32_t lds_b, const uint32_t lds_w, ISSUE&& issue = NoIssue{}) {
-  constexpr int NB = 7 - P;
-  u32x4 bf[R + 2], af[2][3];
-  sfor<R + 2>([&](auto IR) __attribute__((always_inline)) { lds_read16<decltype(IR)::value * IW * 32>(bf[decltype(IR)::value], lds_b); });
-  sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(af[0][decltype(KH)::value], lds_w); });
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]),
-               "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]));
-  sfor<NB>([&](auto BI) __attribute__((always_inline)) {
-    constexpr int bi = decltype(BI)::value;       // position in the unit's fragment list
-    constexpr int blk = P - 1 + bi;
-    constexpr int cur = bi & 1, nxt = cur ^ 1;
-    // the 12 (input row, kh) pairs in issue order: ir-major, rows r = ir - kh
-    sfor<R + 2>([&](auto IR) __attribute__((always_inline)) {
-      constexpr int ir = decltype(IR)::value;
-      sfor<3>([&](auto KH) __attribute__((always_inline)) {
-        constexpr int kh = decltype(KH)::value;
-        constexpr int r = ir - kh;
-        if constexpr (r >= 0 && r < R) mma_cls<T, acc_in_agpr(blk), FIRST && kh == 0 && !(CARRY45 && blk >= 4)>(acc_br<blk, r>(acc), af[cur][kh], bf[ir]);
-      });
-      if constexpr (ir == 2 && bi + 1 < NB) {     // after MFMA 6 of 12
-        sfor<3>([&](auto KH) __attribute__((always_inline)) {
-          lds_read16<((bi + 1) * 3 + decltype(KH)::value) * 1024>(af[nxt][decltype(KH)::value], lds_w);
-        });
-      }
-    });
-    if constexpr (bi + 1 < NB) lds_wait3(af[nxt][0], af[nxt][1], af[nxt][2]);
-    __builtin_amdgcn_sched_barrier(0);
-    issue(bi);
-    if constexpr (bi + 1 == NB) {
-#pragma unroll
-      for (int i = NB; i < 5; ++i) issue(i);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  });
-}
-
-// ---- resident path (fp16): the unit schedule of a dense block ----------------------------------------
-// The five convs of a block form a dependent chain: conv_p -> epilogue (x_p) -> halo exchange with the 8
-// neighbouring tiles -> conv_{p+1}.  Of a phase's MFMAs (stage x_{p-1} into conv_p..conv5) only conv_p's
-// are on that chain, so every phase is split:
-//     crit_p   stage x_{p-1} -> conv_p only                 (cout block p-1; conv5: blocks 4, 5)
-//     epilogue x_p: border pixels to memory, own pixels to the LDS
-//     bulk_p   stage x_{p-1} -> conv_{p+1}..conv5           (blocks p..5) — nothing waits for these, so the
-//              hand-off hides under them: the stores drain while the first bulk units run, the flag goes out
-//              at the second unit's barrier, and the neighbours' flags are long up when the bulk ends
-//     poll, fetch x_p's halo ring, crit_{p+1} ...
-// Units (one weight-ring slot each, in stream order; K = 4 K-steps for x, 2 for x1..x4):
-//     crit_p (p<5): K units (c)      = 3 kw x 1 block x 3 kh  =  9 fragments, 36 MFMAs
-//     bulk_p (p<5): 3K units (c, kw) = (5-p)+1 blocks x 3 kh  = 15/12/9/6 fragments
-//     1x1         : 1 unit after bulk_1 (K fragments)
-//     crit_5      : 3K units (c, kw) = 2 blocks x 3 kh        =  6 fragments
-// Stage slots: x -> 0..3; x1 -> 0,1 (after the 1x1 has read x); x2 -> 2,3; x3 -> 0,1; x4 -> 2,3; the block
-// output -> 0..3.  A stage is overwritten only after the bulk that read its predecessor in those slots.
-enum { U_CRIT = 0, U_BULK = 1, U_ONE = 2 };
-struct UDesc { int kind, P, c, kw, nf, off; };        // off: fragments from the start of the block's stream
-template <typename T> struct Sched {
-  using CF = Cfg<T>;
-  // idx < 0: {.., nf = number of units, off = fragments of the whole stream}
-  static constexpr UDesc at(int idx) {
-    int i = 0, off = 0;
-    for (int P = 1; P <= 5; ++P) {
-      const int K = CF::ksteps(P);
-      if (P < 5) {
-        for (int c = 0; c < K; ++c) { if (i == idx) return {U_CRIT, P, c, 0, 9, off}; ++i; off += 9; }
-        const int nf = (6 - P) * 3;
-        for (int c = 0; c < K; ++c)
-          for (int kw = 0; kw < 3; ++kw) { if (i == idx) return {U_BULK, P, c, kw, nf, off}; ++i; off += nf; }
-        if (P == 1) { if (i == idx) return {U_ONE, 1, 0, 0, CF::KX, off}; ++i; off += CF::KX; }
-      } else {
-        for (int c = 0; c < K; ++c)
-          for (int kw = 0; kw < 3; ++kw) { if (i == idx) return {U_CRIT, 5, c, kw, 6, off}; ++i; off += 6; }
-      }
-    }
-    return {-1, 0, 0, 0, i, off};
-  }
-  static constexpr int N = at(-1).nf;
-  static constexpr int first(int kind, int P) {
-    for (int i = 0; i < N; ++i) if (at(i).kind == kind && at(i).P == P) return i;
-    return -1;
-  }
-  static constexpr int end(int kind, int P) {
-    int e = -1;
-    for (int i = 0; i < N; ++i) if (at(i).kind == kind && at(i).P == P) e = i + 1;
-    return e;
-  }
-  static constexpr int nkw(const UDesc d) { return (d.kind == U_CRIT && d.P < 5) ? 3 : 1; }     // B-fragment sets
-  static constexpr int nblk(const UDesc d) { return d.kind == U_BULK ? 6 - d.P : (d.P < 5 ? 1 : 2); }
-  static constexpr int blk0(const UDesc d) { return d.kind == U_BULK ? d.P : d.P - 1; }
-  static constexpr int slot(const UDesc d) { return ((d.P == 3 || d.P == 5) ? 2 : 0) + d.c; }  // stage slot
-  // fragments of unit j, continuing into the next block's stream (none: that block does not exist)
-  static constexpr int nf_at(int j, bool has_next) { return j < N ? at(j).nf : (has_next ? at(j - N).nf : 0); }
-  // Counted waits.  Unit i's weights are requested during unit i-3 (wave w copies fragments w, w+4, ..: one
-  // per step, the rest after the last step), so every wave has requested AT LEAST nf >> 2 fragments of a unit.
-  // Vector memory operations retire in order: `vmcnt(n)` with n = the requests certainly issued SINCE the
-  // wanted ones proves those landed whatever else (epilogue stores, bias / halo loads) is in flight as well.
-  //   top(i): before unit i, units i+1 and i+2 were requested since;
-  //   mid(i): opening unit i+1 inside unit i's last step: unit i+2, and unit i+3's first steps(i)-1 requests.
-  static constexpr int steps(int i) { return nkw(at(i)) * nblk(at(i)); }
-  static constexpr int wait_top(int i, bool has_next) { return (nf_at(i + 1, has_next) >> 2) + (nf_at(i + 2, has_next) >> 2); }
-  static constexpr int wait_mid(int i, bool has_next) {
-    const int part = nf_at(i + 3, has_next) >> 2, done = steps(i) - 1;
-    return (nf_at(i + 2, has_next) >> 2) + (part < done ? part : done);
-  }
-  // mid(i) of the FIRST unit after an epilogue, strict form: nothing but this unit's own requests may still be
-  // in flight, i.e. the epilogue's stores (older than those, younger than unit i+2's requests) have landed
-  static constexpr int wait_mid_strict(int i, bool has_next) {
-    const int part = nf_at(i + 3, has_next) >> 2, done = steps(i) - 1;
-    return part < done ? part : done;
-  }
-  // steps of units [i0, i): which of the two A-fragment register sets unit i starts on
-  static constexpr int parity(int i0, int i) {
-    int p = 0;
-    for (int u = i0; u < i; ++u) p += steps(u);
-    return p & 1;
-  }
-};
-
-// One unit = NKW x NBLK steps of 12 MFMAs (3 kh x 4 rows against one set of 6 B fragments).  Fragments sit
-// in ONE set of B registers and two of A (48 registers), refilled in place as their last reader has issued:
-// a step's MFMAs 1..6 read B rows 0..2, MFMAs 7..12 rows 3..5, so when the next step (or unit) reads another
-// column tap its rows 0..2 are requested after MFMA 6 — together with its A fragments, into the other A set
-// — and its rows 3..5 after MFMA 12; the wait in front of a step leaves those last three reads in flight
-// (`lgkmcnt(3)`: LDS operations return in order), they are first needed 6 MFMAs later.
-// Units run back to back: the next unit's first fragments are requested the same way during this unit's
-// last step — after `mid()`, the next unit's DMA wait + barrier, which therefore hides under the remaining
-// MFMAs — so a unit opens straight with its MFMAs.  PAR = the A set the unit starts on.
-struct UFrags { u32x4 bf[R + 2]; u32x4 a[2][3]; };
-template <typename T, int BLK0, int NBLK, int NKW, bool FIRST, bool PRE, bool NXT, int PAR, typename ISSUE, typename MID>
-__device__ __forceinline__ void unit_steps(Acc24& acc, UFrags& f, const uint32_t (&lb)[3], const uint32_t lw,
-                                           const uint32_t lbn, const uint32_t lwn, ISSUE&& issue, MID&& mid) {
-  constexpr int NS = NKW * NBLK;
-  u32x4 (&bf)[R + 2] = f.bf;
-  if constexpr (!PRE) {
-    sfor<R + 2>([&](auto IR) __attribute__((always_inline)) { lds_read16<decltype(IR)::value * IW * 32>(bf[decltype(IR)::value], lb[0]); });
-    sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(f.a[PAR][decltype(KH)::value], lw); });
-  }
-  sfor<NS>([&](auto SI) __attribute__((always_inline)) {
-    constexpr int s = decltype(SI)::value;
-    constexpr int kwi = s / NBLK, bi = s % NBLK, blk = BLK0 + bi;
-    constexpr bool fresh = s == 0 ? PRE : (s / NBLK != (s - 1) / NBLK);   // B rows 3..5 of this step still in flight
-    constexpr bool newset = s + 1 < NS && (s + 1) / NBLK != kwi;          // the next step reads another column tap
-    u32x4 (&af)[3] = f.a[(PAR + s) & 1];
-    u32x4 (&an)[3] = f.a[(PAR + s + 1) & 1];
-    // this step's A fragments and B rows 0..2
-    if constexpr (fresh) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]));
-    else if constexpr (s == 0)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]),
-                   "+v"(af[0]), "+v"(af[1]), "+v"(af[2]));
-    else lds_wait3(af[0], af[1], af[2]);
-    sfor<R + 2>([&](auto IR) __attribute__((always_inline)) {
-      constexpr int ir = decltype(IR)::value;
-      sfor<3>([&](auto KH) __attribute__((always_inline)) {
-        constexpr int kh = decltype(KH)::value;
-        constexpr int r = ir - kh;
-        if constexpr (r >= 0 && r < R) mma_cls<T, acc_in_agpr(blk), FIRST && kwi == 0 && kh == 0 && blk < 4>(acc_br<blk, r>(acc), af[kh], bf[ir]);
-      });
-      if constexpr (ir == 2) {                    // after MFMA 6 of 12
-        if constexpr (fresh) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]));
-        if constexpr (s + 1 < NS) {
-          if constexpr (newset && !(ESR_ABL & 4))
-            sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<decltype(IR2)::value * IW * 32>(bf[decltype(IR2)::value], lb[newset ? kwi + 1 : 0]); });
-          if constexpr (!(ESR_ABL & 2))
-            sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<((s + 1) * 3 + decltype(KH)::value) * 1024>(an[decltype(KH)::value], lw); });
-        } else if constexpr (NXT) {
-          if constexpr (!(ESR_ABL & 8)) mid();
-          if constexpr (!(ESR_ABL & 4))
-            sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<decltype(IR2)::value * IW * 32>(bf[decltype(IR2)::value], lbn); });
-          sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(an[decltype(KH)::value], lwn); });
-        }
-      }
-    });
-    // after MFMA 12: rows 3..5 of the next column tap
-    if constexpr (newset && !(ESR_ABL & 4))
-      sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<(3 + decltype(IR2)::value) * IW * 32>(bf[3 + decltype(IR2)::value], lb[newset ? kwi + 1 : 0]); });
-    if constexpr (s + 1 == NS && NXT && !(ESR_ABL & 4))
-      sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<(3 + decltype(IR2)::value) * IW * 32>(bf[3 + decltype(IR2)::value], lbn); });
-    __builtin_amdgcn_sched_barrier(0);
-    issue(std::integral_constant<int, s>{});
-    if constexpr (s + 1 == NS && NS < 4)
-      sfor<4 - NS>([&](auto X) __attribute__((always_inline)) { issue(std::integral_constant<int, NS + decltype(X)::value>{}); });
-    __builtin_amdgcn_sched_barrier(0);
-  });
-}
-
-// ---- one phase: K steps x 3 column taps over NB cout blocks ----------------------------------------
-// The first three weight units are already in flight (issue_w_head, before the neighbour poll).
-template <int NB> __device__ __forceinline__ void issue_w_head(const char* wsrc, int K, char* smem, const Tile& t) {
-  issue_w<NB * 3>(wsrc, 0, smem, t);
-  issue_w<NB * 3>(wsrc, 1, smem, t);
-  issue_w<NB * 3>(wsrc, 2, smem, t);      // every phase has >= 6 units
-}
-
-template <typename T, int P>
-__device__ __forceinline__ void run_phase(Acc24& acc, const char* wsrc, const char* aplane, const int64_t a_gs,
-                                          const int K, char* smem, const Tile& t) {
-  constexpr int NB = 7 - P, NF = NB * 3;
-  const int NU = 3 * K;
-  const int nW = (NF + 3 - t.wave) >> 2;                 // weight DMAs this wave issues per unit
-  constexpr int nA = NLD;                                // activation DMAs per stage
-  issue_a(aplane, 0, smem, t);
-  if (K > 1) issue_a(aplane + a_gs, 1, smem, t);
-  int g1 = K > 1 ? nA : 0, g2 = 0;                       // DMAs issued in the previous two units
-  int sa = 0;
-  const int lane = t.lane();
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
-  // one K step = 3 units.  The block's very first K step (phase 1, c = 0) is peeled: its first unit writes
-  // the accumulators (SrcC = 0) and must not share a control-flow join with the accumulating form (the phi
-  // of a fully allocated AGPR file is resolved through scratch).
-  auto kstep = [&](const int c, auto FIRSTC) __attribute__((always_inline)) {
-    constexpr bool firstc = decltype(FIRSTC)::value;
-    sfor<3>([&](auto KW) __attribute__((always_inline)) {
-      constexpr int kw = decltype(KW)::value;
-      const int u = 3 * c + kw;
-      // in-order return: unit u's weights (issued 3 units ago) and K step c's activations (6 units ago)
-      // have landed once only what was issued after them is outstanding
-      int n = g1 + g2;
-      if (kw == 0) n = firstc ? g1 : n + (c + 1 < K ? nA : 0);
-      wait_vm_dyn(n);
-      __builtin_amdgcn_s_barrier();       // unit u visible to all waves; all waves done with unit u-1
-      int cnt = 0;
-      if (u + 3 < NU) { issue_w<NF>(wsrc, u + 3, smem, t); cnt += nW; }
-      if (kw == 0 && c + 2 < K) {
-        int sn = sa + 2; if (sn >= AR) sn -= AR;
-        issue_a(aplane + (int64_t)(c + 2) * a_gs, sn, smem, t);
-        cnt += nA;
-      }
-      g2 = g1; g1 = cnt;
-      const uint32_t lb = lds_rows + sa * ASLOT + Tile::colofs(lane, kw);
-      const uint32_t lw = lds0 + WOFF + (u & (WR - 1)) * WSLOT + lane * 16;
-      unit_mma<T, P, P == 1 && firstc && kw == 0>(acc, lb, lw);
-    });
-    if (++sa == AR) sa = 0;
-  };
-  kstep(0, std::true_type{});
-#pragma unroll 1
-  for (int c = 1; c < K; ++c) kstep(c, std::false_type{});
-}
-
-// Resident form: the stages sit in activation slots (Sched::slot); only weights stream, and they stream
-// CONTINUOUSLY across units, phases and blocks: unit i of a block sits in ring slot (ring + i) & 3, and while
-// it runs the wave issues (between its steps) its share of the unit 3 places further down the schedule (the
-// next block's stream after this block's last units).  Everything about a unit except the ring position and
-// "is there a next block" is a compile-time constant: the units execute once per block out of a cold
-// instruction cache, where every data-dependent branch costs a fetch round trip.
-struct WStream {
-  const char* w;       // this block's fused weight stream
-  const char* wnext;   // the next block's (nullptr: none)
-  int ring;            // ring slot of this block's unit 0
-};
-template <typename T, int A, int B> __device__ __forceinline__ void wait_units(const WStream& s) {
-  if constexpr (A == B) wait_vm<A>();
-  else { if (s.wnext) wait_vm<A>(); else wait_vm<B>(); }
-}
-// This wave's share of the unit 3 places after unit I: the nf fragments of a unit are split into four
-// contiguous runs, wave w copies fragments [w nf / 4, (w+1) nf / 4) — at least nf >> 2, at most 4 — one per
-// step.  Source and LDS address of a run are set up ONCE per unit; the requests themselves differ only in the
-// instruction's immediate offset, which the LDS-DMA adds to the global AND the LDS address (i * 1024 here): a
-// request is one instruction in the shadow of the MFMA issued before it, not an address computation.
-struct Ahead { const char* src; char* dst; int cnt; };
-template <typename T, int I>
-__device__ __forceinline__ Ahead ahead_of(const WStream& s, const Tile& t, char* smem, uint32_t lane16) {
-  using S = Sched<T>;
-  constexpr int J = I + 3;
-  constexpr bool wrap = J >= S::N;
-  constexpr UDesc dj = S::at(wrap ? J - S::N : J);
-  const int start = (t.wave * dj.nf) >> 2;
-  Ahead a;
-  a.cnt = (((t.wave + 1) * dj.nf) >> 2) - start;
-  if ((wrap && !s.wnext) || (ESR_ABL & 1)) a.cnt = 0;
-  a.src = (wrap ? s.wnext : s.w) + (dj.off + start) * 1024 + (size_t)lane16;
-  a.dst = smem + WOFF + ((s.ring + J) & (WR - 1)) * WSLOT + start * 1024;
-  return a;
-}
-// SURE = requests every wave issues unconditionally (nf >> 2 of a unit of this block; none when the unit may
-// belong to a next block that does not exist)
-template <int I_, int SURE = 0> __device__ __forceinline__ void issue_one(const Ahead& a) {
-  if constexpr (I_ < 4) {
-    if (I_ < SURE || I_ < a.cnt)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a.src,
-                                       (__attribute__((address_space(3))) void*)a.dst, 16, I_ * 1024, 0);
-  }
-}
-template <typename T, int I> constexpr int sure_ahead() {
-  using S = Sched<T>;
-  return (I + 3 >= S::N || (ESR_ABL & 1)) ? 0 : (S::at(I + 3).nf >> 2);
-}
-// units [I0, I1) of the schedule, back to back.  `hook(I)` runs inside unit I after the barrier that opens
-// unit I+1 (every wave has waited for everything older than unit I+2's requests by then).
-struct NoHook { template <typename X> __device__ __forceinline__ void operator()(X) const {} };
-// TRAIL: barrier after the last unit.  The slot of a segment's last unit is next written by the request of a unit
-// that runs behind the NEXT segment's opening barrier, so the barrier is only needed where the code that follows
-// writes LDS the last unit reads (the block tail's own-pixel writes over x4's slots).
-template <typename T, int I0, int I1, bool STRICT0 = false, bool TRAIL = true, typename HOOK = NoHook>
-__device__ __forceinline__ void run_units(Acc24& acc, const WStream& s, char* smem, const Tile& t, HOOK&& hook = NoHook{}) {
-  using S = Sched<T>;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
-  UFrags f;
-  const int lane = t.lane();
-  const uint32_t lane16 = (uint32_t)lane * 16u;
-  const int colofs[3] = {Tile::colofs(lane, 0), Tile::colofs(lane, 1), Tile::colofs(lane, 2)};
-  wait_units<T, S::wait_top(I0, true), S::wait_top(I0, false)>(s);      // the first unit's weights
-  __builtin_amdgcn_s_barrier();
-  sfor<I1 - I0>([&](auto II) __attribute__((always_inline)) {
-    constexpr int I = I0 + decltype(II)::value;
-    constexpr UDesc d = S::at(I);
-    constexpr UDesc dn = S::at(I + 1 < I1 ? I + 1 : I);
-    constexpr int NKW = S::nkw(d);
-    const uint32_t lrow = lds_rows + S::slot(d) * ASLOT;
-    const uint32_t lb[3] = {lrow + colofs[NKW == 3 ? 0 : d.kw], lrow + colofs[1], lrow + colofs[2]};
-    const uint32_t lw = lds0 + WOFF + ((s.ring + I) & (WR - 1)) * WSLOT + lane16;
-    const uint32_t lbn = lds_rows + S::slot(dn) * ASLOT + colofs[S::nkw(dn) == 3 ? 0 : dn.kw];
-    const uint32_t lwn = lds0 + WOFF + ((s.ring + I + 1) & (WR - 1)) * WSLOT + lane16;
-    const Ahead ah = ahead_of<T, I>(s, t, smem, lane16);
-    auto issue = [&](auto SI) __attribute__((always_inline)) { issue_one<decltype(SI)::value, sure_ahead<T, I>()>(ah); };
-    auto mid = [&]() __attribute__((always_inline)) {
-      if constexpr (STRICT0 && I == I0) wait_units<T, S::wait_mid_strict(I, true), S::wait_mid_strict(I, false)>(s);
-      else wait_units<T, S::wait_mid(I, true), S::wait_mid(I, false)>(s);   // the next unit's weights
-      __builtin_amdgcn_s_barrier();        // next unit visible to all waves; all waves past this unit's LDS reads
-      hook(std::integral_constant<int, I>{});
-    };
-    unit_steps<T, S::blk0(d), S::nblk(d), NKW, (d.P == 1 && d.c == 0 && d.kw == 0), (I > I0), (I + 1 < I1), S::parity(I0, I)>(
-        acc, f, lb, lw, lbn, lwn, issue, mid);
-  });
-  if constexpr (TRAIL) __builtin_amdgcn_s_barrier();            // every wave done with the last unit's slots
-}
-
-// P = conv1x1(x) from the resident x stages (slots 0..KX-1); its fragments are one unit of the weight
-// stream (after bulk_1).
-template <typename T>
-__device__ __forceinline__ void run_1x1_res(Acc24& acc, const WStream& s, char* smem, const Tile& t) {
-  using CF = Cfg<T>;
-  using S = Sched<T>;
-  constexpr int K = CF::KX;
-  constexpr int I = S::first(U_ONE, 1);
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int lane = t.lane();
-  const uint32_t lb = lds0 + t.wave * (R * IW * 32) + IW * 32 + Tile::colofs(lane, 1);   // centre tap: rows 1..4, col j+1
-  const uint32_t lw = lds0 + WOFF + ((s.ring + I) & (WR - 1)) * WSLOT + lane * 16;
-  wait_units<T, S::wait_top(I, true), S::wait_top(I, false)>(s);
-  __builtin_amdgcn_s_barrier();
-  { const Ahead ah = ahead_of<T, I>(s, t, smem, (uint32_t)lane * 16u);
-    sfor<4>([&](auto X) __attribute__((always_inline)) { issue_one<decltype(X)::value>(ah); }); }
-  // two fragment sets: K step c+1 is requested before the MFMAs of step c (one exposed LDS round trip, not K)
-  u32x4 fa[2], fb[2][R];
-  auto rd = [&](auto CI, auto SET) __attribute__((always_inline)) {
-    constexpr int c = decltype(CI)::value, st = decltype(SET)::value;
-    lds_read16<c * 1024>(fa[st], lw);
-    sfor<R>([&](auto RR) __attribute__((always_inline)) { lds_read16<c * ASLOT + decltype(RR)::value * IW * 32>(fb[st][decltype(RR)::value], lb); });
-  };
-  rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-  sfor<K>([&](auto CI) __attribute__((always_inline)) {
-    constexpr int c = decltype(CI)::value, st = c & 1;
-    if constexpr (c + 1 < K) {
-      rd(std::integral_constant<int, c + 1>{}, std::integral_constant<int, st ^ 1>{});
-      asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fa[st]), "+v"(fb[st][0]), "+v"(fb[st][1]), "+v"(fb[st][2]), "+v"(fb[st][3]));
-    } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[st]), "+v"(fb[st][0]), "+v"(fb[st][1]), "+v"(fb[st][2]), "+v"(fb[st][3]));
-    }
-    sfor<R>([&](auto RR) __attribute__((always_inline)) {
-      mma_cls<T, acc_in_agpr(0), c == 0>(acc_br<0, decltype(RR)::value>(acc), fa[st], fb[st][decltype(RR)::value]);
-    });
-  });
-}
-
-// ---- P = conv1x1(x) on the tile's own pixels (block.py:263), into cout block 0's registers ----------
-template <typename T>
-__device__ __forceinline__ void run_1x1(Acc24& acc, const char* w1, const char* aplane, const int64_t a_gs,
-                                        char* smem, const Tile& t) {
-  constexpr int K = Cfg<T>::KX;
-  const int lane = t.lane();
-  // all K fragments -> weight slot 0 (wave w copies fragments w, w+4, ...)
-#pragma unroll
-  for (int i = 0; i < (K + 3) / 4; ++i) {
-    const int q = t.wave + 4 * i;
-    if (q < K) dma16(w1 + q * 1024 + lane * 16, smem + WOFF + q * 1024);
-  }
-  issue_a(aplane, 0, smem, t);
-  issue_a(aplane + a_gs, 1, smem, t);
-  int sa = 0;
-  const char* lds_rows = smem + t.wave * (R * IW * 32) + IW * 32 + Tile::colofs(lane, 1);   // centre tap: rows 1..4, col j+1
-#pragma unroll 1
-  for (int c = 0; c < K; ++c) {
-    if (c + 1 < K) wait_vm<NLD>(); else wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    if (c + 2 < K) {
-      int sn = sa + 2; if (sn >= AR) sn -= AR;
-      issue_a(aplane + (int64_t)(c + 2) * a_gs, sn, smem, t);
-    }
-    {                                       // the 1x1 lands in conv1's vacated registers (block 0)
-      const u32x4 a = *(const u32x4*)(smem + WOFF + c * 1024 + lane * 16);
-      const char* lb = lds_rows + sa * ASLOT;
-      u32x4 bq[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) bq[r] = *(const u32x4*)(lb + r * IW * 32);
-      if (c == 0) {
-        mma_cls<T, acc_in_agpr(0), true>(acc_br<0, 0>(acc), a, bq[0]);
-        mma_cls<T, acc_in_agpr(0), true>(acc_br<0, 1>(acc), a, bq[1]);
-        mma_cls<T, acc_in_agpr(0), true>(acc_br<0, 2>(acc), a, bq[2]);
-        mma_cls<T, acc_in_agpr(0), true>(acc_br<0, 3>(acc), a, bq[3]);
-      } else {
-        mma_cls<T, acc_in_agpr(0)>(acc_br<0, 0>(acc), a, bq[0]);
-        mma_cls<T, acc_in_agpr(0)>(acc_br<0, 1>(acc), a, bq[1]);
-        mma_cls<T, acc_in_agpr(0)>(acc_br<0, 2>(acc), a, bq[2]);
-        mma_cls<T, acc_in_agpr(0)>(acc_br<0, 3>(acc), a, bq[3]);
-      }
-    }
-    if (++sa == AR) sa = 0;
-  }
-}
-
-// measurement only: time stamps (100 MHz) of the tile's SECOND block (the first one stages x differently)
-__device__ __forceinline__ void trace_ev(const esr_rdb_chain& p, int tile, int& ev) {
-  if (p.trace && ev >= 0 && ev < 64 && threadIdx.x == 0) p.trace[(int64_t)tile * 64 + ev] = (ESR_ABL & 16) ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();
-  if (ev >= 0) ++ev;
-}
-
-// ---- publish / consume ------------------------------------------------------------------------------
-typedef __attribute__((address_space(1))) unsigned gu32;
-
-__device__ __forceinline__ void publish(unsigned* flags, int tile, unsigned epoch, const Tile& t,
-                                        const esr_rdb_chain* tp = nullptr, int* ev = nullptr) {
-  if (tp) trace_ev(*tp, tile, *ev);                      // epilogue done (stores issued)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its sc1 stores
-  if (tp) trace_ev(*tp, tile, *ev);                      // own stores drained
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// wave 0, lanes 0..7 poll one neighbour each (relaxed, agent scope) until all reached `epoch`.
-// Returns false (whole workgroup) on abort / time-out.
-__device__ __forceinline__ bool wait_neighbours(unsigned* ws, unsigned epoch, char* smem, const Tile& t,
-                                                const esr_rdb_chain* tp = nullptr, int* ev = nullptr, int tile_ = 0) {
-  if (t.wave == 0) {
-    // the neighbour this lane polls (lanes 0..7)
-    const int lane = t.lane();
-    int my_nbr_tile = -1;
-    if (lane < 8) {
-      const int k = lane < 4 ? lane : lane + 1;
-      const int ny = t.ty + k / 3 - 1, nx = t.tx + k % 3 - 1;
-      if (ny >= 0 && ny < t.tiles_y && nx >= 0 && nx < t.tiles_x) my_nbr_tile = (t.b * t.tiles_y + ny) * t.tiles_x + nx;
-    }
-    bool ok = my_nbr_tile < 0;
-    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    bool dead = false;
-    for (unsigned it = 1;; ++it) {
-      if (!ok) ok = __hip_atomic_load((gu32*)(ws + WS_HDR + my_nbr_tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
-      if (__all(ok)) break;
-      // the abort word is a second dependent round trip: look at it (and at the clock) every 16th turn only
-      if ((it & 15u) == 0u && ((__builtin_amdgcn_s_memrealtime() - t0) > 100000000ull ||      // 1 s of the 100 MHz counter
-                               __hip_atomic_load((gu32*)(ws + WS_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-        dead = true;
-        break;
-      }
-    }
-    if (lane == 0) {
-      if (dead) __hip_atomic_store((gu32*)(ws + WS_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *(volatile int*)(smem + LDS_CTRL + 16) = dead ? 1 : 0;
-    }
-  }
-  if (tp) trace_ev(*tp, tile_, *ev);                     // neighbours' flags seen (wave 0)
-  __syncthreads();
-  const int dead = *(volatile int*)(smem + LDS_CTRL + 16);
-  return dead == 0;
-}
-
-// Non-blocking form for the bulks (wave 0 only): the 8 flags are fetched by LDS-DMA into LDS_FLAGS — no
-// register result, hence nothing to wait for — and looked at two units later with plain LDS reads: a flag that
-// has not landed yet simply still shows its older (smaller) value and sends the tile through the blocking
-// poll after the bulk.  LDS accesses here are inline asm: hipcc orders a visible LDS access after every
-// LDS-DMA in flight with `vmcnt(0)`, which would drain the weight stream.
-__device__ __forceinline__ void poll_issue(unsigned* ws, int tile, char* smem, const Tile& t) {
-  const int lane = t.lane();
-  int nbr = tile;                                         // no neighbour: the tile's own flag (already up)
-  if (lane < 8) {
-    const int k = lane < 4 ? lane : lane + 1;
-    const int ny = t.ty + k / 3 - 1, nx = t.tx + k % 3 - 1;
-    if (ny >= 0 && ny < t.tiles_y && nx >= 0 && nx < t.tiles_x) nbr = (t.b * t.tiles_y + ny) * t.tiles_x + nx;
-  }
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws + WS_HDR + nbr),
-                                   (__attribute__((address_space(3))) void*)(smem + LDS_FLAGS), 4, 0, 16);
-}
-__device__ __forceinline__ unsigned lds_peek(uint32_t addr) {
-  unsigned v;
-  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+bool coop_launch() {
+  static const bool v = [] { const char* e = getenv("ESR_RDB_COOP"); return e && atoi(e) != 0; }();
   return v;
 }
-__device__ __forceinline__ void poll_check(unsigned epoch, char* smem, const Tile& t) {
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int lane = t.lane();
-  const bool ok = __all(lds_peek(lds0 + LDS_FLAGS + lane * 4) >= epoch);
-  const unsigned tag = ok ? epoch : 0u;
-  if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + LDS_CTRL + 32), "v"(tag) : "memory");
-}
-
-// ---- epilogue of one finished 32-cout block ---------------------------------------------------------
-// MODE 0: v = lrelu(acc + bias)                               (x1, x3)
-// MODE 1: v = lrelu(acc + bias) + P (block 0's accumulators)  (x2, block.py:263)
-// MODE 2: v = lrelu(acc + bias) + ex[own pixel]               (x4 = lrelu(conv4) + x2, block.py:266)
-// MODE 3: v = (acc + bias)*0.2 + ex; noise1; [v = v*0.2 + r2; noise2]   (block.py:267-268, 291)
-// ex / r2 = the lane's own pixels of 4 rows in storage form, fetched by load_rows() well ahead of use
-// (a conditional load inside the row loop makes hipcc wait for every load separately) or kept from the
-// epilogue that produced them.
-// LW (fp16 resident path), bit 0: also write the lane's pixels into activation slots slot0 + h of the LDS
-// (the next phase's stage); bit 1: hand them back in `keep` (conv1: the 1x1 still reads x in those slots;
-// conv2: x2 is the residual of x4).
-template <typename T> struct RowsRaw { typename Ch16<T>::Raw q[R]; };
-
-template <typename T>
-__device__ __forceinline__ void load_rows(const ImgView& v, int cb, const esr_rdb_chain& p, const Tile& t, RowsRaw<T>& o) {
-  const int lane = t.lane();
-  const int ox = t.ox0 + (lane & 31), oyb = t.oy0 + t.wave * R, wp32 = p.dense.wp * 32;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int oy = oyb + r < p.H ? oyb + r : p.H - 1;            // clamped: rows / columns past the image are not used
-    Ch16<T>::load(v, cb, lane >> 5, (oy + 1) * wp32 + (ox < p.W ? ox + 1 : 1) * 32, o.q[r]);
-  }
-}
-
-struct Bias16 { f32x4 q[4]; };
-// the lane's 16 biases of a cout block (bias = wave-uniform pointer): requested at the START of the phase
-// whose epilogue adds them — a load placed in the epilogue itself exposes a memory round trip per phase
-__device__ __forceinline__ void load_bias(const float* bias, const Tile& t, Bias16& b) {
-  const f32x4* bp = (const f32x4*)bias + 4 * (t.lane() >> 5);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) b.q[i] = bp[i];
-}
-// fp16 path: the block's biases sit in the LDS (copied by DMA at the top of the block): a register copy would
-// be a vector-memory load whose first use makes hipcc drain every weight DMA in flight (vmcnt(0))
-__device__ __forceinline__ void stage_bias(const float* bias, char* smem, const Tile& t) {
-  if (t.wave < 3)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bias + t.wave * 64 + t.lane()),
-                                     (__attribute__((address_space(3))) void*)(smem + LDS_BIAS + t.wave * 256), 4, 0, 0);
-}
-__device__ __forceinline__ void lds_bias(const char* smem, int first, const Tile& t, Bias16& b) {
-  const f32x4* bp = (const f32x4*)(smem + LDS_BIAS + first * 4) + 4 * (t.lane() >> 5);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) b.q[i] = bp[i];
-}
-// the block-table entry's scalars, read ONCE per block into SGPRs (a field referenced through the table is
-// re-loaded with a vector load + full wait wherever it is used)
-struct BlkS {
-  const float* bias;       // [192]: conv1..conv4 (32 each), conv5 (64)
-  uint32_t layer1, layer2;
-  bool has_res2, full_out;
-};
-// NOISE (MODE 3): false = the instantiation without the Philox layers and the explicit `+ x` (the fp16 path's
-// common case takes it through one uniform branch: the tail is executed once per block out of a cold
-// instruction cache, so what is not needed should not be in the way)
-template <typename T, int BLK, int MODE, int LW = 0, bool NOISE = true>
-__device__ __forceinline__ void epilogue(Acc24& acc, const esr_rdb_chain& p, const BlkS& blk, const Bias16& bias,
-                                         const ImgView& out, int out_cb, int ch_cb, const RowsRaw<T>* ex,
-                                         const RowsRaw<T>* r2, bool has_res2, const Tile& t, char* smem = nullptr,
-                                         int slot0 = 0, RowsRaw<T>* keep = nullptr, float carry_scale = 0.f,
-                                         bool full_store = true) {
-  using C16 = Ch16<T>;
-  const int lane = t.lane(), tj = lane & 31, th = lane >> 5;
-  int own_px = 0, own_swz = 0;
-  if constexpr ((LW & 1) != 0) t.own(lane, own_px, own_swz);
-  const int ox = t.ox0 + tj;
-  const int oyb = t.oy0 + t.wave * R;
-  const f32x4 (&bq)[4] = bias.q;
-  const int wp32 = p.dense.wp * 32;
-  const bool ragged = t.oy0 + TH > p.H || t.ox0 + TW > p.W;      // wave-uniform
-  const uint32_t layer1 = blk.layer1, layer2 = blk.layer2;
-  const bool n1 = MODE == 3 && NOISE && p.noise_mode == ESR_NOISE_PHILOX && layer1 != ESR_NO_LAYER;
-  const bool n2 = MODE == 3 && NOISE && p.noise_mode == ESR_NOISE_PHILOX && layer2 != ESR_NO_LAYER && has_res2;
-  uint64_t seed = p.seed;
-  if ((n1 || n2) && p.seed_dev) seed = __builtin_nontemporal_load(p.seed_dev);
-  sfor<R>([&](auto RR) __attribute__((always_inline)) {
-    constexpr int r = decltype(RR)::value;
-    const int oy = oyb + r;
-    const f32x16 a = acc_br<BLK, r>(acc);
-    float v[16], tmp[16];
-    // pairs: v_pk_add_f32 / v_pk_mul_f32 do two elements per instruction (same IEEE results as the scalar forms)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int e = 0; e < 16; e += 2) {
-      const f32x2 av = {a[e], a[e + 1]}, bv = {bq[e >> 2][e & 3], bq[e >> 2][(e & 3) + 1]};
-      const f32x2 x = av + bv;
-      if constexpr (MODE != 3) {
-        const f32x2 y = x * ESR_LRELU_SLOPE;                                     // LeakyReLU(0.2) = max(x, 0.2 x)
-        v[e] = __builtin_fmaxf(x[0], y[0]);
-        v[e + 1] = __builtin_fmaxf(x[1], y[1]);
-      } else {
-        v[e] = x[0];
-        v[e + 1] = x[1];
-      }
-    }
-    if constexpr (MODE == 1) {
-      const f32x16 a1 = acc_br<0, r>(acc);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] += a1[e];
-    }
-    if constexpr (MODE == 2) {
-      C16::get(ex->q[r], tmp);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = v[e] * 1.0f + tmp[e];
-    }
-    if constexpr (MODE == 3) {
-      if (NOISE && ex) {           // explicit residual (fp32 path, noise): out = conv5*0.2 + x
-        C16::get(ex->q[r], tmp);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = v[e] * 0.2f + tmp[e];
-      } else {                     // folded: the accumulators started at 5 x
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] *= 0.2f;
-      }
-      const uint32_t pix = (uint32_t)((t.b * p.H + oy) * p.W + ox);
-      if (n1) {
-#pragma unroll 1
-        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + th * 4 + q), layer1, seed, &tmp[4 * q]);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);     // block.py:119-121
-      }
-      if (has_res2) {
-        C16::get(r2->q[r], tmp);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = v[e] * 0.2f + tmp[e];
-        if (n2) {
-#pragma unroll 1
-          for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + th * 4 + q), layer2, seed, &tmp[4 * q]);
-#pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
-        }
-      }
-    }
-    // pixels beyond the image: offset 2^31 lies past num_records (2^31 - 1), the buffer range check drops the store
-    const bool inside = oy < p.H && ox < p.W;
-    const int po = (oy + 1) * wp32 + (ox + 1) * 32;
-    if constexpr (LW == 0) {
-      C16::store(out, inside ? out_cb : 0, th, inside ? po : (int)0x80000000u, v);
-    } else {
-      typename C16::Raw q;
-      C16::pack(v, q.q);
-      // x1..x4 are only ever read back as HALO pixels by the neighbouring tiles (the tile's own pixels stay
-      // in the LDS / registers): unless the caller wants the dense slices in memory (save_dense), only the
-      // tile's border pixels are stored — 82 % fewer bytes through the lock-stepped store bursts
-      const bool edge = (MODE == 3 && full_store) || p.save_dense || tj == 0 || tj == TW - 1 || (t.wave == 0 && r == 0) ||
-                        (t.wave == NT / 64 - 1 && r == R - 1);
-      C16::store_packed(out, (inside && edge) ? out_cb : 0, th, (inside && edge) ? po : (int)0x80000000u, q.q);
-      // beyond the image: the zero padding (only tiles that stick out of the image have such pixels: one scalar test)
-      if (ragged && !inside) { q.q[0] = u32x4{0, 0, 0, 0}; q.q[1] = u32x4{0, 0, 0, 0}; }
-      if constexpr (LW & 1) lds_put_row(smem, slot0 + th, r, q.q, own_px, own_swz);
-      if constexpr (LW & 2) keep->q[r] = q;
-      if constexpr (MODE == 3) {
-        // carry into the next block: its conv5 accumulators start at 5 x (x = this output AS STORED), so
-        // that block's tail `conv5*0.2 + x` needs no residual read (zero when it adds x explicitly)
-        float xs[16];
-        C16::get(q, xs);
-        f32x16 nx;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) nx[e] = carry_scale * xs[e];
-        acc_br<BLK, r>(acc) = nx;
-      }
-    }
-  });
-}
-
-template <typename T>
-__global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p, const int ntiles, const int tiles_x,
-                                                          const int tiles_y) {
-  using CF = Cfg<T>;
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-  unsigned* const ws = (unsigned*)p.workspace;
-  unsigned* const flags = ws + WS_HDR;
-  Tile t;
-  t.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tpi = tiles_x * tiles_y;
-  const int wp = p.dense.wp;
-
-  for (;;) {
-    // ---- claim the next tile (tickets go out in order, so an image's tiles are co-resident)
-    if (threadIdx.x < 64) ((volatile unsigned*)(smem + LDS_FLAGS))[threadIdx.x] = 0u;   // flags restart at 0 with the tile
-    __syncthreads();
-    if (threadIdx.x == 0)
-      *(volatile int*)(smem + LDS_CTRL) = (int)__hip_atomic_fetch_add((gu32*)(ws + WS_TICKET), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int tile = __builtin_amdgcn_readfirstlane(*(volatile int*)(smem + LDS_CTRL));
-    if (tile >= ntiles) break;
-    t.b = tile / tpi;
-    const int rem = tile - t.b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
-    t.oy0 = ty * TH;
-    t.ox0 = tx * TW;
-    t.ty = ty; t.tx = tx; t.tiles_y = tiles_y; t.tiles_x = tiles_x;
-    t.wp = wp;
-    if constexpr (sizeof(T) == 2) {   // each thread's halo source offset, for the requests issued from inside the bulks
-      int hsrc, hdst;
-      t.halo(hsrc, hdst);
-      *(volatile int*)(smem + LDS_HALO + t.tid() * 8) = hsrc;
-      *(volatile int*)(smem + LDS_HALO + t.tid() * 8 + 4) = hdst;
-    }
-    const ImgView dense = img_view(p.dense, t.b);
-    const char* const dense_b = (const char*)p.dense.ptr + (int64_t)t.b * p.dense.batch_stride;
-    const int64_t d_gs = p.dense.group_stride;
-
-
-    unsigned epoch = 0;      // phases this tile has published
-    WStream ws_{};
-    Acc24 acc;               // never zeroed: an accumulator's first MFMA of a block takes SrcC = 0 — except conv5's
-                             // (fp16 path), which carry 5 x in from the previous block's epilogue
-    int ev = -1;
-    if constexpr (sizeof(T) == 2) {
-      // conv5's accumulators of the FIRST block start at 5 x (zero when the tail adds x explicitly, i.e. with
-      // noise); later blocks get theirs from the previous epilogue.  Done ahead of the block loop: a second
-      // definition inside it would join the carried one through scratch copies.
-      const ImgView xin0 = img_view(p.blocks[0].x_in, t.b);
-      const bool noisy = p.noise_mode != ESR_NOISE_OFF;
-      RowsRaw<T> c0, c1;
-      load_rows<T>(xin0, 0, p, t, c0); load_rows<T>(xin0, 1, p, t, c1);
-      const float cs = noisy ? 0.f : 5.f;
-      sfor<R>([&](auto RR) __attribute__((always_inline)) {
-        constexpr int r = decltype(RR)::value;
-        float xs[16];
-        f32x16 nx;
-        Ch16<T>::get(c0.q[r], xs);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) nx[e] = cs * xs[e];
-        acc_br<4, r>(acc) = nx;
-        Ch16<T>::get(c1.q[r], xs);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) nx[e] = cs * xs[e];
-        acc_br<5, r>(acc) = nx;
-      });
-    }
-    for (int rb = 0; rb < p.n_blocks; ++rb) {
-      const esr_rdb_block& blk = p.blocks[rb];
-      ev = rb == 1 ? 0 : -1;
-      trace_ev(p, tile, ev);
-      const char* const w = uniform_ptr(blk.w);
-      const char* const xin_b = (const char*)blk.x_in.ptr + (int64_t)t.b * blk.x_in.batch_stride;
-      const ImgView xin = img_view(blk.x_in, t.b), xout = img_view(blk.x_out, t.b);
-      // block-table fields are wave-uniform, but only readfirstlane makes that provable: without it every
-      // test on them becomes an exec-masked region and every use a fresh vector load
-      const bool noisy = p.noise_mode != ESR_NOISE_OFF;
-      BlkS bs;
-      bs.bias = (const float*)uniform_ptr(blk.bias);
-      bs.layer1 = __builtin_amdgcn_readfirstlane(blk.layer1);
-      bs.layer2 = __builtin_amdgcn_readfirstlane(blk.layer2);
-      bs.has_res2 = __builtin_amdgcn_readfirstlane((int)(blk.res2.ptr != nullptr)) != 0;
-      bs.full_out = __builtin_amdgcn_readfirstlane((int)((blk.flags & ESR_RDB_FULL_OUT) != 0)) != 0 || noisy || p.save_dense;
-      const bool has_res2 = bs.has_res2, full_out = bs.full_out;
-      const ImgView res2 = img_view(has_res2 ? blk.res2 : blk.x_in, t.b);
-      constexpr bool RES = sizeof(T) == 2;      // fp16: LDS-resident slices (fp32 stages by DMA, 8 K steps of x)
-      const char* const wnext = rb + 1 < p.n_blocks ? (const char*)p.blocks[rb + 1].w : nullptr;
-
-      if constexpr (RES) {
-        // =========================== fp16: own pixels stay in the LDS ===========================
-        using S = Sched<T>;
-        ws_.w = w;
-        ws_.wnext = wnext;
-        // The hand-off of x_p runs INSIDE bulk_p (hooks at the barriers that open the bulk's next units):
-        //   unit 0: every wave has waited for its epilogue stores (strict wait) -> thread 0 raises the flag;
-        //   5th unit from the end: wave 0 requests the 8 neighbours' flags;  3rd: it looks at them -> LDS word;
-        //   2nd: all up -> every halo thread requests its 16 bytes per stage; they land under the last unit.
-        // A neighbour that is late (flag not up yet at unit 3) sends the tile through the blocking poll after
-        // the bulk instead.
-        int early = 0;
-        HaloRegs<CF::KD> hq;
-        auto bulk_hook = [&](auto IDX, auto FIRST_, auto END_, int g0) __attribute__((always_inline)) {
-          constexpr int I = decltype(IDX)::value, rel = I - decltype(FIRST_)::value, left = decltype(END_)::value - 1 - I;
-          if constexpr (rel == 0) {
-            if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else if constexpr (left == 4 && !(ESR_ABL & 64)) {
-            if (t.wave == 0) poll_issue(ws, tile, smem, t);
-          } else if constexpr (left == 2 && !(ESR_ABL & 64)) {
-            if (t.wave == 0) poll_check(epoch, smem, t);
-          } else if constexpr (left == 1 && !(ESR_ABL & 64)) {
-            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-            early = __builtin_amdgcn_readfirstlane((int)(lds_peek(lds0 + LDS_CTRL + 32) == epoch));
-            if (early) halo_issue<CF::KD>(dense, g0, (int)lds_peek(lds0 + LDS_HALO + t.tid() * 8), hq);
-          }
-        };
-        // after the bulk: the halo of stage g0 into slots slot0..
-        auto finish_halo = [&](int g0, int slot0) __attribute__((always_inline)) -> bool {
-          const int hsrc = *(volatile int*)(smem + LDS_HALO + t.tid() * 8), hdst = *(volatile int*)(smem + LDS_HALO + t.tid() * 8 + 4);
-          if (!early) {
-            if (!wait_neighbours(ws, epoch, smem, t, &p, &ev, tile)) return false;
-            halo_issue<CF::KD>(dense, g0, hsrc, hq);
-          } else {
-            trace_ev(p, tile, ev);
-          }
-          halo_put<CF::KD>(smem, slot0, hsrc, hdst, hq);
-          __syncthreads();
-          return true;
-        };
-        stage_bias(bs.bias, smem, t);          // every wave is past the previous block's tail (publish)
-        if (rb == 0) {
-          // the chain's input comes from another launch: stage all of x (with halo) by DMA, and start
-          // the weight stream (its first three units)
-          sfor<3>([&](auto UI) __attribute__((always_inline)) {
-            const Ahead ah = ahead_of<T, decltype(UI)::value - 3>(ws_, t, smem, (uint32_t)t.lane() * 16u);
-            sfor<4>([&](auto X) __attribute__((always_inline)) { issue_one<decltype(X)::value>(ah); });
-          });
-          sfor<CF::KX>([&](auto CI) __attribute__((always_inline)) {
-            issue_a(xin_b + decltype(CI)::value * blk.x_in.group_stride, decltype(CI)::value, smem, t);
-          });
-          wait_vm<0>();
-        } else {
-          // own pixels were written by the previous block's epilogue; weights are in flight already
-          if (!wait_neighbours(ws, epoch, smem, t, &p, &ev, tile)) return;
-          halo_fetch<CF::KX>(xin, 0, smem, t);
-        }
-        __syncthreads();
-        Bias16 bb;
-        trace_ev(p, tile, ev);
-        // ---------------- conv1
-        run_units<T, S::first(U_CRIT, 1), S::end(U_CRIT, 1), false, false>(acc, ws_, smem, t);
-        trace_ev(p, tile, ev);
-        lds_bias(smem, 0, t, bb);
-        mfma_drain();
-        RowsRaw<T> x1, x2;
-        epilogue<T, 0, 0, 2>(acc, p, bs, bb, dense, 0, 0, nullptr, nullptr, false, t, smem, 0, &x1);     // x1 (kept: x still occupies its slots)
-        ++epoch;
-        trace_ev(p, tile, ev);
-        run_units<T, S::first(U_BULK, 1), S::end(U_BULK, 1), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 1)>{}, std::integral_constant<int, S::end(U_BULK, 1)>{}, 0); });
-        trace_ev(p, tile, ev);
-        // ---------------- P = conv1x1(x) from the resident x; then x1 may take x's slots
-        run_1x1_res<T>(acc, ws_, smem, t);
-        __builtin_amdgcn_s_barrier();          // every wave done reading x
-        { const int lane = t.lane(); int opx, osw; t.own(lane, opx, osw);
-#pragma unroll
-          for (int r = 0; r < R; ++r) lds_put_row(smem, lane >> 5, r, x1.q[r].q, opx, osw); }
-        trace_ev(p, tile, ev);
-        if (!finish_halo(0, 0)) return;
-        trace_ev(p, tile, ev);
-        // ---------------- conv2
-        run_units<T, S::first(U_CRIT, 2), S::end(U_CRIT, 2), false, false>(acc, ws_, smem, t);
-        trace_ev(p, tile, ev);
-        lds_bias(smem, 32, t, bb);
-        mfma_drain();
-        epilogue<T, 1, 1, 1>(acc, p, bs, bb, dense, 1, 0, nullptr, nullptr, false, t, smem, 2);       // x2
-        ++epoch;
-        trace_ev(p, tile, ev);
-        run_units<T, S::first(U_BULK, 2), S::end(U_BULK, 2), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 2)>{}, std::integral_constant<int, S::end(U_BULK, 2)>{}, CF::KD); });
-        trace_ev(p, tile, ev);
-        if (!finish_halo(CF::KD, 2)) return;
-        trace_ev(p, tile, ev);
-        // ---------------- conv3
-        run_units<T, S::first(U_CRIT, 3), S::end(U_CRIT, 3), false, false>(acc, ws_, smem, t);
-        trace_ev(p, tile, ev);
-        lds_bias(smem, 64, t, bb);
-        mfma_drain();
-        epilogue<T, 2, 0, 1>(acc, p, bs, bb, dense, 2, 0, nullptr, nullptr, false, t, smem, 0);       // x3
-        ++epoch;
-        trace_ev(p, tile, ev);
-        run_units<T, S::first(U_BULK, 3), S::end(U_BULK, 3), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD); });
-        trace_ev(p, tile, ev);
-        if (!finish_halo(2 * CF::KD, 0)) return;
-        trace_ev(p, tile, ev);
-        // ---------------- conv4
-        run_units<T, S::first(U_CRIT, 4), S::end(U_CRIT, 4), false, false>(acc, ws_, smem, t);
-        trace_ev(p, tile, ev);
-        lds_bias(smem, 96, t, bb);
-        lds_get_rows(smem, 2, x2.q, t);   // x2's own pixels still sit in the slots x4 is about to take
-        mfma_drain();
-        epilogue<T, 3, 2, 1>(acc, p, bs, bb, dense, 3, 0, &x2, nullptr, false, t, smem, 2);           // x4 (+ x2)
-        RowsRaw<T> tx0, tx1, tr0, tr1;
-        ++epoch;
-        trace_ev(p, tile, ev);
-        run_units<T, S::first(U_BULK, 4), S::end(U_BULK, 4), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD); });
-        trace_ev(p, tile, ev);
-        if (!finish_halo(3 * CF::KD, 2)) return;
-        // the block tail's residual (every third block): requested here, used after conv5
-        if (has_res2) { load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1); }
-        trace_ev(p, tile, ev);
-        // ---------------- conv5; block tail (+ RRDB tail)
-        run_units<T, S::first(U_CRIT, 5), S::end(U_CRIT, 5)>(acc, ws_, smem, t);
-        if (noisy) { load_rows<T>(xin, 0, p, t, tx0); load_rows<T>(xin, 1, p, t, tx1); }   // rare path: latency exposed
-        trace_ev(p, tile, ev);
-        mfma_drain();
-        Bias16 bb2;
-        lds_bias(smem, 128, t, bb);
-        lds_bias(smem, 160, t, bb2);
-        if (noisy) {
-          epilogue<T, 4, 3, 1, true>(acc, p, bs, bb, xout, 0, 0, &tx0, &tr0, has_res2, t, smem, 0, nullptr, 0.f, full_out);
-          epilogue<T, 5, 3, 1, true>(acc, p, bs, bb2, xout, 1, 1, &tx1, &tr1, has_res2, t, smem, 2, nullptr, 0.f, full_out);
-        } else {
-          epilogue<T, 4, 3, 1, false>(acc, p, bs, bb, xout, 0, 0, nullptr, &tr0, has_res2, t, smem, 0, nullptr, 5.f, full_out);
-          epilogue<T, 5, 3, 1, false>(acc, p, bs, bb2, xout, 1, 1, nullptr, &tr1, has_res2, t, smem, 2, nullptr, 5.f, full_out);
-        }
-        publish(flags, tile, ++epoch, t, &p, &ev);
-        ws_.ring = (ws_.ring + S::N) & (WR - 1);
-        trace_ev(p, tile, ev);
-      } else {
-      // =========================== fp32: every stage by DMA ===========================
-      Bias16 fb[6];
-      for (int i = 0; i < 5; ++i) load_bias(bs.bias + 32 * i, t, fb[i]);
-      load_bias(bs.bias + 160, t, fb[5]);
-      // ---------------- phase 1: x -> conv1..conv5
-      issue_w_head<6>(w + CF::phase_off(1), CF::KX, smem, t);
-      if (epoch > 0 && !wait_neighbours(ws, epoch, smem, t)) return;
-      trace_ev(p, tile, ev);
-      run_phase<T, 1>(acc, w + CF::phase_off(1), xin_b, blk.x_in.group_stride, CF::KX, smem, t);
-      trace_ev(p, tile, ev);
-      mfma_drain();
-      epilogue<T, 0, 0>(acc, p, bs, fb[0], dense, 0, 0, nullptr, nullptr, false, t);       // x1
-      publish(flags, tile, ++epoch, t);
-      trace_ev(p, tile, ev);
-      // ---------------- P = conv1x1(x) on own pixels, then phase 2: x1 -> conv2..conv5
-      run_1x1<T>(acc, w + CF::phase_off(6), xin_b, blk.x_in.group_stride, smem, t);
-      trace_ev(p, tile, ev);
-      __syncthreads();                      // every wave done with the 1x1's LDS before phase 2 refills it
-      issue_w_head<5>(w + CF::phase_off(2), CF::KD, smem, t);
-      if (!wait_neighbours(ws, epoch, smem, t)) return;
-      trace_ev(p, tile, ev);
-      run_phase<T, 2>(acc, w + CF::phase_off(2), dense_b, d_gs, CF::KD, smem, t);
-      trace_ev(p, tile, ev);
-      mfma_drain();
-      epilogue<T, 1, 1>(acc, p, bs, fb[1], dense, 1, 0, nullptr, nullptr, false, t);     // x2
-      publish(flags, tile, ++epoch, t);
-      trace_ev(p, tile, ev);
-      // ---------------- phase 3: x2 -> conv3..conv5
-      issue_w_head<4>(w + CF::phase_off(3), CF::KD, smem, t);
-      if (!wait_neighbours(ws, epoch, smem, t)) return;
-      trace_ev(p, tile, ev);
-      run_phase<T, 3>(acc, w + CF::phase_off(3), dense_b + CF::KD * d_gs, d_gs, CF::KD, smem, t);
-      trace_ev(p, tile, ev);
-      mfma_drain();
-      epilogue<T, 2, 0>(acc, p, bs, fb[2], dense, 2, 0, nullptr, nullptr, false, t);     // x3
-      publish(flags, tile, ++epoch, t);
-      trace_ev(p, tile, ev);
-      // ---------------- phase 4: x3 -> conv4, conv5
-      issue_w_head<3>(w + CF::phase_off(4), CF::KD, smem, t);
-      if (!wait_neighbours(ws, epoch, smem, t)) return;
-      trace_ev(p, tile, ev);
-      run_phase<T, 4>(acc, w + CF::phase_off(4), dense_b + 2 * CF::KD * d_gs, d_gs, CF::KD, smem, t);
-      trace_ev(p, tile, ev);
-      mfma_drain();
-      { RowsRaw<T> x2r; load_rows<T>(dense, 1, p, t, x2r);
-        epilogue<T, 3, 2>(acc, p, bs, fb[3], dense, 3, 0, &x2r, nullptr, false, t); }     // x4 (+ x2)
-      publish(flags, tile, ++epoch, t);
-      trace_ev(p, tile, ev);
-      // ---------------- phase 5: x4 -> conv5; block tail (+ RRDB tail)
-      issue_w_head<2>(w + CF::phase_off(5), CF::KD, smem, t);
-      if (!wait_neighbours(ws, epoch, smem, t)) return;
-      trace_ev(p, tile, ev);
-      run_phase<T, 5>(acc, w + CF::phase_off(5), dense_b + 3 * CF::KD * d_gs, d_gs, CF::KD, smem, t);
-      trace_ev(p, tile, ev);
-      mfma_drain();
-      { RowsRaw<T> tx0, tx1, tr0, tr1;
-        load_rows<T>(xin, 0, p, t, tx0); load_rows<T>(xin, 1, p, t, tx1);
-        load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1);
-        epilogue<T, 4, 3>(acc, p, bs, fb[4], xout, 0, 0, &tx0, &tr0, has_res2, t);
-        epilogue<T, 5, 3>(acc, p, bs, fb[5], xout, 1, 1, &tx1, &tr1, has_res2, t); }
-      publish(flags, tile, ++epoch, t);
-      trace_ev(p, tile, ev);
-      }
-    }
-  }
-}
-
-int g_num_cus = 0;
-std::once_flag g_cu_once;
-int num_cus() {
-  std::call_once(g_cu_once, [] {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
-    if (g_num_cus <= 0) g_num_cus = 256;
-  });
-  return g_num_cus;
-}
-
-bool same_geometry(const esr_g32& a, const esr_g32& b) { return a.wp == b.wp; }
-
 }  // namespace
+
+extern "C" int esr_rdb_check_abort(void) {
+  unsigned* w = abort_word();
+  if (!w) return 0;
+  const unsigned v = __atomic_exchange_n(w, 0u, __ATOMIC_RELAXED);
+  return v != 0u;
+}
 
 extern "C" size_t esr_rdb_weight_stream_bytes(int32_t dtype) {
   return dtype == ESR_F16 ? (size_t)Cfg<_Float16>::STREAM_BYTES : (size_t)Cfg<float>::STREAM_BYTES;
@@ -1367,42 +51,83 @@ extern "C" size_t esr_rdb_workspace_bytes(int32_t B, int32_t H, int32_t W) {
   return (WS_HDR + tiles) * sizeof(uint32_t);
 }
 
+extern "C" size_t esr_rdb_mask_bytes(int32_t B, int32_t H, int32_t W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return (size_t)B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * MASK_TILE;
+}
+
 extern "C" int esr_rdb_max_tiles_per_image(void) { return num_cus(); }
 
-extern "C" int esr_rdb_forward(const esr_rdb_chain* p, esr_stream_t stream) {
-  if (!p || !p->blocks || p->n_blocks <= 0 || !p->dense.ptr || !p->workspace || p->B <= 0 || p->H <= 0 || p->W <= 0) {
-    esr_set_error("esr_rdb_forward: invalid arguments");
+namespace {
+int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, int want_mode) {
+  if (!p || !p->blocks || p->n_blocks <= 0 || !p->workspace || p->B <= 0 || p->H <= 0 || p->W <= 0 ||
+      (p->mode == 0 && !p->dense.ptr)) {
+    esr_set_error("%s: invalid arguments", who);
     return ESR_ERR_INVALID;
   }
+  if ((want_mode == 2) != (p->mode == 2) || p->mode < 0 || p->mode > 2) {
+    esr_set_error("%s: esr_rdb_chain.mode %d (esr_rdb_forward: 0 / 1, esr_rdb_backward: 2)", who, p->mode);
+    return ESR_ERR_INVALID;
+  }
+  if (p->mode != 0 && p->dtype != ESR_F16) {
+    esr_set_error("%s: the training forward / backward chains are fp16 (fp32 training runs the per-conv launches)", who);
+    return ESR_ERR_UNSUPPORTED;
+  }
+  if (esr_rdb_check_abort()) {
+    esr_set_error("%s: an earlier fused-chain launch aborted (a tile waited > 1 s for its neighbours: CUs held by other work?) — its results are invalid", who);
+    return ESR_ERR_LAUNCH;
+  }
   if (p->noise_mode != ESR_NOISE_OFF && p->noise_mode != ESR_NOISE_PHILOX) {
-    esr_set_error("esr_rdb_forward: noise_mode must be OFF or PHILOX (explicit z: use the per-conv path)");
+    esr_set_error("%s: noise_mode must be OFF or PHILOX (explicit z: use the per-conv path)", who);
     return ESR_ERR_UNSUPPORTED;
   }
   const int tiles_x = (p->W + TW - 1) / TW, tiles_y = (p->H + TH - 1) / TH;
   const int tpi = tiles_x * tiles_y, ntiles = tpi * p->B;
   const int cus = num_cus();
   if (tpi > cus) {
-    esr_set_error("esr_rdb_forward: %d tiles per image > %d CUs (all tiles of an image must be co-resident)", tpi, cus);
+    esr_set_error("%s: %d tiles per image > %d CUs (all tiles of an image must be co-resident)", who, tpi, cus);
     return ESR_ERR_UNSUPPORTED;
   }
   if (p->workspace_bytes < esr_rdb_workspace_bytes(p->B, p->H, p->W)) {
-    esr_set_error("esr_rdb_forward: workspace too small");
+    esr_set_error("%s: workspace too small", who);
     return ESR_ERR_INVALID;
   }
   const int gpb = p->dtype == ESR_F16 ? 2 : 4;
-  if (p->dense.ngroups < 4 * gpb) { esr_set_error("esr_rdb_forward: dense scratch needs 128 channels"); return ESR_ERR_INVALID; }
+  if (p->mode == 0 && p->dense.ngroups < 4 * gpb) { esr_set_error("%s: dense scratch needs 128 channels", who); return ESR_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   // flags / ticket / abort word restart at zero on every call (a memset node under graph capture)
   if (hipMemsetAsync(p->workspace, 0, esr_rdb_workspace_bytes(p->B, p->H, p->W), st) != hipSuccess) {
-    esr_set_error("esr_rdb_forward: hipMemsetAsync failed");
+    esr_set_error("%s: hipMemsetAsync failed", who);
     return ESR_ERR_LAUNCH;
   }
   const int grid = ntiles < cus ? ntiles : cus;
-  if (p->dtype == ESR_F16) hipLaunchKernelGGL(rdb_chain_kernel<_Float16>, dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y);
-  else if (p->dtype == ESR_F32) hipLaunchKernelGGL(rdb_chain_kernel<float>, dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y);
-  else { esr_set_error("esr_rdb_forward: bad dtype %d", p->dtype); return ESR_ERR_INVALID; }
+  unsigned* const ha = abort_word_dev();
+  if (p->mode == 1) return esr_rdb_launch_train(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
+  if (p->mode == 2) return esr_rdb_launch_bwd(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
+  if (p->dtype != ESR_F16 && p->dtype != ESR_F32) { esr_set_error("%s: bad dtype %d", who, p->dtype); return ESR_ERR_INVALID; }
+  if (coop_launch()) {
+    // ESR_RDB_COOP=1: the runtime checks the grid against the occupancy query and refuses a grid that cannot be
+    // co-resident (a plain launch of the same grid has the same residency, MI355X_MICROARCH.md; the check costs
+    // ~17 us per launch)
+    esr_rdb_chain arg = *p;
+    int a1 = ntiles, a2 = tiles_x, a3 = tiles_y;
+    unsigned* a4 = ha;
+    void* args[] = {&arg, &a1, &a2, &a3, &a4};
+    const void* fn = p->dtype == ESR_F16 ? (const void*)rdb_chain_kernel<_Float16, 0> : (const void*)rdb_chain_kernel<float, 0>;
+    if (hipLaunchCooperativeKernel(fn, dim3(grid), dim3(NT), args, 0, st) != hipSuccess) {
+      esr_set_error("%s: cooperative launch refused: %s", who, hipGetErrorString(hipGetLastError()));
+      return ESR_ERR_LAUNCH;
+    }
+    return ESR_OK;
+  }
+  if (p->dtype == ESR_F16) hipLaunchKernelGGL((rdb_chain_kernel<_Float16, 0>), dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y, ha);
+  else hipLaunchKernelGGL((rdb_chain_kernel<float, 0>), dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y, ha);
   return esr_check_launch("rdb_chain_kernel");
 }
+}  // namespace
+
+extern "C" int esr_rdb_forward(const esr_rdb_chain* p, esr_stream_t stream) { return chain_launch(p, stream, "esr_rdb_forward", 0); }
+extern "C" int esr_rdb_backward(const esr_rdb_chain* p, esr_stream_t stream) { return chain_launch(p, stream, "esr_rdb_backward", 2); }
 
 // Fused weight stream of a block = 1 KB fragments gathered from the per-conv packed weights
 // (esr_pack_conv_weights order [cout_block][cin_group][kh][kw][lane][16 B]).

@@ -86,7 +86,6 @@ constexpr SetDesc kSets[4] = {
 // that is meant to land UNDER this step's MFMAs.  One 8-pixel MFMA fragment = two transposed reads (4 pixels each);
 // OFF goes into the instructions' offset fields; completion is counted by hand (lgkmcnt, in-order) through wait
 // statements that name the registers they release (cdna guide 5.7, form ii).
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 struct Frag { u32x2 lo, hi; };
 template <int OFF> __device__ __forceinline__ void tr_issue(Frag& f, uint32_t a) {
   asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"

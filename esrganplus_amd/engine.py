@@ -253,6 +253,77 @@ class RdbStreams:
             self._gen = gen
 
 
+class RdbBwdStreams:
+    """Fused weight streams of the BACKWARD chain (esr_rdb_backward; include/esrgan_hip.h, "Backward weight stream"):
+    per block the 1 KB fragments of its gather-form operands (DgradPack entries .g4 .g3 .c2 .g1 .c0 = cout blocks
+    0..3, 4/5) in the forward stream's crit / bulk unit order, the transposed 1x1 (.o1) behind crit_3 — a pure gather
+    out of the DgradPack arena, re-run after every re-pack."""
+
+    def __init__(self, dp, prefixes):
+        self.dp, self.prefixes = dp, list(prefixes)
+        assert dp.esr_dtype == L.ESR_F16
+        self.cpg = dp.cpg
+        self.stream_bytes = L.lib().esr_rdb_weight_stream_bytes(dp.esr_dtype)
+        self.arena = torch.zeros(len(self.prefixes) * self.stream_bytes, dtype=torch.uint8, device=dp.arena.device)
+        self._gen, self.ops = None, None
+
+    def w_ptr(self, i):
+        return self.arena.data_ptr() + i * self.stream_bytes
+
+    def _table(self):
+        cpg, base = self.cpg, self.dp.arena.data_ptr()
+        kx, kd = 64 // cpg, 32 // cpg
+        offs = []
+        for p in self.prefixes:
+            ent = [self.dp.entries[p + sfx] for sfx in ('.g4', '.g3', '.c2', '.g1', '.c0')]
+            nch = [(64 + 32 * k) // cpg for k in range(5)]            # K chunks of the five slice convs
+
+            def frag(blk, c, kh, kw):
+                k, cb = (blk, 0) if blk < 4 else (4, blk - 4)
+                return ent[k].w_ptr - base + (((cb * nch[k] + c) * 3 + kh) * 3 + kw) * 1024
+            one = [self.dp.entries[p + '.o1'].w_ptr - base + f * 1024 for f in range(4)]
+            for ph in range(1, 6):
+                c0 = 0 if ph == 1 else kx + (ph - 2) * kd
+                ks = kx if ph == 1 else kd
+                if ph < 5:
+                    for c in range(ks):
+                        offs += [frag(ph - 1, c0 + c, kh, kw) for kw in range(3) for kh in range(3)]
+                    if ph == 3:
+                        offs += one
+                    for c in range(ks):
+                        for kw in range(3):
+                            offs += [frag(blk, c0 + c, kh, kw) for blk in range(ph, 6) for kh in range(3)]
+                else:
+                    for c in range(ks):
+                        for kw in range(3):
+                            offs += [frag(blk, c0 + c, kh, kw) for blk in (4, 5) for kh in range(3)]
+        assert len(offs) * 1024 == len(self.prefixes) * self.stream_bytes, (len(offs), self.stream_bytes)
+        return offs
+
+    def ensure(self, stream, force=False):
+        """Call after dp.ensure(): re-gathers when the packed arena was rewritten."""
+        if self.ops is None:
+            self._tab = torch.tensor(self._table(), dtype=torch.int64, device=self.arena.device)
+            g = L.esr_frag_gather()
+            g.src_off, g.src_base, g.dst, g.n = (self._tab.data_ptr(), self.dp.arena.data_ptr(),
+                                                 self.arena.data_ptr(), self._tab.numel())
+            self.ops = L.OpList()
+            self.ops.add(L.OP_FRAG_GATHER, 'frag_gather', g)
+        gen = getattr(self.dp, 'pack_count', 0)
+        if force or gen != self._gen:
+            self.ops.run(stream)
+            self._gen = gen
+
+
+def use_train_chain(dtype_e, B, H, W, explicit_z):
+    """fp16 training passes run the dense blocks as fused chains — training forward (esr_rdb_chain.mode 1) and
+    backward (esr_rdb_backward) — when the image fits the chain (all tiles co-resident) and z is the fused Philox
+    stream (explicit z: per-conv launches).  ESR_RDB_TRAIN_CHAIN=0 restores the per-conv training plan."""
+    if dtype_e != L.ESR_F16 or explicit_z or os.environ.get('ESR_RDB_TRAIN_CHAIN', '1') == '0':
+        return False
+    return rdb_chain_ok(B, H, W, False, False)
+
+
 def rdb_chain_ok(B, H, W, noise, explicit_z):
     """The fused dense-block chain handles eval / fused-Philox passes whose images have at most
     esr_rdb_max_tiles_per_image() 16x32 tiles (all tiles of an image are co-resident, one per CU)."""
@@ -318,10 +389,11 @@ class Plan:
         else:
             o.u.layout.nchw = out.data_ptr()
         mode = L.NOISE_OFF
-        for i in self.chain_ops:
-            ch = arr[i].u.rdb_chain
-            ch.noise_mode = L.NOISE_PHILOX if self.chain_noise else L.NOISE_OFF
-            ch.seed = seed
+        if not getattr(self, 'graph_bound', False):
+            for i in self.chain_ops:
+                ch = arr[i].u.rdb_chain
+                ch.noise_mode = L.NOISE_PHILOX if self.chain_noise else L.NOISE_OFF
+                ch.seed = seed
         if self.noise_ops:
             if zs is not None:
                 assert len(zs) == len(self.z_ops), (len(zs), len(self.z_ops))
@@ -660,15 +732,30 @@ class DgradPack:
             ks_out = 4 if special.get(key, {}).get('ups') else ks
             offs.append(total)
             total += L.packed_weight_bytes(cin, cout, ks_out, self.esr_dtype)
+        # a gather entry is (key, dst_cout, [(weight, src_co0, scale[, fold_co0]), ...]) or, for the transposed 1x1 of
+        # the backward chain, (key, 'one_t', conv1x1.weight) — 4 KB of fragments (esr_pack.one_t; fp16 only)
+        self.ones = [g for g in self.gathers if g[1] == 'one_t']
+        self.gathers = [g for g in self.gathers if g[1] != 'one_t']
+        if self.esr_dtype != L.ESR_F16:
+            self.ones = []
         goffs = []
         for key, dst_cout, pieces in self.gathers:
-            k_total = sum(w.shape[0] for w, _, _ in pieces)
+            k_total = sum(pc[0].shape[0] for pc in pieces)
             goffs.append(total)
             total += L.packed_weight_bytes(dst_cout, k_total, 3, self.esr_dtype)
+        ooffs = []
+        for key, _, w in self.ones:
+            ooffs.append(total)
+            total += 4096
         self.arena = torch.zeros(total, dtype=torch.uint8, device=device)
         for (key, dst_cout, pieces), off in zip(self.gathers, goffs):
             e = ConvW()
-            e.key, e.cout, e.cin, e.ks = key, dst_cout, sum(w.shape[0] for w, _, _ in pieces), 3
+            e.key, e.cout, e.cin, e.ks = key, dst_cout, sum(pc[0].shape[0] for pc in pieces), 3
+            e.w_ptr, e.bias_ptr, e.has_bias = self.arena.data_ptr() + off, None, False
+            self.entries[key] = e
+        for (key, _, w), off in zip(self.ones, ooffs):
+            e = ConvW()
+            e.key, e.cout, e.cin, e.ks = key, 64, 32, 1
             e.w_ptr, e.bias_ptr, e.has_bias = self.arena.data_ptr() + off, None, False
             self.entries[key] = e
         for (key, w), off in zip(convs, offs):
@@ -686,13 +773,14 @@ class DgradPack:
         """force=False (a frozen eval-mode net, the VGG feature extractor): re-pack only when a parameter's
         storage or version changed, like WeightPack.ensure."""
         ptrs = tuple(w.data_ptr() for _, w in self.convs) + tuple(
-            w.data_ptr() for _, _, pieces in self.gathers for w, _, _ in pieces)
+            pc[0].data_ptr() for _, _, pieces in self.gathers for pc in pieces) + tuple(w.data_ptr() for _, _, w in self.ones)
         if ptrs != self._ptrs:
             packs = []
             for key, dst_cout, pieces in self.gathers:
                 e = self.entries[key]
                 nchunks, chunk0 = e.cin // self.cpg, 0
-                for w, src_co0, scale in pieces:
+                for pc in pieces:
+                    w, src_co0, scale = pc[:3]
                     assert w.shape[0] % self.cpg == 0 and src_co0 + dst_cout <= w.shape[1]
                     pk = L.esr_pack()
                     pk.src, pk.dst = w.data_ptr(), e.w_ptr
@@ -700,8 +788,14 @@ class DgradPack:
                     pk.dtype, pk.transpose_flip, pk.gather = self.esr_dtype, 1, 1
                     pk.dst_cout, pk.dst_chunk0, pk.dst_nchunks = dst_cout, chunk0, nchunks
                     pk.src_co0, pk.src_ks, pk.scale = src_co0, w.shape[2], scale
+                    pk.fold_co0 = pc[3] if len(pc) > 3 else 0
                     packs.append(pk)
                     chunk0 += w.shape[0] // self.cpg
+            for key, _, w in self.ones:
+                pk = L.esr_pack()
+                pk.src, pk.dst = w.data_ptr(), self.entries[key].w_ptr
+                pk.cout, pk.cin, pk.ks, pk.dtype, pk.one_t, pk.scale = w.shape[0], w.shape[1], 1, self.esr_dtype, 1, 1.0
+                packs.append(pk)
             for key, w in self.convs:
                 e = self.entries[key]
                 sp = self.special.get(key, {})
@@ -720,10 +814,11 @@ class DgradPack:
             ops.add(L.OP_PACK_BATCH, 'pack_batch', bp)
             self.ops, self._ptrs = ops, ptrs
             self._sig = None
-        sig = tuple(w._version for _, w in self.convs) + tuple(w._version for _, _, pieces in self.gathers for w, _, _ in pieces)
+        sig = tuple(w._version for _, w in self.convs) + tuple(pc[0]._version for _, _, pieces in self.gathers for pc in pieces)
         if force or sig != getattr(self, '_sig', None):
             self.ops.run(stream)  # (training nets: weights change every optimizer step, always re-pack)
             self._sig = sig
+            self.pack_count = getattr(self, 'pack_count', 0) + 1
 
 
 class TapMajorGrads:
@@ -780,6 +875,8 @@ class TrainPlan:
         self.segments = None         # segmented backward: [(op_end, elem_lo, elem_hi)] — after ops [.., op_end) the
                                      # gradients in flat[elem_lo:elem_hi] are final (see build_rrdbnet_train_plan)
         self.graph = False           # hipGraph replay with I/O bound to the static tensors below
+        self.bwd_chain_ops = []      # indices of OP_RDB_CHAIN_BWD ops in the backward list (noise mode / seed per run)
+        self.bwd_streams = None      # RdbBwdStreams feeding them
 
     def enable_graph(self, in_shape, device):
         """Bind every per-step pointer / scalar of both launch lists to fixed device buffers so the
@@ -804,6 +901,10 @@ class TrainPlan:
         for i in P.noise_ops:
             arr[i].u.conv.noise_mode = L.NOISE_PHILOX
             arr[i].u.conv.seed_dev = self.seed_t.data_ptr()
+        for i in P.chain_ops:
+            arr[i].u.rdb_chain.noise_mode = L.NOISE_PHILOX if P.chain_noise else L.NOISE_OFF
+            arr[i].u.rdb_chain.seed_dev = self.seed_t.data_ptr()
+        P.graph_bound = True         # Plan.run keeps its hands off the chain ops from here on
         barr = self.bwd.array()
         barr[self.gy_op].u.layout.nchw = self.gy_static.data_ptr()
         if self.gx_op is not None:
@@ -811,6 +912,9 @@ class TrainPlan:
         for i in self.bwd_noise_ops:
             barr[i].u.conv.noise_mode = L.NOISE_PHILOX
             barr[i].u.conv.seed_dev = self.seed_t.data_ptr()
+        for i in self.bwd_chain_ops:
+            barr[i].u.rdb_chain.noise_mode = L.NOISE_PHILOX if P.chain_noise else L.NOISE_OFF
+            barr[i].u.rdb_chain.seed_dev = self.seed_t.data_ptr()
         self.graph = True
 
 
@@ -871,8 +975,9 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             setattr(c, 'z%d' % slot, zb[lid].view(0, 64))
 
     # ------------------------------------------------------------------ forward
+    chain = nb > 0 and use_train_chain(dt_e, B, H, W, explicit_z)
     S = [[buf(192) for _ in range(nj)] for _ in range(nb)]
-    AUX = [[buf(64) for _ in range(nj)] for _ in range(nb)]
+    AUX = [[buf(64) for _ in range(nj)] for _ in range(nb)] if not chain else None
     XF = buf(64)                                   # output of the last RRDB
     if block:
         P.in_op = imp(P.ops, S[0][0], 64)          # x straight into the concat buffer's first slice
@@ -882,7 +987,44 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         c = _conv(d, B, H, W, xin.view(0), in_nc, (S[0][0] if nb else XF).view(0, 64), e['model.0'])
         c.aux_out = fea.view(0, 64)
         P.ops.add_conv(c)
-    for i in range(nb):
+    MASKS = None
+    if chain:
+        # ---- fused training forward: ONE esr_rdb_forward launch (mode 1) over all dense blocks; every block keeps
+        # its concat buffer S[i][j] = [x | x1..x4], its output (the next block's x) and its LeakyReLU masks
+        order = [(i, j) for i in range(nb) for j in range(nj)]
+        P.streams = RdbStreams(wp, [pkey(i, j) for i, j in order])
+        mbytes = int(L.lib().esr_rdb_mask_bytes(B, H, W))
+        MASKS = {ij: torch.empty(mbytes, dtype=torch.uint8, device=device) for ij in order}
+        TP.bufs.append(MASKS)
+        cblocks = (L.esr_rdb_block * len(order))()
+        for n, (i, j) in enumerate(order):
+            bf = S[i][j]
+            bn = S[i][j + 1] if j < nj - 1 else (S[i + 1][0] if i + 1 < nb else XF)
+            b = cblocks[n]
+            b.w, b.bias = P.streams.w_ptr(n), P.streams.bias_ptr(n)
+            b.x_in, b.x_out, b.dense = bf.view(0, 64), bn.view(0, 64), bf.view(64, 128)
+            b.mask = MASKS[(i, j)].data_ptr()
+            b.layer1 = (per * i + j) if noise else L.NO_LAYER
+            b.layer2 = L.NO_LAYER
+            if j == 2 and kind != 'rdb':
+                b.res2 = S[i][0].view(0, 64)
+                if noise and variant == 'test_image':
+                    b.layer2 = per * i + 3
+            b.flags = L.RDB_FULL_OUT
+        cblk_t = torch.frombuffer(bytearray(bytes(cblocks)), dtype=torch.uint8).to(device)
+        ws_bytes = L.lib().esr_rdb_workspace_bytes(B, H, W)
+        cws = torch.zeros((ws_bytes + 3) // 4, dtype=torch.int32, device=device)
+        TP.bufs.extend([cblk_t, cws])
+        ch = L.esr_rdb_chain()
+        ch.dtype, ch.B, ch.H, ch.W, ch.mode = dt_e, B, H, W, 1
+        ch._pad2 = int(os.environ.get('ESR_CHAIN_DBG', '0'))     # measurement-only knobs (results invalid when set)
+        ch.n_blocks, ch.noise_mode, ch.sigma, ch.save_dense = len(order), L.NOISE_OFF, SIGMA, 0
+        ch.dense = S[0][0].view(64, 128)                    # (geometry of every view; blocks carry their own)
+        ch.blocks, ch.workspace, ch.workspace_bytes = cblk_t.data_ptr(), cws.data_ptr(), ws_bytes
+        P.chain_ops.append(P.ops.add(L.OP_RDB_CHAIN, 'rdb_chain', ch))
+        P.chain_noise = bool(noise)
+        P.chain_ws = cws
+    for i in range(nb if not chain else 0):
         for j in range(nj):
             bf, ax = S[i][j], AUX[i][j]
             bn = S[i][j + 1] if j < nj - 1 else (S[i + 1][0] if i + 1 < nb else XF)
@@ -1027,10 +1169,10 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
     # The side runs are forked once per RRDB (its three blocks' 18 weight gradients in one run: every fork costs the
     # main stream an event record + wait, ~11 us of idle chip at LR sizes) and joined at the next fork, so a block's
     # Q has to survive two groups: 2 * nj + 1 buffers.
-    NQ = 2 * nj + 1
+    NQ = 2 * nj + 1 if not chain else nb * nj       # fused backward: every block keeps its Q for the weight gradients
     Qs = [buf(224) for _ in range(NQ)]
     gT = [q for q in Qs]                            # g_t of a block = channels [0,64) of its Q
-    X4 = buf(32)                                    # raw g_x4 (identity path x4 = lrelu(a4) + x2)
+    X4 = buf(32) if not chain else None             # raw g_x4 (identity path x4 = lrelu(a4) + x2)
     GF = buf(64)                                    # dL/dfea
 
     if block:
@@ -1083,13 +1225,87 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         close_segment(['model.1.sub.%d' % nb, 'model.3', 'model.6', 'model.8', 'model.10'])
     ca, ct = 0, 0
     fused_wgrad = dt_e == L.ESR_F16 and use_rdb_wgrad() and nb > 0
-    if fused_wgrad:
+    if fused_wgrad and not chain:
         # per-task partial sums of the deterministic two-stage reduction: one arena, reused by every RRDB's pass
         # (the passes are ordered on the side stream; a slot only lives inside one pass)
         rdbw_arena = torch.empty(int(L.lib().esr_rdb_wgrad_workspace_elems(B, H, W, nj)), dtype=torch.float32, device=device)
         TP.bufs.append(rdbw_arena)
     GX = buf(64) if block else None                 # dL/dx of a stand-alone block
-    for i in range(nb - 1, -1, -1):
+    if chain:
+        # ---- fused backward: ONE esr_rdb_backward launch over the dense blocks in backward order (block n reads its
+        # g_t from Qs[n][0:64], leaves g_a4..g_a1 and the raw g_x2 in Qs[n][64:224], and writes the next block's g_t),
+        # then the weight gradients of all blocks in esr_rdb_wgrad passes over (S, Q)
+        border = [(i, j) for i in range(nb - 1, -1, -1) for j in range(nj - 1, -1, -1)]
+        TP.bwd_streams = RdbBwdStreams(dp, [pkey(i, j) for i, j in border])
+        bblocks = (L.esr_rdb_block * len(border))()
+        wblocks = []
+        for n, (i, j) in enumerate(border):
+            Q, bf, p = Qs[n], S[i][j], pkey(i, j)
+            b = bblocks[n]
+            b.w = TP.bwd_streams.w_ptr(n)
+            b.x_in, b.dense, b.aux = Q.view(0, 64), Q.view(64, 128), Q.view(192, 32)
+            b.mask = MASKS[(i, j)].data_ptr()
+            b.layer1 = b.layer2 = L.NO_LAYER
+            b.flags = L.RDB_FULL_OUT
+            if j > 0:
+                # g_x = g_y of RDB j - 1 -> its g_t = g_y * n
+                b.x_out = Qs[n + 1].view(0, 64)
+                if noise:
+                    b.layer1 = per * i + j - 1
+            elif kind == 'rdb':
+                b.x_out = GX.view(0, 64)
+            else:
+                b.res2 = gA[ca].view(0, 64)
+                if block:
+                    b.x_out = GX.view(0, 64)
+                elif i > 0:
+                    b.out_a = gA[ca ^ 1].view(0, 64)
+                    if noise and variant == 'test_image':
+                        b.layer2 = per * (i - 1) + 3
+                    b.x_out = Qs[n + 1].view(0, 64)
+                    if noise:
+                        b.layer1 = per * (i - 1) + 2
+                    ca ^= 1
+                else:
+                    b.x_out = GF.view(0, 64)
+            wb = L.esr_rdb_wgrad_block()
+            wb.in_, wb.q = bf.view(0, 192), Q.view(0, 224)
+            for k in range(5):
+                key = p + '.conv%d.0' % (k + 1)
+                wb.dw[k] = TP.tapmajor.slot(goff[key], 64 if k == 4 else 32, 64 + 32 * k)
+                wb.db[k] = gptr[key][1]
+            wb.dw[5] = gptr[p + '.conv1x1'][0]
+            wblocks.append(wb)
+        bblk_t = torch.frombuffer(bytearray(bytes(bblocks)), dtype=torch.uint8).to(device)
+        ws_bytes = L.lib().esr_rdb_workspace_bytes(B, H, W)
+        bws = torch.zeros((ws_bytes + 3) // 4, dtype=torch.int32, device=device)
+        TP.bufs.extend([bblk_t, bws])
+        ch = L.esr_rdb_chain()
+        ch.dtype, ch.B, ch.H, ch.W, ch.mode = dt_e, B, H, W, 2
+        ch.n_blocks, ch.noise_mode, ch.sigma, ch.save_dense = len(border), L.NOISE_OFF, SIGMA, 1
+        ch.dense = Qs[0].view(64, 128)
+        ch.blocks, ch.workspace, ch.workspace_bytes = bblk_t.data_ptr(), bws.data_ptr(), ws_bytes
+        TP.bwd_chain_ops.append(Bk.add(L.OP_RDB_CHAIN_BWD, 'rdb_chain', ch))
+        TP.bwd_chain_ws = bws
+        # weight gradients: one pass over all blocks — or, data-parallel, one per RRDB so that each RRDB's slice of the
+        # flat gradient buffer goes to its all-reduce while the next pass runs
+        groups = [wblocks] if not segmented else [wblocks[k:k + nj] for k in range(0, len(wblocks), nj)]
+        n_max = max(len(g_) for g_ in groups)
+        warena = torch.empty(int(L.lib().esr_rdb_wgrad_workspace_elems(B, H, W, n_max)), dtype=torch.float32, device=device)
+        TP.bufs.append(warena)
+        for gi, grp in enumerate(groups):
+            arr_ = (L.esr_rdb_wgrad_block * len(grp))(*grp)
+            wt = torch.frombuffer(bytearray(bytes(arr_)), dtype=torch.uint8).to(device)
+            TP.bufs.append(wt)
+            rw = L.esr_rdb_wgrad()
+            rw.dtype, rw.B, rw.H, rw.W = dt_e, B, H, W
+            rw.n_blocks, rw.tap_major, rw.scale5, rw.scale = len(grp), 1, 0.2, 1.0
+            rw.blocks = wt.data_ptr()
+            rw.partial, rw.partial_elems = warena.data_ptr(), warena.numel()
+            Bk.add(L.OP_RDB_WGRAD, 'rdb_wgrad', rw)
+            if segmented:
+                close_segment(['model.1.sub.%d' % (nb - 1 - gi)])
+    for i in range(nb - 1 if not chain else -1, -1, -1):
         for j in range(nj - 1, -1, -1):
             bf, ax = S[i][j], AUX[i][j]
             p = pkey(i, j)

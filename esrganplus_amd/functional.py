@@ -102,6 +102,8 @@ def _train_backward(tp, gy, st, noise, explicit, seed, want_gx, sync=None):
         tp.tapmajor.tm.zero_()
     if tp.graph:
         tp.gy_static.copy_(gy)
+        if tp.bwd_streams is not None:
+            tp.bwd_streams.ensure(st)
         tp.bwd.graph_launch(st)                 # seed_t still holds this step's seed
         return tp.gx_static.clone() if (want_gx and tp.gx_op is not None) else None
     arr = tp.bwd.array()
@@ -117,6 +119,11 @@ def _train_backward(tp, gy, st, noise, explicit, seed, want_gx, sync=None):
     for i in tp.bwd_noise_ops:
         arr[i].u.conv.noise_mode = mode
         arr[i].u.conv.seed = seed
+    for i in tp.bwd_chain_ops:                      # fused backward chain (esr_rdb_backward): same Philox key as the forward
+        arr[i].u.rdb_chain.noise_mode = L.NOISE_PHILOX if noise else L.NOISE_OFF
+        arr[i].u.rdb_chain.seed = seed
+    if tp.bwd_streams is not None:
+        tp.bwd_streams.ensure(st)
     if tp.segments is None or sync is None:
         tp.bwd.run(st)
         return gx

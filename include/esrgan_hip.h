@@ -141,6 +141,13 @@ typedef struct esr_pack {
                           each weighted by the SUM of the 3x3 taps that land on it — 16 instead of 36 MACs per
                           4 outputs.  Packed as a 2x2 conv with 4*cout_blocks blocks, phase-major:
                           [phase = 2 dy + dx][cout_block][chunk][2 a + b] */
+  int32_t fold_co0;    /* gather pieces (3x3): when > 0, the weights of forward input channels fold_co0 + r are ADDED to
+                          those of src_co0 + r — the identity path x4 = lrelu(a4) + x2 (block.py:266) folded into conv5's
+                          x2 columns, so that the backward chain needs no residual for g_x2.  0: off */
+  int32_t one_t;       /* 1: the transposed 1x1 of a dense block (src = conv1x1.weight [32][64]) as the backward chain
+                          consumes it: g_x[64] += W^T g_x2[32]; 2 cout blocks x 2 K chunks of 1 KB, chunk c holding the
+                          K order k = 8 h + i <-> g_x2 channel 16 h + 8 c + i (the lane's packed epilogue registers
+                          are the B fragments).  fp16 only */
 } esr_pack;
 
 /* All weight packs of a network in ONE launch: `table` is a DEVICE array of n esr_pack entries,
@@ -405,8 +412,22 @@ typedef struct esr_rdb_block {
                                tiles' border pixels are stored: the next block takes its input from the LDS and its
                                `+ x` residual from the accumulators this block's epilogue primes with 5 x */
   uint32_t _pad;
+  /* ---- training chains (esr_rdb_chain.mode 1 / 2, fp16) ---- */
+  esr_g32 dense;            /* this block's own 128 channels: mode 1: x1..x4 (kept for the backward);
+                               mode 2: g_a4 | g_a3 | g_a2 | g_a1 (what the weight gradients read) */
+  void* mask;               /* LeakyReLU masks of a1..a4, one bit per element: B * tiles records of 8 KB in the chain's
+                               16x32 tile order, [slice a1..a4][wave][lane][4 rows x u16] (esr_rdb_mask_bytes); written
+                               by mode 1, read by mode 2 of the same geometry */
+  esr_g32 aux;              /* mode 2: unmasked g_x2 (32 channels), input of the 1x1's weight gradient */
+  esr_g32 out_a;            /* mode 2, blocks with res2 (the RDB1 of an RRDB): A' = (acc + res2) (1 + sigma z[layer2]) is
+                               stored here (the skip gradient of the previous RRDB) and x_out = 0.2 A' (1 + sigma z[layer1]);
+                               ptr NULL: x_out = (acc [+ res2]) (1 + sigma z[layer1]) */
 } esr_rdb_block;
 #define ESR_RDB_FULL_OUT 1u
+/* Backward weight stream of a block (mode 2): the forward's layout over the gather-form operands
+ *   blk 0..3 = the x4, x3, x2, x1 slice convs (esr_pack.gather; the x2 one with fold_co0 = the x4 columns of conv5),
+ *   blk 4/5 = the x slice conv's two cout blocks (K = 192: g_t, g_a4..g_a1),
+ * crit_p / bulk_p as in the forward; the 1x1 unit (esr_pack.one_t: 2 cout blocks x 2 chunks) sits behind crit_3. */
 
 typedef struct esr_rdb_chain {
   int32_t dtype, B, H, W;
@@ -423,6 +444,12 @@ typedef struct esr_rdb_chain {
                                launch = a bounded spin timed out (results invalid) */
   size_t workspace_bytes;
   uint64_t* trace;          /* measurement only (NULL = off): per tile 64 x uint64 time stamps (100 MHz) */
+  int32_t mode;             /* 0: inference forward (esr_rdb_forward);  1: TRAINING forward (esr_rdb_forward, fp16): every
+                               block writes x1..x4 to its own `dense`, its output in full and its LeakyReLU masks;
+                               2: BACKWARD (esr_rdb_backward, fp16): blocks in backward order, x_in = the block's g_t
+                               (dL/d(conv5 * 0.2 + x)), weights = the gather-form streams (below), x_out = the next
+                               block's g_t */
+  int32_t _pad2;
 } esr_rdb_chain;
 
 /* Piece gather: dst[f * piece_bytes ..] = src_base[src_off[f] ..] for f < n (src_off: DEVICE int64 byte offsets;
@@ -464,7 +491,8 @@ typedef struct esr_rdb_wgrad {
 enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_NOISE_FILL = 4,
                    ESR_OP_WGRAD = 5, ESR_OP_BN = 6, ESR_OP_POOL = 7, ESR_OP_LINEAR = 8,
                    ESR_OP_UNPERMUTE = 9, ESR_OP_PACK_BATCH = 10,
-                   ESR_OP_RDB_CHAIN = 11, ESR_OP_FRAG_GATHER = 12, ESR_OP_RDB_WGRAD = 13 };
+                   ESR_OP_RDB_CHAIN = 11, ESR_OP_FRAG_GATHER = 12, ESR_OP_RDB_WGRAD = 13,
+                   ESR_OP_RDB_CHAIN_BWD = 14 /* u.rdb_chain with mode 2 */ };
 
 /* esr_op.flags */
 #define ESR_OPF_SIDE 1   /* on a run of consecutive ESR_OP_WGRAD ops: launch the run on the library's side
@@ -524,6 +552,16 @@ int esr_resample_axis(const esr_resample* p, esr_stream_t stream);
 int esr_pack_conv_weights_batch(const esr_pack_batch* p, esr_stream_t stream);
 /* Fused dense-block chain (replaces 5 x n_blocks esr_conv_forward launches; block.py:260-268,287-291). */
 int esr_rdb_forward(const esr_rdb_chain* p, esr_stream_t stream);
+/* Fused dense-block BACKWARD chain (mode 2): the input gradients of n_blocks dense blocks (autograd backward of
+ * block.py:260-268,287-291, triggered at SRRaGAN_model.py:140) in one persistent launch — replaces 5 x n_blocks dgrad
+ * launches; the weight gradients follow with esr_rdb_wgrad_run over the Q buffers this launch leaves complete. */
+int esr_rdb_backward(const esr_rdb_chain* p, esr_stream_t stream);
+size_t esr_rdb_mask_bytes(int32_t B, int32_t H, int32_t W);   /* esr_rdb_block.mask of one block */
+/* Sticky abort report: 1 if a chain launch since the last call gave up on a bounded spin (its results are invalid;
+ * e.g. another kernel held CUs for > 1 s), else 0.  Reads a pinned host word: no synchronisation, but only meaningful
+ * for launches that have completed.  esr_run_ops / esr_rdb_forward / esr_rdb_backward check it on entry and fail with
+ * ESR_ERR_LAUNCH, so an aborted launch cannot go unnoticed past the next call. */
+int esr_rdb_check_abort(void);
 size_t esr_rdb_workspace_bytes(int32_t B, int32_t H, int32_t W);
 size_t esr_rdb_weight_stream_bytes(int32_t dtype);
 int esr_rdb_max_tiles_per_image(void);   /* 16x32 tiles of ONE image must not exceed this (= CUs) */

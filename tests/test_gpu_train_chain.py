@@ -1,0 +1,106 @@
+"""Fused training chains — esr_rdb_forward mode 1 (training forward: every activation kept) and esr_rdb_backward
+(input gradients of block.py:260-268,287-291; autograd backward at SRRaGAN_model.py:140) followed by esr_rdb_wgrad_run —
+against the per-conv training plan they replace (itself pinned to the imported reference's gradients by
+tests/test_gpu_backward.py) and against the fp32 path: outputs, input gradients, parameter gradients, with the
+GaussianNoise layers on (same Philox key), both module variants, ragged sizes; run-to-run bit identity."""
+import numpy as np
+import pytest
+import torch
+
+from esrganplus_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _grads(module_fn, x, gy, seed, monkeypatch, chain, precision='fp16'):
+    monkeypatch.setenv('ESR_RDB_TRAIN_CHAIN', '1' if chain else '0')
+    m = module_fn().set_precision(precision)
+    xr = x.clone().requires_grad_(True)
+    torch.manual_seed(seed)
+    y = m(xr)
+    (y * gy).sum().backward()
+    torch.cuda.synchronize()
+    used_chain = any(getattr(tp, 'bwd_chain_ops', None) for pool in m._plans.values() if isinstance(pool, list) for tp in pool)
+    return y.detach(), xr.grad, {k: p.grad.clone() for k, p in m.named_parameters()}, used_chain
+
+
+def _rel(a, b):
+    return (a.double() - b.double()).norm().item() / (b.double().norm().item() + 1e-30)
+
+
+@pytest.mark.parametrize('kind,shape', [('rdb', (2, 64, 16, 32)), ('rrdb', (2, 64, 24, 40)), ('rrdb_ti', (1, 64, 33, 31)),
+                                        ('rdb', (1, 64, 5, 3))])
+@pytest.mark.parametrize('train', [True, False])
+def test_block_chain_equals_per_conv_plan(dev, monkeypatch, kind, shape, train):
+    """Stand-alone ResidualDenseBlock_5C / RRDB (both variants): fused chains vs per-conv launches, fp16."""
+    from esrganplus_amd import block as B
+
+    def make():
+        torch.manual_seed(3)
+        m = B.ResidualDenseBlock_5C(64) if kind == 'rdb' else B.RRDB(64, extra_noise=(kind == 'rrdb_ti'))
+        with torch.no_grad():
+            for p in m.parameters():
+                p.mul_(1.5)
+        return m.to(dev).train(train)
+    x = synth.normal_like(5, 'tc.x', shape).to(dev)
+    gy = synth.normal_like(6, 'tc.gy', shape).to(dev)
+    y0, gx0, g0, c0 = _grads(make, x, gy, 77, monkeypatch, False)
+    y1, gx1, g1, c1 = _grads(make, x, gy, 77, monkeypatch, True)
+    assert c1 and not c0
+    assert _rel(y1, y0) <= 2e-3, _rel(y1, y0)
+    assert _rel(gx1, gx0) <= 4e-3, _rel(gx1, gx0)
+    worst = max(_rel(g1[k], g0[k]) for k in g0)
+    print('%s %s train=%s: y %.2e gx %.2e worst param grad %.2e' % (kind, shape, train, _rel(y1, y0), _rel(gx1, gx0), worst))
+    # Both fp16 plans sit ~1e-2 from the fp32 gradients on the inner convs (fp16 activations: a pre-activation that
+    # rounds across zero flips a LeakyReLU mask), so that is also their distance from each other; the bar for the chain
+    # is the fp32 path (pinned to the reference in test_gpu_backward.py): at least as close as the per-conv plan.
+    assert worst <= 2.5e-2, worst
+    y2, gx2, g2, _ = _grads(make, x, gy, 77, monkeypatch, False, 'fp32')
+    assert _rel(gx1, gx2) <= 1e-2, _rel(gx1, gx2)
+    for k in g2:
+        e_chain, e_conv = _rel(g1[k], g2[k]), _rel(g0[k], g2[k])
+        assert e_chain <= 2.5e-2 and e_chain <= 1.25 * e_conv + 2e-3, (k, e_chain, e_conv)
+
+
+@pytest.mark.parametrize('cls,nb,shape', [('RRDBNet', 2, (2, 3, 32, 32)), ('RRDB_Net', 1, (1, 3, 20, 36))])
+def test_rrdbnet_chain_equals_per_conv_plan(dev, monkeypatch, cls, nb, shape):
+    from esrganplus_amd import architecture as arch
+    sd = synth.rrdbnet_state_dict(nb=nb, seed=8, gain=0.7)
+
+    def make():
+        net = getattr(arch, cls)(3, 3, 64, nb).to(dev).train()
+        net.load_state_dict(sd)
+        return net
+    x = synth.image_batch(8, *shape, name='tcn.x').to(dev)
+    gy = synth.normal_like(9, 'tcn.gy', (shape[0], 3, 4 * shape[2], 4 * shape[3])).to(dev)
+    # (the LR input needs no gradient: run with a plain tensor)
+    res = []
+    for chain in (False, True):
+        monkeypatch.setenv('ESR_RDB_TRAIN_CHAIN', '1' if chain else '0')
+        net = make().set_precision('fp16')
+        torch.manual_seed(5)
+        y = net(x)
+        (y * gy).sum().backward()
+        torch.cuda.synchronize()
+        res.append((y.detach(), {k: p.grad.clone() for k, p in net.named_parameters()}))
+        if chain:
+            # a second pass reproduces the first bit for bit (deterministic reductions, same Philox key)
+            net.zero_grad(set_to_none=True)
+            torch.manual_seed(5)
+            y2 = net(x)
+            (y2 * gy).sum().backward()
+            torch.cuda.synchronize()
+            assert torch.equal(y2, y)
+            for k, p in net.named_parameters():
+                assert torch.equal(p.grad, res[-1][1][k]), k
+    (y0, g0), (y1, g1) = res
+    assert _rel(y1, y0) <= 2e-3
+    worst = max((_rel(g1[k], g0[k]), k) for k in g0)
+    print('%s nb=%d: y %.2e, worst param grad %.2e (%s)' % (cls, nb, _rel(y1, y0), worst[0], worst[1]))
+    assert worst[0] <= 3e-2, worst

@@ -1,0 +1,37 @@
+"""Per-phase timeline of the TRAINING-forward chain (esr_rdb_chain.mode 1, trace): as tools/chain_trace.py.
+Usage: python tools/chain_trace_train.py [noise 0/1]"""
+import sys, os
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from esrganplus_amd import architecture as arch, synth, _lib as L
+
+B, H, W, nb = 16, 128, 128, 2
+noise = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+dev = torch.device('cuda:0')
+net = arch.RRDBNet(3, 3, 64, nb).to(dev).train(bool(noise)).set_precision('fp16')
+x = torch.rand(B, 3, H, W, device=dev)
+y = net(x)
+pool = [v for k, v in net._plans.items() if isinstance(v, list)][0]
+tp = pool[0]
+plan = tp.fwd
+ntiles = B * ((H + 15) // 16) * ((W + 31) // 32)
+tr = torch.zeros(ntiles * 64, dtype=torch.int64, device=dev)
+arr = plan.ops.array()
+arr[plan.chain_ops[0]].u.rdb_chain.trace = tr.data_ptr()
+del y
+for _ in range(3):
+    y = net(x); del y
+torch.cuda.synchronize()
+t = tr.cpu().numpy().reshape(ntiles, 64).astype(np.int64)
+names = ['poll1', 'halo1', 'crit1', 'ep1', 'bulk1', '1x1+put', 'poll2', 'halo2', 'crit2', 'ep2', 'bulk2',
+         'poll3', 'halo3', 'crit3', 'ep3', 'bulk3', 'poll4', 'halo4', 'crit4', 'ep4+tail', 'bulk4',
+         'poll5', 'halo5', 'crit5', 'ep5', 'drain5', 'flag']
+d = np.diff(t[:, :len(names) + 1], axis=1) / 100.0
+print('train-forward chain, noise %d: timeline of each tile\'s second block (us), mean over tiles [min..max]' % noise)
+tot = 0.0
+for i, n in enumerate(names):
+    col = d[:, i]
+    tot += col.mean()
+    print('  %-10s %7.2f  [%6.2f .. %6.2f]' % (n, col.mean(), col.min(), col.max()))
+print('  total      %7.2f' % tot)
