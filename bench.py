@@ -255,13 +255,15 @@ def gtrain_bench(args, world, rank, dev, dist):
         dist.destroy_process_group()
 
 
-def fwd_bwd_probe(args, dev, steps=5):
+def fwd_bwd_probe(args, dev, steps=20):
     """BASELINE.json's metric string says "fwd+bwd": the same workload as `value` (batch 16 of 128x128 LR, fp16)
     with the generator in training mode — GaussianNoise on, every activation kept, L1 loss against a synthetic
     HR target, loss-scaled backward through every conv (dgrad + wgrad); no optimizer step.  Reported next to
-    the forward headline, not instead of it (north_star's roofline target is on the forward)."""
+    the forward headline, not instead of it (north_star's roofline target is on the forward).  Carries its own
+    `roofline` object: the three fused dense-block kernels (training forward chain, backward chain, weight
+    gradients) timed with HIP events on the launch stream, the slowest of them named as the dominant kernel."""
     import torch.nn.functional as F
-    from esrganplus_amd import architecture as arch, synth
+    from esrganplus_amd import architecture as arch, synth, engine as E, functional as Fn, _lib as L
     netG = arch.RRDBNet(3, 3, 64, NB).to(dev).train().set_precision('fp16')
     netG.load_state_dict(synth.rrdbnet_state_dict(NB, 0, gain=0.5))
     lr = synth.image_batch(300, args.batch, 3, args.lr, args.lr, name='bench.fb.lr').to(dev)
@@ -274,7 +276,7 @@ def fwd_bwd_probe(args, dev, steps=5):
         (loss * 1024.0).backward()
         return loss
 
-    for _ in range(2):
+    for _ in range(3):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -284,11 +286,71 @@ def fwd_bwd_probe(args, dev, steps=5):
     dt = (time.perf_counter() - t0) / steps
     assert torch.isfinite(loss).all()
     fl = 3.0 * 2.0 * MAC_PER_LR_PIXEL * args.batch * args.lr * args.lr      # fwd + dgrad + wgrad
-    return {'ms_per_step': round(dt * 1e3, 3), 'value': round(args.batch * (4 * args.lr) ** 2 / 1e6 / dt, 2),
-            'unit': 'HR-Mpix/s', 'tflops': round(fl / dt / 1e12, 1),
-            'frac_of_f16_mfma_peak': round(fl / dt / 1e12 / PEAK_F16_TFLOPS, 4), 'steps': steps,
-            'what': 'RRDBNet x4 train-mode forward (noise on) + backward (dgrad + wgrad, loss scale 1024), '
-                    'batch %d of %dx%d LR, fp16, no optimizer step' % (args.batch, args.lr, args.lr)}
+    res = {'ms_per_step': round(dt * 1e3, 3), 'value': round(args.batch * (4 * args.lr) ** 2 / 1e6 / dt, 2),
+           'unit': 'HR-Mpix/s', 'tflops': round(fl / dt / 1e12, 1),
+           'frac_of_f16_mfma_peak': round(fl / dt / 1e12 / PEAK_F16_TFLOPS, 4), 'steps': steps, 'warmup': 3,
+           'what': 'RRDBNet x4 train-mode forward (noise on) + backward (dgrad + wgrad, loss scale 1024), '
+                   'batch %d of %dx%d LR, fp16, no optimizer step' % (args.batch, args.lr, args.lr)}
+
+    # ---- per-kernel HIP-event timing of the two recorded launch lists (same buffers, same seed as a real step)
+    tp = next(t for k, pool in netG._plans.items() if isinstance(k, tuple) and k and k[0] == 'train' for t in pool)
+    st = E.current_stream()
+    out = torch.empty(tp.fwd.out_shape, dtype=torch.float32, device=dev)
+    gy = torch.full(tp.fwd.out_shape, 1024.0 / out.numel(), dtype=torch.float32, device=dev)
+    if tp.graph:
+        return res
+    blk_fl = 2.0 * RDB_MAC_PER_PIXEL * args.batch * args.lr * args.lr          # per dense block, any of the three passes
+
+    def name_of(o):
+        if o.kind == L.OP_RDB_CHAIN:
+            return 'rdb_chain_train', blk_fl * o.u.rdb_chain.n_blocks
+        if o.kind == L.OP_RDB_CHAIN_BWD:
+            return 'rdb_chain_bwd', blk_fl * o.u.rdb_chain.n_blocks
+        if o.kind == L.OP_RDB_WGRAD:
+            return 'rdb_wgrad', blk_fl * o.u.rdb_wgrad.n_blocks
+        if o.kind == L.OP_WGRAD:
+            w = o.u.wgrad
+            return 'wgrad', 2.0 * w.B * w.H * w.W * w.cout * w.cin * w.ks * w.ks
+        if o.kind == L.OP_CONV:
+            return 'conv (head / tail / their dgrad)', 0.0
+        return 'other (layout, pack, unpermute)', 0.0
+
+    agg = {}
+    reps = 5
+    for rep in range(reps + 1):
+        tp.fwd.run(lr, out, st, 1234, None)                  # binds I/O + seed (untimed), then the timed replay
+        ms_f = tp.fwd.ops.run_timed(st)
+        Fn._train_backward(tp, gy, st, True, False, 1234, False)
+        ms_b = tp.bwd.run_timed(st)
+        if rep == 0:
+            continue
+        for ops, ms in ((tp.fwd.ops.ops, ms_f), (tp.bwd.ops, ms_b)):
+            for o, t in zip(ops, ms):
+                nm, f = name_of(o)
+                a = agg.setdefault(nm, [0.0, 0.0, 0])
+                a[0] += t
+                a[1] += f
+                a[2] += 1
+    fused = [k for k in ('rdb_chain_train', 'rdb_chain_bwd', 'rdb_wgrad') if k in agg]
+    res['kernels'] = {k: {'launches': a[2] // reps, 'ms_per_step': round(a[0] / reps, 3),
+                          'tflops': round(a[1] / (a[0] * 1e-3) / 1e12, 1) if a[1] else 0.0}
+                      for k, a in sorted(agg.items())}
+    if fused:
+        dom = max(fused, key=lambda k: agg[k][0])
+        t_ms, f, n = agg[dom]
+        ach = f / (t_ms * 1e-3) / 1e12
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')))
+            if dom in tj and args.batch == BATCH and args.lr == LR:
+                traffic = tj[dom]['read_bytes'] + tj[dom]['write_bytes']
+        except (OSError, ValueError, KeyError):
+            pass
+        res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_F16_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
+                           'launches_per_step': n // reps, 'avg_launch_us': round(t_ms / n * 1e3, 2),
+                           'share_of_step_time': round(t_ms / reps / (sum(a[0] for a in agg.values()) / reps), 3)}
+    return res
 
 
 def main():

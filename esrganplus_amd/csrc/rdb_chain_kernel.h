@@ -132,11 +132,7 @@ __device__ __forceinline__ void mma_cls(f32x16& acc, const u32x4& a, const u32x4
   }
 }
 // >= 18 wait states: covers "XDL write VGPR -> VALU / VMEM read or write" for 8- and 16-pass MFMAs
-#ifdef ESR_DBG_SB
-__device__ __forceinline__ void mfma_drain() { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#else
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
-#endif
 
 // The carried accumulators of cout blocks 4 / 5 (written by VALU code: the block tail, the tile set-up) are pinned
 // into their AGPRs HERE, with the VALU-write -> MFMA-SrcC wait states inside the statement: left alone, hipcc keeps
@@ -230,12 +226,6 @@ template <> struct Ch16<_Float16> {
     const int off = (2 * cb + h) * t.gs + pixoff;
     __builtin_amdgcn_raw_buffer_store_b128(q[0], t.r, off, 0, 16);
     __builtin_amdgcn_raw_buffer_store_b128(q[1], t.r, off + 16, 0, 16);
-  }
-  // not write-through: data that only a LATER launch reads
-  static __device__ __forceinline__ void store_packed_plain(const ImgView& t, int cb, int h, int pixoff, const u32x4 (&q)[2]) {
-    const int off = (2 * cb + h) * t.gs + pixoff;
-    __builtin_amdgcn_raw_buffer_store_b128(q[0], t.r, off, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(q[1], t.r, off + 16, 0, 0);
   }
   struct Raw { u32x4 q[2]; };
   static __device__ __forceinline__ void load(const ImgView& t, int cb, int h, int pixoff, Raw& r) {
@@ -1049,12 +1039,8 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const PT& p, const BlkS& bl
         if constexpr (TRAIN) {
           // one v_alignbit per element: shift the sign bit of lrelu(a) (= the sign of a) into the row's mask word
           // (channel e ends up at bit 15 - e; 1 = negative -> slope 0.2)
-#ifdef ESR_DBG_CMPMASK
-          mbits[r] = (mbits[r] << 2) | (v[e] < 0.f ? 2u : 0u) | (v[e + 1] < 0.f ? 1u : 0u);
-#else
           mbits[r] = __builtin_amdgcn_alignbit(mbits[r], __builtin_bit_cast(uint32_t, v[e]), 31);
           mbits[r] = __builtin_amdgcn_alignbit(mbits[r], __builtin_bit_cast(uint32_t, v[e + 1]), 31);
-#endif
         }
       } else {
         v[e] = x[0];
@@ -1321,28 +1307,15 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
   if (threadIdx.x == 0) *(unsigned* volatile*)(smem + LDS_CTRL + 48) = host_abort;   // (visible behind the ticket barrier)
   // what the boundary code reads of the launch: the argument struct itself (inference: unchanged code) or a copy of
   // its scalars in registers (training / backward)
-#ifdef ESR_DBG_NOPS
-  using PT = esr_rdb_chain;
-#else
   using PT = std::conditional_t<DIR == 0, esr_rdb_chain, PS>;
-#endif
   PS ps;
   if constexpr (DIR != 0) {
-#ifdef ESR_DBG_NORFL
-    ps.H = p.H; ps.W = p.W; ps.noise_mode = p.noise_mode; ps.save_dense = 0; ps._pad2 = 0;
-    ps.sigma = p.sigma; ps.seed = p.seed; ps.seed_dev = p.seed_dev; ps.dense.wp = p.dense.wp; ps.trace = p.trace;
-#else
     ps.H = __builtin_amdgcn_readfirstlane(p.H); ps.W = __builtin_amdgcn_readfirstlane(p.W);
     ps.noise_mode = __builtin_amdgcn_readfirstlane(p.noise_mode); ps.save_dense = 0; ps._pad2 = 0;
     ps.sigma = p.sigma; ps.seed = p.seed; ps.seed_dev = p.seed_dev; ps.dense.wp = __builtin_amdgcn_readfirstlane(p.dense.wp);
     ps.trace = p.trace;
-#endif
   }
-#ifdef ESR_DBG_NOPS
-  const PT& q = p;
-#else
   const PT& q = *[&]() { if constexpr (DIR == 0) return &p; else return &ps; }();
-#endif
 
   for (;;) {
     // ---- claim the next tile (tickets go out in order, so an image's tiles are co-resident)

@@ -1017,7 +1017,6 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         TP.bufs.extend([cblk_t, cws])
         ch = L.esr_rdb_chain()
         ch.dtype, ch.B, ch.H, ch.W, ch.mode = dt_e, B, H, W, 1
-        ch._pad2 = int(os.environ.get('ESR_CHAIN_DBG', '0'))     # measurement-only knobs (results invalid when set)
         ch.n_blocks, ch.noise_mode, ch.sigma, ch.save_dense = len(order), L.NOISE_OFF, SIGMA, 0
         ch.dense = S[0][0].view(64, 128)                    # (geometry of every view; blocks carry their own)
         ch.blocks, ch.workspace, ch.workspace_bytes = cblk_t.data_ptr(), cws.data_ptr(), ws_bytes

@@ -88,6 +88,8 @@ def _train_forward(tp, xin, st, seed, zs):
     if tp.graph:
         tp.x_static.copy_(xin)
         tp.seed_t.fill_(seed)
+        if tp.fwd.streams is not None:          # the chain's weight streams are gathered outside the graph
+            tp.fwd.streams.ensure(st)
         tp.fwd.ops.graph_launch(st)
         return tp.out_static.clone()
     out = torch.empty(tp.fwd.out_shape, dtype=torch.float32, device=xin.device)
