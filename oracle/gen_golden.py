@@ -205,6 +205,46 @@ def gen_rrdbnet_full():
     np.savez_compressed(os.path.join(OUT, 'rrdbnet_full.npz'), **res)
 
 
+def grad_probe(key, g, nproj=3, nhead=32):
+    """Compact view of one gradient tensor: (sum, abs-sum, L2) + `nproj` projections on fixed N(0,1) vectors
+    (synth.normal_like(77, 'gproj.<key>.<i>')) + its first `nhead` entries — all float64."""
+    a = npy(g).astype(np.float64).reshape(-1)
+    pr = [float((a * synth.normal_like(77, 'gproj.%s.%d' % (key, i), a.shape).numpy().astype(np.float64)).sum())
+          for i in range(nproj)]
+    head = np.zeros(nhead)
+    head[:min(nhead, a.size)] = a[:nhead]
+    return np.concatenate([[a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum())], pr, head])
+
+
+def gen_rrdbnet_full_grad():
+    """Full-depth backward (nb=23, the depth bench.py's fwd_bwd / gtrain time) of the imported reference on ONE
+    128x128 LR tile, eval mode (GaussianNoise is the identity: block.py:117-123), loss = <y, gy>: every parameter
+    gradient as a grad_probe row.  The GPU test runs the bench-shape batch (16 tiles) with this tile at two batch
+    positions and zero upstream gradient elsewhere — parameter gradients are sums over the batch."""
+    sd = synth.rrdbnet_state_dict(nb=23, seed=0, gain=0.5)
+    net = RI.build_rrdbnet(23, 'codes').eval()
+    net.load_state_dict(sd, strict=True)
+    x = synth.image_batch(41, 1, 3, 128, 128, name='fullgrad.x')
+    gy = synth.normal_like(41, 'fullgrad.gy', (1, 3, 512, 512)) / (3 * 512 * 512)
+    keys = list(sd.keys())
+    y, _, grads = _run_net(net, keys, x, gy, None)
+    # the restatement agrees (forward + a sample of gradients) before anything is written
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo = RT.rrdbnet_forward(x, sdr, 23, None, 'codes')
+    (yo * gy).sum().backward()
+    assert_close(y, yo, 1e-5, 'rrdbnet nb=23 128x128 fwd')
+    rel = max(((grads[k] - sdr[k].grad).norm() / grads[k].norm().clamp_min(1e-30)).item() for k in keys)
+    print('  restatement vs reference  rrdbnet nb=23 128x128 param grads max rel L2 diff = %.3e' % rel)
+    assert rel < 1e-3
+    res = {'y_chk': checks(y), 'y_head': npy(y)[0, :, :8, :8].astype(np.float64),
+           'probe': np.stack([grad_probe(k, grads[k]) for k in keys]),
+           'keys': np.array(keys)}
+    for k in ('model.0.weight', 'model.0.bias', 'model.1.sub.0.RDB1.conv1.0.weight', 'model.1.sub.11.RDB2.conv1x1.weight',
+              'model.1.sub.22.RDB3.conv5.0.bias', 'model.1.sub.22.RDB3.conv4.0.bias', 'model.1.sub.23.weight', 'model.10.weight'):
+        res['g_' + k] = npy(grads[k])
+    np.savez_compressed(os.path.join(OUT, 'rrdbnet_full_grad.npz'), **res)
+
+
 def gen_disc():
     sd = synth.discriminator_state_dict(seed=4)
     net = RI.build_discriminator()
@@ -519,7 +559,7 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['rdb', 'rrdbnet_small', 'rrdbnet_full', 'disc', 'disc_variants', 'vgg', 'train_step',
-                             'psnr', 'imresize', 'metrics', 'metrics_y', 'srresnet']
+                             'psnr', 'imresize', 'metrics', 'metrics_y', 'srresnet', 'rrdbnet_full_grad']
     for w in which:
         print('[gen_golden]', w)
         globals()['gen_' + w]()

@@ -152,3 +152,65 @@ def test_standalone_rrdb_backward_vs_oracle(dev, variant):
         got = dict(m.named_parameters())[k].grad.cpu()
         want = sdr[p + k].grad
         assert (got - want).abs().max().item() <= 2e-3 * max(1e-3, want.abs().max().item()), k
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'fp16'])
+def test_full_depth_backward_at_bench_shape_vs_reference_golden(dev, golden, prec):
+    """nb=23 at the shape bench.py's fwd_bwd times (batch 16 of 128x128 LR: 256-tile chain / 512-tile dgrad
+    instantiations, the fused dense-block wgrad over 69 blocks) under tests/golden/rrdbnet_full_grad.npz — the
+    imported reference's gradients for ONE tile (oracle/gen_golden.py: gen_rrdbnet_full_grad).  Parameter
+    gradients add over the batch: the golden tile sits at batch positions 0 and 9 with upstream gradients gy and
+    gy/2, every other tile gets a zero upstream gradient, so each gradient must equal 1.5 x the golden one."""
+    from esrganplus_amd import architecture as arch
+    g = golden('rrdbnet_full_grad')
+    sd = synth.rrdbnet_state_dict(nb=23, seed=0, gain=0.5)
+    net = arch.RRDBNet(3, 3, 64, 23).to(dev).eval().set_precision(prec)
+    net.load_state_dict(sd, strict=True)
+    x = synth.image_batch(42, 16, 3, 128, 128, name='fullgrad.fill')
+    x[0] = x[9] = synth.image_batch(41, 1, 3, 128, 128, name='fullgrad.x')[0]
+    gy1 = synth.normal_like(41, 'fullgrad.gy', (1, 3, 512, 512))[0] / (3 * 512 * 512)
+    S = 1.0 if prec == 'fp32' else 2.0 ** 17               # loss scale: fp16 gradients would underflow otherwise
+    gy = torch.zeros(16, 3, 512, 512)
+    gy[0], gy[9] = gy1 * S, gy1 * (0.5 * S)
+    y = net(x.to(dev))
+    ytol = 2e-4 if prec == 'fp32' else 6e-3
+    assert np.abs(y[0, :, :8, :8].detach().cpu().numpy() - g['y_head']).max() <= ytol
+    assert torch.equal(y[0], y[9])
+    (y * gy.to(dev)).sum().backward()
+    keys = [str(k) for k in g['keys']]
+    assert keys == list(sd.keys())
+    params = dict(net.named_parameters())
+    errs = []
+    worst = {'l2': (0.0, ''), 'proj': (0.0, ''), 'head': (0.0, '')}
+    for row, k in zip(g['probe'], keys):
+        got = (params[k].grad.double() / (1.5 * S)).reshape(-1)
+        assert torch.isfinite(got).all(), k
+        l2 = float(row[2])
+        e_l2 = abs(got.norm().item() - l2) / max(l2, 1e-30)
+        e_pr = 0.0
+        for i in range(3):
+            r = synth.normal_like(77, 'gproj.%s.%d' % (k, i), tuple(got.shape)).to(dev).double()
+            e_pr = max(e_pr, abs((got * r).sum().item() - float(row[3 + i])) / max(l2, 1e-30))
+        n = min(32, got.numel())
+        head = row[6:6 + n]
+        e_hd = np.abs(got[:n].cpu().numpy() - head).max() / max(np.abs(head).max(), l2 / np.sqrt(got.numel()))
+        errs.append((e_l2, e_pr, e_hd))
+        for name, e in (('l2', e_l2), ('proj', e_pr), ('head', e_hd)):
+            if e > worst[name][0]:
+                worst[name] = (e, k)
+    mean = np.mean(np.array(errs), axis=0)
+    print('full-depth backward %s: worst rel errors' % prec, worst, 'mean (l2, proj, head)', mean)
+    # What bounds the error at this depth is not the arithmetic but LeakyReLU sign flips: a pre-activation within
+    # rounding of zero (fp32: ~1e-7, fp16 storage: ~1e-3 of its scale) takes the other slope, which moves a bias
+    # gradient (a 16384-term sum with cancellation) by ~0.8/128 of its size per flipped pixel.  Hence per-tensor
+    # bounds with room for a few flips and tight bounds on the means over the 700 tensors; a lost tile / block /
+    # tap would show as tens of percent everywhere.
+    lim_w, lim_m = ((4e-3, 2.5e-2, 2.5e-2), (8e-4, 4e-3, 3e-3)) if prec == 'fp32' else ((8e-2, 0.5, 0.5), (1.2e-2, 0.11, 8e-2))
+    assert worst['l2'][0] <= lim_w[0] and worst['proj'][0] <= lim_w[1] and worst['head'][0] <= lim_w[2], worst
+    assert (mean <= np.array(lim_m)).all(), mean
+    for k in [n[2:] for n in g if n.startswith('g_')]:
+        want = g['g_' + k]
+        got = (params[k].grad / (1.5 * S)).cpu().numpy()
+        e = np.abs(got - want).max() / np.abs(want).max()
+        print('  %-40s max|diff| / max|ref| = %.2e' % (k, e))
+        assert e <= (6e-3 if prec == 'fp32' else 0.25), (k, e)
