@@ -15,9 +15,12 @@ def short(name):
         a = re.findall(r'L[ib](\d+)E', m.group(2))
         keys = ['k', 's', 'ups', 'wr', 'wc', 'ncg', 'ncw', 'wlds', '1x1', 'bwd']
         return 'conv<%s,%s>' % ('f16' if m.group(1) != 'f' else 'f32', ','.join('%s%s' % kv for kv in zip(keys, a)))
-    m = re.search(r'rdb_chain_kernelI(DF16_|f)E', name)
+    m = re.search(r'rdb_chain_kernelI(DF16_|f)(?:Li(\d)E)?E', name)
     if m:
-        return 'rdb_chain<%s>' % ('f16' if m.group(1) != 'f' else 'f32')
+        return 'rdb_chain<%s,%s>' % ('f16' if m.group(1) != 'f' else 'f32', {'0': 'forward', '1': 'train-forward', '2': 'backward'}.get(m.group(2) or '0'))
+    m = re.search(r'(rdb_wgrad_reduce_kernel|rdb_wgrad_kernel|wgrad_reduce_kernel)', name)
+    if m:
+        return m.group(1)
     m = re.search(r'(wgrad16_kernel<[^>]*>|wgrad_kernel\w*|pack_batch_kernel|unpermute_kernel|bn_\w+|pool_kernel\w*|linear_\w+)', name)
     return m.group(1)[:70] if m else name[:70]
 
