@@ -198,13 +198,13 @@ __global__ void from_g32_kernel(const esr_layout p) {
 __global__ void noise_fill_kernel(const esr_noise_fill p) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
-  const int cq = blockIdx.z % ((p.C + 3) / 4), b = blockIdx.z / ((p.C + 3) / 4);
+  const int co = blockIdx.z % ((p.C + 7) / 8), b = blockIdx.z / ((p.C + 7) / 8);
   if (x >= p.W) return;
-  float z[4];
-  philox_normal4((uint32_t)((b * p.H + y) * p.W + x), (uint32_t)cq, p.layer, p.seed, z);
+  float z[8];
+  philox_normal8((uint32_t)((b * p.H + y) * p.W + x), (uint32_t)co, p.layer, p.seed, z);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int c = cq * 4 + e;
+  for (int e = 0; e < 8; ++e) {
+    const int c = co * 8 + e;
     if (c < p.C) p.dst[(((int64_t)b * p.C + c) * p.H + y) * p.W + x] = z[e];
   }
 }
@@ -278,7 +278,7 @@ extern "C" int esr_fill_noise(const esr_noise_fill* p, esr_stream_t stream) {
     esr_set_error("esr_fill_noise: invalid arguments");
     return ESR_ERR_INVALID;
   }
-  dim3 grid((p->W + 63) / 64, p->H, p->B * ((p->C + 3) / 4));
+  dim3 grid((p->W + 63) / 64, p->H, p->B * ((p->C + 7) / 8));
   hipLaunchKernelGGL(noise_fill_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
   return esr_check_launch("noise_fill_kernel");
 }

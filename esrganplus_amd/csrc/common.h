@@ -40,15 +40,22 @@ __host__ __device__ inline int esr_pi(int i) {   // packed A-row i -> cout withi
 }
 
 // ------------------------------------------------------------------------------------------
-// Philox-4x32-10 + Box-Muller: 4 N(0,1) per call.  Counter = (pixel, channel/4, layer, 0),
-// key = seed.  The stream is this library's own definition of GaussianNoise's z (block.py:120
-// draws from torch's global generator, which no fused kernel can reproduce); the explicit-z mode
-// is the bit-parity path.
+// GaussianNoise's z when no explicit z tensor is given: a counter-based stream of this library's own definition
+// (block.py:120 draws from torch's global generator, which no fused kernel can reproduce; the explicit-z mode is
+// the bit-parity path).  Counter = (pixel, channel / 8, layer, 0), key = seed, so that the training forward, the
+// backward (which needs the same z again) and esr_fill_noise all compute a value from its coordinates alone.
+//   * Philox-4x32 with 7 rounds: the smallest round count that passes BigCrush (Salmon, Moraes, Dror, Shaw,
+//     "Parallel random numbers: as easy as 1, 2, 3", SC'11, table 2); the customary 10 only adds margin, and
+//     the 32x32->64 multiplies are quarter-rate VALU work executed in the chain's epilogues, where the MFMA
+//     pipe idles (10 rounds + 4 normals per call cost 2.9 ms per fwd+bwd at the bench shape);
+//   * 8 normals per call: word k feeds one Box-Muller pair — radius from its high 16 bits (u in (0, 1] in steps
+//     of 2^-16, |z| <= 4.71), angle from its low 16 bits.
 // ------------------------------------------------------------------------------------------
-__device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                     uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#define ESR_PHILOX_ROUNDS 7
+__device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                  uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) {
+  for (int i = 0; i < ESR_PHILOX_ROUNDS; ++i) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -61,19 +68,16 @@ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__device__ inline void philox_normal4(uint32_t pix, uint32_t cq, uint32_t layer, uint64_t seed,
-                                      float z[4]) {
+// z[0..7] = N(0,1) for channels 8 * oct .. 8 * oct + 7 of pixel `pix` in noise layer `layer`
+__device__ inline void philox_normal8(uint32_t pix, uint32_t oct, uint32_t layer, uint64_t seed, float z[8]) {
   uint32_t r[4];
-  philox4x32_10(pix, cq, layer, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-  // u in (0,1]: (r + 1) * 2^-32 ; Box-Muller on two pairs
-  const float u0 = ((float)r[0] + 1.0f) * 2.3283064365386963e-10f;
-  const float u1 = (float)r[1] * 2.3283064365386963e-10f;
-  const float u2 = ((float)r[2] + 1.0f) * 2.3283064365386963e-10f;
-  const float u3 = (float)r[3] * 2.3283064365386963e-10f;
-  const float ra = sqrtf(-2.0f * __logf(u0)), rb = sqrtf(-2.0f * __logf(u2));
-  float s, c;
-  __sincosf(6.283185307179586f * u1, &s, &c);
-  z[0] = ra * c; z[1] = ra * s;
-  __sincosf(6.283185307179586f * u3, &s, &c);
-  z[2] = rb * c; z[3] = rb * s;
+  philox4x32(pix, oct, layer, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float u0 = (float)((r[k] >> 16) + 1u) * 1.52587890625e-05f;          // (0, 1]
+    const float u1 = (float)(r[k] & 0xFFFFu) * 1.52587890625e-05f;            // [0, 1): the angle in turns
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));   // sqrt(-2 ln u0), v_log_f32 = log2
+    z[2 * k] = rad * __builtin_amdgcn_cosf(u1);                                // v_cos_f32 / v_sin_f32 take turns
+    z[2 * k + 1] = rad * __builtin_amdgcn_sinf(u1);
+  }
 }

@@ -90,7 +90,7 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
       if (xz) Px16<T>::load(p.z1, b, cb, h, (int64_t)(oy + 1) * p.z1.wp + ox + 1, tmp);
       else {
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer1, noise_seed(p), &tmp[4 * q]);
+        for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(cb * 4 + h * 2 + o), p.layer1, noise_seed(p), &tmp[8 * o]);
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);   // block.py:119-121
@@ -104,7 +104,7 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
       if (xz) Px16<T>::load(p.z2, b, cb, h, (int64_t)(oy + 1) * p.z2.wp + ox + 1, tmp);
       else {
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer2, noise_seed(p), &tmp[4 * q]);
+        for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(cb * 4 + h * 2 + o), p.layer2, noise_seed(p), &tmp[8 * o]);
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
@@ -126,7 +126,7 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
         if (xz) Px16<T>::load(p.z3, b, cb, h, (int64_t)(oy + 1) * p.z3.wp + ox + 1, tmp);
         else {
 #pragma unroll 1
-          for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(cb * 8 + h * 4 + q), p.layer3, noise_seed(p), &tmp[4 * q]);
+          for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(cb * 4 + h * 2 + o), p.layer3, noise_seed(p), &tmp[8 * o]);
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);

@@ -1069,7 +1069,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const PT& p, const BlkS& bl
       const uint32_t pix = (uint32_t)((t.b * p.H + oy) * p.W + ox);
       if (n1) {
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + th * 4 + q), layer1, seed, &tmp[4 * q]);
+        for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(ch_cb * 4 + th * 2 + o), layer1, seed, &tmp[8 * o]);
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);     // block.py:119-121
       }
@@ -1079,7 +1079,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const PT& p, const BlkS& bl
         for (int e = 0; e < 16; ++e) v[e] = v[e] * 0.2f + tmp[e];
         if (n2) {
 #pragma unroll 1
-          for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + th * 4 + q), layer2, seed, &tmp[4 * q]);
+          for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(ch_cb * 4 + th * 2 + o), layer2, seed, &tmp[8 * o]);
 #pragma unroll
           for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
         }
@@ -1256,7 +1256,7 @@ __device__ __forceinline__ void tail_bwd(Acc24& acc, const PT& p, const BlkS& bl
     if (out_a) {
       if (n2) {
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + th * 4 + q), layer2, seed, &tmp[4 * q]);
+        for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(ch_cb * 4 + th * 2 + o), layer2, seed, &tmp[8 * o]);
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
       }
@@ -1268,7 +1268,7 @@ __device__ __forceinline__ void tail_bwd(Acc24& acc, const PT& p, const BlkS& bl
     }
     if (n1) {
 #pragma unroll 1
-      for (int q = 0; q < 4; ++q) philox_normal4(pix, (uint32_t)(ch_cb * 8 + th * 4 + q), layer1, seed, &tmp[4 * q]);
+      for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(ch_cb * 4 + th * 2 + o), layer1, seed, &tmp[8 * o]);
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
     }

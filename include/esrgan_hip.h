@@ -176,7 +176,7 @@ typedef struct esr_layout {
   float inv_std_c[4];
 } esr_layout;
 
-/* Philox-4x32-10 N(0,1) fill, NCHW fp32 — the exact z the fused noise epilogue uses for
+/* Philox-4x32-7 + Box-Muller N(0,1) fill (csrc/common.h), NCHW fp32 — the exact z the fused noise epilogue uses for
  * (seed, layer); lets tests feed the same z to the oracle (GaussianNoise, block.py:117-122). */
 typedef struct esr_noise_fill {
   float* dst; int32_t B, C, H, W; uint64_t seed; uint32_t layer;

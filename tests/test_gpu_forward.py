@@ -275,3 +275,28 @@ def test_two_stream_forward_matches_single_stream(dev, monkeypatch):
         y3 = net(x)
     torch.cuda.synchronize()
     assert torch.equal(y1, y2) and torch.equal(y1, y3)
+
+
+def test_philox_stream_statistics(dev):
+    """The fused noise stream (Philox-4x32-7 + 16-bit Box-Muller, csrc/common.h) as a distribution: moments of
+    N(0,1), the tail it can represent, and no correlation between neighbouring channels / pixels / layers / seeds."""
+    from esrganplus_amd import ops
+    z = ops.philox_normal((4, 64, 96, 128), 12345, 3, dev).double()
+    n = z.numel()
+    m1, m2 = z.mean().item(), (z * z).mean().item()
+    m3, m4 = (z ** 3).mean().item(), (z ** 4).mean().item()
+    assert abs(m1) < 4 / n ** 0.5 and abs(m2 - 1) < 6 / n ** 0.5            # 3.1e6 samples: ~4 sigma bands
+    assert abs(m3) < 10 / n ** 0.5 and abs(m4 - 3) < 40 / n ** 0.5
+    assert 4.0 < z.abs().max().item() <= 4.72                               # sqrt(-2 ln 2^-16) = 4.71
+    frac = [(z.abs() > t).double().mean().item() for t in (1.0, 2.0, 3.0)]
+    for f, want in zip(frac, (0.3173105, 0.0455003, 0.0026998)):
+        assert abs(f - want) < 5 * (want / n) ** 0.5 + 1e-5, (f, want)
+
+    def corr(a, b):
+        return ((a * b).mean() / (a.std() * b.std())).abs().item()
+    lim = 5 / (n / 2) ** 0.5
+    assert corr(z[:, :-1], z[:, 1:]) < lim and corr(z[:, ::2], z[:, 1::2]) < lim      # channels (same / next Philox call)
+    assert corr(z[..., :-1], z[..., 1:]) < lim and corr(z[:, :, :-1], z[:, :, 1:]) < lim   # pixels
+    z2 = ops.philox_normal((4, 64, 96, 128), 12345, 4, dev).double()
+    z3 = ops.philox_normal((4, 64, 96, 128), 12346, 3, dev).double()
+    assert corr(z, z2) < lim and corr(z, z3) < lim
