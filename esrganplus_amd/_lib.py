@@ -151,6 +151,7 @@ class esr_rdb_block(C.Structure):
 
 
 RDB_FULL_OUT = 1
+RDB_BAND_OWN = 2
 
 
 class esr_rdb_chain(C.Structure):
@@ -158,7 +159,8 @@ class esr_rdb_chain(C.Structure):
                 ('n_blocks', C.c_int32), ('noise_mode', C.c_int32), ('sigma', C.c_float), ('save_dense', C.c_int32),
                 ('seed', C.c_uint64), ('seed_dev', C.c_void_p), ('dense', esr_g32), ('blocks', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('trace', C.c_void_p),
-                ('mode', C.c_int32), ('_pad2', C.c_int32)]
+                ('mode', C.c_int32), ('_pad2', C.c_int32),
+                ('band_rows', C.c_int32), ('band_margin', C.c_int32), ('img_H', C.c_int32), ('_pad3', C.c_int32)]
 
 
 class esr_l1_loss(C.Structure):
@@ -216,7 +218,7 @@ EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_p
            'esr_abi_version', 'esr_sizeof_op', 'esr_rdb_forward', 'esr_rdb_workspace_bytes', 'esr_rdb_weight_stream_bytes',
            'esr_rdb_max_tiles_per_image', 'esr_gather_fragments', 'esr_image_metrics', 'esr_wgrad_workspace_elems',
            'esr_l1_loss_forward', 'esr_ragan_loss_forward', 'esr_rdb_wgrad_run', 'esr_rdb_wgrad_workspace_elems', 'esr_rdb_backward',
-           'esr_rdb_mask_bytes', 'esr_rdb_check_abort']
+           'esr_rdb_mask_bytes', 'esr_rdb_check_abort', 'esr_debug_hold_cus']
 
 _lib = None
 _lock = threading.Lock()

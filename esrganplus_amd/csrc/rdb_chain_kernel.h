@@ -850,6 +850,10 @@ struct PS {
   struct { int wp; } dense;
   uint64_t* trace;
 };
+// banded launch (esr_rdb_chain.band_rows): the scalars + the band geometry
+struct PSB : PS {
+  int band_rows, band_margin, img_H;
+};
 template <typename PT>
 __device__ __forceinline__ void trace_ev(const PT& p, int tile, int& ev) {
   if (p.trace && ev >= 0 && ev < 64 && threadIdx.x == 0) p.trace[(int64_t)tile * 64 + ev] = (ESR_ABL & 16) ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();
@@ -991,6 +995,7 @@ struct BlkS {
   const float* bias;       // [192]: conv1..conv4 (32 each), conv5 (64)
   uint32_t layer1, layer2;
   bool has_res2, full_out;
+  bool band_own;           // banded launch: x_out takes only the band's own rows
 };
 // NOISE (MODE 3): false = the instantiation without the Philox layers and the explicit `+ x` (the fp16 path's
 // common case takes it through one uniform branch: the tail is executed once per block out of a cold
@@ -1014,7 +1019,8 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const PT& p, const BlkS& bl
   const int oyb = t.oy0 + t.wave * R;
   const f32x4 (&bq)[4] = bias.q;
   const int wp32 = p.dense.wp * 32;
-  const bool ragged = t.oy0 + TH > p.H || t.ox0 + TW > p.W;      // wave-uniform
+  constexpr bool BAND = std::is_same_v<PT, PSB>;
+  const bool ragged = BAND || t.oy0 + TH > p.H || t.ox0 + TW > p.W;      // wave-uniform
   const uint32_t layer1 = blk.layer1, layer2 = blk.layer2;
   const bool n1 = MODE == 3 && NOISE && p.noise_mode == ESR_NOISE_PHILOX && layer1 != ESR_NO_LAYER;
   const bool n2 = MODE == 3 && NOISE && p.noise_mode == ESR_NOISE_PHILOX && layer2 != ESR_NO_LAYER && has_res2;
@@ -1086,7 +1092,15 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const PT& p, const BlkS& bl
       }
     }
     // pixels beyond the image: offset 2^31 lies past num_records (2^31 - 1), the buffer range check drops the store
-    const bool inside = oy < p.H && ox < p.W;
+    bool live = oy < p.H && ox < p.W;          // a pixel of the image
+    bool inside = live;                        // ... that this epilogue stores
+    if constexpr (BAND) {
+      // a band's view covers band_margin rows of its neighbours (recomputed here, owned there) and, at the ends of
+      // the image, rows that do not exist: those stay zero everywhere (the padding the convs must see)
+      const int g = t.b * p.band_rows - p.band_margin + oy;
+      live = live && g >= 0 && g < p.img_H;
+      inside = live && (!(MODE == 3 && blk.band_own) || (oy >= p.band_margin && oy < p.band_margin + p.band_rows));
+    }
     const int po = (oy + 1) * wp32 + (ox + 1) * 32;
     if constexpr (LW == 0) {
       C16::store(out, inside ? out_cb : 0, th, inside ? po : (int)0x80000000u, v);
@@ -1100,7 +1114,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const PT& p, const BlkS& bl
                         (t.wave == NT / 64 - 1 && r == R - 1);
       C16::store_packed(out, (inside && edge) ? out_cb : 0, th, (inside && edge) ? po : (int)0x80000000u, q.q);
       // beyond the image: the zero padding (only tiles that stick out of the image have such pixels: one scalar test)
-      if (ragged && !inside) { q.q[0] = u32x4{0, 0, 0, 0}; q.q[1] = u32x4{0, 0, 0, 0}; }
+      if (ragged && !live) { q.q[0] = u32x4{0, 0, 0, 0}; q.q[1] = u32x4{0, 0, 0, 0}; }
       if constexpr (LW & 1) lds_put_row(smem, slot0 + th, r, q.q, own_px, own_swz);
       if constexpr (LW & 2) keep->q[r] = q;
       if constexpr (MODE == 3) {
@@ -1292,11 +1306,13 @@ __device__ __forceinline__ void tail_bwd(Acc24& acc, const PT& p, const BlkS& bl
 // unit (rdb_fused.hip / rdb_fused_train.hip / rdb_fused_bwd.hip: they compile in parallel).
 // host_abort: a pinned HOST word (may be null): set when a bounded spin timed out, so that the library can report
 // the aborted launch at its next entry without synchronising (esr_rdb_check_abort).
-template <typename T, int DIR = 0>
+// BAND (DIR 0): the row-band form for images with more tiles than CUs (esr_rdb_chain.band_rows).
+template <typename T, int DIR = 0, bool BAND = false>
 __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p, const int ntiles, const int tiles_x,
                                                           const int tiles_y, unsigned* const host_abort) {
   using CF = Cfg<T>;
   static_assert(DIR == 0 || sizeof(T) == 2, "training forward / backward chains: fp16");
+  static_assert(DIR == 0 || !BAND, "row bands: inference forward only");
   __shared__ __attribute__((aligned(16))) char smem[DIR == 2 ? LDS_BYTES_BWD : LDS_BYTES];
   unsigned* const ws = (unsigned*)p.workspace;
   unsigned* const flags = ws + WS_HDR;
@@ -1307,15 +1323,17 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
   if (threadIdx.x == 0) *(unsigned* volatile*)(smem + LDS_CTRL + 48) = host_abort;   // (visible behind the ticket barrier)
   // what the boundary code reads of the launch: the argument struct itself (inference: unchanged code) or a copy of
   // its scalars in registers (training / backward)
-  using PT = std::conditional_t<DIR == 0, esr_rdb_chain, PS>;
-  PS ps;
-  if constexpr (DIR != 0) {
+  using PT = std::conditional_t<BAND, PSB, std::conditional_t<DIR == 0, esr_rdb_chain, PS>>;
+  PSB ps;
+  if constexpr (DIR != 0 || BAND) {
     ps.H = __builtin_amdgcn_readfirstlane(p.H); ps.W = __builtin_amdgcn_readfirstlane(p.W);
-    ps.noise_mode = __builtin_amdgcn_readfirstlane(p.noise_mode); ps.save_dense = 0; ps._pad2 = 0;
+    ps.noise_mode = __builtin_amdgcn_readfirstlane(p.noise_mode); ps.save_dense = BAND ? __builtin_amdgcn_readfirstlane(p.save_dense) : 0; ps._pad2 = 0;
     ps.sigma = p.sigma; ps.seed = p.seed; ps.seed_dev = p.seed_dev; ps.dense.wp = __builtin_amdgcn_readfirstlane(p.dense.wp);
     ps.trace = p.trace;
+    ps.band_rows = __builtin_amdgcn_readfirstlane(p.band_rows); ps.band_margin = __builtin_amdgcn_readfirstlane(p.band_margin);
+    ps.img_H = __builtin_amdgcn_readfirstlane(p.img_H);
   }
-  const PT& q = *[&]() { if constexpr (DIR == 0) return &p; else return &ps; }();
+  const PT& q = *[&]() { if constexpr (DIR == 0 && !BAND) return &p; else return (const PT*)&ps; }();
 
   for (;;) {
     // ---- claim the next tile (tickets go out in order, so an image's tiles are co-resident)
@@ -1389,6 +1407,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       bs.layer2 = __builtin_amdgcn_readfirstlane(blk.layer2);
       bs.has_res2 = __builtin_amdgcn_readfirstlane((int)(blk.res2.ptr != nullptr)) != 0;
       bs.full_out = __builtin_amdgcn_readfirstlane((int)((blk.flags & ESR_RDB_FULL_OUT) != 0)) != 0 || noisy || p.save_dense;
+      bs.band_own = BAND && __builtin_amdgcn_readfirstlane((int)((blk.flags & ESR_RDB_BAND_OWN) != 0)) != 0;
       const bool has_res2 = bs.has_res2, full_out = bs.full_out;
       const ImgView res2 = img_view(has_res2 ? blk.res2 : blk.x_in, t.b);
       constexpr bool RES = sizeof(T) == 2;      // fp16: LDS-resident slices (fp32 stages by DMA, 8 K steps of x)
@@ -1729,7 +1748,7 @@ if constexpr (DIR == 2) {
       run_phase<T, 1>(acc, w + CF::phase_off(1), xin_b, blk.x_in.group_stride, CF::KX, smem, t);
       trace_ev(p, tile, ev);
       mfma_drain();
-      epilogue<T, 0, 0>(acc, p, bs, fb[0], dense, 0, 0, nullptr, nullptr, false, t);       // x1
+      epilogue<T, 0, 0>(acc, q, bs, fb[0], dense, 0, 0, nullptr, nullptr, false, t);       // x1
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- P = conv1x1(x) on own pixels, then phase 2: x1 -> conv2..conv5
@@ -1742,7 +1761,7 @@ if constexpr (DIR == 2) {
       run_phase<T, 2>(acc, w + CF::phase_off(2), dense_b, d_gs, CF::KD, smem, t);
       trace_ev(p, tile, ev);
       mfma_drain();
-      epilogue<T, 1, 1>(acc, p, bs, fb[1], dense, 1, 0, nullptr, nullptr, false, t);     // x2
+      epilogue<T, 1, 1>(acc, q, bs, fb[1], dense, 1, 0, nullptr, nullptr, false, t);     // x2
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- phase 3: x2 -> conv3..conv5
@@ -1752,7 +1771,7 @@ if constexpr (DIR == 2) {
       run_phase<T, 3>(acc, w + CF::phase_off(3), dense_b + CF::KD * d_gs, d_gs, CF::KD, smem, t);
       trace_ev(p, tile, ev);
       mfma_drain();
-      epilogue<T, 2, 0>(acc, p, bs, fb[2], dense, 2, 0, nullptr, nullptr, false, t);     // x3
+      epilogue<T, 2, 0>(acc, q, bs, fb[2], dense, 2, 0, nullptr, nullptr, false, t);     // x3
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- phase 4: x3 -> conv4, conv5
@@ -1763,7 +1782,7 @@ if constexpr (DIR == 2) {
       trace_ev(p, tile, ev);
       mfma_drain();
       { RowsRaw<T> x2r; load_rows<T>(dense, 1, p, t, x2r);
-        epilogue<T, 3, 2>(acc, p, bs, fb[3], dense, 3, 0, &x2r, nullptr, false, t); }     // x4 (+ x2)
+        epilogue<T, 3, 2>(acc, q, bs, fb[3], dense, 3, 0, &x2r, nullptr, false, t); }     // x4 (+ x2)
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       // ---------------- phase 5: x4 -> conv5; block tail (+ RRDB tail)
@@ -1776,8 +1795,8 @@ if constexpr (DIR == 2) {
       { RowsRaw<T> tx0, tx1, tr0, tr1;
         load_rows<T>(xin, 0, p, t, tx0); load_rows<T>(xin, 1, p, t, tx1);
         load_rows<T>(res2, 0, p, t, tr0); load_rows<T>(res2, 1, p, t, tr1);
-        epilogue<T, 4, 3>(acc, p, bs, fb[4], xout, 0, 0, &tx0, &tr0, has_res2, t);
-        epilogue<T, 5, 3>(acc, p, bs, fb[5], xout, 1, 1, &tx1, &tr1, has_res2, t); }
+        epilogue<T, 4, 3>(acc, q, bs, fb[4], xout, 0, 0, &tx0, &tr0, has_res2, t);
+        epilogue<T, 5, 3>(acc, q, bs, fb[5], xout, 1, 1, &tx1, &tr1, has_res2, t); }
       publish(flags, tile, ++epoch, t);
       trace_ev(p, tile, ev);
       }

@@ -6,6 +6,7 @@
 // defined next to their kernels
 int esr_rdb_launch_train(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 int esr_rdb_launch_bwd(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
+int esr_rdb_launch_band(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 
 namespace {
 // pinned host word the kernels raise when a bounded spin times out (one per process; first use allocates it)
@@ -33,6 +34,30 @@ bool coop_launch() {
   return v;
 }
 }  // namespace
+
+namespace {
+// Diagnostic: a workgroup that takes 120 KB of LDS (so that no chain workgroup fits next to it on the CU) and sleeps
+// until the host raises *release or max_ms have passed — bounded, it cannot hang the device.
+__global__ __launch_bounds__(64) void hold_kernel(const unsigned* release, const unsigned max_ms, unsigned* sink) {
+  __shared__ char pad[120 * 1024];
+  pad[threadIdx.x * 64] = (char)threadIdx.x;
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  const uint64_t lim = (uint64_t)max_ms * 100000ull;                       // 100 MHz counter
+  while (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u &&
+         __builtin_amdgcn_s_memrealtime() - t0 < lim)
+    __builtin_amdgcn_s_sleep(100);
+  if (sink && pad[threadIdx.x * 64] == 123) *sink = 1u;                    // keeps the LDS allocation alive
+}
+}  // namespace
+
+extern "C" int esr_debug_hold_cus(int32_t n_workgroups, const uint32_t* release, uint32_t max_ms, esr_stream_t stream) {
+  if (n_workgroups <= 0 || !release || max_ms == 0 || max_ms > 10000) {
+    esr_set_error("esr_debug_hold_cus: invalid arguments (max_ms in 1..10000)");
+    return ESR_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(hold_kernel, dim3(n_workgroups), dim3(64), 0, (hipStream_t)stream, (const unsigned*)release, max_ms, (unsigned*)nullptr);
+  return esr_check_launch("hold_kernel");
+}
 
 extern "C" int esr_rdb_check_abort(void) {
   unsigned* w = abort_word();
@@ -81,6 +106,20 @@ int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, i
     esr_set_error("%s: noise_mode must be OFF or PHILOX (explicit z: use the per-conv path)", who);
     return ESR_ERR_UNSUPPORTED;
   }
+  if (p->band_rows != 0) {
+    // row bands: B bands of band_rows + 2 * band_margin rows each (include/esrgan_hip.h)
+    if (p->mode != 0 || p->noise_mode != ESR_NOISE_OFF) {
+      esr_set_error("%s: row bands are for the inference forward without noise", who);
+      return ESR_ERR_UNSUPPORTED;
+    }
+    if (p->band_rows < 0 || p->band_margin < 5 * p->n_blocks || p->H != p->band_rows + 2 * p->band_margin || p->img_H <= 0 ||
+        (int64_t)(p->B - 1) * p->band_rows >= p->img_H) {
+      esr_set_error("%s: band geometry: H %d must be band_rows %d + 2 * band_margin %d, band_margin >= 5 * n_blocks (%d), "
+                    "and every one of the %d bands must own a row of the %d-row image", who, p->H, p->band_rows, p->band_margin,
+                    5 * p->n_blocks, p->B, p->img_H);
+      return ESR_ERR_INVALID;
+    }
+  }
   const int tiles_x = (p->W + TW - 1) / TW, tiles_y = (p->H + TH - 1) / TH;
   const int tpi = tiles_x * tiles_y, ntiles = tpi * p->B;
   const int cus = num_cus();
@@ -102,6 +141,10 @@ int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, i
   }
   const int grid = ntiles < cus ? ntiles : cus;
   unsigned* const ha = abort_word_dev();
+  if (p->band_rows != 0) {
+    if (p->dtype != ESR_F16 && p->dtype != ESR_F32) { esr_set_error("%s: bad dtype %d", who, p->dtype); return ESR_ERR_INVALID; }
+    return esr_rdb_launch_band(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
+  }
   if (p->mode == 1) return esr_rdb_launch_train(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
   if (p->mode == 2) return esr_rdb_launch_bwd(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
   if (p->dtype != ESR_F16 && p->dtype != ESR_F32) { esr_set_error("%s: bad dtype %d", who, p->dtype); return ESR_ERR_INVALID; }

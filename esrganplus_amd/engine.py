@@ -47,13 +47,14 @@ class G32:
         self.gs = self.Hp * self.Wp * 32
         self.bs = self.ng * self.gs
 
-    def view(self, c0=0, nch=None):
-        """esr_g32 view starting at channel c0 (must be group aligned)."""
+    def view(self, c0=0, nch=None, row0=0):
+        """esr_g32 view starting at channel c0 (must be group aligned) and, for the taller buffers of the banded
+        chain, at row row0 (the rows above / below the view's image are zero padding that nothing writes)."""
         assert c0 % self.cpg == 0, (c0, self.cpg)
         g0 = c0 // self.cpg
         ng = self.ng - g0 if nch is None else (nch + self.cpg - 1) // self.cpg
         v = L.esr_g32()
-        v.ptr = self.t.data_ptr() + g0 * self.gs
+        v.ptr = self.t.data_ptr() + g0 * self.gs + row0 * self.Wp * 32
         v.batch_stride = self.bs
         v.group_stride = self.gs
         v.wp = self.Wp
@@ -333,6 +334,31 @@ def rdb_chain_ok(B, H, W, noise, explicit_z):
     return tpi <= L.lib().esr_rdb_max_tiles_per_image()
 
 
+def use_rdb_bands(dtype_e, H, W):
+    """Images with more tiles than CUs: the fused trunk in row bands for fp16 (339x510, nb=23: 9.2 ms against 10.3 ms
+    of per-conv launches); fp32 keeps the per-conv launches, which are 6 % faster there (73.5 / 68.9 ms,
+    tools/big_image_probe.py).  ESR_RDB_BANDS=1 forces bands for both, =0 turns them off."""
+    mode = os.environ.get('ESR_RDB_BANDS', 'auto')
+    if mode == '0' or os.environ.get('ESR_RDB_FUSED', '1') == '0' or rdb_band_geometry(H, W) is None:
+        return False
+    return mode == '1' or dtype_e == L.ESR_F16
+
+
+def rdb_band_geometry(H, W):
+    """Row bands for an image with more 16x32 tiles than CUs (include/esrgan_hip.h: esr_rdb_chain.band_rows):
+    (band_rows, band_margin, n_bands), or None when not even a one-tile-row band fits (W > 32 * CUs / 3).
+    One launch runs the three dense blocks of an RRDB, so a band recomputes 15 rows of each neighbour: margin 16
+    (a whole tile row), bands as tall as the CU count allows and evened out over the image."""
+    margin = 16
+    tiles_x = (W + 31) // 32
+    t = L.lib().esr_rdb_max_tiles_per_image() // tiles_x - 2 * (margin // 16)
+    if t < 1:
+        return None
+    n = (H + 16 * t - 1) // (16 * t)
+    rows = ((H + n - 1) // n + 15) // 16 * 16
+    return rows, margin, n
+
+
 def _conv(dtype_e, B, H, W, src, src_ch, dst, cw, act=L.ACT_NONE, ks=None, stride=1, upsample=0):
     c = L.esr_conv()
     c.dtype = dtype_e
@@ -555,6 +581,58 @@ class Builder:
         P.chain_ws = ws
         return i
 
+    def rdb_chain_banded(self, nb, geom, head):
+        """The trunk of an image too large for one chain launch: per RRDB (and per image of the batch) one launch
+        over row bands.  RRDB i reads the 64-channel buffer xs[i % 2] and writes xs[(i + 1) % 2] — out of place: a
+        band's margin rows are its neighbours' own rows, so nothing a band reads may change during the launch —
+        with the two intermediate block outputs and the dense scratch in band-local buffers.  head(view): emits
+        the op(s) that fill xs[0]'s image rows.  Returns the view of the result's image rows."""
+        P = self.plan
+        S, m, nbands = geom
+        hb = S + 2 * m
+        B, H, W = self.B, self.H, self.W
+        tall = [G32(B, 64, nbands * S + 2 * m, W, self.dtype, self.device) for _ in range(2)]
+        mid = G32(nbands, 64, hb, W, self.dtype, self.device)
+        dense = G32(nbands, 128, hb, W, self.dtype, self.device)
+        P.bufs.extend(tall + [mid, dense])
+        prefixes = ['model.1.sub.%d.RDB%d' % (i, j + 1) for i in range(nb) for j in range(3)]
+        P.streams = RdbStreams(self.wp, prefixes)
+        ws_bytes = L.lib().esr_rdb_workspace_bytes(nbands, hb, W)
+        ws = torch.zeros((ws_bytes + 3) // 4, dtype=torch.int32, device=self.device)
+        P.bufs.append(ws)
+        head(tall[0].view(0, 64, m))
+
+        def band(buf, bi):
+            v = buf.view(0, 64)
+            v.ptr += bi * buf.bs
+            v.batch_stride = S * buf.Wp * 32
+            return v
+        for i in range(nb):
+            src, dst = tall[i % 2], tall[(i + 1) % 2]
+            for bi in range(B):
+                blocks = (L.esr_rdb_block * 3)()
+                for j in range(3):
+                    b = blocks[j]
+                    b.w, b.bias = P.streams.w_ptr(3 * i + j), P.streams.bias_ptr(3 * i + j)
+                    b.x_in = band(src, bi) if j == 0 else mid.view(0, 64)
+                    b.x_out = band(dst, bi) if j == 2 else mid.view(0, 64)
+                    b.layer1 = b.layer2 = L.NO_LAYER
+                    b.flags = 0
+                blocks[2].res2 = band(src, bi)
+                blocks[2].flags = L.RDB_FULL_OUT | L.RDB_BAND_OWN
+                blk_t = torch.frombuffer(bytearray(bytes(blocks)), dtype=torch.uint8).to(self.device)
+                P.bufs.append(blk_t)
+                ch = L.esr_rdb_chain()
+                ch.dtype, ch.B, ch.H, ch.W = self.dt_e, nbands, hb, W
+                ch.n_blocks, ch.noise_mode, ch.sigma = 3, L.NOISE_OFF, SIGMA
+                ch.dense = dense.view(0, 128)
+                ch.blocks, ch.workspace, ch.workspace_bytes = blk_t.data_ptr(), ws.data_ptr(), ws_bytes
+                ch.band_rows, ch.band_margin, ch.img_H = S, m, H
+                P.chain_ops.append(P.ops.add(L.OP_RDB_CHAIN, 'rdb_chain', ch))
+        P.chain_noise = False
+        P.chain_ws = ws
+        return tall[nb % 2].view(0, 64, m)
+
     def n_noise_layers(self, nb):
         return (4 if self.variant == 'test_image' else 3) * nb if self.noise else 0
 
@@ -585,6 +663,17 @@ class Builder:
                 specs.append((pre + '.RDB3', xb, xa, xa, self.variant == 'test_image'))
             self.rdb_chain(specs)
             x0, x1 = xa, xb
+        elif nb and not self.noise and use_rdb_bands(self.dt_e, H, W):
+            # more tiles than CUs (a DIV2K-sized LR image): the fused trunk in row bands, one launch per RRDB
+            def head(dst):
+                c = _conv(d, B, H, W, xin.view(0), in_nc, dst, e['model.0'])
+                c.aux_out = fea.view(0, 64)
+                P.ops.add_conv(c)
+            res, x1 = self.rdb_chain_banded(nb, rdb_band_geometry(H, W), head), self.buf(64)
+            c = _conv(d, B, H, W, res, 64, x1.view(0, 64), e['model.1.sub.%d' % nb])
+            c.res1, c.alpha = fea.view(0, 64), 1.0
+            P.ops.add_conv(c)
+            x0 = None
         else:
             x0, x1, x2 = self.buf(192), self.buf(192), self.buf(192)
             c = _conv(d, B, H, W, xin.view(0), in_nc, x0.view(0, 64), e['model.0'])
@@ -592,9 +681,10 @@ class Builder:
             P.ops.add_conv(c)
             for i in range(nb):
                 self.rrdb('model.1.sub.%d' % i, x0, x1, x2)
-        c = _conv(d, B, H, W, x0.view(0), 64, x1.view(0, 64), e['model.1.sub.%d' % nb])
-        c.res1, c.alpha = fea.view(0, 64), 1.0
-        P.ops.add_conv(c)
+        if x0 is not None:
+            c = _conv(d, B, H, W, x0.view(0), 64, x1.view(0, 64), e['model.1.sub.%d' % nb])
+            c.res1, c.alpha = fea.view(0, 64), 1.0
+            P.ops.add_conv(c)
         u1 = self.buf(64, 2 * H, 2 * W)
         P.ops.add_conv(_conv(d, B, 2 * H, 2 * W, x1.view(0), 64, u1.view(0, 64), e['model.3'],
                              L.ACT_LRELU, upsample=1))

@@ -424,6 +424,7 @@ typedef struct esr_rdb_block {
                                ptr NULL: x_out = (acc [+ res2]) (1 + sigma z[layer1]) */
 } esr_rdb_block;
 #define ESR_RDB_FULL_OUT 1u
+#define ESR_RDB_BAND_OWN 2u  /* banded launch (esr_rdb_chain.band_rows): x_out receives only the band's OWN rows */
 /* Backward weight stream of a block (mode 2): the forward's layout over the gather-form operands
  *   blk 0..3 = the x4, x3, x2, x1 slice convs (esr_pack.gather; the x2 one with fold_co0 = the x4 columns of conv5),
  *   blk 4/5 = the x slice conv's two cout blocks (K = 192: g_t, g_a4..g_a1),
@@ -450,6 +451,15 @@ typedef struct esr_rdb_chain {
                                (dL/d(conv5 * 0.2 + x)), weights = the gather-form streams (below), x_out = the next
                                block's g_t */
   int32_t _pad2;
+  /* Row bands (mode 0, noise off): an image with more 16x32 tiles than CUs cannot run as one chain (a tile spins on
+   * its neighbours, so all tiles of an image must be resident).  It is cut into bands of `band_rows` rows and the
+   * bands take the place of the batch: B = number of bands, H = band_rows + 2 * band_margin, every view's
+   * batch_stride = band_rows rows, and view row 0 of band b is image row b * band_rows - band_margin (the caller's
+   * buffers carry band_margin rows of zero padding above and below the image).  A band recomputes band_margin rows
+   * of its neighbours on either side — band_margin >= 5 * n_blocks, the chain's dependency radius — and the kernel
+   * writes only rows that exist in the image (0 <= row < img_H), and into an ESR_RDB_BAND_OWN block's x_out only the
+   * band's own rows.  band_rows = 0: off. */
+  int32_t band_rows, band_margin, img_H, _pad3;
 } esr_rdb_chain;
 
 /* Piece gather: dst[f * piece_bytes ..] = src_base[src_off[f] ..] for f < n (src_off: DEVICE int64 byte offsets;
@@ -562,6 +572,9 @@ size_t esr_rdb_mask_bytes(int32_t B, int32_t H, int32_t W);   /* esr_rdb_block.m
  * for launches that have completed.  esr_run_ops / esr_rdb_forward / esr_rdb_backward check it on entry and fail with
  * ESR_ERR_LAUNCH, so an aborted launch cannot go unnoticed past the next call. */
 int esr_rdb_check_abort(void);
+/* Diagnostic (tests/test_gpu_rdb_chain.py: starved launch): n_workgroups workgroups that each take a CU's LDS and
+ * sleep until *release (device-visible memory) becomes non-zero or max_ms (<= 10000) have passed. */
+int esr_debug_hold_cus(int32_t n_workgroups, const uint32_t* release, uint32_t max_ms, esr_stream_t stream);
 size_t esr_rdb_workspace_bytes(int32_t B, int32_t H, int32_t W);
 size_t esr_rdb_weight_stream_bytes(int32_t dtype);
 int esr_rdb_max_tiles_per_image(void);   /* 16x32 tiles of ONE image must not exceed this (= CUs) */

@@ -299,3 +299,74 @@ def test_short_tiles_equal_sixteen_row_tiles(dev, monkeypatch, shape, rows):
     assert (tiles <= 128) == (rows == 4) and tiles <= 384
     for a, b in zip(res['0'], res['256']):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize('shape', [(1, 3, 339, 510), (2, 3, 270, 500), (1, 3, 130, 1100)])
+def test_images_with_more_tiles_than_cus_run_the_chain_in_row_bands(dev, monkeypatch, shape):
+    """A DIV2K-sized LR image (339x510 = 352 tiles of 16x32: test_image/test.py:26-40 feeds whole images) has more
+    tiles than the GPU has CUs, so it cannot be one chain launch; the trunk runs as one launch per RRDB over row bands
+    (esr_rdb_chain.band_rows: every band recomputes 16 rows of its neighbours).  Same function: fp32 equals the
+    per-conv launches to 1e-5 and the oracle to 1e-4; fp16 within fp16 rounding; batch > 1 and a band count of 2..3."""
+    from oracle import ref_torch as RT
+    from esrganplus_amd import engine as E
+    nb = 2
+    geom = E.rdb_band_geometry(shape[2], shape[3])
+    assert not E.rdb_chain_ok(shape[0], shape[2], shape[3], False, False) and geom is not None and geom[2] >= 2
+    sd = synth.rrdbnet_state_dict(nb=nb, seed=33)
+    x = synth.image_batch(33, *shape, name='band.x')
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = RT.rrdbnet_forward(x, sd, nb)
+        out = {}
+        monkeypatch.setenv('ESR_RDB_BANDS', '1')          # fp32 too (by default it keeps the per-conv launches)
+        for prec in ('fp32', 'fp16'):
+            monkeypatch.setenv('ESR_RDB_FUSED', '1')
+            net = _net('RRDBNet', nb, sd, dev, prec)
+            out[prec, 'band'] = net(x.to(dev)).cpu()
+            plans = _chain_plans(net)
+            assert len(plans) == 1 and len(plans[0].chain_ops) == nb * shape[0], 'one banded launch per RRDB and image'
+            assert int(plans[0].chain_ws[1].item()) == 0, 'a bounded spin of the chain kernel timed out'
+            assert torch.equal(net(x.to(dev)).cpu(), out[prec, 'band'])          # replay: same buffers, same result
+            monkeypatch.setenv('ESR_RDB_FUSED', '0')
+            net2 = _net('RRDBNet', nb, sd, dev, prec)
+            out[prec, 'conv'] = net2(x.to(dev)).cpu()
+            assert not _chain_plans(net2)
+    assert (out['fp32', 'band'] - ref).abs().max().item() <= 1e-4
+    assert (out['fp32', 'band'] - out['fp32', 'conv']).abs().max().item() <= 1e-5
+    assert (out['fp16', 'band'] - ref).abs().max().item() <= 2e-3
+    assert (out['fp16', 'band'] - out['fp16', 'conv']).abs().max().item() <= 2e-3
+
+
+def test_starved_chain_launch_is_reported_at_the_next_call(dev):
+    """The chain's tiles wait for their neighbours, so all tiles of an image must be resident together.  If other
+    work holds the CUs (here: esr_debug_hold_cus takes all but one for up to 4 s) a tile's bounded spin (1 s) gives
+    up, the launch finishes with an invalid result, and the library must SAY so: the kernel raises a pinned host
+    word that the next library entry reads without synchronising — that call fails with the abort message instead
+    of handing back garbage silently — and the call after that works again."""
+    import ctypes as C
+    from esrganplus_amd import _lib as L
+    sd = synth.rrdbnet_state_dict(nb=1, seed=35)
+    net = _net('RRDBNet', 1, sd, dev, 'fp16')
+    x = synth.image_batch(35, 1, 3, 16, 96, name='starve.x').to(dev)       # 3 tiles side by side
+    with torch.no_grad():
+        good = net(x).clone()
+        assert len(_chain_plans(net)) == 1
+        release = torch.zeros(16, dtype=torch.int32, device=dev)
+        side, side2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        L.check(L.lib().esr_debug_hold_cus(cus - 1, C.c_void_p(release.data_ptr()), 4000, C.c_void_p(side.cuda_stream)),
+                'esr_debug_hold_cus')
+        import time
+        time.sleep(0.2)                                   # the hold kernel is resident before the chain arrives
+        bad = net(x)                                      # one CU left: tile 0 spins for its neighbours, then aborts
+        torch.cuda.current_stream().synchronize()
+        with torch.cuda.stream(side2):
+            release.fill_(1)                              # lets the hold workgroups go (they also give up after 4 s)
+        torch.cuda.synchronize()
+        with pytest.raises(L.HipExtensionError, match='aborted'):
+            net(x)
+        again = net(x)
+        torch.cuda.synchronize()
+        assert torch.equal(again, good)
+        del bad
