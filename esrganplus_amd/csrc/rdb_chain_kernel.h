@@ -59,8 +59,15 @@
 
 namespace {
 
-constexpr int R = 4;                        // output rows per wave
-constexpr int TH = 16, TW = 32;             // tile of a workgroup (4 waves stacked vertically)
+// ESR_R: output rows per wave.  4 = the 16x32 tile every launch with enough tiles uses; the 2- and 1-row builds
+// (8x32 / 4x32 tiles, rdb_fused_rows.hip) are for launches whose 16-row tiles would leave most CUs idle — the
+// reference's training crops (batch 16 of 32x32 LR = 32 tiles of 16x32 on 256 CUs, SRRaGAN train configs).
+#ifndef ESR_R
+#define ESR_R 4
+#endif
+constexpr int R = ESR_R;                    // output rows per wave
+static_assert(R == 1 || R == 2 || R == 4, "rows per wave");
+constexpr int TH = 4 * R, TW = 32;          // tile of a workgroup (4 waves stacked vertically)
 constexpr int IH = TH + 2, IW = TW + 2;     // staged halo tile
 constexpr int NT = 256;                     // 4 waves, one per SIMD
 constexpr int NSLOT = IH * IW * 2;          // 16-byte slots of one activation stage
@@ -75,10 +82,10 @@ constexpr int LDS_BIAS = LDS_CTRL + 64;        // fp16 path: the block's 192 bia
 constexpr int LDS_FLAGS = LDS_BIAS + 192 * 4;  // fp16 path: the neighbours' flags as wave 0 last fetched them (64 words)
 constexpr int LDS_HALO = LDS_FLAGS + 256;      // fp16 path: per thread {source, destination} offset of its halo slot
 constexpr int LDS_BYTES = LDS_HALO + NT * 8;   // 158784
-constexpr int LDS_MASK = LDS_BYTES;            // backward: two 2 KB buffers of LeakyReLU masks (one dense slice each)
-constexpr int LDS_BYTES_BWD = LDS_MASK + 2 * 2048;
-constexpr int MASK_SLICE = 2048;               // bytes of one slice's masks of a tile: [wave][lane][4 rows x u16]
+constexpr int MASK_SLICE = 512 * R;            // bytes of one slice's masks of a tile: [wave][lane][R rows x u16]
 constexpr int MASK_TILE = 4 * MASK_SLICE;
+constexpr int LDS_MASK = LDS_BYTES;            // backward: two buffers of LeakyReLU masks (one dense slice each)
+constexpr int LDS_BYTES_BWD = LDS_MASK + 2 * MASK_SLICE;
 constexpr int NHALO = 2 * 2 * IW + 2 * 2 * TH;  // 16-byte slots of the 1-pixel halo ring of one stage (200)
 constexpr int WS_HDR = 16;                  // workspace words before the per-tile flags
 enum { WS_TICKET = 0, WS_ABORT = 1 };
@@ -138,17 +145,41 @@ __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 1
 // into their AGPRs HERE, with the VALU-write -> MFMA-SrcC wait states inside the statement: left alone, hipcc keeps
 // them in VGPRs and copies them over (v_accvgpr_write) lazily BETWEEN the asm MFMAs of the next block's first bulk
 // unit, where nothing pads that hazard (cdna guide 5.7 item 2) — seen as 4 stale accumulator registers of one row.
-__device__ __forceinline__ void pin_acc45(Acc24& acc) {
-  asm volatile("s_nop 7" : "+a"(acc.v16), "+a"(acc.v17), "+a"(acc.v18), "+a"(acc.v19), "+a"(acc.v20), "+a"(acc.v21), "+a"(acc.v22), "+a"(acc.v23));
-}
+#if ESR_R == 4
+#define ESR_ACC45_OPS(a) "+a"(a.v16), "+a"(a.v17), "+a"(a.v18), "+a"(a.v19), "+a"(a.v20), "+a"(a.v21), "+a"(a.v22), "+a"(a.v23)
+#elif ESR_R == 2
+#define ESR_ACC45_OPS(a) "+a"(a.v8), "+a"(a.v9), "+a"(a.v10), "+a"(a.v11)
+#else
+#define ESR_ACC45_OPS(a) "+a"(a.v4), "+a"(a.v5)
+#endif
+__device__ __forceinline__ void pin_acc45(Acc24& acc) { asm volatile("s_nop 7" : ESR_ACC45_OPS(acc)); }
 // Fences of an MFMA segment.  With all 256 AGPRs holding accumulators hipcc
 // sometimes parks one accumulator tuple in VGPRs around the boundary code (v_accvgpr_read right behind a segment's
 // last MFMA, v_accvgpr_write in front of the next segment's first use).  It cannot know that the asm statements are
 // MFMAs, so it pads neither "XDL write -> v_accvgpr_read" (18 wait states) nor "VALU write -> MFMA SrcC" — seen as a
 // few accumulator registers that miss the last MFMA's contribution.  These statements take every AGPR accumulator
 // as an operand: the copies can only sit outside [seg_open, seg_close], and the wait states are inside the strings.
+#if ESR_R == 4
 #define ESR_ACC_AGPR_OPS(a) "+a"(a.v8), "+a"(a.v9), "+a"(a.v10), "+a"(a.v11), "+a"(a.v12), "+a"(a.v13), "+a"(a.v14), "+a"(a.v15), \
                             "+a"(a.v16), "+a"(a.v17), "+a"(a.v18), "+a"(a.v19), "+a"(a.v20), "+a"(a.v21), "+a"(a.v22), "+a"(a.v23)
+#elif ESR_R == 2
+#define ESR_ACC_AGPR_OPS(a) "+a"(a.v4), "+a"(a.v5), "+a"(a.v6), "+a"(a.v7), "+a"(a.v8), "+a"(a.v9), "+a"(a.v10), "+a"(a.v11)
+#else
+#define ESR_ACC_AGPR_OPS(a) "+a"(a.v2), "+a"(a.v3), "+a"(a.v4), "+a"(a.v5)
+#endif
+// register lists of the B-row fragments (R + 2 staged rows feed R output rows) for the hand-placed LDS waits
+#if ESR_R == 4
+#define ESR_BF_ALL(b) "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5])
+#define ESR_BF_HI(b) "+v"(b[3]), "+v"(b[4]), "+v"(b[5])
+#define ESR_ROWS(b) "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+#elif ESR_R == 2
+#define ESR_BF_ALL(b) "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+#define ESR_BF_HI(b) "+v"(b[3])
+#define ESR_ROWS(b) "+v"(b[0]), "+v"(b[1])
+#else
+#define ESR_BF_ALL(b) "+v"(b[0]), "+v"(b[1]), "+v"(b[2])
+#define ESR_ROWS(b) "+v"(b[0])
+#endif
 #ifndef ESR_FENCE_OPEN_NOP
 #define ESR_FENCE_OPEN_NOP "s_nop 4"
 #endif
@@ -422,8 +453,7 @@ __device__ __forceinline__ void unit_mma(Acc24& acc, const uint32_t lds_b, const
   u32x4 bf[R + 2], af[2][3];
   sfor<R + 2>([&](auto IR) __attribute__((always_inline)) { lds_read16<decltype(IR)::value * IW * 32>(bf[decltype(IR)::value], lds_b); });
   sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<decltype(KH)::value * 1024>(af[0][decltype(KH)::value], lds_w); });
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]),
-               "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]));
+  asm volatile("s_waitcnt lgkmcnt(0)" : ESR_BF_ALL(bf), "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]));
   sfor<NB>([&](auto BI) __attribute__((always_inline)) {
     constexpr int bi = decltype(BI)::value;       // position in the unit's fragment list
     constexpr int blk = P - 1 + bi;
@@ -568,10 +598,9 @@ __device__ __forceinline__ void unit_steps(Acc24& acc, UFrags& f, const uint32_t
     u32x4 (&af)[3] = f.a[(PAR + s) & 1];
     u32x4 (&an)[3] = f.a[(PAR + s + 1) & 1];
     // this step's A fragments and B rows 0..2
-    if constexpr (fresh) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]));
+    if constexpr (fresh) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]) : "n"(R - 1));
     else if constexpr (s == 0)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]),
-                   "+v"(af[0]), "+v"(af[1]), "+v"(af[2]));
+      asm volatile("s_waitcnt lgkmcnt(0)" : ESR_BF_ALL(bf), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]));
     else lds_wait3(af[0], af[1], af[2]);
     sfor<R + 2>([&](auto IR) __attribute__((always_inline)) {
       constexpr int ir = decltype(IR)::value;
@@ -581,7 +610,9 @@ __device__ __forceinline__ void unit_steps(Acc24& acc, UFrags& f, const uint32_t
         if constexpr (r >= 0 && r < R) mma_cls<T, acc_in_agpr(blk), FIRST && kwi == 0 && kh == 0 && blk < 4>(acc_br<blk, r>(acc), af[kh], bf[ir]);
       });
       if constexpr (ir == 2) {                    // after MFMA 6 of 12
-        if constexpr (fresh) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]));
+#if ESR_R > 1
+        if constexpr (fresh) asm volatile("s_waitcnt lgkmcnt(0)" : ESR_BF_HI(bf));
+#endif
         if constexpr (s + 1 < NS) {
           if constexpr (newset && !(ESR_ABL & 4))
             sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<decltype(IR2)::value * IW * 32>(bf[decltype(IR2)::value], lb[newset ? kwi + 1 : 0]); });
@@ -597,9 +628,9 @@ __device__ __forceinline__ void unit_steps(Acc24& acc, UFrags& f, const uint32_t
     });
     // after MFMA 12: rows 3..5 of the next column tap
     if constexpr (newset && !(ESR_ABL & 4))
-      sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<(3 + decltype(IR2)::value) * IW * 32>(bf[3 + decltype(IR2)::value], lb[newset ? kwi + 1 : 0]); });
+      sfor<R - 1>([&](auto IR2) __attribute__((always_inline)) { lds_read16<(3 + decltype(IR2)::value) * IW * 32>(bf[3 + decltype(IR2)::value], lb[newset ? kwi + 1 : 0]); });
     if constexpr (s + 1 == NS && NXT && !(ESR_ABL & 4))
-      sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<(3 + decltype(IR2)::value) * IW * 32>(bf[3 + decltype(IR2)::value], lbn); });
+      sfor<R - 1>([&](auto IR2) __attribute__((always_inline)) { lds_read16<(3 + decltype(IR2)::value) * IW * 32>(bf[3 + decltype(IR2)::value], lbn); });
     __builtin_amdgcn_sched_barrier(0);
     issue(std::integral_constant<int, s>{});
     if constexpr (s + 1 == NS && NS < 4)
@@ -782,9 +813,9 @@ __device__ __forceinline__ void run_1x1_res(Acc24& acc, const WStream& s, char* 
     constexpr int c = decltype(CI)::value, st = c & 1;
     if constexpr (c + 1 < K) {
       rd(std::integral_constant<int, c + 1>{}, std::integral_constant<int, st ^ 1>{});
-      asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fa[st]), "+v"(fb[st][0]), "+v"(fb[st][1]), "+v"(fb[st][2]), "+v"(fb[st][3]));
+      asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(fa[st]), ESR_ROWS(fb[st]) : [n] "n"(R + 1));
     } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[st]), "+v"(fb[st][0]), "+v"(fb[st][1]), "+v"(fb[st][2]), "+v"(fb[st][3]));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[st]), ESR_ROWS(fb[st]));
     }
     sfor<R>([&](auto RR) __attribute__((always_inline)) {
       mma_cls<T, acc_in_agpr(0), c == 0>(acc_br<0, decltype(RR)::value>(acc), fa[st], fb[st][decltype(RR)::value]);
@@ -823,15 +854,9 @@ __device__ __forceinline__ void run_1x1(Acc24& acc, const char* w1, const char* 
 #pragma unroll
       for (int r = 0; r < R; ++r) bq[r] = *(const u32x4*)(lb + r * IW * 32);
       if (c == 0) {
-        mma_cls<T, acc_in_agpr(0), true>(acc_br<0, 0>(acc), a, bq[0]);
-        mma_cls<T, acc_in_agpr(0), true>(acc_br<0, 1>(acc), a, bq[1]);
-        mma_cls<T, acc_in_agpr(0), true>(acc_br<0, 2>(acc), a, bq[2]);
-        mma_cls<T, acc_in_agpr(0), true>(acc_br<0, 3>(acc), a, bq[3]);
+        sfor<R>([&](auto RR) __attribute__((always_inline)) { mma_cls<T, acc_in_agpr(0), true>(acc_br<0, decltype(RR)::value>(acc), a, bq[decltype(RR)::value]); });
       } else {
-        mma_cls<T, acc_in_agpr(0)>(acc_br<0, 0>(acc), a, bq[0]);
-        mma_cls<T, acc_in_agpr(0)>(acc_br<0, 1>(acc), a, bq[1]);
-        mma_cls<T, acc_in_agpr(0)>(acc_br<0, 2>(acc), a, bq[2]);
-        mma_cls<T, acc_in_agpr(0)>(acc_br<0, 3>(acc), a, bq[3]);
+        sfor<R>([&](auto RR) __attribute__((always_inline)) { mma_cls<T, acc_in_agpr(0)>(acc_br<0, decltype(RR)::value>(acc), a, bq[decltype(RR)::value]); });
       }
     }
     if (++sa == AR) sa = 0;
@@ -1026,7 +1051,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const PT& p, const BlkS& bl
   const bool n2 = MODE == 3 && NOISE && p.noise_mode == ESR_NOISE_PHILOX && layer2 != ESR_NO_LAYER && has_res2;
   uint64_t seed = p.seed;
   if ((n1 || n2) && p.seed_dev) seed = __builtin_nontemporal_load(p.seed_dev);
-  uint32_t mbits[R] = {0u, 0u, 0u, 0u};
+  uint32_t mbits[4] = {0u, 0u, 0u, 0u};
   sfor<R>([&](auto RR) __attribute__((always_inline)) {
     constexpr int r = decltype(RR)::value;
     const int oy = oyb + r;
@@ -1130,8 +1155,11 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const PT& p, const BlkS& bl
     }
   });
   if constexpr (TRAIN && MODE != 3) {
-    const u32x2 m = {(mbits[0] & 0xFFFFu) | (mbits[1] << 16), (mbits[2] & 0xFFFFu) | (mbits[3] << 16)};
-    *(u32x2*)(mask_base + mask_slice * MASK_SLICE + t.wave * 512 + lane * 8) = m;
+    // 2 R bytes per lane: [wave][lane][row] u16
+    char* const mp = mask_base + mask_slice * MASK_SLICE + (t.wave * 64 + lane) * (2 * R);
+    if constexpr (R == 4) *(u32x2*)mp = u32x2{(mbits[0] & 0xFFFFu) | (mbits[1] << 16), (mbits[2] & 0xFFFFu) | (mbits[3] << 16)};
+    else if constexpr (R == 2) *(uint32_t*)mp = (mbits[0] & 0xFFFFu) | (mbits[1] << 16);
+    else *(uint16_t*)mp = (uint16_t)mbits[0];
   }
 }
 
@@ -1155,10 +1183,13 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const PT& p, const BlkS& bl
 // The block tail mirrors block.py:267-268,291 backwards:  v = acc (started at g_t: d(0.2 conv5 + x)/dx) [+ A];
 // [A' = v n2' -> out_a;  v = 0.2 A'];  t = v n1' -> x_out = the next block's g_t.
 
-// lane's mask word pair of a slice: LDS read in asm (a compiler-visible LDS read next to DMAs in flight costs a vmcnt(0))
+// lane's mask words of a slice (R x u16: row r = bits 16 (r & 1).. of word r >> 1): LDS read in asm (a compiler-visible
+// LDS read next to DMAs in flight costs a vmcnt(0))
 __device__ __forceinline__ u32x2 lds_mask(uint32_t addr) {
-  u32x2 v;
-  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  u32x2 v = {0u, 0u};
+  if constexpr (R == 4) asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  else if constexpr (R == 2) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v[0]) : "v"(addr) : "memory");
+  else asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v[0]) : "v"(addr) : "memory");
   return v;
 }
 // MFMA whose B operand was just written by VALU code (the packed gradient): the VALU-write -> MFMA-read wait states
@@ -1201,7 +1232,7 @@ __device__ __forceinline__ void epilogue_bwd(Acc24& acc, const PT& p, const ImgV
   const int wp32 = p.dense.wp * 32;
   const bool ragged = t.oy0 + TH > p.H || t.ox0 + TW > p.W;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const u32x2 mw = lds_mask(lds0 + LDS_MASK + mask_buf * MASK_SLICE + t.wave * 512 + lane * 8);
+  const u32x2 mw = lds_mask(lds0 + LDS_MASK + mask_buf * MASK_SLICE + (t.wave * 64 + lane) * (2 * R));
   sfor<R>([&](auto RR) __attribute__((always_inline)) {
     constexpr int r = decltype(RR)::value;
     const int oy = oyb + r;
@@ -1425,10 +1456,10 @@ if constexpr (DIR == 2) {
         const ImgView out_a = img_view(has_out_a ? blk.out_a : blk.x_out, t.b);
         const char* const mbase = uniform_ptr(blk.mask) + (int64_t)tile * MASK_TILE;
         // masks of slice s (0..3 = a1..a4 of the forward block; the backward consumes a4, a3, a2, a1) -> LDS buffer
-        // `buf`: 2 KB by waves 0 and 1.  Landing: every consumer sits behind weight requests that were issued after
+        // `buf`: MASK_SLICE bytes, 16 per lane (2 KB by waves 0 and 1 for 4 rows per wave).  Landing: every consumer sits behind weight requests that were issued after
         // this one and have been waited for (in-order retirement) + a barrier.
         auto mask_dma = [&](int slice, int buf) __attribute__((always_inline)) {
-          if (t.wave < 2)
+          if (R >= 2 ? t.wave < MASK_SLICE / 1024 : (t.wave == 0 && t.lane() < MASK_SLICE / 16))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mbase + slice * MASK_SLICE + (t.wave * 64 + t.lane()) * 16),
                                              (__attribute__((address_space(3))) void*)(smem + LDS_MASK + buf * MASK_SLICE + t.wave * 1024), 16, 0, 0);
         };

@@ -7,6 +7,11 @@
 int esr_rdb_launch_train(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 int esr_rdb_launch_bwd(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 int esr_rdb_launch_band(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
+// the same chains built for 2 / 1 rows per wave (8x32 / 4x32 tiles): rdb_rows{2,1}_{train,bwd}.hip
+int esr_rdb_launch_train_r2(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
+int esr_rdb_launch_train_r1(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
+int esr_rdb_launch_bwd_r2(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
+int esr_rdb_launch_bwd_r1(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 
 namespace {
 // pinned host word the kernels raise when a bounded spin times out (one per process; first use allocates it)
@@ -70,15 +75,35 @@ extern "C" size_t esr_rdb_weight_stream_bytes(int32_t dtype) {
   return dtype == ESR_F16 ? (size_t)Cfg<_Float16>::STREAM_BYTES : (size_t)Cfg<float>::STREAM_BYTES;
 }
 
+// Tile height of a launch: 16 rows (4 per wave) whenever that gives the GPU enough tiles; the training forward /
+// backward of small crops (the reference trains on batches of 16 32x32 LR crops = 32 such tiles for 256 CUs) run
+// the 8- or 4-row builds: the largest tile that still puts a tile on at least half of the CUs, else the smallest.
+// A training forward and its backward get the same answer (same B, H, W): the mask records depend on it.
+// ESR_RDB_ROWS = 4 | 2 | 1 forces one (measurement).
+static int rows_per_wave(const esr_rdb_chain* p, int cus) {
+  if (p->mode == 0 || p->band_rows != 0) return 4;
+  const char* const env = getenv("ESR_RDB_ROWS");
+  const int ev = env ? atoi(env) : 0, forced = (ev == 1 || ev == 2 || ev == 4) ? ev : 0;
+  const int tx = (p->W + TW - 1) / TW;
+  auto tiles_per_image = [&](int r) { return ((p->H + 4 * r - 1) / (4 * r)) * tx; };
+  if (forced && tiles_per_image(forced) <= cus) return forced;
+  for (int r = 4; r > 1; r >>= 1)
+    if ((int64_t)p->B * tiles_per_image(r) * 2 >= cus || tiles_per_image(r >> 1) > cus) return r;
+  return 1;
+}
+
+// sized for the smallest tile (4 rows) any build uses
 extern "C" size_t esr_rdb_workspace_bytes(int32_t B, int32_t H, int32_t W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  const size_t tiles = (size_t)B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  const size_t tiles = (size_t)B * ((H + 3) / 4) * ((W + TW - 1) / TW);
   return (WS_HDR + tiles) * sizeof(uint32_t);
 }
 
+// LeakyReLU masks of one block: 4 slices x 16 bits per pixel position of a tile = 512 bytes per tile row, whole tiles:
+// the 16-row build needs the most (its last tile row is padded to 16 rows)
 extern "C" size_t esr_rdb_mask_bytes(int32_t B, int32_t H, int32_t W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  return (size_t)B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * MASK_TILE;
+  return (size_t)B * ((H + 15) / 16) * ((W + TW - 1) / TW) * 8192;
 }
 
 extern "C" int esr_rdb_max_tiles_per_image(void) { return num_cus(); }
@@ -120,9 +145,10 @@ int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, i
       return ESR_ERR_INVALID;
     }
   }
-  const int tiles_x = (p->W + TW - 1) / TW, tiles_y = (p->H + TH - 1) / TH;
-  const int tpi = tiles_x * tiles_y, ntiles = tpi * p->B;
   const int cus = num_cus();
+  const int rows = rows_per_wave(p, cus);
+  const int tiles_x = (p->W + TW - 1) / TW, tiles_y = (p->H + 4 * rows - 1) / (4 * rows);
+  const int tpi = tiles_x * tiles_y, ntiles = tpi * p->B;
   if (tpi > cus) {
     esr_set_error("%s: %d tiles per image > %d CUs (all tiles of an image must be co-resident)", who, tpi, cus);
     return ESR_ERR_UNSUPPORTED;
@@ -145,8 +171,10 @@ int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, i
     if (p->dtype != ESR_F16 && p->dtype != ESR_F32) { esr_set_error("%s: bad dtype %d", who, p->dtype); return ESR_ERR_INVALID; }
     return esr_rdb_launch_band(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
   }
-  if (p->mode == 1) return esr_rdb_launch_train(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
-  if (p->mode == 2) return esr_rdb_launch_bwd(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
+  if (p->mode == 1)
+    return (rows == 4 ? esr_rdb_launch_train : rows == 2 ? esr_rdb_launch_train_r2 : esr_rdb_launch_train_r1)(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
+  if (p->mode == 2)
+    return (rows == 4 ? esr_rdb_launch_bwd : rows == 2 ? esr_rdb_launch_bwd_r2 : esr_rdb_launch_bwd_r1)(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
   if (p->dtype != ESR_F16 && p->dtype != ESR_F32) { esr_set_error("%s: bad dtype %d", who, p->dtype); return ESR_ERR_INVALID; }
   if (coop_launch()) {
     // ESR_RDB_COOP=1: the runtime checks the grid against the occupancy query and refuses a grid that cannot be

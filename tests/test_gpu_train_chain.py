@@ -105,3 +105,30 @@ def test_rrdbnet_chain_equals_per_conv_plan(dev, monkeypatch, cls, nb, shape):
     worst = max((_rel(g1[k], g0[k]), k) for k in g0)
     print('%s nb=%d: y %.2e, worst param grad %.2e (%s)' % (cls, nb, _rel(y1, y0), worst[0], worst[1]))
     assert worst[0] <= 3e-2, worst
+
+
+@pytest.mark.parametrize('kind,shape', [('rrdb', (2, 64, 24, 40)), ('rrdb_ti', (1, 64, 33, 31)), ('rdb', (3, 64, 7, 70))])
+def test_chain_tile_heights_are_bit_identical(dev, monkeypatch, kind, shape):
+    """The training chains exist in three builds — 4, 2 and 1 output rows per wave (16-, 8- and 4-row tiles;
+    rdb_fused.hip: rows_per_wave picks by tile count so that small crops still fill the GPU).  Every output element
+    accumulates the same products in the same order whatever the tile height, and the Philox counter is the pixel's
+    position in the image: output, input gradient and parameter gradients must agree bit for bit."""
+    from esrganplus_amd import block as B
+
+    def make():
+        torch.manual_seed(3)
+        m = B.ResidualDenseBlock_5C(64) if kind == 'rdb' else B.RRDB(64, extra_noise=(kind == 'rrdb_ti'))
+        return m.to(dev).train()
+    x = synth.normal_like(15, 'th.x', shape).to(dev)
+    gy = synth.normal_like(16, 'th.gy', shape).to(dev)
+    res = {}
+    for rows in ('4', '2', '1'):
+        monkeypatch.setenv('ESR_RDB_ROWS', rows)
+        y, gx, g, used = _grads(make, x, gy, 77, monkeypatch, True)
+        assert used
+        res[rows] = (y, gx, g)
+    for rows in ('2', '1'):
+        assert torch.equal(res[rows][0], res['4'][0]), rows
+        assert torch.equal(res[rows][1], res['4'][1]), rows
+        for k in res['4'][2]:
+            assert torch.equal(res[rows][2][k], res['4'][2][k]), (rows, k)
