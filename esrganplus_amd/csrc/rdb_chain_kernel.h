@@ -332,6 +332,8 @@ struct Tile {
   int ty, tx, tiles_y, tiles_x;
   int wave;
   int wp;            // row pitch (pixels) of every view
+  int hlim, wlim;    // H + 1 / W + 1: the zero halo row / column behind the image — staging reads of a tile that sticks
+                     // out of the image are clamped to them (beyond lies another plane, or the end of the allocation)
   __device__ __forceinline__ int lane() const { return fresh_lane(); }
   __device__ __forceinline__ int tid() const { return wave * 64 + fresh_lane(); }
   // per-lane B-fragment offset of column tap kw (pixel j + kw, half h; halves swapped by (col >> 3) & 1)
@@ -354,7 +356,8 @@ struct Tile {
     int row, col, hs;
     if (i < 4 * IW) { const int s = i % (2 * IW); row = i < 2 * IW ? 0 : IH - 1; col = s >> 1; hs = s & 1; }
     else { const int s = (i - 4 * IW) % (2 * TH); row = 1 + (s >> 1); col = i < 4 * IW + 2 * TH ? 0 : IW - 1; hs = s & 1; }
-    src = i < NHALO ? ((oy0 + row) * wp + ox0 + col) * 32 + ((hs ^ ((col >> 3) & 1)) << 4) : -1;
+    const int sy = oy0 + row < hlim ? oy0 + row : hlim, sx = ox0 + col < wlim ? ox0 + col : wlim;
+    src = i < NHALO ? (sy * wp + sx) * 32 + ((hs ^ ((col >> 3) & 1)) << 4) : -1;
     dst = (row * IW + col) * 32 + hs * 16;
   }
 };
@@ -382,7 +385,8 @@ __device__ __forceinline__ void issue_a(const char* plane, int sa, char* smem, c
     if (s >= NSLOT) s = NSLOT - 1;            // tail lanes: harmless re-copy into the padding
     const int row = s / (2 * IW), r2 = s - row * 2 * IW;
     const int col = r2 >> 1, hs = r2 & 1, half = hs ^ ((col >> 3) & 1);
-    dma16_sc1(plane + ((t.oy0 + row) * t.wp + t.ox0 + col) * 32 + half * 16, dst + NT * 16 * i);
+    const int sy = t.oy0 + row < t.hlim ? t.oy0 + row : t.hlim, sx = t.ox0 + col < t.wlim ? t.ox0 + col : t.wlim;
+    dma16_sc1(plane + (sy * t.wp + sx) * 32 + half * 16, dst + NT * 16 * i);
   }
 }
 
@@ -1381,6 +1385,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
     t.ox0 = tx * TW;
     t.ty = ty; t.tx = tx; t.tiles_y = tiles_y; t.tiles_x = tiles_x;
     t.wp = wp;
+    t.hlim = p.H + 1; t.wlim = p.W + 1;
     if constexpr (sizeof(T) == 2) {   // each thread's halo source offset, for the requests issued from inside the bulks
       int hsrc, hdst;
       t.halo(hsrc, hdst);
