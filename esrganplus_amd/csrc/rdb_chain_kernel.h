@@ -160,12 +160,17 @@ __device__ __forceinline__ void pin_acc45(Acc24& acc) { asm volatile("s_nop 7" :
 // few accumulator registers that miss the last MFMA's contribution.  These statements take every AGPR accumulator
 // as an operand: the copies can only sit outside [seg_open, seg_close], and the wait states are inside the strings.
 #if ESR_R == 4
-#define ESR_ACC_AGPR_OPS(a) "+a"(a.v8), "+a"(a.v9), "+a"(a.v10), "+a"(a.v11), "+a"(a.v12), "+a"(a.v13), "+a"(a.v14), "+a"(a.v15), \
-                            "+a"(a.v16), "+a"(a.v17), "+a"(a.v18), "+a"(a.v19), "+a"(a.v20), "+a"(a.v21), "+a"(a.v22), "+a"(a.v23)
+#define ESR_ACC_B4(a) "+a"(a.v16), "+a"(a.v17), "+a"(a.v18), "+a"(a.v19), "+a"(a.v20), "+a"(a.v21), "+a"(a.v22), "+a"(a.v23)
+#define ESR_ACC_B3(a) "+a"(a.v12), "+a"(a.v13), "+a"(a.v14), "+a"(a.v15), ESR_ACC_B4(a)
+#define ESR_ACC_AGPR_OPS(a) "+a"(a.v8), "+a"(a.v9), "+a"(a.v10), "+a"(a.v11), ESR_ACC_B3(a)
 #elif ESR_R == 2
-#define ESR_ACC_AGPR_OPS(a) "+a"(a.v4), "+a"(a.v5), "+a"(a.v6), "+a"(a.v7), "+a"(a.v8), "+a"(a.v9), "+a"(a.v10), "+a"(a.v11)
+#define ESR_ACC_B4(a) "+a"(a.v8), "+a"(a.v9), "+a"(a.v10), "+a"(a.v11)
+#define ESR_ACC_B3(a) "+a"(a.v6), "+a"(a.v7), ESR_ACC_B4(a)
+#define ESR_ACC_AGPR_OPS(a) "+a"(a.v4), "+a"(a.v5), ESR_ACC_B3(a)
 #else
-#define ESR_ACC_AGPR_OPS(a) "+a"(a.v2), "+a"(a.v3), "+a"(a.v4), "+a"(a.v5)
+#define ESR_ACC_B4(a) "+a"(a.v4), "+a"(a.v5)
+#define ESR_ACC_B3(a) "+a"(a.v3), ESR_ACC_B4(a)
+#define ESR_ACC_AGPR_OPS(a) "+a"(a.v2), ESR_ACC_B3(a)
 #endif
 // register lists of the B-row fragments (R + 2 staged rows feed R output rows) for the hand-placed LDS waits
 #if ESR_R == 4
@@ -1342,7 +1347,10 @@ __device__ __forceinline__ void tail_bwd(Acc24& acc, const PT& p, const BlkS& bl
 // host_abort: a pinned HOST word (may be null): set when a bounded spin timed out, so that the library can report
 // the aborted launch at its next entry without synchronising (esr_rdb_check_abort).
 // BAND (DIR 0): the row-band form for images with more tiles than CUs (esr_rdb_chain.band_rows).
-template <typename T, int DIR = 0, bool BAND = false>
+// NZ (DIR 1): 1 = the launch has noise layers, 0 = it has none (one instantiation each: with both block tails in one
+// kernel hipcc parks a live accumulator tuple in scratch around every hand-off — a vmcnt(0) per reload with weight
+// DMAs in flight, +0.9 us per phase); -1 = decided at run time (DIR 0).
+template <typename T, int DIR = 0, bool BAND = false, int NZ = -1>
 __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p, const int ntiles, const int tiles_x,
                                                           const int tiles_y, unsigned* const host_abort) {
   using CF = Cfg<T>;
@@ -1363,7 +1371,9 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
   if constexpr (DIR != 0 || BAND) {
     ps.H = __builtin_amdgcn_readfirstlane(p.H); ps.W = __builtin_amdgcn_readfirstlane(p.W);
     ps.noise_mode = __builtin_amdgcn_readfirstlane(p.noise_mode); ps.save_dense = BAND ? __builtin_amdgcn_readfirstlane(p.save_dense) : 0; ps._pad2 = 0;
-    ps.sigma = p.sigma; ps.seed = p.seed; ps.seed_dev = p.seed_dev; ps.dense.wp = __builtin_amdgcn_readfirstlane(p.dense.wp);
+    // the Philox key is resolved here, once (graph replay reads it from device memory)
+    ps.sigma = p.sigma; ps.seed = p.seed_dev ? __builtin_nontemporal_load(p.seed_dev) : p.seed; ps.seed_dev = nullptr;
+    ps.dense.wp = __builtin_amdgcn_readfirstlane(p.dense.wp);
     ps.trace = p.trace;
     ps.band_rows = __builtin_amdgcn_readfirstlane(p.band_rows); ps.band_margin = __builtin_amdgcn_readfirstlane(p.band_margin);
     ps.img_H = __builtin_amdgcn_readfirstlane(p.img_H);
@@ -1559,7 +1569,7 @@ if constexpr (DIR == 2) {
           load_1x1t<S>(one, ws_, smem, t);
           mfma_drain();
           epilogue_bwd<T, 2, 1, true>(acc, q, dblk, 2, t, smem, 0, nullptr, 0, &aux, &one);
-          seg_close(acc); }                    // (the epilogue's own MFMAs into g_x)
+          seg_close(acc); }                 // (the epilogue's own MFMAs into g_x)
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open(acc);
@@ -1753,7 +1763,7 @@ if constexpr (DIR == 2) {
         if constexpr (TR) {
           // training: the folded form with the noise layers (the carried 5 x makes `conv5 * 0.2 + x` one multiply);
           // every block output is kept for the backward
-          if (noisy) {
+          if (NZ == 1 || (NZ < 0 && noisy)) {
             epilogue<T, 4, 3, 1, true, true>(acc, q, bs, bb, xout, 0, 0, nullptr, &tr0, has_res2, t, smem, 0, nullptr, 5.f, true);
             epilogue<T, 5, 3, 1, true, true>(acc, q, bs, bb2, xout, 1, 1, nullptr, &tr1, has_res2, t, smem, 2, nullptr, 5.f, true);
           } else {

@@ -43,9 +43,10 @@ bool coop_launch() {
 namespace {
 // Diagnostic: a workgroup that takes 120 KB of LDS (so that no chain workgroup fits next to it on the CU) and sleeps
 // until the host raises *release or max_ms have passed — bounded, it cannot hang the device.
-__global__ __launch_bounds__(64) void hold_kernel(const unsigned* release, const unsigned max_ms, unsigned* sink) {
+__global__ __launch_bounds__(64) void hold_kernel(const unsigned* release, const unsigned max_ms, unsigned* started, unsigned* sink) {
   __shared__ char pad[120 * 1024];
   pad[threadIdx.x * 64] = (char)threadIdx.x;
+  if (started && threadIdx.x == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
   const uint64_t lim = (uint64_t)max_ms * 100000ull;                       // 100 MHz counter
   while (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u &&
@@ -55,12 +56,12 @@ __global__ __launch_bounds__(64) void hold_kernel(const unsigned* release, const
 }
 }  // namespace
 
-extern "C" int esr_debug_hold_cus(int32_t n_workgroups, const uint32_t* release, uint32_t max_ms, esr_stream_t stream) {
+extern "C" int esr_debug_hold_cus(int32_t n_workgroups, const uint32_t* release, uint32_t max_ms, uint32_t* started, esr_stream_t stream) {
   if (n_workgroups <= 0 || !release || max_ms == 0 || max_ms > 10000) {
     esr_set_error("esr_debug_hold_cus: invalid arguments (max_ms in 1..10000)");
     return ESR_ERR_INVALID;
   }
-  hipLaunchKernelGGL(hold_kernel, dim3(n_workgroups), dim3(64), 0, (hipStream_t)stream, (const unsigned*)release, max_ms, (unsigned*)nullptr);
+  hipLaunchKernelGGL(hold_kernel, dim3(n_workgroups), dim3(64), 0, (hipStream_t)stream, (const unsigned*)release, max_ms, (unsigned*)started, (unsigned*)nullptr);
   return esr_check_launch("hold_kernel");
 }
 

@@ -4,6 +4,9 @@
 #include "rdb_chain_kernel.h"
 
 int esr_rdb_launch_train_r1(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st) {
-  hipLaunchKernelGGL((rdb_chain_kernel<_Float16, 1>), dim3(grid), dim3(NT), 0, st, p, ntiles, tiles_x, tiles_y, host_abort);
+  if (p.noise_mode != ESR_NOISE_OFF)
+    hipLaunchKernelGGL((rdb_chain_kernel<_Float16, 1, false, 1>), dim3(grid), dim3(NT), 0, st, p, ntiles, tiles_x, tiles_y, host_abort);
+  else
+    hipLaunchKernelGGL((rdb_chain_kernel<_Float16, 1, false, 0>), dim3(grid), dim3(NT), 0, st, p, ntiles, tiles_x, tiles_y, host_abort);
   return esr_check_launch("rdb_chain_kernel<train, 1 rows>");
 }

@@ -573,8 +573,9 @@ size_t esr_rdb_mask_bytes(int32_t B, int32_t H, int32_t W);   /* esr_rdb_block.m
  * ESR_ERR_LAUNCH, so an aborted launch cannot go unnoticed past the next call. */
 int esr_rdb_check_abort(void);
 /* Diagnostic (tests/test_gpu_rdb_chain.py: starved launch): n_workgroups workgroups that each take a CU's LDS and
- * sleep until *release (device-visible memory) becomes non-zero or max_ms (<= 10000) have passed. */
-int esr_debug_hold_cus(int32_t n_workgroups, const uint32_t* release, uint32_t max_ms, esr_stream_t stream);
+ * sleep until *release (device-visible memory) becomes non-zero or max_ms (<= 10000) have passed; every workgroup
+ * that has started adds 1 to *started (optional). */
+int esr_debug_hold_cus(int32_t n_workgroups, const uint32_t* release, uint32_t max_ms, uint32_t* started, esr_stream_t stream);
 size_t esr_rdb_workspace_bytes(int32_t B, int32_t H, int32_t W);
 size_t esr_rdb_weight_stream_bytes(int32_t dtype);
 int esr_rdb_max_tiles_per_image(void);   /* 16x32 tiles of ONE image must not exceed this (= CUs) */

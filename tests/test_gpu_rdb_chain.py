@@ -355,12 +355,20 @@ def test_starved_chain_launch_is_reported_at_the_next_call(dev):
         side, side2 = torch.cuda.Stream(), torch.cuda.Stream()
         torch.cuda.synchronize()
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        L.check(L.lib().esr_debug_hold_cus(cus - 1, C.c_void_p(release.data_ptr()), 4000, C.c_void_p(side.cuda_stream)),
-                'esr_debug_hold_cus')
+        L.check(L.lib().esr_debug_hold_cus(cus - 1, C.c_void_p(release.data_ptr()), 4000, C.c_void_p(release.data_ptr() + 4),
+                                           C.c_void_p(side.cuda_stream)), 'esr_debug_hold_cus')
         import time
-        time.sleep(0.2)                                   # the hold kernel is resident before the chain arrives
+        for _ in range(300):                              # every hold workgroup is resident before the chain arrives
+            if int(release[1].item()) == cus - 1:
+                break
+            time.sleep(0.01)
+        assert int(release[1].item()) == cus - 1
+        t0 = time.perf_counter()
         bad = net(x)                                      # one CU left: tile 0 spins for its neighbours, then aborts
         torch.cuda.current_stream().synchronize()
+        spun = time.perf_counter() - t0
+        ws_abort = int(_chain_plans(net)[0].chain_ws[1].item())
+        assert ws_abort == 1 and spun > 0.9, ('the launch was not starved', ws_abort, spun)
         with torch.cuda.stream(side2):
             release.fill_(1)                              # lets the hold workgroups go (they also give up after 4 s)
         torch.cuda.synchronize()
