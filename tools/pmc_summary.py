@@ -15,7 +15,7 @@ def short(name):
         a = re.findall(r'L[ib](\d+)E', m.group(2))
         keys = ['k', 's', 'ups', 'wr', 'wc', 'ncg', 'ncw', 'wlds', '1x1', 'bwd']
         return 'conv<%s,%s>' % ('f16' if m.group(1) != 'f' else 'f32', ','.join('%s%s' % kv for kv in zip(keys, a)))
-    m = re.search(r'rdb_chain_kernelI(DF16_|f)(?:Li(\d)E)?E', name)
+    m = re.search(r'rdb_chain_kernelI(DF16_|f)(?:Li(\d)E)?', name)
     if m:
         return 'rdb_chain<%s,%s>' % ('f16' if m.group(1) != 'f' else 'f32', {'0': 'forward', '1': 'train-forward', '2': 'backward'}.get(m.group(2) or '0'))
     m = re.search(r'(rdb_wgrad_reduce_kernel|rdb_wgrad_kernel|wgrad_reduce_kernel)', name)
@@ -33,7 +33,7 @@ def main(root):
             a[0] += float(r['Counter_Value'])
             a[1] += 1
     for k in sorted(agg, key=lambda k: -agg[k].get('SQ_BUSY_CYCLES', [0, 0])[0]):
-        if not (k.startswith('conv<') or k.startswith('rdb_chain<')):
+        if not (k.startswith('conv<') or k.startswith('rdb_chain<') or k.startswith('rdb_wgrad') or k.startswith('wgrad')):
             continue
         c = agg[k]
         n = max(v[1] for v in c.values())
