@@ -191,8 +191,19 @@ __device__ __forceinline__ void pin_acc45(Acc24& acc) { asm volatile("s_nop 7" :
 #ifndef ESR_FENCE_CLOSE_NOP
 #define ESR_FENCE_CLOSE_NOP "s_nop 15\n\ts_nop 15"
 #endif
-__device__ __forceinline__ void seg_open(Acc24& acc) { asm volatile(ESR_FENCE_OPEN_NOP : ESR_ACC_AGPR_OPS(acc)); }
-__device__ __forceinline__ void seg_close(Acc24& acc) { asm volatile(ESR_FENCE_CLOSE_NOP : ESR_ACC_AGPR_OPS(acc)); }
+// B0: the first cout block that is still live (<= 2: all AGPR accumulators).  A fence that names a finished block's
+// registers keeps them occupied, and what is fetched ahead of conv5 for the block tail (the RRDB residual rows: 64
+// registers) then has nowhere to live but scratch.
+template <int B0 = 2> __device__ __forceinline__ void seg_open(Acc24& acc) {
+  if constexpr (B0 <= 2) asm volatile(ESR_FENCE_OPEN_NOP : ESR_ACC_AGPR_OPS(acc));
+  else if constexpr (B0 == 3) asm volatile(ESR_FENCE_OPEN_NOP : ESR_ACC_B3(acc));
+  else asm volatile(ESR_FENCE_OPEN_NOP : ESR_ACC_B4(acc));
+}
+template <int B0 = 2> __device__ __forceinline__ void seg_close(Acc24& acc) {
+  if constexpr (B0 <= 2) asm volatile(ESR_FENCE_CLOSE_NOP : ESR_ACC_AGPR_OPS(acc));
+  else if constexpr (B0 == 3) asm volatile(ESR_FENCE_CLOSE_NOP : ESR_ACC_B3(acc));
+  else asm volatile(ESR_FENCE_CLOSE_NOP : ESR_ACC_B4(acc));
+}
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_vm_dyn(int n) {   // n is wave-uniform; conservative above 47
@@ -1347,9 +1358,11 @@ __device__ __forceinline__ void tail_bwd(Acc24& acc, const PT& p, const BlkS& bl
 // host_abort: a pinned HOST word (may be null): set when a bounded spin timed out, so that the library can report
 // the aborted launch at its next entry without synchronising (esr_rdb_check_abort).
 // BAND (DIR 0): the row-band form for images with more tiles than CUs (esr_rdb_chain.band_rows).
-// NZ (DIR 1): 1 = the launch has noise layers, 0 = it has none (one instantiation each: with both block tails in one
-// kernel hipcc parks a live accumulator tuple in scratch around every hand-off — a vmcnt(0) per reload with weight
-// DMAs in flight, +0.9 us per phase); -1 = decided at run time (DIR 0).
+// NZ: 1 = the launch has noise layers, 0 = it has none, -1 = decided at run time (DIR 2, whose tail handles both in one
+// body).  One instantiation per form: with both block tails in one kernel hipcc parks a live accumulator tuple in
+// scratch around every hand-off of the training forward (a vmcnt(0) per reload with weight DMAs in flight, +0.9 us
+// per phase), and the inference kernel spilled 64 KB per tile and block on behalf of a noisy tail it never ran
+// (2.5 GB of HBM writes per launch, profiles/r03_experiments.md).
 template <typename T, int DIR = 0, bool BAND = false, int NZ = -1>
 __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p, const int ntiles, const int tiles_x,
                                                           const int tiles_y, unsigned* const host_abort) {
@@ -1417,7 +1430,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       // noise); later blocks get theirs from the previous epilogue.  Done ahead of the block loop: a second
       // definition inside it would join the carried one through scratch copies.
       const ImgView xin0 = img_view(p.blocks[0].x_in, t.b);
-      const bool noisy = p.noise_mode != ESR_NOISE_OFF;
+      const bool noisy = NZ != 0 && p.noise_mode != ESR_NOISE_OFF;
       RowsRaw<T> c0, c1;
       load_rows<T>(xin0, 0, q, t, c0); load_rows<T>(xin0, 1, q, t, c1);
       // (backward: g_x's accumulators start at g_t itself; training forward: always the folded form)
@@ -1446,7 +1459,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       const ImgView xin = img_view(blk.x_in, t.b), xout = img_view(blk.x_out, t.b);
       // block-table fields are wave-uniform, but only readfirstlane makes that provable: without it every
       // test on them becomes an exec-masked region and every use a fresh vector load
-      const bool noisy = p.noise_mode != ESR_NOISE_OFF;
+      const bool noisy = NZ != 0 && p.noise_mode != ESR_NOISE_OFF;
       BlkS bs;
       bs.bias = (const float*)uniform_ptr(blk.bias);
       bs.layer1 = __builtin_amdgcn_readfirstlane(blk.layer1);
@@ -1572,33 +1585,33 @@ if constexpr (DIR == 2) {
           seg_close(acc); }                 // (the epilogue's own MFMAs into g_x)
         ++epoch;
         trace_ev(q, tile, ev);
-        seg_open(acc);
+        seg_open<3>(acc);
         run_units_s<S, S::first(U_BULK, 3), S::end(U_BULK, 3), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD, -1, 0); });
-        seg_close(acc);
+        seg_close<3>(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(2 * CF::KD, 0)) return;
         trace_ev(q, tile, ev);
         // ---------------- g_x1 -> g_a1
-        seg_open(acc);
+        seg_open<3>(acc);
         run_units_s<S, S::first(U_CRIT, 4), S::end(U_CRIT, 4), false, false>(acc, ws_, smem, t);
-        seg_close(acc);
+        seg_close<3>(acc);
         trace_ev(q, tile, ev);
         mfma_drain();
         epilogue_bwd<T, 3, 1>(acc, q, dblk, 3, t, smem, 2, nullptr, 1);
         ++epoch;
         trace_ev(q, tile, ev);
-        seg_open(acc);
+        seg_open<4>(acc);
         run_units_s<S, S::first(U_BULK, 4), S::end(U_BULK, 4), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD, -1, 0); });
-        seg_close(acc);
+        seg_close<4>(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(3 * CF::KD, 2)) return;
         trace_ev(q, tile, ev);
         RowsRaw<T> tr0, tr1;
-        if (has_res2) { load_rows<T>(res2, 0, q, t, tr0); load_rows<T>(res2, 1, q, t, tr1); }
         // ---------------- g_x; block tail
-        seg_open(acc);
+        seg_open<4>(acc);
         run_units_s<S, S::first(U_CRIT, 5), S::end(U_CRIT, 5)>(acc, ws_, smem, t);
-        seg_close(acc);
+        seg_close<4>(acc);
+        if (has_res2) { load_rows<T>(res2, 0, q, t, tr0); load_rows<T>(res2, 1, q, t, tr1); }   // (see the forward)
         trace_ev(q, tile, ev);
         mfma_drain();
         tail_bwd<T, 4>(acc, q, bs, xout, 0, &tr0, has_res2, has_out_a ? &out_a : nullptr, t, smem, 0);
@@ -1724,16 +1737,16 @@ if constexpr (DIR == 2) {
         epilogue<T, 2, 0, 1, true, TR>(acc, q, bs, bb, dblk, 2, 0, nullptr, nullptr, false, t, smem, 0, nullptr, 0.f, true, mbase, 2);       // x3
         ++epoch;
         trace_ev(q, tile, ev);
-        seg_open(acc);
+        seg_open<3>(acc);
         run_units<T, S::first(U_BULK, 3), S::end(U_BULK, 3), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD); });
-        seg_close(acc);
+        seg_close<3>(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(2 * CF::KD, 0)) return;
         trace_ev(q, tile, ev);
         // ---------------- conv4
-        seg_open(acc);
+        seg_open<3>(acc);
         run_units<T, S::first(U_CRIT, 4), S::end(U_CRIT, 4), false, false>(acc, ws_, smem, t);
-        seg_close(acc);
+        seg_close<3>(acc);
         trace_ev(q, tile, ev);
         lds_bias(smem, 96, t, bb);
         lds_get_rows(smem, 2, x2.q, t);   // x2's own pixels still sit in the slots x4 is about to take
@@ -1742,18 +1755,19 @@ if constexpr (DIR == 2) {
         RowsRaw<T> tx0, tx1, tr0, tr1;
         ++epoch;
         trace_ev(q, tile, ev);
-        seg_open(acc);
+        seg_open<4>(acc);
         run_units<T, S::first(U_BULK, 4), S::end(U_BULK, 4), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD); });
-        seg_close(acc);
+        seg_close<4>(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(3 * CF::KD, 2)) return;
-        // the block tail's residual (every third block): requested here, used after conv5
-        if (has_res2) { load_rows<T>(res2, 0, q, t, tr0); load_rows<T>(res2, 1, q, t, tr1); }
         trace_ev(q, tile, ev);
         // ---------------- conv5; block tail (+ RRDB tail)
-        seg_open(acc);
+        seg_open<4>(acc);
         run_units<T, S::first(U_CRIT, 5), S::end(U_CRIT, 5)>(acc, ws_, smem, t);
-        seg_close(acc);
+        seg_close<4>(acc);
+        // the block tail's residual (every third block).  Requested only now: ahead of conv5 hipcc has no registers for
+        // the 16 rows and sends every one through scratch behind its own vmcnt(0)
+        if (has_res2) { load_rows<T>(res2, 0, q, t, tr0); load_rows<T>(res2, 1, q, t, tr1); }
         if constexpr (!TR) { if (noisy) { load_rows<T>(xin, 0, q, t, tx0); load_rows<T>(xin, 1, q, t, tx1); } }   // rare path: latency exposed
         trace_ev(q, tile, ev);
         mfma_drain();

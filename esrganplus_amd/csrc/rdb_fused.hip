@@ -7,6 +7,7 @@
 int esr_rdb_launch_train(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 int esr_rdb_launch_bwd(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 int esr_rdb_launch_band(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
+int esr_rdb_launch_noisy(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 // the same chains built for 2 / 1 rows per wave (8x32 / 4x32 tiles): rdb_rows{2,1}_{train,bwd}.hip
 int esr_rdb_launch_train_r2(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 int esr_rdb_launch_train_r1(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
@@ -177,6 +178,8 @@ int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, i
   if (p->mode == 2)
     return (rows == 4 ? esr_rdb_launch_bwd : rows == 2 ? esr_rdb_launch_bwd_r2 : esr_rdb_launch_bwd_r1)(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
   if (p->dtype != ESR_F16 && p->dtype != ESR_F32) { esr_set_error("%s: bad dtype %d", who, p->dtype); return ESR_ERR_INVALID; }
+  // inference with the fused Philox noise layers (a train-mode module under no_grad): its own instantiations
+  if (p->noise_mode != ESR_NOISE_OFF) return esr_rdb_launch_noisy(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
   if (coop_launch()) {
     // ESR_RDB_COOP=1: the runtime checks the grid against the occupancy query and refuses a grid that cannot be
     // co-resident (a plain launch of the same grid has the same residency, MI355X_MICROARCH.md; the check costs
@@ -185,15 +188,15 @@ int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, i
     int a1 = ntiles, a2 = tiles_x, a3 = tiles_y;
     unsigned* a4 = ha;
     void* args[] = {&arg, &a1, &a2, &a3, &a4};
-    const void* fn = p->dtype == ESR_F16 ? (const void*)rdb_chain_kernel<_Float16, 0> : (const void*)rdb_chain_kernel<float, 0>;
+    const void* fn = p->dtype == ESR_F16 ? (const void*)rdb_chain_kernel<_Float16, 0, false, 0> : (const void*)rdb_chain_kernel<float, 0, false, 0>;
     if (hipLaunchCooperativeKernel(fn, dim3(grid), dim3(NT), args, 0, st) != hipSuccess) {
       esr_set_error("%s: cooperative launch refused: %s", who, hipGetErrorString(hipGetLastError()));
       return ESR_ERR_LAUNCH;
     }
     return ESR_OK;
   }
-  if (p->dtype == ESR_F16) hipLaunchKernelGGL((rdb_chain_kernel<_Float16, 0>), dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y, ha);
-  else hipLaunchKernelGGL((rdb_chain_kernel<float, 0>), dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y, ha);
+  if (p->dtype == ESR_F16) hipLaunchKernelGGL((rdb_chain_kernel<_Float16, 0, false, 0>), dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y, ha);
+  else hipLaunchKernelGGL((rdb_chain_kernel<float, 0, false, 0>), dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y, ha);
   return esr_check_launch("rdb_chain_kernel");
 }
 }  // namespace
