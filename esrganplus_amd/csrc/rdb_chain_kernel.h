@@ -411,6 +411,13 @@ __device__ __forceinline__ void issue_a(const char* plane, int sa, char* smem, c
 // writes them into the stage slots the next phase reads (slot = channel group of the slice).  Only the
 // 1-pixel ring around the tile is fetched (sc1 loads, after the neighbours published): one 16-byte load
 // + one ds_write per thread and stage.
+// one LDS word through inline asm: a compiler-visible access of the generic `smem` pointer becomes a FLAT load that is
+// waited for with vmcnt(0) — a full drain of the weight DMAs in flight, at every hand-off
+__device__ __forceinline__ int lds_word(const char* smem, int off) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)off) : "memory");
+  return v;
+}
 template <int K> struct HaloRegs { u32x4 q[K]; };
 template <int K> __device__ __forceinline__ void halo_issue(const ImgView& v, int g0, int hsrc, HaloRegs<K>& h) {
   // threads without a slot read (and later drop) the view's first bytes: a branch around the loads would
@@ -427,7 +434,7 @@ template <int K> __device__ __forceinline__ void halo_put(char* smem, int slot0,
 template <int K> __device__ __forceinline__ void halo_fetch(const ImgView& v, int g0, char* smem, const Tile& t, int slot0 = 0) {
   HaloRegs<K> h;
   // the thread's slot as the tile set-up cached it (LDS_HALO)
-  const int hsrc = *(volatile int*)(smem + LDS_HALO + t.tid() * 8), hdst = *(volatile int*)(smem + LDS_HALO + t.tid() * 8 + 4);
+  const int hsrc = lds_word(smem, LDS_HALO + t.tid() * 8), hdst = lds_word(smem, LDS_HALO + t.tid() * 8 + 4);
   halo_issue<K>(v, g0, hsrc, h);
   halo_put<K>(smem, slot0, hsrc, hdst, h);
 }
@@ -1509,7 +1516,7 @@ if constexpr (DIR == 2) {
           }
         };
         auto finish_halo = [&](int g0, int slot0) __attribute__((always_inline)) -> bool {
-          const int hsrc = *(volatile int*)(smem + LDS_HALO + t.tid() * 8), hdst = *(volatile int*)(smem + LDS_HALO + t.tid() * 8 + 4);
+          const int hsrc = lds_word(smem, LDS_HALO + t.tid() * 8), hdst = lds_word(smem, LDS_HALO + t.tid() * 8 + 4);
           if (!early) {
             if (!wait_neighbours(ws, epoch, smem, t, &q, &ev, tile)) return false;
             halo_issue<CF::KD>(dblk, g0, hsrc, hq);
@@ -1654,7 +1661,7 @@ if constexpr (DIR == 2) {
         };
         // after the bulk: the halo of stage g0 into slots slot0..
         auto finish_halo = [&](int g0, int slot0) __attribute__((always_inline)) -> bool {
-          const int hsrc = *(volatile int*)(smem + LDS_HALO + t.tid() * 8), hdst = *(volatile int*)(smem + LDS_HALO + t.tid() * 8 + 4);
+          const int hsrc = lds_word(smem, LDS_HALO + t.tid() * 8), hdst = lds_word(smem, LDS_HALO + t.tid() * 8 + 4);
           if (!early) {
             if (!wait_neighbours(ws, epoch, smem, t, &q, &ev, tile)) return false;
             halo_issue<CF::KD>(dblk, g0, hsrc, hq);
