@@ -96,7 +96,7 @@ class esr_pool(C.Structure):
 
 class esr_linear(C.Structure):
     _fields_ = [('mode', C.c_int32), ('B', C.c_int32), ('I', C.c_int32), ('O', C.c_int32),
-                ('act', C.c_int32), ('_pad', C.c_int32),
+                ('act', C.c_int32), ('in_act', C.c_int32),
                 ('x', C.c_void_p), ('w', C.c_void_p), ('b', C.c_void_p), ('y', C.c_void_p),
                 ('g', C.c_void_p), ('ysaved', C.c_void_p), ('gx', C.c_void_p), ('dw', C.c_void_p),
                 ('db', C.c_void_p)]

@@ -332,6 +332,107 @@ class Discriminator_VGG_192(_DiscriminatorVGG):
     _pairs, _final = 6, 3
 
 
+class _SNLayer(nn.Module):
+    """Parameter holder of one spectrally normalised layer with the reference's state-dict entries
+    (spectral_norm.py:55-75): ``weight_orig`` + ``bias`` (parameters), ``weight`` (buffer: the normalised weight the
+    last training forward used; what eval-mode forwards use) and ``weight_u`` (buffer: the left singular vector
+    estimate)."""
+
+    def __init__(self, shape, eps=1e-12):
+        super().__init__()
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        bound = 1.0 / math.sqrt(fan_in)
+        self.weight_orig = nn.Parameter(torch.empty(shape).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(shape[0]).uniform_(-bound, bound))
+        self.register_buffer('weight', self.weight_orig.detach().clone())
+        u = torch.randn(shape[0])
+        self.register_buffer('weight_u', u / u.norm().clamp_min(eps))
+        self.eps = eps
+
+    def normalised(self):
+        """One power iteration (spectral_norm.py:21-41): v = W^T u / |.|, u = W v / |.| without gradients (``weight_u``
+        is updated in place), sigma = u . (W v) and W / sigma WITH the gradient through sigma.  Returns the
+        autograd tensor and refreshes the ``weight`` buffer with its value."""
+        w = self.weight_orig
+        wm = w.reshape(w.shape[0], -1)
+        with torch.no_grad():
+            v = wm.t().mv(self.weight_u)
+            v = v / v.norm().clamp_min(self.eps)
+            u = wm.mv(v)
+            u = u / u.norm().clamp_min(self.eps)
+            self.weight_u.copy_(u)
+        sigma = torch.dot(u, wm.mv(v))
+        w_eff = w / sigma
+        with torch.no_grad():
+            self.weight.copy_(w_eff)
+        return w_eff
+
+
+class Discriminator_VGG_128_SN(_SeqNet):
+    """codes/models/modules/architecture.py:131-175 (``which_model_D: discriminator_vgg_128_SN``, networks.py:130-131):
+    the 128x128 VGG-style discriminator without BatchNorm, every conv / linear weight divided by its spectral norm
+    (spectral_norm.py: one power iteration per training forward).  Same state-dict keys (``conv0.weight_orig``,
+    ``conv0.bias``, ``conv0.weight``, ``conv0.weight_u``, ... ``linear1.*``).  The ten convs and two linears run on the
+    discriminator plans; the normalisation itself — a handful of matrix-vector products on the weights — is torch
+    code in front of them, and autograd carries the plans' weight gradients through ``W / sigma`` to ``weight_orig``."""
+
+    _has_bn = False
+
+    def __init__(self):
+        super().__init__()
+        chans, cin = [], 3
+        for w in (64, 128, 256, 512, 512):
+            chans += [(cin, w, 3, 1), (w, w, 4, 2)]
+            cin = w
+        for i, (ci, co, k, s) in enumerate(chans):
+            setattr(self, 'conv%d' % i, _SNLayer((co, ci, k, k)))
+        self._geom = chans
+        self.linear0 = _SNLayer((100, 512 * 4 * 4))
+        self.linear1 = _SNLayer((1, 100))
+        self.in_nc = 3
+        self._eff = None
+        self._init_planned()
+
+    def _sn_layers(self):
+        return [getattr(self, 'conv%d' % i) for i in range(10)] + [self.linear0, self.linear1]
+
+    def _conv_list(self):
+        return [('conv%d' % i, getattr(self, 'conv%d' % i).weight, getattr(self, 'conv%d' % i).bias) for i in range(10)]
+
+    def _spec(self):
+        return [{'conv': 'conv%d' % i, 'cin': ci, 'cout': co, 'ks': k, 'stride': s, 'act': L.ACT_LRELU, 'bn': None}
+                for i, (ci, co, k, s) in enumerate(self._geom)]
+
+    def _head(self):
+        return dict(w1=self.linear0.weight, b1=self.linear0.bias, w2=self.linear1.weight, b2=self.linear1.bias)
+
+    def _pspec(self):
+        # the tensors the plan's gradients belong to: the normalised weights of this forward (autograd carries them on
+        # to weight_orig) or, outside a training forward, the buffers
+        ws = self._eff if self._eff is not None else [m.weight for m in self._sn_layers()]
+        ps = []
+        for i in range(10):
+            ps += [('conv%d.weight' % i, ws[i]), ('conv%d.bias' % i, getattr(self, 'conv%d' % i).bias)]
+        ps += [('head1.weight', ws[10]), ('head1.bias', self.linear0.bias),
+               ('head2.weight', ws[11]), ('head2.bias', self.linear1.bias)]
+        return ps
+
+    def forward(self, x):
+        if self.training:
+            self._eff = [m.normalised() for m in self._sn_layers()]
+            self.invalidate()                   # the buffers the plans pack from were rewritten in place
+        try:
+            return super().forward(x)
+        finally:
+            self._eff = None
+
+    def forward_pair(self, a, b):
+        # two calls, as the reference makes them: each runs its own power iteration
+        return self(a), self(b)
+
+
 VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M',
              512, 512, 512, 512, 'M']
 

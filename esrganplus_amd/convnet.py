@@ -221,13 +221,19 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
         if g1 is not None:
             bk.add(L.OP_LINEAR, 'linear', lin(2, Bb, I1, O1, L.ACT_LRELU, x=F_.data_ptr(), g=gH1.data_ptr(),
                                               ysaved=H1.data_ptr(), dw=g1[0], db=g1[1], w=head['w1'].data_ptr()))
-        bk.add(L.OP_LINEAR, 'linear', lin(1, Bb, I1, O1, L.ACT_LRELU, g=gH1.data_ptr(), ysaved=H1.data_ptr(),
-                                          w=head['w1'].data_ptr(), gx=gF.data_ptr()))
+        # a last conv that feeds the head through its activation without a norm layer (Discriminator_VGG_128_SN):
+        # the head's input gradient is masked by that activation here (F_ holds the activation's output)
+        last = recs[-1]
+        head_masks = last['kind'] == 'conv' and last['bn'] is None and last['act'] != L.ACT_NONE
+        o = lin(1, Bb, I1, O1, L.ACT_LRELU, g=gH1.data_ptr(), ysaved=H1.data_ptr(), w=head['w1'].data_ptr(), gx=gF.data_ptr())
+        if head_masks:
+            o.x, o.in_act = F_.data_ptr(), last['act']
+        bk.add(L.OP_LINEAR, 'linear', o)
         gcur = _g32(P, Bb, ch, h, w, dtype, dev)
         _layout(bk, dt_e, 1, Bb, ch, gcur, nchw_ptr=gF.data_ptr())
 
     # gcur_masked: True when gcur already is the gradient w.r.t. the producing conv's pre-activation
-    masked = False
+    masked = head is not None and head_masks
     for li in range(len(recs) - 1, -1, -1):
         r = recs[li]
         if r['kind'] == 'pool':

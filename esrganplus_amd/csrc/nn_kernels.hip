@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const esr_linear p) {
     p.y[(int64_t)b * p.O + o] = act_fwd(v, p.act);
   }
 }
-// gx[b][i] = sum_o (g[b][o] * act'(ysaved[b][o])) w[o][i]
+// gx[b][i] = sum_o (g[b][o] * act'(ysaved[b][o])) w[o][i]   [* in_act'(x[b][i]): the activation that produced this input]
 __global__ __launch_bounds__(256) void linear_bwdx_kernel(const esr_linear p) {
   const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
   if (i >= p.I) return;
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void linear_bwdx_kernel(const esr_linear p) {
     if (p.ysaved) gg *= act_bwd(p.ysaved[(int64_t)b * p.O + o], p.act);
     s += gg * p.w[(int64_t)o * p.I + i];
   }
+  if (p.in_act != ESR_ACT_NONE && p.x) s *= act_bwd(p.x[(int64_t)b * p.I + i], p.in_act);
   p.gx[(int64_t)b * p.I + i] = s;
 }
 // dw[o][i] += sum_b g'[b][o] x[b][i];  db[o] += sum_b g'[b][o]

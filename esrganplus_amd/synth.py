@@ -129,6 +129,26 @@ def discriminator_state_dict(seed=0, size=128):
     return sd
 
 
+def discriminator_sn_state_dict(seed=0):
+    """Discriminator_VGG_128_SN (architecture.py:131-175 + spectral_norm.py:55-75): per layer ``weight_orig``, ``bias``,
+    ``weight`` (buffer) and ``weight_u`` (buffer, unit norm)."""
+    sd = OrderedDict()
+    shapes, cin = [], 3
+    for w in (64, 128, 256, 512, 512):
+        shapes += [(w, cin, 3, 3), (w, w, 4, 4)]
+        cin = w
+    layers = [('conv%d' % i, sh) for i, sh in enumerate(shapes)] + [('linear0', (100, 512 * 16)), ('linear1', (1, 100))]
+    for name, sh in layers:
+        fan_in = int(np.prod(sh[1:]))
+        w = _uniform(seed, name + '.weight_orig', sh, np.sqrt(3.0) / np.sqrt(fan_in))
+        sd[name + '.weight_orig'] = w
+        sd[name + '.bias'] = _uniform(seed, name + '.bias', (sh[0],), 1.0 / np.sqrt(fan_in))
+        sd[name + '.weight'] = w.clone()
+        u = normal_like(seed, name + '.weight_u', (sh[0],))
+        sd[name + '.weight_u'] = u / u.norm()
+    return sd
+
+
 def vgg19_conv_indices(feature_layer=34):
     idx, out, cin = 0, [], 3
     for v in VGG19_CFG:

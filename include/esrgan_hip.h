@@ -263,7 +263,9 @@ typedef struct esr_pool {
 /* nn.Linear on row-major fp32 (Discriminator classifier, architecture.py:121-123).
  * mode 0: y = act(x W^T + b);  mode 1: gx = (g * act'(y_saved)) W ... see fields;  mode 2: dw, db. */
 typedef struct esr_linear {
-  int32_t mode, B, I, O, act, _pad;
+  int32_t mode, B, I, O, act;
+  int32_t in_act;               /* mode 1 (input gradient): the activation that PRODUCED x (a conv + LeakyReLU feeding the
+                                   head without a norm layer, architecture.py:163-170): gx *= in_act'(x); 0 = none */
   const float* x; const float* w; const float* b; float* y;
   const float* g;               /* dL/dy (already multiplied by act' by the caller kernel: see gmask) */
   const float* ysaved;          /* bwd: saved activation output of THIS layer for act' (may be NULL) */

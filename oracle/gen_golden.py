@@ -296,6 +296,39 @@ def gen_disc():
     np.savez_compressed(os.path.join(OUT, 'disc.npz'), **res)
 
 
+def gen_disc_sn():
+    """Discriminator_VGG_128_SN (architecture.py:131-175, spectral_norm.py): two training forwards (each runs one
+    power iteration), the first one's backward, then an eval forward on the buffers they left."""
+    sd = synth.discriminator_sn_state_dict(seed=6)
+    net = RI.build_discriminator_sn()
+    net.load_state_dict(sd, strict=True)
+    assert sorted(net.state_dict().keys()) == sorted(sd.keys())
+    x = synth.image_batch(6, 3, 3, 128, 128, name='dsn.x')
+    gy = synth.normal_like(6, 'dsn.gy', (3, 1))
+    net.train()
+    xr = x.clone().requires_grad_(True)
+    y1 = net(xr)
+    (y1 * gy).sum().backward()
+    params = dict(net.named_parameters())
+    res = {'y1': npy(y1), 'gx_chk': checks(xr.grad), 'gx_sub8': npy(xr.grad)[:, :, ::8, ::8],
+           'keys': np.array(sorted(params.keys())),
+           'gchk': np.stack([checks(params[k].grad) for k in sorted(params.keys())])}
+    for k in ('conv0.weight_orig', 'conv0.bias', 'conv3.bias', 'linear1.weight_orig', 'linear0.bias'):
+        res['g_' + k] = npy(params[k].grad)
+    res['g_conv5.weight_orig_sub'] = npy(params['conv5.weight_orig'].grad)[::8, ::8]
+    with torch.no_grad():
+        y2 = net(x * 0.75)
+    res['y2'] = npy(y2)
+    bufs = dict(net.named_buffers())
+    for k in ('conv0', 'conv4', 'conv9', 'linear0', 'linear1'):
+        res['u_' + k] = npy(bufs[k + '.weight_u'])
+        res['wchk_' + k] = checks(bufs[k + '.weight'])
+    net.eval()
+    with torch.no_grad():
+        res['y_eval'] = npy(net(x))
+    np.savez_compressed(os.path.join(OUT, 'disc_sn.npz'), **res)
+
+
 def gen_disc_variants():
     """Discriminator_VGG_96 / _192 (architecture.py:178-270): eval + train forward, gradient checksums."""
     for size, batch in ((96, 3), (192, 2)):
@@ -559,7 +592,7 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['rdb', 'rrdbnet_small', 'rrdbnet_full', 'disc', 'disc_variants', 'vgg', 'train_step',
-                             'psnr', 'imresize', 'metrics', 'metrics_y', 'srresnet', 'rrdbnet_full_grad']
+                             'psnr', 'imresize', 'metrics', 'metrics_y', 'srresnet', 'rrdbnet_full_grad', 'disc_sn']
     for w in which:
         print('[gen_golden]', w)
         globals()['gen_' + w]()

@@ -109,6 +109,11 @@ def build_discriminator(size=128):
     return cls(in_nc=3, base_nf=64, norm_type='batch', mode='CNA', act_type='leakyrelu')
 
 
+def build_discriminator_sn():
+    arch, _ = codes_arch()
+    return arch.Discriminator_VGG_128_SN()
+
+
 def data_util():
     """codes/data/util.py (imresize / augment).  It imports lmdb and cv2 at module level (absent here,
     unused by the functions we pin) -> empty stub modules; loaded by file path under a private name."""

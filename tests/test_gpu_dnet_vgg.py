@@ -271,3 +271,47 @@ def test_vgg_forward_pair_matches_two_calls(dev):
         out[how] = (fa.detach(), fb, a.grad)
     for x, y in zip(out['pair'], out['two']):
         assert torch.equal(x, y)
+
+
+def test_discriminator_sn_matches_reference_golden(dev, golden):
+    """Discriminator_VGG_128_SN (architecture.py:131-175 + spectral_norm.py) against tests/golden/disc_sn.npz, captured
+    from the imported reference: the first training forward's logits, input gradient and ALL parameter gradients
+    (through W / sigma to weight_orig), the second training forward (another power iteration on the updated u), the u
+    and normalised-weight buffers both calls leave, and an eval forward on those buffers."""
+    from esrganplus_amd import architecture as arch
+    g = golden('disc_sn')
+    sd = synth.discriminator_sn_state_dict(seed=6)
+    net = arch.Discriminator_VGG_128_SN().to(dev)
+    net.load_state_dict(sd, strict=True)
+    assert sorted(net.state_dict().keys()) == sorted(sd.keys())
+    x = synth.image_batch(6, 3, 3, 128, 128, name='dsn.x').to(dev)
+    gy = synth.normal_like(6, 'dsn.gy', (3, 1)).to(dev)
+    net.train()
+    xr = x.clone().requires_grad_(True)
+    y1 = net(xr)
+    assert np.abs(y1.detach().cpu().numpy() - g['y1']).max() <= 2e-4 * max(1.0, np.abs(g['y1']).max())
+    (y1 * gy).sum().backward()
+    assert np.abs(checks(xr.grad) - g['gx_chk']).max() <= 2e-3 * max(1.0, abs(g['gx_chk'][1]))
+    assert np.abs(xr.grad.cpu().numpy()[:, :, ::8, ::8] - g['gx_sub8']).max() <= 2e-3 * max(1e-6, np.abs(g['gx_sub8']).max())
+    params = dict(net.named_parameters())
+    keys = [str(k) for k in g['keys']]
+    assert keys == sorted(params.keys())
+    chk = np.stack([checks(params[k].grad) for k in keys])
+    rel = np.abs(chk - g['gchk']) / np.maximum(1e-3, np.abs(g['gchk'][:, 1:2]))
+    assert rel.max() <= 3e-3, (keys[int(rel.argmax() // 3)], rel.max())
+    for k in ('conv0.weight_orig', 'conv0.bias', 'conv3.bias', 'linear1.weight_orig', 'linear0.bias'):
+        want = g['g_' + k]
+        assert np.abs(params[k].grad.cpu().numpy() - want).max() <= 3e-3 * max(1e-6, np.abs(want).max()), k
+    want = g['g_conv5.weight_orig_sub']
+    assert np.abs(params['conv5.weight_orig'].grad.cpu().numpy()[::8, ::8] - want).max() <= 3e-3 * np.abs(want).max()
+    with torch.no_grad():
+        y2 = net(x * 0.75)
+    assert np.abs(y2.cpu().numpy() - g['y2']).max() <= 2e-4 * max(1.0, np.abs(g['y2']).max())
+    bufs = dict(net.named_buffers())
+    for k in ('conv0', 'conv4', 'conv9', 'linear0', 'linear1'):
+        assert np.abs(bufs[k + '.weight_u'].cpu().numpy() - g['u_' + k]).max() <= 1e-5, k
+        assert np.abs(checks(bufs[k + '.weight']) - g['wchk_' + k]).max() <= 1e-4 * max(1.0, g['wchk_' + k][1]), k
+    net.eval()
+    with torch.no_grad():
+        ye = net(x)
+    assert np.abs(ye.cpu().numpy() - g['y_eval']).max() <= 2e-4 * max(1.0, np.abs(g['y_eval']).max())

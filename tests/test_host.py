@@ -228,3 +228,28 @@ print('ok')
 ''' % ROOT
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+
+
+def test_discriminator_sn_state_dict_keys_and_power_iteration():
+    """Discriminator_VGG_128_SN keeps the reference's state-dict entries (spectral_norm.py:55-75: weight_orig, bias,
+    weight, weight_u per layer) and its one-step power iteration / sigma are the textbook ones (CPU tensors)."""
+    import torch
+    from esrganplus_amd import architecture as arch, synth
+    net = arch.Discriminator_VGG_128_SN()
+    sd = synth.discriminator_sn_state_dict(seed=2)
+    net.load_state_dict(sd, strict=True)
+    assert sorted(net.state_dict().keys()) == sorted(sd.keys()) and len(sd) == 48
+    m = net.conv3
+    w, u0 = sd['conv3.weight_orig'], sd['conv3.weight_u']
+    wm = w.reshape(w.shape[0], -1).double()
+    v = wm.t() @ u0.double()
+    v = v / v.norm()
+    u = wm @ v
+    u = u / u.norm()
+    sigma = u @ (wm @ v)
+    w_eff = m.normalised()
+    assert (m.weight_u.double() - u).abs().max().item() < 1e-6
+    assert (w_eff.detach().double() - w.double() / sigma).abs().max().item() < 1e-6
+    assert torch.equal(m.weight, w_eff.detach())
+    w_eff.sum().backward()                                 # the gradient runs through sigma to weight_orig
+    assert m.weight_orig.grad is not None and torch.isfinite(m.weight_orig.grad).all()
