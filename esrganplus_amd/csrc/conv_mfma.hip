@@ -89,7 +89,7 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
     if (n1) {
       if (xz) Px16<T>::load(p.z1, b, cb, h, (int64_t)(oy + 1) * p.z1.wp + ox + 1, tmp);
       else {
-#pragma unroll 1
+#pragma unroll
         for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(cb * 4 + h * 2 + o), p.layer1, noise_seed(p), &tmp[8 * o]);
       }
 #pragma unroll
@@ -103,7 +103,7 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
     if (n2) {
       if (xz) Px16<T>::load(p.z2, b, cb, h, (int64_t)(oy + 1) * p.z2.wp + ox + 1, tmp);
       else {
-#pragma unroll 1
+#pragma unroll
         for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(cb * 4 + h * 2 + o), p.layer2, noise_seed(p), &tmp[8 * o]);
       }
 #pragma unroll
@@ -125,7 +125,7 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
       if (n3) {
         if (xz) Px16<T>::load(p.z3, b, cb, h, (int64_t)(oy + 1) * p.z3.wp + ox + 1, tmp);
         else {
-#pragma unroll 1
+#pragma unroll
           for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(cb * 4 + h * 2 + o), p.layer3, noise_seed(p), &tmp[8 * o]);
         }
 #pragma unroll

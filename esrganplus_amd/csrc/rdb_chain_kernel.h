@@ -1010,14 +1010,18 @@ __device__ __forceinline__ void poll_check(unsigned epoch, char* smem, const Til
 // conv2: x2 is the residual of x4).
 template <typename T> struct RowsRaw { typename Ch16<T>::Raw q[R]; };
 
+// `live` false: the same loads at an offset past num_records — the buffer range check answers 0 without touching
+// memory.  The RRDB residual rows are fetched this way in EVERY block: a load under `if (has_res2)` whose result is
+// used under another `if (has_res2)` makes hipcc send the rows through scratch one by one, each behind a vmcnt(0).
 template <typename T, typename PT>
-__device__ __forceinline__ void load_rows(const ImgView& v, int cb, const PT& p, const Tile& t, RowsRaw<T>& o) {
+__device__ __forceinline__ void load_rows(const ImgView& v, int cb, const PT& p, const Tile& t, RowsRaw<T>& o, bool live = true) {
   const int lane = t.lane();
   const int ox = t.ox0 + (lane & 31), oyb = t.oy0 + t.wave * R, wp32 = p.dense.wp * 32;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int oy = oyb + r < p.H ? oyb + r : p.H - 1;            // clamped: rows / columns past the image are not used
-    Ch16<T>::load(v, cb, lane >> 5, (oy + 1) * wp32 + (ox < p.W ? ox + 1 : 1) * 32, o.q[r]);
+    const int off = (oy + 1) * wp32 + (ox < p.W ? ox + 1 : 1) * 32;
+    Ch16<T>::load(v, live ? cb : 0, lane >> 5, live ? off : (int)0x80000000u, o.q[r]);
   }
 }
 
@@ -1126,7 +1130,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const PT& p, const BlkS& bl
       }
       const uint32_t pix = (uint32_t)((t.b * p.H + oy) * p.W + ox);
       if (n1) {
-#pragma unroll 1
+#pragma unroll
         for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(ch_cb * 4 + th * 2 + o), layer1, seed, &tmp[8 * o]);
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);     // block.py:119-121
@@ -1136,7 +1140,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const PT& p, const BlkS& bl
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = v[e] * 0.2f + tmp[e];
         if (n2) {
-#pragma unroll 1
+#pragma unroll
           for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(ch_cb * 4 + th * 2 + o), layer2, seed, &tmp[8 * o]);
 #pragma unroll
           for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
@@ -1296,8 +1300,8 @@ __device__ __forceinline__ void epilogue_bwd(Acc24& acc, const PT& p, const ImgV
 //   v = acc [+ r2];  [a = v (1 + sigma z2) -> out_a;  v = 0.2 a];  t = v (1 + sigma z1) -> out, LDS stage, next block's carry
 template <typename T, int BLK, typename PT = esr_rdb_chain>
 __device__ __forceinline__ void tail_bwd(Acc24& acc, const PT& p, const BlkS& blk, const ImgView& out, int ch_cb,
-                                         const RowsRaw<T>* r2, bool has_res2, const ImgView* out_a, const Tile& t, char* smem,
-                                         int slot0) {
+                                         const RowsRaw<T>* r2, bool has_res2, const ImgView& out_a, const bool has_out_a,
+                                         const Tile& t, char* smem, int slot0) {
   using C16 = Ch16<T>;
   const int lane = t.lane(), tj = lane & 31, th = lane >> 5;
   int own_px = 0, own_swz = 0;
@@ -1307,7 +1311,7 @@ __device__ __forceinline__ void tail_bwd(Acc24& acc, const PT& p, const BlkS& bl
   const bool ragged = t.oy0 + TH > p.H || t.ox0 + TW > p.W;
   const uint32_t layer1 = blk.layer1, layer2 = blk.layer2;
   const bool n1 = p.noise_mode == ESR_NOISE_PHILOX && layer1 != ESR_NO_LAYER;
-  const bool n2 = p.noise_mode == ESR_NOISE_PHILOX && layer2 != ESR_NO_LAYER && out_a != nullptr;
+  const bool n2 = p.noise_mode == ESR_NOISE_PHILOX && layer2 != ESR_NO_LAYER && has_out_a;
   uint64_t seed = p.seed;
   if ((n1 || n2) && p.seed_dev) seed = __builtin_nontemporal_load(p.seed_dev);
   sfor<R>([&](auto RR) __attribute__((always_inline)) {
@@ -1325,21 +1329,21 @@ __device__ __forceinline__ void tail_bwd(Acc24& acc, const PT& p, const BlkS& bl
     const bool inside = oy < p.H && ox < p.W;
     const int po = (oy + 1) * wp32 + (ox + 1) * 32;
     const uint32_t pix = (uint32_t)((t.b * p.H + oy) * p.W + ox);
-    if (out_a) {
+    if (has_out_a) {      // (a view by reference + a flag: a pointer selected at run time sends the descriptor through scratch)
       if (n2) {
-#pragma unroll 1
+#pragma unroll
         for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(ch_cb * 4 + th * 2 + o), layer2, seed, &tmp[8 * o]);
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
       }
       typename C16::Raw qa;
       C16::pack(v, qa.q);
-      C16::store_packed(*out_a, inside ? ch_cb : 0, th, inside ? po : (int)0x80000000u, qa.q);
+      C16::store_packed(out_a, inside ? ch_cb : 0, th, inside ? po : (int)0x80000000u, qa.q);
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] *= 0.2f;
     }
     if (n1) {
-#pragma unroll 1
+#pragma unroll
       for (int o = 0; o < 2; ++o) philox_normal8(pix, (uint32_t)(ch_cb * 4 + th * 2 + o), layer1, seed, &tmp[8 * o]);
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = v[e] + tmp[e] * (p.sigma * v[e]);
@@ -1618,11 +1622,11 @@ if constexpr (DIR == 2) {
         seg_open<4>(acc);
         run_units_s<S, S::first(U_CRIT, 5), S::end(U_CRIT, 5)>(acc, ws_, smem, t);
         seg_close<4>(acc);
-        if (has_res2) { load_rows<T>(res2, 0, q, t, tr0); load_rows<T>(res2, 1, q, t, tr1); }   // (see the forward)
+        load_rows<T>(res2, 0, q, t, tr0, has_res2); load_rows<T>(res2, 1, q, t, tr1, has_res2);   // (see the forward)
         trace_ev(q, tile, ev);
         mfma_drain();
-        tail_bwd<T, 4>(acc, q, bs, xout, 0, &tr0, has_res2, has_out_a ? &out_a : nullptr, t, smem, 0);
-        tail_bwd<T, 5>(acc, q, bs, xout, 1, &tr1, has_res2, has_out_a ? &out_a : nullptr, t, smem, 2);
+        tail_bwd<T, 4>(acc, q, bs, xout, 0, &tr0, has_res2, out_a, has_out_a, t, smem, 0);
+        tail_bwd<T, 5>(acc, q, bs, xout, 1, &tr1, has_res2, out_a, has_out_a, t, smem, 2);
         pin_acc45(acc);
         publish(flags, tile, ++epoch, t, &q, &ev);
         ws_.ring = (ws_.ring + S::N) & (WR - 1);
@@ -1774,7 +1778,7 @@ if constexpr (DIR == 2) {
         seg_close<4>(acc);
         // the block tail's residual (every third block).  Requested only now: ahead of conv5 hipcc has no registers for
         // the 16 rows and sends every one through scratch behind its own vmcnt(0)
-        if (has_res2) { load_rows<T>(res2, 0, q, t, tr0); load_rows<T>(res2, 1, q, t, tr1); }
+        load_rows<T>(res2, 0, q, t, tr0, has_res2); load_rows<T>(res2, 1, q, t, tr1, has_res2);
         if constexpr (!TR) { if (noisy) { load_rows<T>(xin, 0, q, t, tx0); load_rows<T>(xin, 1, q, t, tx1); } }   // rare path: latency exposed
         trace_ev(q, tile, ev);
         mfma_drain();
