@@ -13,6 +13,8 @@ int esr_rdb_launch_train_r2(const esr_rdb_chain& p, int grid, int ntiles, int ti
 int esr_rdb_launch_train_r1(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 int esr_rdb_launch_bwd_r2(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 int esr_rdb_launch_bwd_r1(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
+int esr_rdb_launch_fwd_r2(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
+int esr_rdb_launch_fwd_r1(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 
 namespace {
 // pinned host word the kernels raise when a bounded spin times out (one per process; first use allocates it)
@@ -78,20 +80,23 @@ extern "C" size_t esr_rdb_weight_stream_bytes(int32_t dtype) {
 }
 
 // Tile height of a launch: 16 rows (4 per wave) whenever that gives the GPU enough tiles; the training forward /
-// backward of small crops (the reference trains on batches of 16 32x32 LR crops = 32 such tiles for 256 CUs) run
-// the 8- or 4-row builds: the largest tile that still puts a tile on at least half of the CUs, else the smallest.
+// backward of small crops (the reference trains on batches of 16 32x32 LR crops = 32 such tiles for 256 CUs) and the inference of small inputs (one 128x128 LR tile: 32 tiles) run
+// the 8- or 4-row builds when those still fit one round of workgroups.
 // A training forward and its backward get the same answer (same B, H, W): the mask records depend on it.
 // ESR_RDB_ROWS = 4 | 2 | 1 forces one (measurement).
 static int rows_per_wave(const esr_rdb_chain* p, int cus) {
-  if (p->mode == 0 || p->band_rows != 0) return 4;
+  // (inference: the short-tile builds exist for fp16 without noise layers; bands, fp32 and the noisy form keep 16 rows)
+  if (p->band_rows != 0 || (p->mode == 0 && (p->dtype != ESR_F16 || p->noise_mode != ESR_NOISE_OFF))) return 4;
   const char* const env = getenv("ESR_RDB_ROWS");
   const int ev = env ? atoi(env) : 0, forced = (ev == 1 || ev == 2 || ev == 4) ? ev : 0;
   const int tx = (p->W + TW - 1) / TW;
   auto tiles_per_image = [&](int r) { return ((p->H + 4 * r - 1) / (4 * r)) * tx; };
   if (forced && tiles_per_image(forced) <= cus) return forced;
-  for (int r = 4; r > 1; r >>= 1)
-    if ((int64_t)p->B * tiles_per_image(r) * 2 >= cus || tiles_per_image(r >> 1) > cus) return r;
-  return 1;
+  // the smallest tile whose launch is still ONE round of workgroups (tools/sweep_rows.py, 128x128 LR, ms per forward
+  // with 16- / 8- / 4-row tiles: batch 2: 3.27 / 2.36 / 2.11, batch 4: 3.51 / 2.79 / 4.16, batch 8: 4.46 / 5.31 / 8.13)
+  for (int r = 1; r < 4; r <<= 1)
+    if ((int64_t)p->B * tiles_per_image(r) <= cus) return r;
+  return 4;
 }
 
 // sized for the smallest tile (4 rows) any build uses
@@ -180,6 +185,7 @@ int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, i
   if (p->dtype != ESR_F16 && p->dtype != ESR_F32) { esr_set_error("%s: bad dtype %d", who, p->dtype); return ESR_ERR_INVALID; }
   // inference with the fused Philox noise layers (a train-mode module under no_grad): its own instantiations
   if (p->noise_mode != ESR_NOISE_OFF) return esr_rdb_launch_noisy(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
+  if (rows != 4) return (rows == 2 ? esr_rdb_launch_fwd_r2 : esr_rdb_launch_fwd_r1)(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
   if (coop_launch()) {
     // ESR_RDB_COOP=1: the runtime checks the grid against the occupancy query and refuses a grid that cannot be
     // co-resident (a plain launch of the same grid has the same residency, MI355X_MICROARCH.md; the check costs

@@ -378,3 +378,26 @@ def test_starved_chain_launch_is_reported_at_the_next_call(dev):
         torch.cuda.synchronize()
         assert torch.equal(again, good)
         del bad
+
+
+@pytest.mark.parametrize('shape', [(1, 3, 128, 128), (2, 3, 33, 70), (1, 3, 7, 20)])
+def test_inference_chain_tile_heights_are_bit_identical(dev, monkeypatch, shape):
+    """The fp16 inference chain also exists for 8- and 4-row tiles (a single 128x128 LR tile — BASELINE configs[0],
+    what test_image/test.py feeds — is 32 tiles of 16x32 on 256 CUs; rdb_fused.hip: rows_per_wave picks 4-row tiles
+    for it).  Same products in the same order per output element: the three builds agree bit for bit, and with the
+    per-conv launches to fp16 rounding."""
+    sd = synth.rrdbnet_state_dict(nb=2, seed=51)
+    x = synth.image_batch(51, *shape, name='rows.x').to(dev)
+    ys = {}
+    with torch.no_grad():
+        for rows in ('4', '2', '1'):
+            monkeypatch.setenv('ESR_RDB_ROWS', rows)
+            net = _net('RRDBNet', 2, sd, dev, 'fp16')
+            ys[rows] = net(x).clone()
+            assert len(_chain_plans(net)) == 1
+            assert int(_chain_plans(net)[0].chain_ws[1].item()) == 0
+        monkeypatch.delenv('ESR_RDB_ROWS')
+        monkeypatch.setenv('ESR_RDB_FUSED', '0')
+        yc = _net('RRDBNet', 2, sd, dev, 'fp16')(x)
+    assert torch.equal(ys['2'], ys['4']) and torch.equal(ys['1'], ys['4'])
+    assert (ys['4'] - yc).abs().max().item() <= 2e-3
