@@ -1,3 +1,5 @@
+"""Inference forward (nb = 23, fp16, 128x128 LR) per batch size and chain tile height (ESR_RDB_ROWS = 4 / 2 / 1): the data
+behind rdb_fused.hip: rows_per_wave().  Usage (GPU box): python tools/sweep_rows.py"""
 import os, sys, time
 sys.path.insert(0, '.')
 import torch
