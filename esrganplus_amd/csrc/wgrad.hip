@@ -550,6 +550,15 @@ Wg16Grid wgrad16_grid(const esr_wgrad& p, int64_t min_wgs, int min_rows, int cap
   // still give ~min_wgs workgroups: start from whole column strips and halve only while the grid is tiny.
   int rows = ((p.H + 3) / 4) * 4;
   if (rows > cap_rows) rows = cap_rows;       // bound the serial load->LDS->MFMA iterations of one workgroup
+  // With the two-stage reduction a spatial split costs one partial tile, not a set of atomics: the kernel is fastest
+  // with ~32 workgroups per CU to hide each other's load -> wait -> MFMA latency (tools/train_op_times.py, 16 images,
+  // cap 32 / 16 / 8 / 4 rows: 512^2 64->64: 0.46 / 0.36 / 0.41 / 0.51 ms; 256^2 up-conv: 0.35 / 0.21 / 0.15 / 0.14 ms)
+  {
+    const int64_t base = (int64_t)p.B * strips * g.gy * g.gz;
+    int want = (int)(((int64_t)p.H * base / 8192) / 4 * 4);
+    if (want < 4) want = 4;
+    if (rows > want) rows = want;
+  }
   while (rows > min_rows && (int64_t)p.B * strips * ((p.H + rows - 1) / rows) * g.gy * g.gz < min_wgs) rows = ((rows / 2 + 3) / 4) * 4;
   const int rchunks = (p.H + rows - 1) / rows;
   int ipw = wgrad16_packed<S, UPS>(p) ? 32 >> pack_wl<S>(p.W) : 1;   // images per workgroup (packed: >= one tile of them)
