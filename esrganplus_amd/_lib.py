@@ -104,11 +104,11 @@ class esr_linear(C.Structure):
 
 class esr_unperm_entry(C.Structure):
     _fields_ = [('src_off', C.c_int64), ('dst_off', C.c_int64), ('elem_begin', C.c_int64),
-                ('cout', C.c_int32), ('cin', C.c_int32), ('ntap', C.c_int32), ('_pad', C.c_int32)]
+                ('cout', C.c_int32), ('cin', C.c_int32), ('ntap', C.c_int32), ('pair_begin', C.c_int32)]
 
 
 class esr_unpermute(C.Structure):
-    _fields_ = [('table', C.c_void_p), ('n', C.c_int32), ('_pad', C.c_int32), ('total', C.c_int64),
+    _fields_ = [('table', C.c_void_p), ('n', C.c_int32), ('n_pairs', C.c_int32), ('total', C.c_int64),
                 ('src', C.c_void_p), ('dst', C.c_void_p)]
 
 

@@ -663,12 +663,41 @@ __global__ void unpermute_kernel(const esr_unpermute p) {
   const int ci = (int)(r % e.cin), co = (int)(r / e.cin);
   p.dst[e.dst_off + k] = p.src[e.src_off + ((int64_t)t * e.cout + co) * e.cin + ci];
 }
+// one thread per (cout, cin) pair: for every tap the lanes of a wave read consecutive cin (coalesced), each lane writes
+// its ntap adjacent OIHW elements; one table search per pair instead of per element
+__global__ void unpermute_pairs_kernel(const esr_unpermute p) {
+  const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (idx >= p.n_pairs) return;
+  int lo = 0, hi = p.n - 1;                      // last entry with pair_begin <= idx
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (p.table[mid].pair_begin <= idx) lo = mid; else hi = mid - 1;
+  }
+  const esr_unperm_entry e = p.table[lo];
+  const int k = idx - e.pair_begin;              // co * cin + ci
+  const float* src = p.src + e.src_off + k;
+  float* dst = p.dst + e.dst_off + (int64_t)k * e.ntap;
+  const int64_t plane = (int64_t)e.cout * e.cin;
+  if (e.ntap == 9) {
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = src[t * plane];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dst[t] = v[t];
+  } else {
+    for (int t = 0; t < e.ntap; ++t) dst[t] = src[t * plane];
+  }
+}
 }  // namespace
 
 extern "C" int esr_grad_unpermute(const esr_unpermute* p, esr_stream_t stream) {
   if (!p || !p->table || p->n <= 0 || p->total <= 0 || !p->src || !p->dst) {
     esr_set_error("esr_grad_unpermute: invalid arguments");
     return ESR_ERR_INVALID;
+  }
+  if (p->n_pairs > 0) {
+    hipLaunchKernelGGL(unpermute_pairs_kernel, dim3((unsigned)((p->n_pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    return esr_check_launch("unpermute_pairs_kernel");
   }
   hipLaunchKernelGGL(unpermute_kernel, dim3((unsigned)((p->total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
   return esr_check_launch("unpermute_kernel");

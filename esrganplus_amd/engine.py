@@ -934,16 +934,18 @@ class TapMajorGrads:
         if not rows:
             return None
         arr = (L.esr_unperm_entry * len(rows))()
-        begin = 0
+        begin = pairs = 0
         for i, r in enumerate(rows):
             arr[i].src_off, arr[i].dst_off, arr[i].elem_begin = r[0], r[1], begin
-            arr[i].cout, arr[i].cin, arr[i].ntap = r[3], r[4], r[5]
+            arr[i].cout, arr[i].cin, arr[i].ntap, arr[i].pair_begin = r[3], r[4], r[5], pairs
             begin += r[3] * r[4] * r[5]
+            pairs += r[3] * r[4]
         raw = bytes(arr)
         table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.flat.device)
         self.tables = getattr(self, 'tables', []) + [table]
         up = L.esr_unpermute()
         up.table, up.n, up.total = table.data_ptr(), len(rows), begin
+        up.n_pairs = pairs if pairs < 2 ** 31 else 0
         up.src, up.dst = self.tm.data_ptr(), self.flat.data_ptr()
         return up
 

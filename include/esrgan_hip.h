@@ -210,11 +210,14 @@ typedef struct esr_wgrad {
  * src/dst are fp32 arenas. */
 typedef struct esr_unperm_entry {
   int64_t src_off, dst_off, elem_begin;
-  int32_t cout, cin, ntap, _pad;
+  int32_t cout, cin, ntap;
+  int32_t pair_begin;       /* number of (cout, cin) pairs of the entries before this one (used when n_pairs > 0) */
 } esr_unperm_entry;
 typedef struct esr_unpermute {
   const esr_unperm_entry* table;
-  int32_t n, _pad;
+  int32_t n;
+  int32_t n_pairs;          /* > 0: the sum of cout * cin over the table; the kernel then runs one thread per pair
+                               (ntap coalesced reads, ntap adjacent writes, one table search per pair); 0: per element */
   int64_t total;
   const float* src;
   float* dst;
