@@ -367,8 +367,6 @@ def main():
                          'full ESRGAN+ step, batch 16 of 32x32 LR per GPU, DP over RCCL; '
                          "'gtrain' = configs[4]: noise-on generator fwd+bwd+Adam on mixed 128/192/256 LR tiles")
     ap.add_argument('--precision', choices=['fp16', 'fp32'], default='fp16')
-    ap.add_argument('--two-stream', action='store_true',
-                    help='forward mode: also time the two-half-batches-on-two-streams variant (extra field)')
     ap.add_argument('--train-batch', type=int, default=16,
                     help="--mode train: LR tiles per GPU per step (the reference's config uses 16)")
     args = ap.parse_args()
@@ -496,23 +494,6 @@ def main():
         res['kernels'] = {k: {'launches': a[2] // reps, 'ms_per_step': round(a[0] / reps, 3),
                               'tflops': round(a[1] / (a[0] * 1e-3) / 1e12, 1) if a[1] else 0.0}
                           for k, a in sorted(agg.items())}
-        if world == 1 and args.two_stream and args.batch % 2 == 0:
-            # informational (opt-in, so that profiling the default command sees ONE launch form): the same forward as two half-batches on two streams (ESR_FWD_STREAMS=2).  Not
-            # the headline: with two kernels in flight the per-launch roofline above no longer applies.
-            from esrganplus_amd import functional as Fn
-            old_streams, Fn._FWD_STREAMS = Fn._FWD_STREAMS, 2
-            with torch.no_grad():
-                for _ in range(2):
-                    net(x)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    y2 = net(x)
-                torch.cuda.synchronize()
-                dt2 = (time.perf_counter() - t0) / args.steps
-            Fn._FWD_STREAMS = old_streams
-            res['two_stream_variant'] = {'value': round(hr_mpix_per_step / dt2, 2), 'ms_per_step': round(dt2 * 1e3, 4),
-                                         'identical_output': bool(torch.equal(y, y2))}
         if world == 1 and not args.no_fwd_bwd:
             del y
             net = None

@@ -2,6 +2,7 @@
 // (csrc/rdb_chain_kernel.h; the training-forward and backward instantiations live in rdb_fused_train.hip /
 // rdb_fused_bwd.hip so that the three compile in parallel).
 #include "rdb_chain_kernel.h"
+#include <mutex>
 
 // defined next to their kernels
 int esr_rdb_launch_train(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
@@ -40,6 +41,60 @@ unsigned* abort_word_dev() {
 bool coop_launch() {
   static const bool v = [] { const char* e = getenv("ESR_RDB_COOP"); return e && atoi(e) != 0; }();
   return v;
+}
+
+// Chains on DIFFERENT streams.  Every chain launch assumes its whole grid becomes resident (a tile spins on the flags
+// of its neighbours); two launches in flight on two streams may each get a part of the CUs and then starve each
+// other until the 1 s abort.  So the library keeps the launches it has not yet seen complete: a launch whose grid does
+// not fit next to the ones still in flight on other streams is ordered after them with an event wait on the device
+// (the host never blocks; launches on one stream are ordered anyway; chains that fit side by side still overlap).
+// Streams under graph capture are left alone (their order is the graph's).
+struct InFlight { hipEvent_t ev; hipStream_t st; int grid; bool live; };
+constexpr int N_INFLIGHT = 8;
+InFlight g_inflight[N_INFLIGHT];
+std::mutex g_inflight_mu;
+
+bool capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool c = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+  (void)hipGetLastError();
+  return c;
+}
+
+bool chain_order_on() {                          // ESR_RDB_ORDER=0: measurement only (tools / experiments)
+  static const bool v = [] { const char* e = getenv("ESR_RDB_ORDER"); return !e || atoi(e) != 0; }();
+  return v;
+}
+
+void chain_order_before_launch(hipStream_t st, int grid, int cus) {
+  if (!chain_order_on() || capturing(st)) return;
+  std::lock_guard<std::mutex> lk(g_inflight_mu);
+  int others = 0;
+  for (InFlight& e : g_inflight) {
+    if (!e.live) continue;
+    if (hipEventQuery(e.ev) == hipSuccess) e.live = false;
+    else if (e.st != st) others += e.grid;
+  }
+  if (others + grid > cus)
+    for (InFlight& e : g_inflight)
+      if (e.live && e.st != st) (void)hipStreamWaitEvent(st, e.ev, 0);
+  (void)hipGetLastError();                       // hipEventQuery's "not ready" is not an error of this launch
+}
+
+void chain_record_launch(hipStream_t st, int grid) {
+  if (!chain_order_on() || capturing(st)) return;
+  std::lock_guard<std::mutex> lk(g_inflight_mu);
+  static unsigned next = 0;
+  InFlight* slot = nullptr;
+  for (InFlight& e : g_inflight)
+    if (!e.live) { slot = &e; break; }
+  if (!slot) {                                   // table full of running chains: order this one after the oldest
+    slot = &g_inflight[next++ % N_INFLIGHT];
+    if (slot->st != st) (void)hipStreamWaitEvent(st, slot->ev, 0);
+  }
+  if (!slot->ev && hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (hipEventRecord(slot->ev, st) != hipSuccess) { (void)hipGetLastError(); slot->live = false; return; }
+  slot->st = st; slot->grid = grid; slot->live = true;
 }
 }  // namespace
 
@@ -174,36 +229,42 @@ int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, i
   }
   const int grid = ntiles < cus ? ntiles : cus;
   unsigned* const ha = abort_word_dev();
-  if (p->band_rows != 0) {
-    if (p->dtype != ESR_F16 && p->dtype != ESR_F32) { esr_set_error("%s: bad dtype %d", who, p->dtype); return ESR_ERR_INVALID; }
-    return esr_rdb_launch_band(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
-  }
-  if (p->mode == 1)
-    return (rows == 4 ? esr_rdb_launch_train : rows == 2 ? esr_rdb_launch_train_r2 : esr_rdb_launch_train_r1)(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
-  if (p->mode == 2)
-    return (rows == 4 ? esr_rdb_launch_bwd : rows == 2 ? esr_rdb_launch_bwd_r2 : esr_rdb_launch_bwd_r1)(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
-  if (p->dtype != ESR_F16 && p->dtype != ESR_F32) { esr_set_error("%s: bad dtype %d", who, p->dtype); return ESR_ERR_INVALID; }
-  // inference with the fused Philox noise layers (a train-mode module under no_grad): its own instantiations
-  if (p->noise_mode != ESR_NOISE_OFF) return esr_rdb_launch_noisy(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
-  if (rows != 4) return (rows == 2 ? esr_rdb_launch_fwd_r2 : esr_rdb_launch_fwd_r1)(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
-  if (coop_launch()) {
-    // ESR_RDB_COOP=1: the runtime checks the grid against the occupancy query and refuses a grid that cannot be
-    // co-resident (a plain launch of the same grid has the same residency, MI355X_MICROARCH.md; the check costs
-    // ~17 us per launch)
-    esr_rdb_chain arg = *p;
-    int a1 = ntiles, a2 = tiles_x, a3 = tiles_y;
-    unsigned* a4 = ha;
-    void* args[] = {&arg, &a1, &a2, &a3, &a4};
-    const void* fn = p->dtype == ESR_F16 ? (const void*)rdb_chain_kernel<_Float16, 0, false, 0> : (const void*)rdb_chain_kernel<float, 0, false, 0>;
-    if (hipLaunchCooperativeKernel(fn, dim3(grid), dim3(NT), args, 0, st) != hipSuccess) {
-      esr_set_error("%s: cooperative launch refused: %s", who, hipGetErrorString(hipGetLastError()));
-      return ESR_ERR_LAUNCH;
+  chain_order_before_launch(st, grid, cus);
+  auto dispatch = [&]() -> int {
+    if (p->band_rows != 0) {
+      if (p->dtype != ESR_F16 && p->dtype != ESR_F32) { esr_set_error("%s: bad dtype %d", who, p->dtype); return ESR_ERR_INVALID; }
+      return esr_rdb_launch_band(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
     }
-    return ESR_OK;
-  }
-  if (p->dtype == ESR_F16) hipLaunchKernelGGL((rdb_chain_kernel<_Float16, 0, false, 0>), dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y, ha);
-  else hipLaunchKernelGGL((rdb_chain_kernel<float, 0, false, 0>), dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y, ha);
-  return esr_check_launch("rdb_chain_kernel");
+    if (p->mode == 1)
+      return (rows == 4 ? esr_rdb_launch_train : rows == 2 ? esr_rdb_launch_train_r2 : esr_rdb_launch_train_r1)(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
+    if (p->mode == 2)
+      return (rows == 4 ? esr_rdb_launch_bwd : rows == 2 ? esr_rdb_launch_bwd_r2 : esr_rdb_launch_bwd_r1)(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
+    if (p->dtype != ESR_F16 && p->dtype != ESR_F32) { esr_set_error("%s: bad dtype %d", who, p->dtype); return ESR_ERR_INVALID; }
+    // inference with the fused Philox noise layers (a train-mode module under no_grad): its own instantiations
+    if (p->noise_mode != ESR_NOISE_OFF) return esr_rdb_launch_noisy(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
+    if (rows != 4) return (rows == 2 ? esr_rdb_launch_fwd_r2 : esr_rdb_launch_fwd_r1)(*p, grid, ntiles, tiles_x, tiles_y, ha, st);
+    if (coop_launch()) {
+      // ESR_RDB_COOP=1: the runtime checks the grid against the occupancy query and refuses a grid that cannot be
+      // co-resident (a plain launch of the same grid has the same residency, MI355X_MICROARCH.md; the check costs
+      // ~17 us per launch)
+      esr_rdb_chain arg = *p;
+      int a1 = ntiles, a2 = tiles_x, a3 = tiles_y;
+      unsigned* a4 = ha;
+      void* args[] = {&arg, &a1, &a2, &a3, &a4};
+      const void* fn = p->dtype == ESR_F16 ? (const void*)rdb_chain_kernel<_Float16, 0, false, 0> : (const void*)rdb_chain_kernel<float, 0, false, 0>;
+      if (hipLaunchCooperativeKernel(fn, dim3(grid), dim3(NT), args, 0, st) != hipSuccess) {
+        esr_set_error("%s: cooperative launch refused: %s", who, hipGetErrorString(hipGetLastError()));
+        return ESR_ERR_LAUNCH;
+      }
+      return ESR_OK;
+    }
+    if (p->dtype == ESR_F16) hipLaunchKernelGGL((rdb_chain_kernel<_Float16, 0, false, 0>), dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y, ha);
+    else hipLaunchKernelGGL((rdb_chain_kernel<float, 0, false, 0>), dim3(grid), dim3(NT), 0, st, *p, ntiles, tiles_x, tiles_y, ha);
+    return esr_check_launch("rdb_chain_kernel");
+  };
+  const int rc = dispatch();
+  if (rc == ESR_OK) chain_record_launch(st, grid);
+  return rc;
 }
 }  // namespace
 

@@ -308,35 +308,6 @@ class _BlockFn(torch.autograd.Function):
         return (gx if ctx.needs_input_grad[0] else None, None, None, None, None) + tuple(grads)
 
 
-_FWD_STREAMS = int(os.environ.get('ESR_FWD_STREAMS', '1'))   # opt-in two-stream inference (README: knobs)
-
-
-def _forward_two_streams(net, wp, xin):
-    """Inference on two half-batches, one on torch's current stream and one on a second stream, so the
-    epilogue / launch phases of one half overlap the K loops of the other (measured +3 %)."""
-    B, _, H, W = xin.shape
-    hb = B // 2
-    plans = []
-    for tag in ('2s-a', '2s-b'):
-        key = (tag, hb, H, W, net.precision, wp.generation)
-        plan = net._plans.get(key)
-        if plan is None:
-            plan = E.build_rrdbnet_plan(wp, net.nb, net.in_nc, net.out_nc, hb, H, W, net.precision,
-                                        xin.device, False, net.variant, False)
-            net._plans[key] = plan
-        plans.append(plan)
-    out = torch.empty((B,) + tuple(plans[0].out_shape[1:]), dtype=torch.float32, device=xin.device)
-    side = net.__dict__.get('_side_stream')
-    if side is None:
-        side = net.__dict__['_side_stream'] = torch.cuda.Stream(device=xin.device)
-    cur = torch.cuda.current_stream(xin.device)
-    side.wait_stream(cur)
-    plans[0].run(xin[:hb], out[:hb], cur.cuda_stream)
-    plans[1].run(xin[hb:], out[hb:], side.cuda_stream)
-    cur.wait_stream(side)
-    return out
-
-
 def run_rrdbnet(net, x, z=None):
     """RRDBNet.forward (architecture.py:76-78) on the HIP path."""
     if x.dim() == 4 and x.shape[0] == 0:          # empty batch: torch returns an empty result
@@ -358,8 +329,6 @@ def run_rrdbnet(net, x, z=None):
     noise = bool(net.training)
     per = 4 if net.variant == 'test_image' else 3
     zs = _zs_list(z, per * net.nb, (B, 64, H, W), xin.device) if noise else None
-    if _FWD_STREAMS == 2 and not noise and B >= 2 and B % 2 == 0:
-        return _forward_two_streams(net, wp, xin)
     key = (B, H, W, net.precision, noise, zs is not None, wp.generation)
     plan = net._plans.get(key)
     if plan is None:

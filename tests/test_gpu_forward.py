@@ -262,19 +262,37 @@ def test_full_size_batch_independence_and_determinism(dev):
         assert (a - b).abs().max().item() <= 5e-2
 
 
-def test_two_stream_forward_matches_single_stream(dev, monkeypatch):
-    """ESR_FWD_STREAMS=2 (two half-batches on two streams) must return exactly the single-stream result."""
-    from esrganplus_amd import architecture as arch, functional as Fn
-    net = arch.RRDBNet(3, 3, 64, 2).to(dev).eval().set_precision('fp16')
-    net.load_state_dict(synth.rrdbnet_state_dict(2, 3))
-    x = synth.image_batch(11, 6, 3, 40, 24, name='2s.x').to(dev)
+def test_chains_launched_on_two_streams_do_not_starve_each_other(dev):
+    """Two networks driven from two streams: each fused-chain launch wants every CU (256 tiles) and spins on its
+    neighbours' flags, so two of them resident by halves would wait for each other until the 1 s abort.  The library
+    orders a chain that does not fit next to the ones in flight on other streams after them (rdb_fused.hip:
+    chain_order_before_launch); chains that fit side by side are left to overlap.  Results equal the serial ones."""
+    from esrganplus_amd import architecture as arch, _lib as L
+    nets, xs = [], []
+    for i in range(2):
+        net = arch.RRDBNet(3, 3, 64, 3).to(dev).eval().set_precision('fp16')
+        net.load_state_dict(synth.rrdbnet_state_dict(3, 20 + i))
+        nets.append(net)
+        xs.append(synth.image_batch(30 + i, 16, 3, 128, 128, name='2s.big%d' % i).to(dev))
+    small = [synth.image_batch(40 + i, 2, 3, 64, 64, name='2s.small%d' % i).to(dev) for i in range(2)]
     with torch.no_grad():
-        y1 = net(x)
-        monkeypatch.setattr(Fn, '_FWD_STREAMS', 2)
-        y2 = net(x)
-        y3 = net(x)
-    torch.cuda.synchronize()
-    assert torch.equal(y1, y2) and torch.equal(y1, y3)
+        want = [nets[i](xs[i]) for i in range(2)]
+        want_s = [nets[i](small[i]) for i in range(2)]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        got, got_s = [[], []], [[], []]
+        for rep in range(6):
+            for i in range(2):
+                with torch.cuda.stream(streams[i]):
+                    got[i].append(nets[i](xs[i]))
+                    got_s[i].append(nets[i](small[i]))
+        torch.cuda.synchronize()
+    assert not L.lib().esr_rdb_check_abort()
+    for i in range(2):
+        for y in got[i]:
+            assert torch.equal(y, want[i])
+        for y in got_s[i]:
+            assert torch.equal(y, want_s[i])
 
 
 def test_philox_stream_statistics(dev):

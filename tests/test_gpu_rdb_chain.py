@@ -351,27 +351,48 @@ def test_starved_chain_launch_is_reported_at_the_next_call(dev):
     with torch.no_grad():
         good = net(x).clone()
         assert len(_chain_plans(net)) == 1
-        release = torch.zeros(16, dtype=torch.int32, device=dev)
-        side, side2 = torch.cuda.Stream(), torch.cuda.Stream()
-        torch.cuda.synchronize()
-        cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        L.check(L.lib().esr_debug_hold_cus(cus - 1, C.c_void_p(release.data_ptr()), 4000, C.c_void_p(release.data_ptr() + 4),
-                                           C.c_void_p(side.cuda_stream)), 'esr_debug_hold_cus')
+        # release / started words in pinned host memory: the device reads and bumps them in place, the host polls
+        # them without a stream operation (a copy on a stream that shares its hardware queue with the hold kernel
+        # would sit behind it)
+        words = torch.zeros(16, dtype=torch.int32).pin_memory()
+        p_release, p_started = C.c_void_p(words.data_ptr()), C.c_void_p(words.data_ptr() + 4)
         import time
+        torch.cuda.synchronize()
+        # HIP maps streams onto a few hardware queues; a stream that lands on the queue of the current stream would
+        # make the chain wait BEHIND the hold kernel instead of next to it: probe for one that runs concurrently
+        side = None
+        for _ in range(8):
+            cand = torch.cuda.Stream()
+            words.zero_()
+            L.check(L.lib().esr_debug_hold_cus(1, p_release, 200, p_started, C.c_void_p(cand.cuda_stream)), 'esr_debug_hold_cus')
+            t0 = time.perf_counter()
+            torch.zeros(1, device=dev).item()
+            dt = time.perf_counter() - t0
+            words[0] = 1
+            cand.synchronize()
+            if dt < 0.1:
+                side = cand
+                break
+        if side is None:
+            pytest.skip('no stream that runs concurrently with the current one')
+        words.zero_()
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        L.check(L.lib().esr_debug_hold_cus(cus - 1, p_release, 4000, p_started, C.c_void_p(side.cuda_stream)), 'esr_debug_hold_cus')
         for _ in range(300):                              # every hold workgroup is resident before the chain arrives
-            if int(release[1].item()) == cus - 1:
+            if int(words[1]) == cus - 1:
                 break
             time.sleep(0.01)
-        assert int(release[1].item()) == cus - 1
+        assert int(words[1]) == cus - 1
         t0 = time.perf_counter()
         bad = net(x)                                      # one CU left: tile 0 spins for its neighbours, then aborts
         torch.cuda.current_stream().synchronize()
         spun = time.perf_counter() - t0
-        ws_abort = int(_chain_plans(net)[0].chain_ws[1].item())
-        assert ws_abort == 1 and spun > 0.9, ('the launch was not starved', ws_abort, spun)
-        with torch.cuda.stream(side2):
-            release.fill_(1)                              # lets the hold workgroups go (they also give up after 4 s)
+        words[0] = 1                                      # lets the hold workgroups go (they also give up after 4 s)
         torch.cuda.synchronize()
+        ws_abort = int(_chain_plans(net)[0].chain_ws[1].item())
+        # (spun is 1 s when the free CU's XCD is the one the spinning tile was dispatched to and up to the 4 s of the
+        # hold kernel otherwise: workgroups are dealt round-robin to the 8 XCDs and wait for a CU of THEIR XCD)
+        assert ws_abort == 1 and spun > 0.9, ('the launch was not starved', ws_abort, spun)
         with pytest.raises(L.HipExtensionError, match='aborted'):
             net(x)
         again = net(x)
