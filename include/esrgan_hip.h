@@ -565,7 +565,10 @@ int esr_adam_step(const esr_adam* p, esr_stream_t stream);
 int esr_amp_step(const esr_amp* p, esr_stream_t stream);
 int esr_resample_axis(const esr_resample* p, esr_stream_t stream);
 int esr_pack_conv_weights_batch(const esr_pack_batch* p, esr_stream_t stream);
-/* Fused dense-block chain (replaces 5 x n_blocks esr_conv_forward launches; block.py:260-268,287-291). */
+/* Fused dense-block chain (replaces 5 x n_blocks esr_conv_forward launches; block.py:260-268,287-291).
+ * Every launch assumes its whole grid resident.  Launches on one stream are ordered by the stream; a launch whose
+ * grid does not fit next to the chain launches still in flight on OTHER streams is made to wait for them on the
+ * device (event wait; the call itself never blocks).  Streams under graph capture are not tracked. */
 int esr_rdb_forward(const esr_rdb_chain* p, esr_stream_t stream);
 /* Fused dense-block BACKWARD chain (mode 2): the input gradients of n_blocks dense blocks (autograd backward of
  * block.py:260-268,287-291, triggered at SRRaGAN_model.py:140) in one persistent launch — replaces 5 x n_blocks dgrad
