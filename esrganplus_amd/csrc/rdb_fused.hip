@@ -84,16 +84,21 @@ void chain_order_before_launch(hipStream_t st, int grid, int cus) {
 void chain_record_launch(hipStream_t st, int grid) {
   if (!chain_order_on() || capturing(st)) return;
   std::lock_guard<std::mutex> lk(g_inflight_mu);
-  static unsigned next = 0;
+  // one entry per stream (launches on a stream run one after the other: the newest stands for all of them)
   InFlight* slot = nullptr;
   for (InFlight& e : g_inflight)
-    if (!e.live) { slot = &e; break; }
-  if (!slot) {                                   // table full of running chains: order this one after the oldest
+    if (e.ev && e.st == st) { slot = &e; break; }
+  if (!slot)
+    for (InFlight& e : g_inflight)
+      if (!e.live) { slot = &e; break; }
+  if (!slot) {                                   // chains in flight on N_INFLIGHT other streams: let the oldest finish
+    static unsigned next = 0;
     slot = &g_inflight[next++ % N_INFLIGHT];
-    if (slot->st != st) (void)hipStreamWaitEvent(st, slot->ev, 0);
+    (void)hipEventSynchronize(slot->ev);
   }
+  slot->live = false;
   if (!slot->ev && hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
-  if (hipEventRecord(slot->ev, st) != hipSuccess) { (void)hipGetLastError(); slot->live = false; return; }
+  if (hipEventRecord(slot->ev, st) != hipSuccess) { (void)hipGetLastError(); return; }
   slot->st = st; slot->grid = grid; slot->live = true;
 }
 }  // namespace
