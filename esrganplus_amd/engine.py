@@ -35,6 +35,9 @@ def require_cuda(t, what):
             'there is no CPU fallback (use oracle/ for CPU reference results).' % (what, t.device))
 
 
+# ESR_SIDE=0: weight-gradient runs on the launch stream instead of the side stream (A/B)
+_SIDE = L.OPF_SIDE if os.environ.get('ESR_SIDE', '1') != '0' else 0
+
 class G32:
     """[B][ngroups][Hp][Wp][cpg] activation buffer with a physical zero halo."""
 
@@ -1234,7 +1237,7 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         else:
             # head / tail convs: their gradient and input buffers are written once per backward pass,
             # so these launches too can run next to the main chain
-            Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE)
+            Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=_SIDE)
 
     if block:
         GY = buf(64)
@@ -1474,10 +1477,10 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             rw.n_blocks, rw.tap_major, rw.scale5, rw.scale = len(deferred), 1, 0.2, 1.0
             rw.blocks = blk_t.data_ptr()
             rw.partial, rw.partial_elems = rdbw_arena.data_ptr(), rdbw_arena.numel()
-            Bk.add(L.OP_RDB_WGRAD, 'rdb_wgrad', rw, flags=L.OPF_SIDE)
+            Bk.add(L.OP_RDB_WGRAD, 'rdb_wgrad', rw, flags=_SIDE)
         else:
             for wg in deferred:
-                Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE)
+                Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=_SIDE)
         deferred = None
         if not block:
             close_segment(['model.1.sub.%d' % i])
