@@ -46,12 +46,17 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
   f32x4 bq[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) bq[i] = p.bias ? *(const f32x4*)(p.bias + cb * 32 + 16 * h + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-  Raw16<T> r1[R], r2[R];   // prefetched; explicit-z / mask operands (test & dgrad modes) load in phase 2
+  Raw16<T> r1[R], r2[R];   // prefetched; explicit-z operands (test mode) load in phase 2
+  // dgrad: the activation mask rides in r2's registers when there is no second residual (every dgrad conv of the
+  // networks here), so its R loads are in flight with the rest instead of one load -> use -> store chain per row
+  const bool mask_on = BWD && p.mask.ptr && cb >= p.mask_cb_begin;
+  const bool mask_pre = mask_on && !p.res2.ptr;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int oy = oyb + RS * r < p.H ? oyb + RS * r : p.H - 1;     // clamp: rows past the image are not stored
     if (p.res1.ptr) r1[r].load(p.res1, b, cb, h, (int64_t)(oy + 1) * p.res1.wp + ox + 1);
     if (p.res2.ptr) r2[r].load(p.res2, b, cb, h, (int64_t)(oy + 1) * p.res2.wp + ox + 1);
+    else if (mask_pre) r2[r].load(p.mask, b, cb - p.mask_cb_begin, h, (int64_t)(oy + 1) * p.mask.wp + ox + 1);
   }
   sfor<R>([&](auto RR) __attribute__((always_inline)) {
     constexpr int r = decltype(RR)::value;
@@ -111,9 +116,10 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
     }
     if (p.out.ptr) Px16<T>::store(p.out, b, cb, h, (int64_t)(oy + 1) * p.out.wp + ox + 1, v, (p.debug_flags >> 3) & 3);
     if constexpr (BWD) {
-    if (p.mask.ptr && cb >= p.mask_cb_begin) {
+    if (mask_on) {
       const int mb = cb - p.mask_cb_begin;
-      Px16<T>::load(p.mask, b, mb, h, (int64_t)(oy + 1) * p.mask.wp + ox + 1, tmp);
+      if (mask_pre) r2[r].get(tmp);
+      else Px16<T>::load(p.mask, b, mb, h, (int64_t)(oy + 1) * p.mask.wp + ox + 1, tmp);
       const float neg = p.mask_act == ESR_ACT_RELU ? 0.f : ESR_LRELU_SLOPE;
 #pragma unroll
       for (int e = 0; e < 16; ++e) tmp[e] = tmp[e] > 0.f ? v[e] : v[e] * neg;
