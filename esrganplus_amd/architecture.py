@@ -180,6 +180,8 @@ class _SeqNet(B._PlannedModule):
         xin = x.detach().contiguous().float()
         Bn, C_, H, W = xin.shape
         dev = xin.device
+        order = E.StreamOrder.of(self) if not need_bwd else None      # inference calls: one at a time per module
+        cur = order.enter() if order else None
         st = E.current_stream()
         wp = self._weights(dev)
         dp = None
@@ -213,7 +215,10 @@ class _SeqNet(B._PlannedModule):
             plan.fwd.array()[plan.in_op].u.layout.nchw = xin.data_ptr()
             plan.fwd.run(st)
         plan.keep_x = xin       # (num_batches_tracked is advanced by the BN finalize launches)
-        return plan.out_tensor.clone(), lease
+        y = plan.out_tensor.clone()
+        if order:
+            order.leave(cur)
+        return y, lease
 
     def forward(self, x):
         need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))

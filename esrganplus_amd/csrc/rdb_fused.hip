@@ -227,14 +227,15 @@ int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, i
   const int gpb = p->dtype == ESR_F16 ? 2 : 4;
   if (p->mode == 0 && p->dense.ngroups < 4 * gpb) { esr_set_error("%s: dense scratch needs 128 channels", who); return ESR_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
-  // flags / ticket / abort word restart at zero on every call (a memset node under graph capture)
+  const int grid = ntiles < cus ? ntiles : cus;
+  unsigned* const ha = abort_word_dev();
+  chain_order_before_launch(st, grid, cus);
+  // flags / ticket / abort word restart at zero on every call (a memset node under graph capture); behind the
+  // ordering wait, so that a workspace shared by launches on two streams is not cleared under the running one
   if (hipMemsetAsync(p->workspace, 0, esr_rdb_workspace_bytes(p->B, p->H, p->W), st) != hipSuccess) {
     esr_set_error("%s: hipMemsetAsync failed", who);
     return ESR_ERR_LAUNCH;
   }
-  const int grid = ntiles < cus ? ntiles : cus;
-  unsigned* const ha = abort_word_dev();
-  chain_order_before_launch(st, grid, cus);
   auto dispatch = [&]() -> int {
     if (p->band_rows != 0) {
       if (p->dtype != ESR_F16 && p->dtype != ESR_F32) { esr_set_error("%s: bad dtype %d", who, p->dtype); return ESR_ERR_INVALID; }

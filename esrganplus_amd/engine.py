@@ -758,6 +758,41 @@ def current_stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class StreamOrder:
+    """A module's launch plans own their activation buffers, packed weights and chain workspaces, so two inference
+    calls of ONE module from two streams must not overlap (torch modules are stateless in that respect; a second
+    stream is how users overlap independent work).  enter() makes the calling stream wait — on the device — for the
+    module's previous call when that ran on another stream; leave() marks the end of this call.  Skipped under
+    graph capture (the graph's order applies)."""
+
+    def __init__(self):
+        self.last = None
+        self.event = None
+
+    @staticmethod
+    def of(mod):
+        so = mod.__dict__.get('_stream_order')
+        if so is None:
+            so = mod.__dict__['_stream_order'] = StreamOrder()
+        return so
+
+    def enter(self):
+        cur = torch.cuda.current_stream()
+        if torch.cuda.is_current_stream_capturing():
+            return cur
+        if self.last is not None and self.last != cur.cuda_stream:
+            cur.wait_event(self.event)
+        return cur
+
+    def leave(self, cur):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self.event is None:
+            self.event = torch.cuda.Event()
+        self.event.record(cur)
+        self.last = cur.cuda_stream
+
+
 def use_rdb_wgrad():
     """fp16 training plans: the six weight gradients of a dense block as ONE esr_rdb_wgrad pass over its saved
     concat buffer and gradient concat (csrc/rdb_wgrad.hip) instead of six esr_conv_wgrad problems

@@ -68,6 +68,8 @@ def run_block(mod, kind, x, z=None):
     B, C_, H, W = xin.shape
     if C_ != 64:
         raise ValueError('expected 64 input channels, got %d' % C_)
+    order = E.StreamOrder.of(mod)
+    cur = order.enter()
     wp = mod._weights(xin.device)
     has_noise = getattr(mod, 'noise', None) is not None if kind == 'rdb' else True
     noise = bool(mod.training and has_noise)
@@ -81,6 +83,7 @@ def run_block(mod, kind, x, z=None):
         mod._plans = {key: plan}
     out = torch.empty(plan.out_shape, dtype=torch.float32, device=xin.device)
     plan.run(xin, out, E.current_stream(), _draw_seed() if (noise and zs is None) else 0, zs)
+    order.leave(cur)
     return out
 
 
@@ -325,6 +328,8 @@ def run_rrdbnet(net, x, z=None):
     B, C_, H, W = xin.shape
     if C_ != net.in_nc:
         raise ValueError('expected %d input channels, got %d' % (net.in_nc, C_))
+    order = E.StreamOrder.of(net)
+    cur = order.enter()
     wp = net._weights(xin.device)
     noise = bool(net.training)
     per = 4 if net.variant == 'test_image' else 3
@@ -339,4 +344,5 @@ def run_rrdbnet(net, x, z=None):
         net._plans[key] = plan
     out = torch.empty(plan.out_shape, dtype=torch.float32, device=xin.device)
     plan.run(xin, out, E.current_stream(), _draw_seed() if (noise and zs is None) else 0, zs)
+    order.leave(cur)
     return out

@@ -295,6 +295,29 @@ def test_chains_launched_on_two_streams_do_not_starve_each_other(dev):
             assert torch.equal(y, want_s[i])
 
 
+def test_chains_on_more_streams_than_the_ordering_table_holds(dev):
+    """Twelve streams, each with whole-GPU chain launches in flight: more than the library's table of in-flight
+    launches (8 streams) — the overflow path waits for the oldest on the host; results equal the serial ones."""
+    from esrganplus_amd import architecture as arch, _lib as L
+    net = arch.RRDBNet(3, 3, 64, 2).to(dev).eval().set_precision('fp16')
+    net.load_state_dict(synth.rrdbnet_state_dict(2, 27))
+    x = synth.image_batch(45, 16, 3, 128, 128, name='12s.x').to(dev)
+    with torch.no_grad():
+        want = net(x)
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=dev) for _ in range(12)]
+        got = []
+        for rep in range(2):
+            for s in streams:
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    got.append(net(x))
+        torch.cuda.synchronize()
+    assert not L.lib().esr_rdb_check_abort()
+    for y in got:
+        assert torch.equal(y, want)
+
+
 def test_philox_stream_statistics(dev):
     """The fused noise stream (Philox-4x32-7 + 16-bit Box-Muller, csrc/common.h) as a distribution: moments of
     N(0,1), the tail it can represent, and no correlation between neighbouring channels / pixels / layers / seeds."""
