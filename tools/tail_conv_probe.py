@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import conv_probe as P   # noqa: E402
 
 P.B, P.H, P.W, P.REP = 16, 512, 512, 6
-print('cin cout | full   noEpi  noMMA  noDMA  noMMA+noDMA  noEpi+noMMA  all-off   [us per launch]')
+print('cin cout | full   noEpi  noMMA  noDMA  noMMA+noDMA  noEpi+noMMA  all-off  nt-store  flavour2  contiguous-store(wrong layout)   [us per launch]')
 for cin, cout in ((64, 64), (64, 3), (16, 64)):
-    r = [P.probe(cin, cout, 0, f) for f in (0, 1, 2, 4, 6, 3, 7)]
+    r = [P.probe(cin, cout, 0, f) for f in (0, 1, 2, 4, 6, 3, 7, 8, 16, 24)]
     print('%3d %3d | %s' % (cin, cout, '  '.join('%6.1f' % v for v in r)))
