@@ -51,6 +51,8 @@ template <> struct Px16<_Float16> {
     if (flavour == 1) {          // non-temporal (measured +1 % on the forward bench, profiles/)
       __builtin_nontemporal_store(a, (u32x4*)p);
       __builtin_nontemporal_store(c, (u32x4*)(p + 16));
+    } else if (flavour == 2) {   // measurement-only (NO output): the epilogue's arithmetic without its store instructions
+      if (a[0] == 0x7fc07fc1u && c[3] == 0x12345678u) *(u32x4*)p = a;      // (keeps the values alive)
     } else if (flavour == 3) {   // measurement-only (WRONG layout): each store instruction of a half-wave
                                  // covers 512 contiguous bytes instead of every other 16 bytes of 1 KB
       const int j = __lane_id() & 31;
