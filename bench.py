@@ -138,10 +138,26 @@ def cpu_baseline(seconds_budget=25.0):
             'cpu_model': model}
 
 
-def train_bench(args, world, rank, dev, dist):
-    """BASELINE configs[2]/[3]: full ESRGAN+ train step (RRDBNet + Discriminator_VGG_128 + VGG19
-    feature loss, Adam x2; train_ESRGANplus.json), per-GPU batch 16 of 32x32 LR -> 128x128 HR, data
-    parallel over RCCL with the gradient exchange overlapped on the other network's pass."""
+TRAIN_STEP_MAC = 1.515e12               # conv/linear MACs of one batch-16 ESRGAN+ step (G + D + VGG, fwd + bwd)
+
+
+def _max_over_ranks(elapsed, dist, dev):
+    if dist is None:
+        return elapsed
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _sync_all(dist):
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def make_train_step(args, rank, dev, data_parallel):
+    """The three networks + optimizers of BASELINE configs[2]/[3] (train_ESRGANplus.json) on synthetic weights."""
     from esrganplus_amd import architecture as arch, synth, train, dp as DP
     prec = args.precision
     netG = arch.RRDBNet(3, 3, 64, NB).to(dev).train().set_precision(prec)
@@ -150,105 +166,266 @@ def train_bench(args, world, rank, dev, dist):
     netG.load_state_dict(synth.rrdbnet_state_dict(NB, 0, gain=0.5))
     netD.load_state_dict(synth.discriminator_state_dict(0))
     netF.load_state_dict(synth.vgg19_state_dict(0, 34), strict=False)
-    for n in (netG, netD):
-        DP.broadcast_parameters(n)
-    st = train.ESRGANPlusStep(netG, netD, netF, loss_scale=1024.0 if prec == 'fp16' else 1.0)
+    if data_parallel:
+        for n in (netG, netD):
+            DP.broadcast_parameters(n)
+    st = train.ESRGANPlusStep(netG, netD, netF, loss_scale=1024.0 if prec == 'fp16' else 1.0,
+                              data_parallel=data_parallel)
     tb = args.train_batch
     lr = synth.image_batch(200 + rank, tb, 3, 32, 32, name='bench.lr').to(dev)
     hr = synth.image_batch(300 + rank, tb, 3, 128, 128, name='bench.hr').to(dev)
-    for _ in range(max(args.warmup, 1)):
+    return st, lr, hr
+
+
+def measure_train(args, world, rank, dev, dist, steps, warmup, data_parallel=None):
+    """ms per full ESRGAN+ step (max over ranks) + the step object (kept for the per-kernel pass)."""
+    dp_on = (world > 1) if data_parallel is None else data_parallel
+    st, lr, hr = make_train_step(args, rank, dev, dp_on)
+    for _ in range(max(warmup, 1)):
         st.step(lr, hr, sync_log=False)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-        torch.cuda.synchronize()
+    _sync_all(dist if dp_on or dist is not None else None)
+    if dp_on:
+        st.comm_reset()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         log = st.step(lr, hr, sync_log=False)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = _max_over_ranks(time.perf_counter() - t0, dist, dev)
     assert all(torch.isfinite(v).all() for v in log.values())
+    return elapsed / steps, st, (lr, hr)
+
+
+def train_object(args, world, rank, dev, dist, steps, warmup, kernels=True):
+    """BASELINE configs[2]: the full ESRGAN+ train step on ONE GPU's batch (no exchange), as an object of the
+    default bench line: ms/step, TFLOP/s against SURVEY §8a's 1.515 TMAC per batch-16 step, and the generator's
+    fused kernels (the dominant launches of the step) timed with HIP events."""
+    dt, st, (lr, hr) = measure_train(args, 1, rank, dev, None, steps, warmup, data_parallel=False)
+    tb = args.train_batch
+    fl = 2.0 * TRAIN_STEP_MAC * tb / 16
+    res = {'ms_per_step': round(dt * 1e3, 3), 'value': round(tb * 128 * 128 / 1e6 / dt, 3), 'unit': 'HR-Mpix/s',
+           'tflops': round(fl / dt / 1e12, 1), 'frac_of_f16_mfma_peak': round(fl / dt / 1e12 / PEAK_F16_TFLOPS, 4),
+           'steps': steps, 'warmup': warmup,
+           'what': 'full ESRGAN+ train step (RRDBNet nb=23 noise on + Discriminator_VGG_128 + VGG19[:35] feature loss, '
+                   'Adam x2, loss scale 1024), batch %d of 32x32 LR -> 128x128 HR, %s (BASELINE configs[2])'
+                   % (tb, args.precision)}
+    if kernels and args.precision == 'fp16':
+        k = generator_kernel_times(st.netG, lr, tb, 32)
+        if k:
+            res.update(k)
+    return res, st
+
+
+def generator_kernel_times(netG, lr, batch, size, reps=5):
+    """HIP-event times of the generator's recorded training launch lists (same buffers as a real step): the fused
+    dense-block kernels by name, the slowest of them as the `roofline` object."""
+    from esrganplus_amd import engine as E, functional as Fn, _lib as L
+    tps = [t for k, pool in netG._plans.items() if isinstance(k, tuple) and k and k[0] == 'train' for t in pool]
+    tps = [t for t in tps if t.fwd.out_shape[0] == batch and t.fwd.out_shape[2] == 4 * size and not t.graph]
+    if not tps:
+        return None
+    tp = tps[0]
+    dev = lr.device
+    st = E.current_stream()
+    out = torch.empty(tp.fwd.out_shape, dtype=torch.float32, device=dev)
+    gy = torch.full(tp.fwd.out_shape, 1024.0 / out.numel(), dtype=torch.float32, device=dev)
+    blk_fl = 2.0 * RDB_MAC_PER_PIXEL * batch * size * size          # per dense block, any of the three passes
+
+    def name_of(o):
+        if o.kind == L.OP_RDB_CHAIN:
+            return 'rdb_chain_train', blk_fl * o.u.rdb_chain.n_blocks
+        if o.kind == L.OP_RDB_CHAIN_BWD:
+            return 'rdb_chain_bwd', blk_fl * o.u.rdb_chain.n_blocks
+        if o.kind == L.OP_RDB_WGRAD:
+            return 'rdb_wgrad', blk_fl * o.u.rdb_wgrad.n_blocks
+        if o.kind == L.OP_WGRAD:
+            w = o.u.wgrad
+            return 'wgrad', 2.0 * w.B * w.H * w.W * w.cout * w.cin * w.ks * w.ks
+        if o.kind == L.OP_CONV:
+            return 'conv (head / tail / their dgrad)', 0.0
+        return 'other (layout, pack, unpermute)', 0.0
+
+    agg = {}
+    for rep in range(reps + 1):
+        tp.fwd.run(lr, out, st, 1234, None)                  # binds I/O + seed (untimed), then the timed replay
+        ms_f = tp.fwd.ops.run_timed(st)
+        Fn._train_backward(tp, gy, st, True, False, 1234, False)
+        ms_b = tp.bwd.run_timed(st, tp.gx_begin)     # (the ops behind gx_begin give dL/dx: not part of a training step)
+        if rep == 0:
+            continue
+        for ops, ms in ((tp.fwd.ops.ops, ms_f), (tp.bwd.ops, ms_b)):
+            for o, t in zip(ops, ms):
+                nm, f = name_of(o)
+                a = agg.setdefault(nm, [0.0, 0.0, 0])
+                a[0] += t
+                a[1] += f
+                a[2] += 1
+    res = {'kernels': {k: {'launches': a[2] // reps, 'ms_per_step': round(a[0] / reps, 3),
+                           'tflops': round(a[1] / (a[0] * 1e-3) / 1e12, 1) if a[1] else 0.0}
+                       for k, a in sorted(agg.items())}}
+    fused = [k for k in ('rdb_chain_train', 'rdb_chain_bwd', 'rdb_wgrad') if k in agg]
+    if fused:
+        dom = max(fused, key=lambda k: agg[k][0])
+        t_ms, f, n = agg[dom]
+        ach = f / (t_ms * 1e-3) / 1e12
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')))
+            if dom in tj and batch == BATCH and size == LR:
+                traffic = tj[dom]['read_bytes'] + tj[dom]['write_bytes']
+        except (OSError, ValueError, KeyError):
+            pass
+        res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_F16_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
+                           'launches_per_step': n // reps, 'avg_launch_us': round(t_ms / n * 1e3, 2),
+                           'share_of_kernel_time': round(t_ms / reps / (sum(a[0] for a in agg.values()) / reps), 3)}
+    return res
+
+
+def dp_train_object(args, world, rank, dev, dist, steps=20, warmup=3):
+    """BASELINE configs[3] at world > 1: the SAME train step data-parallel over the process group (RCCL; gloo only
+    for one-GPU dry runs) next to this process's own no-exchange figure — bytes all-reduced per step, the time the
+    compute streams spent blocked on the exchanges (HIP events around the waits), per-GPU step time with and
+    without the exchange."""
+    dt1, st1, _ = measure_train(args, 1, rank, dev, dist, steps, warmup, data_parallel=False)
+    del st1
+    torch.cuda.empty_cache()
+    dtn, st, _ = measure_train(args, world, rank, dev, dist, steps, warmup, data_parallel=True)
+    comm = st.comm_report()
+    nG = sum(p.numel() for p in st.netG.parameters() if p.requires_grad)
+    nD = sum(p.numel() for p in st.netD.parameters())
+    tb = args.train_batch
+    t = torch.tensor([comm['exposed_ms_per_step']], dtype=torch.float64,
+                     device=dev if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return {'n_ranks': dist.get_world_size(), 'backend': dist.get_backend(),
+            'ms_per_step': round(dtn * 1e3, 3), 'ms_per_step_no_exchange': round(dt1 * 1e3, 3),
+            'value': round(world * tb * 128 * 128 / 1e6 / dtn, 3), 'unit': 'HR-Mpix/s', 'scaling': 'weak',
+            'allreduce_bytes_per_step': 4 * (nG + nD) + 4 * 10,
+            'allreduce_calls_per_step': comm['calls_per_step'],
+            'exposed_comm_ms_per_step': round(float(t.item()), 3),
+            'steps': steps, 'warmup': warmup,
+            'what': 'ESRGAN+ train step, batch %d of 32x32 LR per rank, G gradients all-reduced in buckets inside the '
+                    'backward (per RRDB), D gradients under the G backward, global-batch RaGAN means '
+                    '(BASELINE configs[3])' % tb}
+
+
+def train_bench(args, world, rank, dev, dist):
+    """BASELINE configs[2]/[3]: full ESRGAN+ train step (RRDBNet + Discriminator_VGG_128 + VGG19
+    feature loss, Adam x2; train_ESRGANplus.json), per-GPU batch 16 of 32x32 LR -> 128x128 HR, data
+    parallel over RCCL with the gradient exchange overlapped on the other network's pass."""
+    dt, st, _ = measure_train(args, world, rank, dev, dist, args.steps, args.warmup)
+    tb = args.train_batch
     if rank == 0:
-        step_flops = 2.0 * 1.515e12 * tb / 16          # ~1.515 TMAC per batch-16 step
+        step_flops = 2.0 * TRAIN_STEP_MAC * tb / 16
         res = {'metric': 'HR megapixels/sec (x4 SR) full ESRGAN+ train step', 'unit': 'HR-Mpix/s',
-               'value': round(world * tb * 128 * 128 / 1e6 / (elapsed / args.steps), 3), 'n_gpus': world,
-               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+               'value': round(world * tb * 128 * 128 / 1e6 / dt, 3), 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt * 1e3, 3),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f16' if prec == 'fp16' else 'f32', 'data': 'synthetic',
+               'dtype': 'f16' if args.precision == 'fp16' else 'f32', 'data': 'synthetic',
                'config': {'workload': 'ESRGAN+ train step (RRDBNet nb=23 + Discriminator_VGG_128 + VGG19[:35] '
                                       'feature loss, Adam x2), batch %d of 32x32 LR per GPU (BASELINE configs[2]/[3])' % tb,
                           'global_batch': world * tb, 'parallelism': 'dp%d, RCCL grad all-reduce overlapped' % world},
-               'tflops_per_gpu': round(step_flops / (elapsed / args.steps) / 1e12, 1)}
+               'tflops_per_gpu': round(step_flops / dt / 1e12, 1)}
+        if world > 1:
+            res['comm'] = st.comm_report()
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def gtrain_bench(args, world, rank, dev, dist):
+GTRAIN_BUCKETS = ((16, 128), (8, 192), (4, 256))
+
+
+def measure_gtrain(args, world, rank, dev, dist, steps, warmup):
     """BASELINE configs[4]: the noise-injection generator in TRAIN mode (noise
     on), forward + backward + Adam with an L1 pixel loss, on mixed LR tiles bucketed by size
     (128/192/256 -> HR 512/768/1024).  The reference's discriminators only accept HR 96/128/192
     crops, so at these sizes there is no GAN step to reproduce: generator-only, as SURVEY.md reads it.
-    One bench "step" = one optimizer iteration per bucket (16x128^2, 8x192^2, 4x256^2 LR per GPU: ~45 GB of saved activations, sized for 288 GB HBM)."""
-    import torch.nn.functional as F
-    from esrganplus_amd import architecture as arch, synth, dp as DP
+    One bench "step" = one optimizer iteration per bucket (16x128^2, 8x192^2, 4x256^2 LR per GPU: ~45 GB of saved
+    activations, sized for 288 GB HBM).  Returns (seconds per step, per-bucket ms from HIP events, lr pixels)."""
+    from esrganplus_amd import architecture as arch, synth, dp as DP, losses as LS
     prec = args.precision
     netG = arch.RRDBNet(3, 3, 64, NB).to(dev).train().set_precision(prec)
     netG.load_state_dict(synth.rrdbnet_state_dict(NB, 0, gain=0.5))
-    DP.broadcast_parameters(netG)
+    if world > 1:
+        DP.broadcast_parameters(netG)
     from esrganplus_amd.optim import FusedAdam
     opt = FusedAdam(netG.parameters(), lr=1e-4, betas=(0.9, 0.999))
     ex = DP.GradExchange(netG)
-    scale = 1024.0 if prec == 'fp16' else 1.0
+    scale = torch.full((), 1024.0 if prec == 'fp16' else 1.0, dtype=torch.float32, device=dev)
+    inv = 1.0 / float(scale)
     buckets = []
-    for k, (n, sz) in enumerate(((16, 128), (8, 192), (4, 256))):
+    for k, (n, sz) in enumerate(GTRAIN_BUCKETS):
         lr = synth.image_batch(400 + 10 * rank + k, n, 3, sz, sz, name='bench.glr').to(dev)
         hr = synth.image_batch(500 + 10 * rank + k, n, 3, 4 * sz, 4 * sz, name='bench.ghr').to(dev)
         buckets.append((lr, hr))
     lr_pix = sum(l.shape[0] * l.shape[2] * l.shape[3] for l, _ in buckets)
+    marks = []
 
-    def step():
+    def step(timed=False):
         for lr, hr in buckets:
+            if timed:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append(e)
             opt.zero_grad(set_to_none=True)
-            loss = F.l1_loss(netG(lr), hr)
-            (loss * scale).backward()
+            loss = LS.l1_loss(netG(lr), hr)
+            torch.autograd.backward([loss], [scale])
             ex.start()
             ex.wait()
-            opt.step(grad_scale=1.0 / scale)
+            opt.step(grad_scale=inv)
+        if timed:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(e)
         return loss
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-        torch.cuda.synchronize()
+    _sync_all(dist)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    for _ in range(steps):
+        loss = step(True)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = _max_over_ranks(time.perf_counter() - t0, dist, dev)
     assert torch.isfinite(loss).all()
+    nbk = len(buckets) + 1
+    per = [0.0] * len(buckets)
+    for s_ in range(steps):
+        ev = marks[s_ * nbk:(s_ + 1) * nbk]
+        for k in range(len(buckets)):
+            per[k] += ev[k].elapsed_time(ev[k + 1]) / steps
+    return elapsed / steps, per, lr_pix
+
+
+def gtrain_fields(dt, per, lr_pix, world=1):
+    step_flops = 3.0 * 2.0 * MAC_PER_LR_PIXEL * lr_pix      # fwd + dgrad + wgrad (first-layer dgrad omitted: <0.1 %)
+    bk = {}
+    for (n, sz), ms in zip(GTRAIN_BUCKETS, per):
+        fl = 3.0 * 2.0 * MAC_PER_LR_PIXEL * n * sz * sz
+        tiles = ((sz + 15) // 16) * ((sz + 31) // 32)
+        bk['%dx%d^2' % (n, sz)] = {'ms': round(ms, 3), 'tflops': round(fl / (ms * 1e-3) / 1e12, 1),
+                                   'frac_of_f16_mfma_peak': round(fl / (ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
+                                   'tiles_16x32_per_image': tiles, 'workgroups': n * tiles}
+    return {'ms_per_step': round(dt * 1e3, 3), 'value': round(world * 16 * lr_pix / 1e6 / dt, 3), 'unit': 'HR-Mpix/s',
+            'tflops_per_gpu': round(step_flops / dt / 1e12, 1),
+            'frac_of_f16_mfma_peak': round(step_flops / dt / 1e12 / PEAK_F16_TFLOPS, 4), 'buckets': bk}
+
+
+def gtrain_bench(args, world, rank, dev, dist):
+    dt, per, lr_pix = measure_gtrain(args, world, rank, dev, dist, args.steps, args.warmup)
     if rank == 0:
-        step_flops = 3.0 * 2.0 * MAC_PER_LR_PIXEL * lr_pix      # fwd + dgrad + wgrad (first-layer dgrad omitted: <0.1 %)
+        f = gtrain_fields(dt, per, lr_pix, world)
         res = {'metric': 'HR megapixels/sec (x4 SR) generator train step (noise on, L1)', 'unit': 'HR-Mpix/s',
-               'value': round(world * 16 * lr_pix / 1e6 / (elapsed / args.steps), 3), 'n_gpus': world,
-               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+               'value': f['value'], 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': f['ms_per_step'],
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f16' if prec == 'fp16' else 'f32', 'data': 'synthetic',
+               'dtype': 'f16' if args.precision == 'fp16' else 'f32', 'data': 'synthetic',
                'config': {'workload': 'nESRGAN+ generator (RRDBNet nb=23, GaussianNoise on) fwd+bwd+Adam, L1 loss, mixed LR '
                                       'tiles bucketed by size: 16x128^2 + 8x192^2 + 4x256^2 per GPU per step (BASELINE configs[4])',
                           'lr_pixels_per_gpu_step': lr_pix, 'parallelism': 'dp%d, RCCL grad all-reduce per bucket' % world},
-               'tflops_per_gpu': round(step_flops / (elapsed / args.steps) / 1e12, 1)}
+               'tflops_per_gpu': f['tflops_per_gpu'], 'buckets': f['buckets']}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
@@ -263,7 +440,7 @@ def fwd_bwd_probe(args, dev, steps=20):
     `roofline` object: the three fused dense-block kernels (training forward chain, backward chain, weight
     gradients) timed with HIP events on the launch stream, the slowest of them named as the dominant kernel."""
     import torch.nn.functional as F
-    from esrganplus_amd import architecture as arch, synth, engine as E, functional as Fn, _lib as L
+    from esrganplus_amd import architecture as arch, synth
     netG = arch.RRDBNet(3, 3, 64, NB).to(dev).train().set_precision('fp16')
     netG.load_state_dict(synth.rrdbnet_state_dict(NB, 0, gain=0.5))
     lr = synth.image_batch(300, args.batch, 3, args.lr, args.lr, name='bench.fb.lr').to(dev)
@@ -292,64 +469,9 @@ def fwd_bwd_probe(args, dev, steps=20):
            'what': 'RRDBNet x4 train-mode forward (noise on) + backward (dgrad + wgrad, loss scale 1024), '
                    'batch %d of %dx%d LR, fp16, no optimizer step' % (args.batch, args.lr, args.lr)}
 
-    # ---- per-kernel HIP-event timing of the two recorded launch lists (same buffers, same seed as a real step)
-    tp = next(t for k, pool in netG._plans.items() if isinstance(k, tuple) and k and k[0] == 'train' for t in pool)
-    st = E.current_stream()
-    out = torch.empty(tp.fwd.out_shape, dtype=torch.float32, device=dev)
-    gy = torch.full(tp.fwd.out_shape, 1024.0 / out.numel(), dtype=torch.float32, device=dev)
-    if tp.graph:
-        return res
-    blk_fl = 2.0 * RDB_MAC_PER_PIXEL * args.batch * args.lr * args.lr          # per dense block, any of the three passes
-
-    def name_of(o):
-        if o.kind == L.OP_RDB_CHAIN:
-            return 'rdb_chain_train', blk_fl * o.u.rdb_chain.n_blocks
-        if o.kind == L.OP_RDB_CHAIN_BWD:
-            return 'rdb_chain_bwd', blk_fl * o.u.rdb_chain.n_blocks
-        if o.kind == L.OP_RDB_WGRAD:
-            return 'rdb_wgrad', blk_fl * o.u.rdb_wgrad.n_blocks
-        if o.kind == L.OP_WGRAD:
-            w = o.u.wgrad
-            return 'wgrad', 2.0 * w.B * w.H * w.W * w.cout * w.cin * w.ks * w.ks
-        if o.kind == L.OP_CONV:
-            return 'conv (head / tail / their dgrad)', 0.0
-        return 'other (layout, pack, unpermute)', 0.0
-
-    agg = {}
-    reps = 5
-    for rep in range(reps + 1):
-        tp.fwd.run(lr, out, st, 1234, None)                  # binds I/O + seed (untimed), then the timed replay
-        ms_f = tp.fwd.ops.run_timed(st)
-        Fn._train_backward(tp, gy, st, True, False, 1234, False)
-        ms_b = tp.bwd.run_timed(st)
-        if rep == 0:
-            continue
-        for ops, ms in ((tp.fwd.ops.ops, ms_f), (tp.bwd.ops, ms_b)):
-            for o, t in zip(ops, ms):
-                nm, f = name_of(o)
-                a = agg.setdefault(nm, [0.0, 0.0, 0])
-                a[0] += t
-                a[1] += f
-                a[2] += 1
-    fused = [k for k in ('rdb_chain_train', 'rdb_chain_bwd', 'rdb_wgrad') if k in agg]
-    res['kernels'] = {k: {'launches': a[2] // reps, 'ms_per_step': round(a[0] / reps, 3),
-                          'tflops': round(a[1] / (a[0] * 1e-3) / 1e12, 1) if a[1] else 0.0}
-                      for k, a in sorted(agg.items())}
-    if fused:
-        dom = max(fused, key=lambda k: agg[k][0])
-        t_ms, f, n = agg[dom]
-        ach = f / (t_ms * 1e-3) / 1e12
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')))
-            if dom in tj and args.batch == BATCH and args.lr == LR:
-                traffic = tj[dom]['read_bytes'] + tj[dom]['write_bytes']
-        except (OSError, ValueError, KeyError):
-            pass
-        res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_F16_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
-                           'launches_per_step': n // reps, 'avg_launch_us': round(t_ms / n * 1e3, 2),
-                           'share_of_step_time': round(t_ms / reps / (sum(a[0] for a in agg.values()) / reps), 3)}
+    k = generator_kernel_times(netG, lr, args.batch, args.lr)
+    if k:
+        res.update(k)
     return res
 
 
@@ -362,6 +484,9 @@ def main():
     ap.add_argument('--lr', type=int, default=LR)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fwd-bwd', action='store_true', help='forward mode: skip the fwd+bwd side measurement')
+    ap.add_argument('--dp-steps', type=int, default=20, help='timed steps of the dp_train object (N > 1); 3 warm-up steps')
+    ap.add_argument('--no-train', action='store_true',
+                    help='forward mode: skip the train_step / gtrain objects (N = 1) and the dp_train object (N > 1)')
     ap.add_argument('--mode', choices=['forward', 'train', 'gtrain'], default='forward',
                     help="'forward' = BASELINE configs[1] (the headline metric); 'train' = configs[2]/[3]: "
                          'full ESRGAN+ step, batch 16 of 32x32 LR per GPU, DP over RCCL; '
@@ -411,13 +536,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # set-up, not measurement: the first forward builds the launch plan and packs the weights, and the first ~10
-    # forwards of a process run 1-2 % below the steady state (tools/step_trend.py) — when the caller asks for fewer
-    # warm-up steps than that, the difference is run here, before the W warm-up steps the contract names
-    settle = max(0, 10 - args.warmup)
-    with torch.no_grad():
-        for _ in range(settle):
-            net(x)
+    # exactly W warm-up steps, as the contract says (the first forward builds the launch plan and packs the weights; the
+    # first ~10 forwards of a process run 1-2 % below the steady state, tools/step_trend.py — a caller who asks for
+    # fewer warm-up steps than that measures that)
     with torch.no_grad():
         for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
             y = net(x)
@@ -440,7 +561,6 @@ def main():
 
     res = {'metric': 'HR megapixels/sec (x4 SR) RRDBNet forward', 'value': round(value, 2),
            'unit': 'HR-Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-           'settle_steps': settle,
            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
            'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
            'config': {'workload': 'RRDBNet x4 (23 RRDB, nf=64, gc=32) fp16 forward-only, batch %d of '
@@ -499,8 +619,28 @@ def main():
             net = None
             torch.cuda.empty_cache()
             res['fwd_bwd'] = fwd_bwd_probe(args, dev)
+        if world == 1 and not args.no_train:
+            # BASELINE configs[2] and configs[4] next to the headline, so that the driver's line carries them
+            torch.cuda.empty_cache()
+            res['train_step'], st_ = train_object(args, 1, 0, dev, None, steps=30, warmup=5)
+            del st_
+            torch.cuda.empty_cache()
+            dt, per, lr_pix = measure_gtrain(args, 1, 0, dev, None, steps=5, warmup=2)
+            res['gtrain'] = dict(gtrain_fields(dt, per, lr_pix), steps=5, warmup=2,
+                                 what='nESRGAN+ generator (noise on) fwd+bwd+Adam, L1 loss, 16x128^2 + 8x192^2 + 4x256^2 '
+                                      'LR tiles per step, fp16 (BASELINE configs[4], one GPU)')
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
+    if world > 1 and not args.no_train:
+        # BASELINE configs[3]: every rank runs the data-parallel train step (the collective path of this repo); the
+        # forward headline above has no data-path collective (independent tiles)
+        net = None
+        torch.cuda.empty_cache()
+        dpo = dp_train_object(args, world, rank, dev, dist, steps=args.dp_steps)
+        if rank == 0:
+            res['dp_train'] = dpo
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -336,11 +336,12 @@ class OpList:
             self._arr = (esr_op * len(self.ops))(*self.ops)
         return self._arr
 
-    def run_timed(self, stream):
-        """Measurement only: per-op elapsed ms (hipEvents on `stream`; synchronises)."""
+    def run_timed(self, stream, n=None):
+        """Measurement only: per-op elapsed ms of the first n ops (default: all; hipEvents on `stream`; synchronises)."""
         arr = self.array()
-        ms = (C.c_float * len(self.ops))()
-        check(lib().esr_run_ops_timed(C.cast(arr, C.c_void_p), len(self.ops), C.c_void_p(stream),
+        n = len(self.ops) if n is None else n
+        ms = (C.c_float * n)()
+        check(lib().esr_run_ops_timed(C.cast(arr, C.c_void_p), n, C.c_void_p(stream),
                                       C.cast(ms, C.c_void_p)), 'esr_run_ops_timed')
         return list(ms)
 

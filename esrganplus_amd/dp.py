@@ -83,11 +83,24 @@ def flat_grad_spans(params):
 class GradExchange:
     """Mean all-reduce of a module's gradients, bucketed, asynchronous."""
 
-    def __init__(self, module, bucket_bytes=32 << 20, overlap=True):
+    def __init__(self, module, bucket_bytes=32 << 20, overlap=True, enabled=True, measure=False):
+        # enabled=False: a no-op stand-in (one rank's own step inside a multi-rank job: bench.py's no-exchange figure)
+        # measure=True: HIP events around every wait on the compute stream -> exposed_ms() (bench.py dp_train)
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.bucket_bytes = bucket_bytes
         self.handles = []
         self._staged = []
+        self.enabled = bool(enabled)
+        self.measure = bool(measure)
+        self.calls = 0
+        self.bytes = 0
+        self._events = []
+        if not self.enabled:
+            self.inline = False
+            self.bucket_elems = max(1, bucket_bytes // 4)
+            if getattr(module, '_grad_sync', None) is not None:
+                module.attach_grad_sync(None)
+            return
         # In-backward exchange (networks.py:105-107 reduces implicitly inside DataParallel's backward): a module
         # whose backward is one fused node (RRDBNet) runs it in segments and calls `reduce_slice` on every
         # finished span of its flat gradient buffer, so the all-reduce of the last layers' gradients runs
@@ -104,10 +117,35 @@ class GradExchange:
         the kernels that wrote it).  Returns the work handle (None on one rank)."""
         if world_size() == 1:
             return None
+        self.calls += 1
+        self.bytes += flat_slice.numel() * flat_slice.element_size()
         if dist.get_backend() == 'nccl':
             return dist.all_reduce(flat_slice, op=dist.ReduceOp.AVG, async_op=True)
         flat_slice.div_(float(world_size()))            # gloo has no AVG
         return dist.all_reduce(flat_slice, async_op=True)
+
+    def wait_handles(self, handles):
+        """Make the current stream wait for these exchanges; with measure=True the wait is bracketed by HIP events on
+        that stream: their distance is the time the compute stream spent blocked on communication."""
+        handles = [h for h in handles if h is not None]
+        if not handles:
+            return
+        if self.measure and torch.cuda.is_available():
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for h in handles:
+            h.wait()
+        if self.measure and torch.cuda.is_available():
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._events.append((e0, e1))
+
+    def reset_counters(self):
+        self.calls, self.bytes, self._events = 0, 0, []
+
+    def exposed_ms(self):
+        """Sum over the measured waits (call after a device synchronize)."""
+        return sum(a.elapsed_time(b) for a, b in self._events)
 
     def _flat_groups(self):
         """Group parameter grads by underlying storage: grads that are views of one flat tensor
@@ -123,7 +161,7 @@ class GradExchange:
     def start(self):
         """Issue the all-reduces (async).  Call right after ``loss.backward()``."""
         self.handles, self._staged = [], []
-        if world_size() == 1 or self.inline:
+        if world_size() == 1 or self.inline or not self.enabled:
             return
         ws = float(world_size())
         for _, ps in self._flat_groups().items():
@@ -141,8 +179,13 @@ class GradExchange:
                     # last slices first: they belong to the layers whose backward finished first
                     for s in range(((hi - lo - 1) // step) * step, -1, -step):
                         chunk = flat[s:s + step]
-                        chunk.div_(ws)
-                        self.handles.append(dist.all_reduce(chunk, async_op=True))
+                        self.calls += 1
+                        self.bytes += chunk.numel() * esz
+                        if dist.get_backend() == 'nccl':
+                            self.handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True))
+                        else:
+                            chunk.div_(ws)
+                            self.handles.append(dist.all_reduce(chunk, async_op=True))
                     continue
             # generic path: stage into a bucket, reduce, copy back on wait()
             bucket, size = [], 0
@@ -157,13 +200,14 @@ class GradExchange:
 
     def _launch_bucket(self, ps, ws):
         flat = torch.cat([p.grad.reshape(-1) for p in ps]).div_(ws)
+        self.calls += 1
+        self.bytes += flat.numel() * flat.element_size()
         self.handles.append(dist.all_reduce(flat, async_op=True))
         self._staged.append((flat, ps))
 
     def wait(self):
         """Block the current stream on the exchange; call right before ``optimizer.step()``."""
-        for h in self.handles:
-            h.wait()
+        self.wait_handles(self.handles)
         for flat, ps in self._staged:
             off = 0
             for p in ps:

@@ -1001,7 +1001,8 @@ class TrainPlan:
         self.grad_flat = None        # fp32 flat gradient buffer; views per parameter
         self.grad_views = None
         self.tapmajor = None
-        self.gx_op = None            # stand-alone blocks: layout op exporting dL/dx (NCHW fp32)
+        self.gx_op = None            # op exporting dL/dx (NCHW fp32): a layout op (stand-alone blocks) or fea_conv's dgrad
+        self.gx_begin = None         # whole generator: ops [gx_begin, end) produce dL/dx and run only when it is wanted
         self.segments = None         # segmented backward: [(op_end, elem_lo, elem_hi)] — after ops [.., op_end) the
                                      # gradients in flat[elem_lo:elem_hi] are final (see build_rrdbnet_train_plan)
         self.graph = False           # hipGraph replay with I/O bound to the static tensors below
@@ -1038,7 +1039,10 @@ class TrainPlan:
         barr = self.bwd.array()
         barr[self.gy_op].u.layout.nchw = self.gy_static.data_ptr()
         if self.gx_op is not None:
-            barr[self.gx_op].u.layout.nchw = self.gx_static.data_ptr()
+            if barr[self.gx_op].kind == L.OP_CONV:
+                barr[self.gx_op].u.conv.nchw_out = self.gx_static.data_ptr()
+            else:
+                barr[self.gx_op].u.layout.nchw = self.gx_static.data_ptr()
         for i in self.bwd_noise_ops:
             barr[i].u.conv.noise_mode = L.NOISE_PHILOX
             barr[i].u.conv.seed_dev = self.seed_t.data_ptr()
@@ -1546,5 +1550,13 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         TP.segments = segs
     if block:
         TP.gx_op = Bk.add(L.OP_LAYOUT, 'layout', gx_layout)
+    else:
+        # dL/dx of the whole generator (autograd through architecture.py:76-78 when the LR input requires a gradient):
+        # fea_conv's input gradient, written straight into the caller's NCHW tensor.  Recorded at the END of the list
+        # and only run on request (TrainPlan.gx_begin: functional._train_backward stops there otherwise).
+        TP.gx_begin = len(Bk.ops)
+        c = dconv(H, W, GF.view(0), 64, None, 'model.0')
+        c.nchw_out_c = in_nc
+        TP.gx_op = add_b(c)
     TP.wgrad_arena = attach_wgrad_arena(Bk, device)
     return TP

@@ -114,10 +114,18 @@ def _train_backward(tp, gy, st, noise, explicit, seed, want_gx, sync=None):
     arr = tp.bwd.array()
     arr[tp.gy_op].u.layout.nchw = gy.data_ptr()
     gx = None
-    if tp.gx_op is not None:
-        lo = arr[tp.gx_op].u.layout
-        gx = torch.empty((lo.B, lo.C, lo.H, lo.W), dtype=torch.float32, device=gy.device)
-        arr[tp.gx_op].u.layout.nchw = gx.data_ptr()
+    n_ops = len(tp.bwd.ops)
+    if tp.gx_begin is not None and not want_gx:
+        n_ops = tp.gx_begin                         # whole generator: fea_conv's input gradient only on request
+    elif tp.gx_op is not None:
+        if arr[tp.gx_op].kind == L.OP_CONV:
+            cv = arr[tp.gx_op].u.conv
+            gx = torch.empty((cv.B, cv.nchw_out_c, cv.H, cv.W), dtype=torch.float32, device=gy.device)
+            cv.nchw_out = gx.data_ptr()
+        else:
+            lo = arr[tp.gx_op].u.layout
+            gx = torch.empty((lo.B, lo.C, lo.H, lo.W), dtype=torch.float32, device=gy.device)
+            lo.nchw = gx.data_ptr()
     mode = L.NOISE_OFF
     if noise:
         mode = L.NOISE_EXPLICIT if explicit else L.NOISE_PHILOX
@@ -130,7 +138,7 @@ def _train_backward(tp, gy, st, noise, explicit, seed, want_gx, sync=None):
     if tp.bwd_streams is not None:
         tp.bwd_streams.ensure(st)
     if tp.segments is None or sync is None:
-        tp.bwd.run(st)
+        tp.bwd.run_range(st, 0, n_ops)
         return gx
     # data-parallel: hand every finished slice of the flat gradient buffer to `sync` (an asynchronous
     # all-reduce, dp.GradExchange) as soon as the ops that produce it are enqueued — slices are merged up to
@@ -148,12 +156,15 @@ def _train_backward(tp, gy, st, noise, explicit, seed, want_gx, sync=None):
         if pend_hi - pend_lo >= limit:
             handles.append(sync(tp.grad_flat[pend_lo:pend_hi]))
             pend_lo = None
-    tp.bwd.run_range(st, i0, len(tp.bwd.ops))
+    tp.bwd.run_range(st, i0, n_ops)
     if pend_lo is not None:
         handles.append(sync(tp.grad_flat[pend_lo:pend_hi]))
-    for h in handles:
-        if h is not None:
-            h.wait()
+    if hasattr(sync, 'wait_handles'):
+        sync.wait_handles(handles)                  # dp.GradExchange (optionally timed: bench.py dp_train)
+    else:
+        for h in handles:
+            if h is not None:
+                h.wait()
     return gx
 
 
@@ -252,15 +263,14 @@ class _RRDBNetFn(torch.autograd.Function):
         if tp is None:
             raise RuntimeError('RRDBNet backward called twice (retain_graph is not supported: the '
                                'saved activations live in a reusable launch plan)')
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError('gradient w.r.t. the LR input image is not provided')
         gy = gy.detach().contiguous().float()
-        _train_backward(tp, gy, E.current_stream(), ctx.noise, ctx.explicit, ctx.seed, False, ctx.sync)
+        gx = _train_backward(tp, gy, E.current_stream(), ctx.noise, ctx.explicit, ctx.seed,
+                             bool(ctx.needs_input_grad[0]), ctx.sync)
         grads = _grad_views(tp)
         ctx.lease.release()
         assert len(grads) == ctx.n_params
         grads = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:])]
-        return (None, None, None) + tuple(grads)
+        return (gx if ctx.needs_input_grad[0] else None, None, None) + tuple(grads)
 
 
 def _block_train_plan(mod, kind, wp, dp, B, H, W, dev, noise, explicit):

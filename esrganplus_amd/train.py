@@ -25,9 +25,12 @@ from .optim import FusedAdam, DynamicLossScaler
 
 class ESRGANPlusStep:
     def __init__(self, netG, netD, netF, lr_G=1e-4, lr_D=1e-4, beta1_G=0.9, beta1_D=0.9,
-                 pixel_weight=1e-2, feature_weight=1.0, gan_weight=5e-3, loss_scale=1.0):
+                 pixel_weight=1e-2, feature_weight=1.0, gan_weight=5e-3, loss_scale=1.0, data_parallel=None):
         self.netG, self.netD, self.netF = netG, netD, netF
         self.l_pix_w, self.l_fea_w, self.l_gan_w = pixel_weight, feature_weight, gan_weight
+        # data_parallel: None = follow torch.distributed (world size > 1); False inside a multi-rank job = this rank's
+        # own step without any exchange (bench.py's no-exchange figure next to the data-parallel one)
+        self.data_parallel = (DP.world_size() > 1) if data_parallel is None else bool(data_parallel)
         # fp16 path: 'dynamic' (default policy of the scaler: start at 1024, halve on overflow and skip that step,
         # double after 2000 clean steps) or a fixed number (1.0 for fp32).  Nothing here synchronises with the host.
         self.scaler = None
@@ -40,16 +43,24 @@ class ESRGANPlusStep:
         self.optimizer_G = FusedAdam([p for p in netG.parameters() if p.requires_grad],
                                      lr=lr_G, betas=(beta1_G, 0.999))
         self.optimizer_D = FusedAdam(netD.parameters(), lr=lr_D, betas=(beta1_D, 0.999))
-        self.exG, self.exD = DP.GradExchange(netG), DP.GradExchange(netD)
+        self.exG = DP.GradExchange(netG, enabled=self.data_parallel, measure=self.data_parallel)
+        self.exD = DP.GradExchange(netD, enabled=self.data_parallel, measure=self.data_parallel)
         self.log = {}
         self.fake_H = None
-        # single-GPU: enqueue the D step on a second stream under the G backward (ESR_TRAIN_OVERLAP=0: in sequence)
-        self.overlap_d_step = os.environ.get('ESR_TRAIN_OVERLAP', '1') != '0'
+        self._steps = 0
+        # stream overlap of the step (ESR_TRAIN_OVERLAP): 0 = everything in sequence on the caller's stream;
+        # 1 = netF(var_H) under the generator's forward and the D step under the G backward (round 3);
+        # 2 (default) = additionally the G step's netD pass on a third stream next to its netF pass, forward AND
+        # backward (autograd runs a node's backward on the stream its forward ran on): both are chains of small
+        # launches that use a fraction of the CUs each
+        self.overlap = int(os.environ.get('ESR_TRAIN_OVERLAP', '2'))
+        self.overlap_d_step = self.overlap >= 1
 
-    def _side(self, dev):
-        s = self.__dict__.get('_side_stream')
+    def _side(self, dev, which=0):
+        ss = self.__dict__.setdefault('_side_streams', {})
+        s = ss.get(which)
         if s is None or s.device != dev:
-            s = self._side_stream = torch.cuda.Stream(device=dev)
+            s = ss[which] = torch.cuda.Stream(device=dev)
         return s
 
     def _scale_t(self, dev):
@@ -59,41 +70,70 @@ class ESRGANPlusStep:
             self._scale_value = float(self.loss_scale)
         return t
 
+    # ---- exchange accounting (bench.py dp_train) ----
+    def comm_reset(self):
+        self._steps = 0
+        self.exG.reset_counters()
+        self.exD.reset_counters()
+
+    def comm_report(self):
+        """Per step: all-reduce calls / bytes of the two gradient exchanges and the milliseconds the compute streams
+        spent blocked on them (HIP events around the waits).  Synchronises the device."""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        n = max(self._steps, 1)
+        return {'calls_per_step': (self.exG.calls + self.exD.calls) / n,
+                'bytes_per_step': (self.exG.bytes + self.exD.bytes) / n,
+                'exposed_ms_per_step': (self.exG.exposed_ms() + self.exD.exposed_ms()) / n,
+                'exposed_ms_per_step_G': self.exG.exposed_ms() / n, 'exposed_ms_per_step_D': self.exD.exposed_ms() / n}
+
     def step(self, var_L, var_H, var_ref=None, z=None, sync_log=True):
         """One optimisation step (SRRaGAN_model.py:113-168)."""
         netG, netD, netF = self.netG, self.netD, self.netF
         var_ref = var_H if var_ref is None else var_ref
+        self._steps += 1
         # batch means of the relativistic terms: over ALL ranks when data-parallel (losses._RaGANGlobalFn: the fused
         # kernel + two scalar all-reduces), else inside the one fused loss launch
-        mean = DP.world_size() > 1
+        mean = self.data_parallel
+        cuda = var_L.is_cuda
+        ov = self.overlap if cuda else 0
         # ---------------- G ----------------
         for p in netD.parameters():
             p.requires_grad = False
         self.optimizer_G.zero_grad(set_to_none=True)
-        early_real = self.overlap_d_step and var_L.is_cuda
-        if early_real:
+        if ov >= 1:
             # netF(var_H) does not depend on G: on the second stream, under the generator's forward
-            main0 = torch.cuda.current_stream()
-            side0 = self._side(var_L.device)
-            side0.wait_stream(main0)
-            with torch.cuda.stream(side0), torch.no_grad():
+            main = torch.cuda.current_stream()
+            side = self._side(var_L.device, 0)
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
                 real_fea = netF(var_H)
-            real_fea.record_stream(main0)
+            real_fea.record_stream(main)
         fake_H = netG(var_L, z=z) if z is not None else netG(var_L)
         self.fake_H = fake_H
         l_g_pix = LS.l1_loss(fake_H, var_H, self.l_pix_w)
-        # both operands of each network in ONE pass (forward_pair: per-half BatchNorm statistics, the detached
-        # ``real`` half costs no backward) — the reference's call order fake, real is the group order
-        if early_real:
+
+        def d_pass():
+            # both operands in ONE pass (forward_pair: per-half BatchNorm statistics, the detached ``real`` half
+            # costs no backward) — the reference's call order fake, real is the group order
+            pg, pr = netD.forward_pair(fake_H, var_ref)
+            return LS.ragan_loss(pr, pg, False, True, self.l_gan_w, mean)[0]
+
+        if ov >= 2:
+            sideD = self._side(var_L.device, 1)
+            sideD.wait_stream(main)
+            with torch.cuda.stream(sideD):
+                l_g_gan = d_pass()
+        if ov >= 1:
             # join BEFORE netF runs on the main stream: the first netF call of a process packs its weights on the
             # side stream, and the side work finished under the generator's forward anyway
-            main0.wait_stream(side0)
+            main.wait_stream(side)
             fake_fea = netF(fake_H)
         else:
             fake_fea, real_fea = netF.forward_pair(fake_H, var_H)
         l_g_fea = LS.l1_loss(fake_fea, real_fea, self.l_fea_w)
-        pred_g_fake, pred_d_real = netD.forward_pair(fake_H, var_ref)
-        l_g_gan, _ = LS.ragan_loss(pred_d_real, pred_g_fake, False, True, self.l_gan_w, mean)
+        if ov < 2:
+            l_g_gan = d_pass()
         scale = self.scaler.scale if self.scaler else self._scale_t(fake_H.device)
 
         def d_step():
@@ -111,22 +151,27 @@ class ESRGANPlusStep:
             # d(scale * (pix + fea + gan)): one backward over the three terms, no sum / multiply launches
             torch.autograd.backward([l_g_pix, l_g_fea, l_g_gan], [scale, scale, scale])
 
-        if self.overlap_d_step and fake_H.is_cuda:
+        if ov >= 1:
             # The D step does not depend on the G backward: it runs on a second stream UNDER it (both are chains of
             # small launches).  Same arithmetic, same order of BatchNorm running-statistics updates (its forward
             # still follows the G step's D pass); the autograd graphs are disjoint.  Data-parallel runs take the
             # same route: every rank issues its collectives in the same program order (D's loss sums, D's gradient
             # buckets on the side stream; G's in-backward buckets on the main stream), each stream-ordered after
             # the kernels that feed it.
-            main = torch.cuda.current_stream()
-            side = self._side(fake_H.device)
-            side.wait_stream(main)
+            if ov >= 2:
+                # fake_H was complete when sideD started; the D step must follow the G step's D pass (BatchNorm
+                # running statistics, the weight pack) but not netF(fake_H) on the main stream
+                side.wait_stream(sideD)
+            else:
+                side.wait_stream(main)
             with torch.cuda.stream(side):
                 aux = d_step()
                 self.exD.start()
             g_backward()
             self.exG.start()
             main.wait_stream(side)
+            if ov >= 2:
+                main.wait_stream(sideD)
         else:
             g_backward()
             self.exG.start()                  # RCCL all-reduce of G grads overlaps the D pass below

@@ -38,7 +38,7 @@ def test_rrdbnet_param_grads_fp32(dev, golden, tag, nb, shape, variant, mode):
     net = cls(3, 3, 64, nb).to(dev)
     net.load_state_dict(sd, strict=True)
     net.train(mode == 'train')
-    x = synth.image_batch(3, *shape, name='small.x.' + tag).to(dev)
+    x = synth.image_batch(3, *shape, name='small.x.' + tag).to(dev).requires_grad_(True)
     gy = synth.normal_like(3, 'small.gy.' + tag, (shape[0], 3, shape[2] * 4, shape[3] * 4)).to(dev)
     z = None
     if mode == 'train':
@@ -46,6 +46,12 @@ def test_rrdbnet_param_grads_fp32(dev, golden, tag, nb, shape, variant, mode):
     y = net(x, z=z)
     assert np.abs(y.detach().cpu().numpy() - g['%s_y_%s' % (tag, mode)]).max() <= 1e-4
     (y * gy).sum().backward()
+    # dL/dx of the whole generator (autograd through architecture.py:76-78) against the reference's
+    gxr = g['%s_gx_%s' % (tag, mode)]
+    assert x.grad is not None and tuple(x.grad.shape) == tuple(x.shape)
+    egx = np.abs(x.grad.cpu().numpy() - gxr).max()
+    print('dL/dx max|diff| %.3e (|ref| max %.3f)' % (egx, np.abs(gxr).max()))
+    assert egx <= 2e-3 * max(1.0, np.abs(gxr).max()), egx
     params = dict(net.named_parameters())
     if mode == 'train':
         for k in FULL:
@@ -214,3 +220,24 @@ def test_full_depth_backward_at_bench_shape_vs_reference_golden(dev, golden, pre
         e = np.abs(got - want).max() / np.abs(want).max()
         print('  %-40s max|diff| / max|ref| = %.2e' % (k, e))
         assert e <= (6e-3 if prec == 'fp32' else 0.25), (k, e)
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', 2e-4), ('fp16', 4e-2)])
+def test_rrdbnet_input_gradient_only(dev, golden, prec, tol):
+    """Frozen generator, gradient w.r.t. the LR image only (e.g. an adversarial / inversion loop around
+    architecture.py:76-78): no parameter gradient is produced, dL/dx matches the reference's (fp32) and the fp16
+    chains track it."""
+    from esrganplus_amd import architecture as arch
+    g = golden('rrdbnet_small')
+    nb, shape = 2, (2, 3, 24, 24)
+    net = arch.RRDBNet(3, 3, 64, nb).to(dev).eval().set_precision(prec)
+    net.load_state_dict(synth.rrdbnet_state_dict(nb=nb, seed=20 + nb), strict=True)
+    for p in net.parameters():
+        p.requires_grad = False
+    x = synth.image_batch(3, *shape, name='small.x.b').to(dev).requires_grad_(True)
+    gy = synth.normal_like(3, 'small.gy.b', (shape[0], 3, shape[2] * 4, shape[3] * 4)).to(dev)
+    (net(x) * gy).sum().backward()
+    ref = g['b_gx_eval']
+    err = np.abs(x.grad.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+    assert err <= tol, err
+    assert all(p.grad is None for p in net.parameters())

@@ -34,6 +34,14 @@ def test_forward_line_follows_the_contract():
     assert abs(r['frac'] - r['achieved'] / r['peak']) <= 1e-3 and 0.2 < r['frac'] < 0.7
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'HR-Mpix/s' and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+    assert 'settle_steps' not in d
+    # BASELINE configs[2] / configs[4] ride in the same line
+    t = d['train_step']
+    assert t['ms_per_step'] > 0 and 0 < t['frac_of_f16_mfma_peak'] < 1 and t['roofline']['kernel'].startswith('rdb_')
+    assert abs(t['tflops'] - 3.03e3 / t['ms_per_step']) <= 0.02 * t['tflops']
+    gt = d['gtrain']
+    assert gt['ms_per_step'] > 0 and set(gt['buckets']) == {'16x128^2', '8x192^2', '4x256^2'}
+    assert abs(sum(b['ms'] for b in gt['buckets'].values()) - gt['ms_per_step']) <= 0.15 * gt['ms_per_step']
 
 
 @pytest.mark.parametrize('mode', ['train', 'gtrain'])

@@ -237,3 +237,29 @@ def test_train_step_two_ranks_equals_global_batch_loss(dev):
     eD = np.linalg.norm(res[0][3] - wantD) / np.linalg.norm(wantD)
     print('relative gradient error  G %.3e  D %.3e' % (eG, eD))
     assert eG <= 2e-4 and eD <= 2e-4
+
+
+def test_bench_two_ranks_prints_the_dp_train_object():
+    """`bench.py --gpus 2` as the driver launches it for the scaling runs, here with both ranks on cuda:0 and gloo in
+    place of RCCL (ESR_BENCH_BACKEND): at world > 1 the default line must carry a `dp_train` object — the configs[3]
+    step over the process group with its all-reduce volume, the exposed communication time and the same process's
+    no-exchange step time — so that the multi-GPU run exercises the collective path, not only independent forwards."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ESR_BENCH_BACKEND='gloo', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                          '--batch', '2', '--lr', '32', '--train-batch', '2', '--dp-steps', '2', '--no-cpu-baseline'],
+                         cwd=root, env=env, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=1500).stdout.decode()
+    lines = [l for l in out.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and 'dp_train' in d and 'train_step' not in d
+    o = d['dp_train']
+    assert o['n_ranks'] == 2 and o['backend'] == 'gloo' and o['scaling'] == 'weak'
+    # G 16 839 299 + D 14 502 281 fp32 gradients + the relativistic means' scalars
+    assert o['allreduce_bytes_per_step'] == 4 * (16839299 + 14502281) + 40
+    assert o['allreduce_calls_per_step'] >= 2
+    assert o['ms_per_step'] > 0 and o['ms_per_step_no_exchange'] > 0 and o['exposed_comm_ms_per_step'] >= 0
+    assert abs(o['value'] - 2 * 2 * 128 * 128 / 1e6 / (o['ms_per_step'] / 1e3)) <= 1e-2 * o['value']

@@ -401,6 +401,108 @@ def test_starved_chain_launch_is_reported_at_the_next_call(dev):
         del bad
 
 
+def _concurrent_stream(dev, words, p_release, p_started):
+    """A stream whose kernels run NEXT TO the current stream's (HIP maps streams onto a few hardware queues; one that
+    shares the current stream's queue would put the chain behind the hold kernel instead of beside it)."""
+    import ctypes as C
+    import time
+    from esrganplus_amd import _lib as L
+    for _ in range(8):
+        cand = torch.cuda.Stream()
+        words.zero_()
+        L.check(L.lib().esr_debug_hold_cus(1, p_release, 200, p_started, C.c_void_p(cand.cuda_stream)), 'esr_debug_hold_cus')
+        t0 = time.perf_counter()
+        torch.zeros(1, device=dev).item()
+        dt = time.perf_counter() - t0
+        words[0] = 1
+        cand.synchronize()
+        if dt < 0.1:
+            return cand
+    return None
+
+
+def test_chains_make_progress_next_to_a_resident_kernel(dev):
+    """A collective's kernel (RCCL all-reduce: a few dozen persistent workgroups) will sit on some CUs while the chains
+    run — the data-parallel step issues its gradient exchanges under the backward.  Stand-in: esr_debug_hold_cus keeps
+    32 CUs (4 per XCD) busy while (a) the inference chain at the bench shape (16 x 128^2 LR: 512 tiles, more than the
+    CUs left) and (b) the training forward + backward chains + rdb_wgrad at the train-step shape (16 x 32^2 LR: 128
+    four-row tiles) run: same results bit for bit, no abort, and the training chains — whose grid still fits the free
+    CUs — at most 1.25x slower (the 512-tile launch walks its tickets in 3 waves instead of 2: <= 1.7x)."""
+    import ctypes as C
+    import time
+    from esrganplus_amd import _lib as L
+    nb = 3
+    sd = synth.rrdbnet_state_dict(nb=nb, seed=61)
+    words = torch.zeros(16, dtype=torch.int32).pin_memory()
+    p_release, p_started = C.c_void_p(words.data_ptr()), C.c_void_p(words.data_ptr() + 4)
+    torch.cuda.synchronize()
+    side = _concurrent_stream(dev, words, p_release, p_started)
+    if side is None:
+        pytest.skip('no stream that runs concurrently with the current one')
+    HOLD = 32
+
+    def held(fn, reps):
+        """fn() reps times with HOLD CUs taken; returns (last result, seconds per call)."""
+        words.zero_()
+        L.check(L.lib().esr_debug_hold_cus(HOLD, p_release, 8000, p_started, C.c_void_p(side.cuda_stream)), 'esr_debug_hold_cus')
+        for _ in range(300):
+            if int(words[1]) == HOLD:
+                break
+            time.sleep(0.01)
+        assert int(words[1]) == HOLD
+        torch.cuda.current_stream().synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.current_stream().synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        words[0] = 1
+        torch.cuda.synchronize()
+        return r, dt
+
+    def free(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize()
+        return r, (time.perf_counter() - t0) / reps
+
+    # (a) inference chain at the bench shape
+    net = _net('RRDBNet', nb, sd, dev, 'fp16')
+    x = synth.image_batch(61, 16, 3, 128, 128, name='hold.x').to(dev)
+    with torch.no_grad():
+        good, t_free = free(lambda: net(x), 5)
+        got, t_held = held(lambda: net(x), 5)
+    assert L.lib().esr_rdb_check_abort() == 0
+    assert torch.equal(got, good)
+    print('inference chain 16x128^2, nb=%d: %.3f ms free, %.3f ms next to %d held CUs (x%.2f)'
+          % (nb, t_free * 1e3, t_held * 1e3, HOLD, t_held / t_free))
+    assert t_held <= 1.7 * t_free + 2e-4
+
+    # (b) training chains at the train-step shape
+    tnet = _net('RRDBNet', nb, sd, dev, 'fp16', train=True)
+    xt = synth.image_batch(62, 16, 3, 32, 32, name='hold.xt').to(dev)
+    gy = synth.normal_like(62, 'hold.gy', (16, 3, 128, 128)).to(dev)
+
+    def fb():
+        torch.manual_seed(5)                       # same Philox key every call
+        for p in tnet.parameters():
+            p.grad = None
+        y = tnet(xt)
+        (y * gy).sum().backward()
+        return y.detach(), torch.cat([p.grad.reshape(-1) for p in tnet.parameters()])
+
+    (y0, g0), t_free = free(fb, 5)
+    (y1, g1), t_held = held(fb, 5)
+    assert L.lib().esr_rdb_check_abort() == 0
+    assert torch.equal(y1, y0) and torch.equal(g1, g0)
+    print('training chains 16x32^2, nb=%d: %.3f ms free, %.3f ms next to %d held CUs (x%.2f)'
+          % (nb, t_free * 1e3, t_held * 1e3, HOLD, t_held / t_free))
+    assert t_held <= 1.25 * t_free + 3e-4
+
+
 @pytest.mark.parametrize('shape', [(1, 3, 128, 128), (2, 3, 33, 70), (1, 3, 7, 20)])
 def test_inference_chain_tile_heights_are_bit_identical(dev, monkeypatch, shape):
     """The fp16 inference chain also exists for 8- and 4-row tiles (a single 128x128 LR tile — BASELINE configs[0],
