@@ -14,6 +14,11 @@ from .functional import run_rrdbnet
 
 
 class _RRDBNetBase(B._PlannedModule):
+    # parameter gradients leave the backward node through the module's flat store (block._PlannedModule._grad_store)
+    # instead of ~770 autograd outputs; ESR_FLAT_GRADS=0 or `net.flat_param_grads = False` restores the per-tensor
+    # route (needed for torch.autograd.grad(y, params) and tensor hooks on the parameters)
+    flat_param_grads = os.environ.get('ESR_FLAT_GRADS', '1') != '0'
+
     def _build(self, in_nc, out_nc, nf, nb, upscale, norm_type, act_type, mode, upsample_mode,
                extra_noise):
         if upsample_mode == 'pixelshuffle':
@@ -175,7 +180,7 @@ class _SeqNet(B._PlannedModule):
     def _dgrad_special(self):
         return {s['conv']: {'ts2': True} for s in self._spec() if 'conv' in s and s['stride'] == 2}
 
-    def _run_forward(self, x, need_bwd, groups=1, bwd_B=None):
+    def _run_forward(self, x, need_bwd, groups=1, bwd_B=None, dual=None):
         E.require_cuda(x, 'input')
         xin = x.detach().contiguous().float()
         Bn, C_, H, W = xin.shape
@@ -185,20 +190,20 @@ class _SeqNet(B._PlannedModule):
         st = E.current_stream()
         wp = self._weights(dev)
         dp = None
-        want_w = any(p.requires_grad for p in self.parameters())
+        want_w = dual is not None or any(p.requires_grad for p in self.parameters())
         if need_bwd:
             dp = self._dgrad_weights(dev)
             dp.ensure(st, force=(bool(self.training) or want_w) and not self.__dict__.get('_weights_clean', False))
         training = bool(self.training) and self._has_bn
         groups = groups if training else 1
-        key = ('seq', Bn, H, W, self.precision, training, need_bwd, want_w, wp.generation, str(dev), groups, bwd_B)
+        key = ('seq', Bn, H, W, self.precision, training, need_bwd, want_w, wp.generation, str(dev), groups, bwd_B, dual)
         pool = self._plans.setdefault(key, [])
         plan = next((p for p in pool if not p.busy), None)
         if plan is None:
             plan = CN.build_seq_plan(self._spec(), wp, dp, self._pspec(), want_w, Bn, H, W, self.precision,
                                      dev, training, need_bwd, self._input_affine(), self._head(),
-                                     groups=groups, bwd_B=bwd_B if need_bwd else None)
-            if E.use_graphs():
+                                     groups=groups, bwd_B=bwd_B if need_bwd else None, dual=dual)
+            if E.use_graphs() and dual is None:
                 # hipGraph replay: the input lands in a fixed staging tensor (everything else these
                 # plans touch — outputs, upstream gradients, BN sums — already lives in fixed buffers)
                 plan.x_static = torch.empty_like(xin)
@@ -252,12 +257,33 @@ class _SeqNet(B._PlannedModule):
         return y[:n], (y[n:].detach() if half else y[n:])
 
 
+    # One forward for the train step's TWO netD pairs (SRRaGAN_model.py:133-134 and 150-151): see forward_shared
+    _shared_ok = False
+
+    def forward_shared(self, a, b):
+        """``self(a), self(b).detach()`` in one pass — as ``forward_pair`` — plus a handle whose ``second_pass()`` gives
+        ``self(b), self(a.detach())`` again WITHOUT a second forward: between the G step's and the D step's pair of
+        calls the weights do not change and the operands are the same values, so the activations are the same; what a
+        real second pair adds — the BatchNorm running-statistics updates, in its own call order — is applied by the
+        handle.  The first pair's backward gives dL/da (parameters frozen, as the G step has them); the second pair's
+        gives the parameter gradients.  Training mode only."""
+        if not (self._shared_ok and self.training and torch.is_grad_enabled() and a.requires_grad):
+            raise RuntimeError('forward_shared: a training-mode pass whose first operand requires a gradient')
+        if a.shape != b.shape:
+            raise ValueError('forward_shared: the two batches must have one shape')
+        holder = []
+        y = CN.SharedFirstFn.apply(a, b, self, holder)
+        n = a.shape[0]
+        return y[:n], y[n:].detach(), holder[0]
+
+
 class _DiscriminatorVGG(_SeqNet):
     """The reference's VGG-style discriminators (architecture.py:87-129, 178-270): 3x3/s1 and 4x4/s2 conv pairs
     (64..512 ch) with BatchNorm2d (batch statistics in train mode) and LeakyReLU(0.2), flatten,
     Linear(F,100), LeakyReLU, Linear(100,1).  State-dict keys as the reference."""
 
     _has_bn = True
+    _shared_ok = True
     _pairs = 5          # conv pairs (128 / 96: 5, 192: 6)
     _final = 4          # side of the final feature map at the nominal input size
 

@@ -238,6 +238,7 @@ class _PlannedModule(nn.Module):
         # parameter copies: anything derived from the ORIGINAL's parameters must not leak into the replica
         replica = super()._replicate_for_data_parallel()
         replica.__dict__['_conv_cache'] = None
+        replica.__dict__['_gstore'] = None
         replica.__dict__['_wp'] = {}
         replica.__dict__['_plans'] = {}
         replica.__dict__['_force_repack'] = True
@@ -261,6 +262,58 @@ class _PlannedModule(nn.Module):
     def load_state_dict(self, *a, **k):
         self._force_repack = True
         return super().load_state_dict(*a, **k)
+
+    # ---- module-owned gradient store (the fused backward of a whole network emits ALL parameter gradients as one
+    # flat fp32 buffer: handing ~770 tensors through autograd one by one — Function inputs, AccumulateGrad nodes,
+    # fresh views — cost ~5 ms of host time per training step, more than enqueueing every kernel of the step) ----
+    flat_param_grads = False      # RRDBNet: True
+
+    def _grad_store(self, device):
+        """Persistent flat gradient buffer + one cached view per parameter, in `_convs()` order."""
+        gs = self.__dict__.get('_gstore')
+        flat_params = self._convs()[1]
+        if gs is None or gs['dev'] != device or gs['params'] is not flat_params:
+            sizes = [p.numel() for p in flat_params]
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+            views = [t.view(p.shape) for t, p in zip(flat.split(sizes), flat_params)]
+            gs = dict(dev=device, params=flat_params, sizes=sizes, flat=flat, views=views, stale=False)
+            self.__dict__['_gstore'] = gs
+        return gs
+
+    def _deliver_flat_grads(self, flat_new):
+        """What AccumulateGrad does for every parameter, on the flat buffer: `.grad` of every parameter becomes (stays) its
+        view of the module's store, which receives `flat_new` — copied when the gradients were None (zero_grad
+        (set_to_none=True)) or marked stale, added otherwise (autograd's accumulation).  Gradients somebody else put in
+        place are honoured tensor by tensor."""
+        gs = self._grad_store(flat_new.device)
+        params, views = gs['params'], gs['views']
+        if all(p.grad is v for p, v in zip(params, views)):
+            if gs['stale']:
+                gs['flat'].copy_(flat_new)
+                gs['stale'] = False
+            else:
+                gs['flat'].add_(flat_new)
+            return
+        if all(p.grad is None for p in params):
+            gs['flat'].copy_(flat_new)
+            gs['stale'] = False
+            for p_, v in zip(params, views):
+                p_.grad = v
+            return
+        new = flat_new.clone().split(gs['sizes'])
+        for p_, g, v in zip(params, new, views):
+            g = g.view(v.shape)
+            p_.grad = g if p_.grad is None else p_.grad + g
+
+    def mark_grads_stale(self):
+        """Cheap stand-in for ``zero_grad`` in a training loop that owns this module's gradients (train.ESRGANPlusStep):
+        the next backward OVERWRITES the store instead of adding to it; `.grad` keeps pointing at the (old) values
+        until then.  Returns False — nothing marked — when the parameters' gradients are not the store's views."""
+        gs = self.__dict__.get('_gstore')
+        if gs is None or not all(p.grad is v for p, v in zip(gs['params'], gs['views'])):
+            return False
+        gs['stale'] = True
+        return True
 
     def _conv_list(self):
         raise NotImplementedError

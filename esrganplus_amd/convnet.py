@@ -51,6 +51,18 @@ class SeqPlan:
         self.sums_f = self.sums_b = None
         self.grad_flat, self.grad_views = None, None
         self.bn_layers = []
+        self.second = None              # BwdPass of a dual plan (build_seq_plan(dual=...)): the G step's input-gradient pass
+        self.restat = None              # OpList replaying the BatchNorm running-statistics updates (dual plans)
+
+
+class BwdPass:
+    """One backward launch list over a plan's saved activations with its own scratch buffers."""
+
+    def __init__(self):
+        self.bwd = L.OpList()
+        self.bufs, self.keep = [], []
+        self.gy_tensor = self.gx_tensor = self.sums_b = None
+        self.grad_flat = self.grad_views = self.tapmajor = self.wgrad_arena = None
 
 
 def _g32(plan, B, C_, H, W, dtype, dev):
@@ -75,8 +87,14 @@ def _layout(ops, dt_e, to_g32, B, C_, buf, nchw_ptr=None, affine=None):
 
 
 def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, training, need_bwd,
-                   input_affine=None, head=None, groups=1, bwd_B=None):
-    """groups: BatchNorm statistics groups of the batch (``forward_pair``: two reference forward calls as one
+                   input_affine=None, head=None, groups=1, bwd_B=None, dual=None):
+    """dual (None | images): ONE forward whose saved activations serve TWO backward passes with their own scratch
+    buffers — P (full batch, parameter gradients: the D step) and P.second (the first `dual` images only, input
+    gradient only: the G step's pass through the frozen discriminator) — plus P.restat, the launch list that applies
+    the BatchNorm running-statistics updates of a second forward call over the same batch in reverse group order
+    (SRRaGAN_model.py:133-134 then 150-151: netD sees fake, real, then real, fake with unchanged weights, i.e. the
+    same activations twice).
+    groups: BatchNorm statistics groups of the batch (``forward_pair``: two reference forward calls as one
     pass; esr_bn.groups).  bwd_B: the backward covers only the first ``bwd_B`` images (the second half of a pair
     that is detached: its saved activations are the batch suffix of every buffer, so the backward launches simply
     run on the prefix) — with groups == 2 that prefix is statistics group 0.
@@ -92,22 +110,8 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
     P = SeqPlan()
     f, bk = P.fwd, P.bwd
     e = wp.entries
-    params_grad, poff = {}, {}
     P.tapmajor = None
     P.grad_views = [(t.numel(), tuple(t.shape)) for _, t in pspec]
-    if need_bwd and want_wgrad:
-        P.grad_flat = torch.zeros(sum(t.numel() for _, t in pspec), dtype=torch.float32, device=dev)
-        if dt_e == L.ESR_F16:
-            P.tapmajor = E.TapMajorGrads(P.grad_flat)
-        ptr, off = {}, 0
-        for name, t in pspec:
-            ptr[name] = P.grad_flat.data_ptr() + 4 * off
-            poff[name] = off
-            off += t.numel()
-        for name in ptr:
-            base = name.rsplit('.', 1)[0]
-            if base not in params_grad:
-                params_grad[base] = (ptr.get(base + '.weight'), ptr.get(base + '.bias'))
 
     # ---------------------------------------------------------------- forward
     cin0 = spec[0]['cin']
@@ -115,11 +119,9 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
     P.in_op = _layout(f, dt_e, 1, B, cin0, xin, affine=input_affine)
     nbn = sum(1 for s in spec if s.get('bn'))
     maxc = max([s['cout'] for s in spec if 'conv' in s] + [1])
-    Bb = B if bwd_B is None else bwd_B
-    gb = groups if Bb == B else 1           # statistics groups the backward sees
-    assert B % groups == 0 and (Bb == B or (groups > 1 and Bb == B // groups) or groups == 1)
+    Bb0 = B if bwd_B is None else bwd_B
+    assert B % groups == 0 and (Bb0 == B or (groups > 1 and Bb0 == B // groups) or groups == 1)
     P.sums_f = torch.zeros(max(nbn, 1) * 2 * maxc * groups, dtype=torch.float64, device=dev)
-    P.sums_b = torch.zeros(max(nbn, 1) * 2 * maxc * groups, dtype=torch.float64, device=dev)
     stats = torch.zeros(max(nbn, 1) * 2 * maxc * groups, dtype=torch.float32, device=dev)   # mean | invstd, [groups][C] each
     P.keep += [stats]
     cur, ch, h, w = xin, cin0, H, W
@@ -150,16 +152,16 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
             cb = _g32(P, B, cpad, ho, wo, dtype, dev)
             f.add_conv(E._conv(dt_e, B, ho, wo, cur.view(0), ch, cb.view(0), e[key], L.ACT_NONE, stride=st))
             base = ibn * 2 * maxc * groups
-            mk = dict(sums_f=P.sums_f.data_ptr() + 8 * base, sums_b=P.sums_b.data_ptr() + 8 * base,
+            mk = dict(sums_f=P.sums_f.data_ptr() + 8 * base, base=base,
                       mean=stats.data_ptr() + 4 * base, invstd=stats.data_ptr() + 4 * (base + maxc * groups))
 
             def bnop(mode, x=cb, y=yb, g=None, gx=None, sums=mk['sums_f'], act=s['act'], bn=bn, mk=mk,
-                     cout=cout, ho=ho, wo=wo):
+                     cout=cout, ho=ho, wo=wo, Bb=None, gb=None):
                 o = L.esr_bn()
-                fwd_op = mode in (L.BN_STATS, L.BN_FINALIZE, L.BN_APPLY)
+                fwd_op = mode in (L.BN_STATS, L.BN_FINALIZE, L.BN_APPLY, L.BN_RESTAT)
                 o.dtype, o.mode, o.B, o.C, o.H, o.W = dt_e, mode, (B if fwd_op else Bb), cout, ho, wo
                 o.groups = groups if fwd_op else gb
-                if mode == L.BN_FINALIZE and training and bn.get('nbt') is not None:
+                if mode in (L.BN_FINALIZE, L.BN_RESTAT) and training and bn.get('nbt') is not None:
                     o.num_batches_tracked = bn['nbt'].data_ptr()
                 o.training, o.act, o.momentum, o.eps = int(training), act, BN_MOMENTUM, BN_EPS
                 o.x, o.y = x.view(0, cout), y.view(0, cout)
@@ -198,112 +200,182 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
     if not need_bwd:
         return P
 
-    # ---------------------------------------------------------------- backward
-    de = dp.entries
-    gcur = None      # G32 gradient w.r.t. the current layer's OUTPUT (post-activation)
-    if head is None:
-        P.gy_tensor = torch.empty(Bb, ch, h, w, dtype=torch.float32, device=dev)
-        gcur = _g32(P, Bb, ch, h, w, dtype, dev)
-        _layout(bk, dt_e, 1, Bb, ch, gcur, nchw_ptr=P.gy_tensor.data_ptr())
-    else:
-        P.gy_tensor = torch.empty(Bb, O2, dtype=torch.float32, device=dev)
-        gH1 = torch.empty(Bb, O1, dtype=torch.float32, device=dev)
-        gF = torch.empty(Bb, I1, dtype=torch.float32, device=dev)
-        P.keep += [gH1, gF]
-        lin = _lin
-        g2 = params_grad.get('head2')
-        g1 = params_grad.get('head1')
-        if g2 is not None:
-            bk.add(L.OP_LINEAR, 'linear', lin(2, Bb, O1, O2, L.ACT_NONE, x=H1.data_ptr(), g=P.gy_tensor.data_ptr(),
-                                              dw=g2[0], db=g2[1], w=head['w2'].data_ptr()))
-        bk.add(L.OP_LINEAR, 'linear', lin(1, Bb, O1, O2, L.ACT_NONE, g=P.gy_tensor.data_ptr(),
-                                          w=head['w2'].data_ptr(), gx=gH1.data_ptr()))
-        if g1 is not None:
-            bk.add(L.OP_LINEAR, 'linear', lin(2, Bb, I1, O1, L.ACT_LRELU, x=F_.data_ptr(), g=gH1.data_ptr(),
-                                              ysaved=H1.data_ptr(), dw=g1[0], db=g1[1], w=head['w1'].data_ptr()))
-        # a last conv that feeds the head through its activation without a norm layer (Discriminator_VGG_128_SN):
-        # the head's input gradient is masked by that activation here (F_ holds the activation's output)
-        last = recs[-1]
-        head_masks = last['kind'] == 'conv' and last['bn'] is None and last['act'] != L.ACT_NONE
-        o = lin(1, Bb, I1, O1, L.ACT_LRELU, g=gH1.data_ptr(), ysaved=H1.data_ptr(), w=head['w1'].data_ptr(), gx=gF.data_ptr())
-        if head_masks:
-            o.x, o.in_act = F_.data_ptr(), last['act']
-        bk.add(L.OP_LINEAR, 'linear', o)
-        gcur = _g32(P, Bb, ch, h, w, dtype, dev)
-        _layout(bk, dt_e, 1, Bb, ch, gcur, nchw_ptr=gF.data_ptr())
+    def build_backward(Q, Bb, want_wgrad):
+        """Backward launch list over the first Bb images into the BwdPass / SeqPlan Q (own scratch buffers)."""
+        gb = groups if Bb == B else 1           # statistics groups the backward sees
+        bk = Q.bwd
+        params_grad, poff = {}, {}
+        Q.tapmajor, Q.grad_flat = None, None
+        Q.grad_views = [(t.numel(), tuple(t.shape)) for _, t in pspec]
+        Q.sums_b = torch.zeros(max(nbn, 1) * 2 * maxc * groups, dtype=torch.float64, device=dev)
+        if want_wgrad:
+            Q.grad_flat = torch.zeros(sum(t.numel() for _, t in pspec), dtype=torch.float32, device=dev)
+            if dt_e == L.ESR_F16:
+                Q.tapmajor = E.TapMajorGrads(Q.grad_flat)
+            ptr, off = {}, 0
+            for name, t in pspec:
+                ptr[name] = Q.grad_flat.data_ptr() + 4 * off
+                poff[name] = off
+                off += t.numel()
+            for name in ptr:
+                base = name.rsplit('.', 1)[0]
+                if base not in params_grad:
+                    params_grad[base] = (ptr.get(base + '.weight'), ptr.get(base + '.bias'))
 
-    # gcur_masked: True when gcur already is the gradient w.r.t. the producing conv's pre-activation
-    masked = head is not None and head_masks
-    for li in range(len(recs) - 1, -1, -1):
-        r = recs[li]
-        if r['kind'] == 'pool':
-            gx = _g32(P, Bb, r['ch'], r['h'] * 2, r['w'] * 2, dtype, dev)
-            pl = L.esr_pool()
-            pl.dtype, pl.mode, pl.B, pl.C, pl.H, pl.W = dt_e, 1, Bb, r['ch'], r['h'], r['w']
-            pl.x, pl.y, pl.g, pl.gx = r['x'].view(0, r['ch']), r['y'].view(0, r['ch']), gcur.view(0, r['ch']), gx.view(0, r['ch'])
+        def g32q(C_, h_, w_):
+            b_ = E.G32(Bb, C_, h_, w_, dtype, dev)
+            Q.bufs.append(b_)
+            return b_
+
+        # ---------------------------------------------------------------- backward
+        de = dp.entries
+        gcur = None      # G32 gradient w.r.t. the current layer's OUTPUT (post-activation)
+        if head is None:
+            Q.gy_tensor = torch.empty(Bb, ch, h, w, dtype=torch.float32, device=dev)
+            gcur = g32q(ch, h, w)
+            _layout(bk, dt_e, 1, Bb, ch, gcur, nchw_ptr=Q.gy_tensor.data_ptr())
+        else:
+            Q.gy_tensor = torch.empty(Bb, O2, dtype=torch.float32, device=dev)
+            gH1 = torch.empty(Bb, O1, dtype=torch.float32, device=dev)
+            gF = torch.empty(Bb, I1, dtype=torch.float32, device=dev)
+            Q.keep += [gH1, gF]
+            lin = _lin
+            g2 = params_grad.get('head2')
+            g1 = params_grad.get('head1')
+            if g2 is not None:
+                bk.add(L.OP_LINEAR, 'linear', lin(2, Bb, O1, O2, L.ACT_NONE, x=H1.data_ptr(), g=Q.gy_tensor.data_ptr(),
+                                                  dw=g2[0], db=g2[1], w=head['w2'].data_ptr()))
+            bk.add(L.OP_LINEAR, 'linear', lin(1, Bb, O1, O2, L.ACT_NONE, g=Q.gy_tensor.data_ptr(),
+                                              w=head['w2'].data_ptr(), gx=gH1.data_ptr()))
+            if g1 is not None:
+                bk.add(L.OP_LINEAR, 'linear', lin(2, Bb, I1, O1, L.ACT_LRELU, x=F_.data_ptr(), g=gH1.data_ptr(),
+                                                  ysaved=H1.data_ptr(), dw=g1[0], db=g1[1], w=head['w1'].data_ptr()))
+            # a last conv that feeds the head through its activation without a norm layer (Discriminator_VGG_128_SN):
+            # the head's input gradient is masked by that activation here (F_ holds the activation's output)
+            last = recs[-1]
+            head_masks = last['kind'] == 'conv' and last['bn'] is None and last['act'] != L.ACT_NONE
+            o = lin(1, Bb, I1, O1, L.ACT_LRELU, g=gH1.data_ptr(), ysaved=H1.data_ptr(), w=head['w1'].data_ptr(), gx=gF.data_ptr())
+            if head_masks:
+                o.x, o.in_act = F_.data_ptr(), last['act']
+            bk.add(L.OP_LINEAR, 'linear', o)
+            gcur = g32q(ch, h, w)
+            _layout(bk, dt_e, 1, Bb, ch, gcur, nchw_ptr=gF.data_ptr())
+
+        # gcur_masked: True when gcur already is the gradient w.r.t. the producing conv's pre-activation
+        masked = head is not None and head_masks
+        for li in range(len(recs) - 1, -1, -1):
+            r = recs[li]
+            if r['kind'] == 'pool':
+                gx = g32q(r['ch'], r['h'] * 2, r['w'] * 2)
+                pl = L.esr_pool()
+                pl.dtype, pl.mode, pl.B, pl.C, pl.H, pl.W = dt_e, 1, Bb, r['ch'], r['h'], r['w']
+                pl.x, pl.y, pl.g, pl.gx = r['x'].view(0, r['ch']), r['y'].view(0, r['ch']), gcur.view(0, r['ch']), gx.view(0, r['ch'])
+                prev = recs[li - 1] if li > 0 else None
+                pl.relu_mask = 1 if (prev and prev['kind'] == 'conv' and prev['act'] == L.ACT_RELU and prev['bn'] is None) else 0
+                bk.add(L.OP_POOL, 'pool', pl)
+                gcur, masked = gx, bool(pl.relu_mask)
+                continue
+            cout, cin_ = r['cout'], r['cin']
+            if r['bn'] is not None:
+                gconv = g32q(((cout + 31) // 32) * 32, r['h'], r['w'])
+                bnop = r['bnop']
+                bk.add(L.OP_BN, 'bn', bnop(L.BN_BWD_REDUCE, g=gcur, sums=Q.sums_b.data_ptr() + 8 * r['mk']['base'], Bb=Bb, gb=gb))
+                gbn = params_grad.get('bn%d' % r['ibn'])
+                if gbn is not None:
+                    o = bnop(L.BN_BWD_FINAL, sums=Q.sums_b.data_ptr() + 8 * r['mk']['base'], Bb=Bb, gb=gb)
+                    o.dgamma, o.dbeta = gbn
+                    bk.add(L.OP_BN, 'bn', o)
+                bk.add(L.OP_BN, 'bn', bnop(L.BN_BWD_APPLY, g=gcur, gx=gconv, sums=Q.sums_b.data_ptr() + 8 * r['mk']['base'], Bb=Bb, gb=gb))
+                gpre = gconv
+            else:
+                if r['act'] != L.ACT_NONE and not masked:
+                    raise RuntimeError('internal: activation mask of %s not applied' % r['key'])
+                gpre = gcur
+            # weight gradient
+            gw = params_grad.get(r['key'])
+            if gw is not None:
+                wg = L.esr_wgrad()
+                wg.dtype, wg.ks, wg.stride, wg.upsample = dt_e, r['ks'], r['st'], 0
+                wg.B, wg.H, wg.W, wg.cout, wg.cin = Bb, r['h'], r['w'], cout, cin_
+                wg.g, wg.in_ = gpre.view(0, cout), r['x'].view(0, cin_)
+                wg.dw, wg.dbias, wg.scale = gw[0], gw[1], 1.0
+                if Q.tapmajor is not None and r['ks'] in (3, 4):
+                    wg.dw, wg.tap_major = Q.tapmajor.slot(poff[r['key'] + '.weight'], cout, cin_, r['ks'] ** 2), 1
+                # every layer owns its gradient buffers, so the weight gradient can run on the side stream
+                # next to the dgrad chain (joined before the unpermute / at the end of the plan)
+                # (no waits between these runs, several in flight: ESR_OPF_SIDE_FREE; each gets its own partial region)
+                bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE | L.OPF_SIDE_FREE)
+            # input gradient
             prev = recs[li - 1] if li > 0 else None
-            pl.relu_mask = 1 if (prev and prev['kind'] == 'conv' and prev['act'] == L.ACT_RELU and prev['bn'] is None) else 0
-            bk.add(L.OP_POOL, 'pool', pl)
-            gcur, masked = gx, bool(pl.relu_mask)
-            continue
-        cout, cin_ = r['cout'], r['cin']
-        if r['bn'] is not None:
-            gconv = _g32(P, Bb, ((cout + 31) // 32) * 32, r['h'], r['w'], dtype, dev)
-            bnop = r['bnop']
-            bk.add(L.OP_BN, 'bn', bnop(L.BN_BWD_REDUCE, g=gcur, sums=r['mk']['sums_b']))
-            gbn = params_grad.get('bn%d' % r['ibn'])
-            if gbn is not None:
-                o = bnop(L.BN_BWD_FINAL, sums=r['mk']['sums_b'])
-                o.dgamma, o.dbeta = gbn
-                bk.add(L.OP_BN, 'bn', o)
-            bk.add(L.OP_BN, 'bn', bnop(L.BN_BWD_APPLY, g=gcur, gx=gconv, sums=r['mk']['sums_b']))
-            gpre = gconv
-        else:
-            if r['act'] != L.ACT_NONE and not masked:
-                raise RuntimeError('internal: activation mask of %s not applied' % r['key'])
-            gpre = gcur
-        # weight gradient
-        gw = params_grad.get(r['key'])
-        if gw is not None:
-            wg = L.esr_wgrad()
-            wg.dtype, wg.ks, wg.stride, wg.upsample = dt_e, r['ks'], r['st'], 0
-            wg.B, wg.H, wg.W, wg.cout, wg.cin = Bb, r['h'], r['w'], cout, cin_
-            wg.g, wg.in_ = gpre.view(0, cout), r['x'].view(0, cin_)
-            wg.dw, wg.dbias, wg.scale = gw[0], gw[1], 1.0
-            if P.tapmajor is not None and r['ks'] in (3, 4):
-                wg.dw, wg.tap_major = P.tapmajor.slot(poff[r['key'] + '.weight'], cout, cin_, r['ks'] ** 2), 1
-            # every layer owns its gradient buffers, so the weight gradient can run on the side stream
-            # next to the dgrad chain (joined before the unpermute / at the end of the plan)
-            # (no waits between these runs, several in flight: ESR_OPF_SIDE_FREE; each gets its own partial region)
-            bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE | L.OPF_SIDE_FREE)
-        # input gradient
-        prev = recs[li - 1] if li > 0 else None
-        gx = _g32(P, Bb, ((cin_ + cpg - 1) // cpg) * cpg, r['hin'], r['win'], dtype, dev)
-        if r['st'] == 1:
-            c = E._conv(dt_e, Bb, r['hin'], r['win'], gpre.view(0), cout, None, de[r['key']], L.ACT_NONE)
-        else:
-            c = E._conv(dt_e, Bb, r['hin'], r['win'], gpre.view(0), cout, None, de[r['key']], L.ACT_NONE,
-                        ks=4, stride=1, upsample=2)
-        c.bias = None
-        need_mask = prev is not None and prev['kind'] == 'conv' and prev['bn'] is None and prev['act'] != L.ACT_NONE
-        if need_mask:
-            c.mask, c.out2, c.mask_cb_begin = prev['y'].view(0, cin_), gx.view(0, cin_), 0
-            c.mask_act = prev['act']
-        else:
-            c.out = gx.view(0, cin_)
-        bk.add_conv(c)
-        gcur, masked = gx, need_mask
-    if P.tapmajor is not None:
-        up = P.tapmajor.op()
-        if up is not None:
-            bk.add(L.OP_UNPERMUTE, 'unpermute', up)
-    P.gx_tensor = torch.empty(Bb, cin0, H, W, dtype=torch.float32, device=dev)
-    aff = None
-    if input_affine is not None:
-        aff = (input_affine[0], input_affine[1])
-    _layout(bk, dt_e, 0, Bb, cin0, gcur, nchw_ptr=P.gx_tensor.data_ptr(), affine=aff)
-    P.wgrad_arena = E.attach_wgrad_arena(bk, dev, exclusive=True)
+            gx = g32q(((cin_ + cpg - 1) // cpg) * cpg, r['hin'], r['win'])
+            if r['st'] == 1:
+                c = E._conv(dt_e, Bb, r['hin'], r['win'], gpre.view(0), cout, None, de[r['key']], L.ACT_NONE)
+            else:
+                c = E._conv(dt_e, Bb, r['hin'], r['win'], gpre.view(0), cout, None, de[r['key']], L.ACT_NONE,
+                            ks=4, stride=1, upsample=2)
+            c.bias = None
+            need_mask = prev is not None and prev['kind'] == 'conv' and prev['bn'] is None and prev['act'] != L.ACT_NONE
+            if need_mask:
+                c.mask, c.out2, c.mask_cb_begin = prev['y'].view(0, cin_), gx.view(0, cin_), 0
+                c.mask_act = prev['act']
+            else:
+                c.out = gx.view(0, cin_)
+            bk.add_conv(c)
+            gcur, masked = gx, need_mask
+        if Q.tapmajor is not None:
+            up = Q.tapmajor.op()
+            if up is not None:
+                bk.add(L.OP_UNPERMUTE, 'unpermute', up)
+        Q.gx_tensor = torch.empty(Bb, cin0, H, W, dtype=torch.float32, device=dev)
+        aff = None
+        if input_affine is not None:
+            aff = (input_affine[0], input_affine[1])
+        _layout(bk, dt_e, 0, Bb, cin0, gcur, nchw_ptr=Q.gx_tensor.data_ptr(), affine=aff)
+        Q.wgrad_arena = E.attach_wgrad_arena(bk, dev, exclusive=True)
+        return Q
+
+    build_backward(P, Bb0, want_wgrad)
+    if dual is not None:
+        # the G step's pass: input gradient of the first `dual` images, parameters frozen
+        P.second = build_backward(BwdPass(), dual, False)
+        # what a SECOND forward call over the same batch (same weights) adds to the BatchNorm buffers: the groups'
+        # momentum updates in reverse order (the reference's netD(real), netD(fake) after netD(fake), netD(real))
+        P.restat = L.OpList()
+        for r in recs:
+            if r['kind'] == 'conv' and r['bn'] is not None:
+                P.restat.add(L.OP_BN, 'bn', r['bnop'](L.BN_RESTAT))
     return P
+
+
+def _run_pass(Q, graph, gy, n_total, want_gx, needs):
+    """Replay one backward pass (a SeqPlan's own or its BwdPass) for the upstream gradient gy; returns
+    (gx or None, [parameter gradients or None])."""
+    st = E.current_stream()
+    nb_ = Q.gy_tensor.shape[0]              # images the pass covers (a pair's first half, or all)
+    Q.gy_tensor.copy_(gy.detach()[:nb_].reshape(Q.gy_tensor.shape))
+    Q.sums_b.zero_()
+    if Q.grad_flat is not None:
+        Q.grad_flat.zero_()
+        if Q.tapmajor is not None:
+            Q.tapmajor.tm.zero_()
+    if graph:
+        Q.bwd.graph_launch(st)
+    else:
+        Q.bwd.run(st)
+    gx = None
+    if want_gx:
+        gx = Q.gx_tensor.clone()
+        if nb_ < n_total:                    # detached second half: zero gradient
+            gx = torch.cat([gx, gx.new_zeros((n_total - nb_,) + tuple(gx.shape[1:]))])
+    grads = [None] * len(needs)
+    if Q.grad_flat is not None:
+        flat = Q.grad_flat.clone()
+        off = 0
+        for i, (numel, shape) in enumerate(Q.grad_views):
+            if needs[i]:
+                grads[i] = flat[off:off + numel].view(shape)
+            off += numel
+    return gx, grads
 
 
 class SeqNetFn(torch.autograd.Function):
@@ -320,31 +392,82 @@ class SeqNetFn(torch.autograd.Function):
         P = ctx.lease.plan
         if P is None:
             raise RuntimeError('backward called twice on the same forward (retain_graph unsupported)')
-        mod = ctx.mod
-        st = E.current_stream()
-        nb_ = P.gy_tensor.shape[0]              # images the backward covers (a pair's first half, or all)
-        P.gy_tensor.copy_(gy.detach()[:nb_].reshape(P.gy_tensor.shape))
-        P.sums_b.zero_()
-        if P.grad_flat is not None:
-            P.grad_flat.zero_()
-            if P.tapmajor is not None:
-                P.tapmajor.tm.zero_()
-        if getattr(P, 'graph', False):
-            P.bwd.graph_launch(st)
-        else:
-            P.bwd.run(st)
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gx = P.gx_tensor.clone()
-            if nb_ < gy.shape[0]:                # detached second half: zero gradient
-                gx = torch.cat([gx, gx.new_zeros((gy.shape[0] - nb_,) + tuple(gx.shape[1:]))])
-        grads = [None] * ctx.n
-        if P.grad_flat is not None:
-            flat = P.grad_flat.clone()
-            off = 0
-            for i, (numel, shape) in enumerate(P.grad_views):
-                if ctx.needs_input_grad[2 + i]:
-                    grads[i] = flat[off:off + numel].view(shape)
-                off += numel
+        gx, grads = _run_pass(P, getattr(P, 'graph', False), gy, gy.shape[0], ctx.needs_input_grad[0],
+                              ctx.needs_input_grad[2:])
         ctx.lease.release()
         return (gx, None) + tuple(grads)
+
+
+class SharedPass:
+    """Handle of ONE forward over [a; b] whose activations serve two backward passes (build_seq_plan(dual=...)):
+    the pass that gave `a` its gradient (first_fn) and `second_pass()`, which re-issues the same outputs attached to
+    the module's parameters — what a second pair of forward calls with unchanged weights would compute
+    (SRRaGAN_model.py:150-151 after 133-134) — and applies that second pair's BatchNorm buffer updates."""
+
+    def __init__(self, mod, lease, out, n):
+        self.mod, self.lease, self.out, self.n = mod, lease, out, n
+        self.pending = 2
+
+    def done(self):
+        self.pending -= 1
+        if self.pending <= 0 and self.lease is not None:
+            self.lease.release()
+            self.lease = None
+
+    def second_pass(self):
+        """(pred_b, pred_a): the second pair in the reference's order (real first), differentiable w.r.t. the module's
+        parameters only."""
+        if self.lease is None or self.lease.plan is None:
+            raise RuntimeError('SharedPass.second_pass: the forward\'s activations were released')
+        y = SharedSecondFn.apply(self, *[t for _, t in self.mod._pspec()])
+        return y[self.n:], y[:self.n]
+
+    def __del__(self):
+        if self.lease is not None:
+            self.lease.release()
+
+
+class SharedFirstFn(torch.autograd.Function):
+    """netD over [a; b] in one pass (BatchNorm statistics per half); backward: input gradient of `a` only."""
+
+    @staticmethod
+    def forward(ctx, a, b, mod, holder):
+        n = a.shape[0]
+        x = torch.cat([a.detach(), b.detach()])
+        out, lease = mod._run_forward(x, need_bwd=True, groups=2 if mod._has_bn else 1, dual=n)
+        h = SharedPass(mod, lease, out, n)
+        holder.append(h)
+        ctx.h = h
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        h = ctx.h
+        if h is None or h.lease is None or h.lease.plan is None:
+            raise RuntimeError('backward called twice on the same forward (retain_graph unsupported)')
+        P = h.lease.plan
+        gx, _ = _run_pass(P.second, False, gy, h.n, True, ())
+        ctx.h = None
+        h.done()
+        return gx, None, None, None
+
+
+class SharedSecondFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, *params):
+        P = h.lease.plan
+        if P.restat is not None and P.restat.ops:
+            P.restat.run(E.current_stream())
+        ctx.h, ctx.n = h, len(params)
+        return h.out.clone()
+
+    @staticmethod
+    def backward(ctx, gy):
+        h = ctx.h
+        if h is None or h.lease is None or h.lease.plan is None:
+            raise RuntimeError('backward called twice on the same forward (retain_graph unsupported)')
+        P = h.lease.plan
+        _, grads = _run_pass(P, False, gy, gy.shape[0], False, ctx.needs_input_grad[1:])
+        ctx.h = None
+        h.done()
+        return (None,) + tuple(grads)

@@ -155,6 +155,22 @@ __global__ void bn_small_kernel(const esr_bn p) {
         p.invstd[q * p.C + c] = 1.0f / sqrtf(p.running_var[c] + p.eps);
       }
     }
+  } else if (p.mode == ESR_BN_RESTAT) {
+    // the running-statistics side of ANOTHER training forward over the same batch with the groups in reverse order
+    // (the sums of the forward that ran are still in place): what the reference's second pair of netD calls leaves
+    if (!p.training || !p.running_mean) return;
+    float rm = p.running_mean[c], rv = p.running_var[c];
+    for (int q = ngrp - 1; q >= 0; --q) {
+      const double* s = p.sums + (int64_t)q * 2 * p.C;
+      const double m = s[c] / N;
+      double var = s[p.C + c] / N - m * m;
+      if (var < 0) var = 0;
+      rm = (float)((1.0 - p.momentum) * rm + p.momentum * m);
+      rv = (float)((1.0 - p.momentum) * rv + p.momentum * var * (N / (N - 1.0)));
+    }
+    p.running_mean[c] = rm;
+    p.running_var[c] = rv;
+    if (p.num_batches_tracked && c == 0) *p.num_batches_tracked += ngrp;
   } else {   // BWD_FINAL
     double sg = 0, sb = 0;
     for (int q = 0; q < ngrp; ++q) {
@@ -255,6 +271,7 @@ int bn_dispatch(const esr_bn& p, hipStream_t st) {
     case ESR_BN_BWD_REDUCE: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_BWD_REDUCE>), rgrid, block, 0, st, p, ppt); break;
     case ESR_BN_BWD_APPLY: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_BWD_APPLY>), grid, block, 0, st, p, 1); break;
     case ESR_BN_FINALIZE:
+    case ESR_BN_RESTAT:
     case ESR_BN_BWD_FINAL: hipLaunchKernelGGL(bn_small_kernel, dim3((p.C + 63) / 64), dim3(64), 0, st, p); break;
     default: esr_set_error("esr_batchnorm: bad mode %d", p.mode); return ESR_ERR_INVALID;
   }

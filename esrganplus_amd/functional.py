@@ -239,7 +239,9 @@ class _RRDBNetFn(torch.autograd.Function):
     autograd backward triggered at SRRaGAN_model.py:140)."""
 
     @staticmethod
-    def forward(ctx, x, net, zs, *params):
+    def forward(ctx, x, net, zs, proxy, *params):
+        # proxy (a 1-element leaf that requires grad) stands for ALL parameters: their gradients then leave the node
+        # through net._deliver_flat_grads instead of one autograd output each; `params` is empty in that mode
         xin = _prep_input(x, 'input')
         B, _, H, W = xin.shape
         dev = xin.device
@@ -254,6 +256,7 @@ class _RRDBNetFn(torch.autograd.Function):
         ctx.explicit = zs is not None
         ctx.noise = noise
         ctx.n_params = len(params)
+        ctx.net = net if proxy is not None else None
         ctx.sync = getattr(net, '_grad_sync', None)
         return _train_forward(tp, xin, st, ctx.seed, zs)
 
@@ -266,11 +269,16 @@ class _RRDBNetFn(torch.autograd.Function):
         gy = gy.detach().contiguous().float()
         gx = _train_backward(tp, gy, E.current_stream(), ctx.noise, ctx.explicit, ctx.seed,
                              bool(ctx.needs_input_grad[0]), ctx.sync)
+        gx = gx if ctx.needs_input_grad[0] else None
+        if ctx.net is not None:
+            ctx.net._deliver_flat_grads(tp.grad_flat)
+            ctx.lease.release()
+            return (gx, None, None, None)
         grads = _grad_views(tp)
         ctx.lease.release()
         assert len(grads) == ctx.n_params
-        grads = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:])]
-        return (gx if ctx.needs_input_grad[0] else None, None, None) + tuple(grads)
+        grads = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[4:])]
+        return (gx, None, None, None) + tuple(grads)
 
 
 def _block_train_plan(mod, kind, wp, dp, B, H, W, dev, noise, explicit):
@@ -333,7 +341,13 @@ def run_rrdbnet(net, x, z=None):
             raise ValueError('expected %d input channels, got %d' % (net.in_nc, C_))
         per = 4 if net.variant == 'test_image' else 3
         zs = _zs_list(z, per * net.nb, (B, 64, H, W), x.device) if net.training else None
-        return _RRDBNetFn.apply(x, net, zs, *net._convs()[1])
+        params = net._convs()[1]
+        if net.flat_param_grads and all(p.requires_grad for p in params):
+            proxy = net.__dict__.get('_grad_proxy')
+            if proxy is None or proxy.device != x.device:
+                proxy = net.__dict__['_grad_proxy'] = torch.zeros(1, device=x.device, requires_grad=True)
+            return _RRDBNetFn.apply(x, net, zs, proxy)
+        return _RRDBNetFn.apply(x, net, zs, None, *params)
     xin = _prep_input(x, 'input')
     B, C_, H, W = xin.shape
     if C_ != net.in_nc:

@@ -54,6 +54,8 @@ class ESRGANPlusStep:
         # backward (autograd runs a node's backward on the stream its forward ran on): both are chains of small
         # launches that use a fraction of the CUs each
         self.overlap = int(os.environ.get('ESR_TRAIN_OVERLAP', '2'))
+        # ESR_SHARED_D=0: the D step runs its own forward pair (round 3) instead of re-using the G step's pass
+        self.shared_d = os.environ.get('ESR_SHARED_D', '1') != '0'
         self.overlap_d_step = self.overlap >= 1
 
     def _side(self, dev, which=0):
@@ -100,7 +102,8 @@ class ESRGANPlusStep:
         # ---------------- G ----------------
         for p in netD.parameters():
             p.requires_grad = False
-        self.optimizer_G.zero_grad(set_to_none=True)
+        if not (hasattr(netG, 'mark_grads_stale') and netG.mark_grads_stale()):
+            self.optimizer_G.zero_grad(set_to_none=True)     # (first step / gradients that are not the module's store)
         if ov >= 1:
             # netF(var_H) does not depend on G: on the second stream, under the generator's forward
             main = torch.cuda.current_stream()
@@ -113,10 +116,18 @@ class ESRGANPlusStep:
         self.fake_H = fake_H
         l_g_pix = LS.l1_loss(fake_H, var_H, self.l_pix_w)
 
+        shared = self.shared_d and getattr(netD, '_shared_ok', False) and netD.training
+        dh = []
+
         def d_pass():
             # both operands in ONE pass (forward_pair: per-half BatchNorm statistics, the detached ``real`` half
-            # costs no backward) — the reference's call order fake, real is the group order
-            pg, pr = netD.forward_pair(fake_H, var_ref)
+            # costs no backward) — the reference's call order fake, real is the group order.  shared: the same pass
+            # also keeps what the D step's pair needs (forward_shared), so that pair costs no second forward
+            if shared:
+                pg, pr, h = netD.forward_shared(fake_H, var_ref)
+                dh.append(h)
+            else:
+                pg, pr = netD.forward_pair(fake_H, var_ref)
             return LS.ragan_loss(pr, pg, False, True, self.l_gan_w, mean)[0]
 
         if ov >= 2:
@@ -141,8 +152,11 @@ class ESRGANPlusStep:
             for p in netD.parameters():
                 p.requires_grad = True
             self.optimizer_D.zero_grad(set_to_none=True)
-            with netD.weights_unchanged():        # no optimizer step since the G step's D pass
-                pred_d_real, pred_d_fake = netD.forward_pair(var_ref, fake_H.detach())
+            if shared:
+                pred_d_real, pred_d_fake = dh.pop().second_pass()
+            else:
+                with netD.weights_unchanged():        # no optimizer step since the G step's D pass
+                    pred_d_real, pred_d_fake = netD.forward_pair(var_ref, fake_H.detach())
             l_d_total, aux = LS.ragan_loss(pred_d_real, pred_d_fake, True, False, 1.0, mean)
             torch.autograd.backward([l_d_total], [scale])
             return aux

@@ -233,7 +233,12 @@ typedef struct esr_unpermute {
  *   BWD_FINAL  dgamma += sums[C+c]; dbeta += sums[c]
  *   BWD_APPLY  gx = gamma*invstd*(g' - sum g'/N - xhat*sum(g' xhat)/N)   (eval: gamma*invstd*g') */
 enum esr_bn_mode { ESR_BN_STATS = 0, ESR_BN_FINALIZE = 1, ESR_BN_APPLY = 2, ESR_BN_BWD_REDUCE = 3,
-                   ESR_BN_BWD_FINAL = 4, ESR_BN_BWD_APPLY = 5 };
+                   ESR_BN_BWD_FINAL = 4, ESR_BN_BWD_APPLY = 5,
+                   ESR_BN_RESTAT = 6   /* training: apply the running-statistics (and num_batches_tracked) updates of
+                                          ANOTHER forward call over the same batch from the sums still in place, groups in
+                                          REVERSE order — the train step calls netD on (fake, real) and then, weights
+                                          unchanged, on (real, fake) (SRRaGAN_model.py:133-134,150-151): the second pair's
+                                          activations equal the first's, only the BatchNorm buffers move */ };
 typedef struct esr_bn {
   int32_t dtype, mode;
   int32_t B, C, H, W;

@@ -252,6 +252,55 @@ def test_discriminator_forward_pair_matches_two_calls(dev, mode, prec, tol):
             assert (x - y).abs().max().item() <= tol * max(y.abs().max().item(), 1e-3 * gmax)
 
 
+@pytest.mark.parametrize('prec,tol', [('fp32', 2e-4), ('fp16', 3e-2)])
+def test_discriminator_forward_shared_matches_four_calls(dev, prec, tol):
+    """The train step calls netD four times with unchanged weights — G step: netD(fake), netD(real).detach() with D
+    frozen (SRRaGAN_model.py:133-134), D step: netD(real), netD(fake.detach()) (150-151) — and the second pair sees
+    the values of the first.  ``forward_shared`` runs ONE forward for all four: its logits, the gradient it gives
+    ``fake`` (first pair's loss), the parameter gradients (second pair's loss), and the BatchNorm buffers after the
+    four calls (updates in call order fake, real, real, fake; num_batches_tracked + 4) against four separate calls."""
+    from esrganplus_amd import architecture as arch
+    sd = synth.discriminator_state_dict(7)
+    f0 = synth.image_batch(81, 3, 3, 128, 128, name='shared.f').to(dev)
+    r0 = synth.image_batch(82, 3, 3, 128, 128, name='shared.r').to(dev)
+    res = {}
+    for how in ('four', 'shared'):
+        net = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision(prec)
+        net.load_state_dict(sd)
+        fake, real = f0.clone().requires_grad_(True), r0.clone()
+        for p in net.parameters():
+            p.requires_grad = False
+        if how == 'four':
+            pg, pr = net(fake), net(real).detach()
+        else:
+            pg, pr, h = net.forward_shared(fake, real)
+            assert not pr.requires_grad
+        _ragan(pr, pg).backward()                       # G step's relativistic term -> d/d fake
+        for p in net.parameters():
+            p.requires_grad = True
+        if how == 'four':
+            dr, df = net(real), net(fake.detach())
+        else:
+            dr, df = h.second_pass()
+        (2.0 * _ragan(dr, df)).backward()               # D step's loss -> parameter gradients
+        bn = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        res[how] = dict(pg=pg.detach(), pr=pr.detach(), dr=dr.detach(), df=df.detach(), gf=fake.grad,
+                        gp=[p.grad for p in net.parameters()],
+                        rm=[m.running_mean.clone() for m in bn], rv=[m.running_var.clone() for m in bn],
+                        nbt=[int(m.num_batches_tracked) for m in bn])
+    four, sh = res['four'], res['shared']
+    assert sh['nbt'] == four['nbt'] == [4] * len(four['nbt'])
+    rel = lambda x, y: ((x - y).abs().max() / y.abs().max().clamp_min(1e-12)).item()
+    for k in ('pg', 'pr', 'dr', 'df', 'gf'):
+        assert rel(sh[k], four[k]) <= tol, k
+    assert torch.equal(sh['dr'], sh['pr']) and torch.equal(sh['df'], sh['pg'])
+    for x, y in zip(sh['rm'] + sh['rv'], four['rm'] + four['rv']):
+        assert rel(x, y) <= max(tol * 0.1, 1e-5)
+    gmax = max(y.abs().max().item() for y in four['gp'])
+    for x, y in zip(sh['gp'], four['gp']):       # (conv biases in front of a BatchNorm: exact gradient 0, noise)
+        assert (x - y).abs().max().item() <= tol * max(y.abs().max().item(), 1e-3 * gmax)
+
+
 def test_vgg_forward_pair_matches_two_calls(dev):
     """netF(fake) / netF(real).detach() (SRRaGAN_model.py:128-129) as one batch: features and d/d fake."""
     from esrganplus_amd import architecture as arch

@@ -253,3 +253,46 @@ def test_discriminator_sn_state_dict_keys_and_power_iteration():
     assert torch.equal(m.weight, w_eff.detach())
     w_eff.sum().backward()                                 # the gradient runs through sigma to weight_orig
     assert m.weight_orig.grad is not None and torch.isfinite(m.weight_orig.grad).all()
+
+
+def test_flat_gradient_store_follows_autograd_accumulation_rules():
+    """block._PlannedModule._deliver_flat_grads — how the fused backward of RRDBNet hands ~770 parameter gradients over
+    without one autograd output per tensor — must behave like AccumulateGrad: None -> set, present -> add, and a
+    store marked stale (train.ESRGANPlusStep's stand-in for zero_grad) -> overwrite; foreign gradients are honoured."""
+    from esrganplus_amd import architecture as arch
+    from esrganplus_amd.optim import FusedAdam
+    net = arch.RRDBNet(3, 3, 64, 1)
+    params = list(net.parameters())
+    n = sum(p.numel() for p in params)
+    assert [id(p) for p in net._convs()[1]] == [id(p) for p in params]     # store order == optimizer order
+    a = torch.arange(n, dtype=torch.float32) / n
+    assert not net.mark_grads_stale()                   # nothing delivered yet
+    net._deliver_flat_grads(a)
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    assert torch.equal(flat, a) and all(p.grad.shape == p.shape for p in params)
+    views = [p.grad for p in params]
+    net._deliver_flat_grads(a)                          # second backward without zero_grad: accumulated
+    assert all(p.grad is v for p, v in zip(params, views))
+    assert torch.equal(torch.cat([p.grad.reshape(-1) for p in params]), 2 * a)
+    assert net.mark_grads_stale()
+    net._deliver_flat_grads(3 * a)                      # stale: overwritten
+    assert torch.equal(torch.cat([p.grad.reshape(-1) for p in params]), 3 * a)
+    net.zero_grad(set_to_none=True)
+    net._deliver_flat_grads(a)                          # None everywhere: set to the store's views again
+    assert all(p.grad is v for p, v in zip(params, views))
+    assert torch.equal(torch.cat([p.grad.reshape(-1) for p in params]), a)
+    # the views tile one storage in optimizer order: FusedAdam's zero-copy test accepts them
+    opt = FusedAdam(params)
+    st = dict(goff=[0] * len(params), total=n)
+    off = 0
+    for i, p in enumerate(params):
+        st['goff'][i] = off
+        off += p.numel()
+    got = opt._flat_grad(st, params)
+    assert got.data_ptr() == views[0].data_ptr() and got.numel() == n
+    assert opt._flat_grad(st, params) is got            # identity fast path on the next step
+    # a foreign gradient on one tensor: tensor-by-tensor accumulation
+    params[3].grad = torch.ones_like(params[3])
+    net._deliver_flat_grads(a)
+    assert torch.equal(params[3].grad, torch.ones_like(params[3]) + a.split([p.numel() for p in params])[3].view_as(params[3]))
+    assert not net.mark_grads_stale()
