@@ -193,7 +193,8 @@ class _SeqNet(B._PlannedModule):
         want_w = dual is not None or any(p.requires_grad for p in self.parameters())
         if need_bwd:
             dp = self._dgrad_weights(dev)
-            dp.ensure(st, force=(bool(self.training) or want_w) and not self.__dict__.get('_weights_clean', False))
+            dp.ensure(st, force=(bool(self.training) or want_w) and not self.__dict__.get('_weights_clean', False)
+                      and not self._dgrad_fresh())
         training = bool(self.training) and self._has_bn
         groups = groups if training else 1
         key = ('seq', Bn, H, W, self.precision, training, need_bwd, want_w, wp.generation, str(dev), groups, bwd_B, dual)

@@ -353,13 +353,33 @@ class _PlannedModule(nn.Module):
         """Keys of up-convs to run in the sub-pixel form (engine.WeightPack)."""
         return ()
 
+    def prepack(self, fwd=True, dgrad=True):
+        """Re-pack the kernel-side weight copies NOW, on the current stream (a training loop calls this right after
+        ``optimizer.step()``, on a stream that runs next to other work): the next training forward then finds them
+        fresh instead of packing at its start.  Only valid when nothing changes the parameters in between except
+        through paths this module sees (load_state_dict / apply / .to set the force flag; in-place edits bump
+        ``_version``).  No-op for packs that do not exist yet."""
+        st = E.current_stream()
+        for key, pk in list(self._wp.items()):
+            if key[0] == 'dgrad':
+                if dgrad and key[1] == self.precision:
+                    pk.ensure(st, force=True, record_sig=True)
+                    self.__dict__['_prepacked_dgrad'] = True
+            elif fwd and key[0] == self.precision:
+                pk.ensure(st, force=True, record_sig=True)
+                self.__dict__['_prepacked_fwd'] = True
+
+    def _dgrad_fresh(self):
+        """True once after prepack(dgrad=True): the caller may skip its forced dgrad re-pack."""
+        return self.__dict__.pop('_prepacked_dgrad', False)
+
     def _weights(self, device):
         key = (self.precision, str(device))
         wp = self._wp.get(key)
         if wp is None:
             wp = E.WeightPack(self._conv_list(), self.precision, device, self._subpix_keys())
             self._wp[key] = wp
-        clean = self.__dict__.get('_weights_clean', False)
+        clean = self.__dict__.get('_weights_clean', False) or self.__dict__.pop('_prepacked_fwd', False)
         wp.ensure(E.current_stream(), force=self._force_repack or (self.training and not clean))
         self._force_repack = False
         return wp

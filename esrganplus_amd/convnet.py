@@ -7,12 +7,17 @@ Convs keep their LeakyReLU / ReLU in the epilogue; BatchNorm2d runs as stats -> 
 passes over the conv output; the backward applies activation masks inside the producing kernels
 (conv epilogue ``out2``, BN backward, max-pool backward).
 """
+import os
+
 import torch
 
 from . import _lib as L
 from . import engine as E
 
 BN_MOMENTUM, BN_EPS = 0.1, 1e-5      # nn.BatchNorm2d defaults (block.py:31)
+# ESR_FUSE_BN=0: the five-launch BatchNorm of round 3 (stats, finalize, apply / reduce, final, apply) for A/B runs
+def fuse_bn():
+    return os.environ.get('ESR_FUSE_BN', '1') != '0'
 
 
 class _Lease(object):
@@ -158,10 +163,10 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
             def bnop(mode, x=cb, y=yb, g=None, gx=None, sums=mk['sums_f'], act=s['act'], bn=bn, mk=mk,
                      cout=cout, ho=ho, wo=wo, Bb=None, gb=None):
                 o = L.esr_bn()
-                fwd_op = mode in (L.BN_STATS, L.BN_FINALIZE, L.BN_APPLY, L.BN_RESTAT)
+                fwd_op = mode in (L.BN_STATS, L.BN_FINALIZE, L.BN_APPLY, L.BN_RESTAT, L.BN_FIN_APPLY)
                 o.dtype, o.mode, o.B, o.C, o.H, o.W = dt_e, mode, (B if fwd_op else Bb), cout, ho, wo
                 o.groups = groups if fwd_op else gb
-                if mode in (L.BN_FINALIZE, L.BN_RESTAT) and training and bn.get('nbt') is not None:
+                if mode in (L.BN_FINALIZE, L.BN_RESTAT, L.BN_FIN_APPLY) and training and bn.get('nbt') is not None:
                     o.num_batches_tracked = bn['nbt'].data_ptr()
                 o.training, o.act, o.momentum, o.eps = int(training), act, BN_MOMENTUM, BN_EPS
                 o.x, o.y = x.view(0, cout), y.view(0, cout)
@@ -173,10 +178,15 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
                 o.gamma, o.beta = bn['weight'].data_ptr(), bn['bias'].data_ptr()
                 o.running_mean, o.running_var = bn['rm'].data_ptr(), bn['rv'].data_ptr()
                 return o
-            if training:
+            if training and fuse_bn():
+                # statistics pass, then ONE pass that finalizes and applies (ESR_BN_FIN_APPLY)
                 f.add(L.OP_BN, 'bn', bnop(L.BN_STATS))
-            f.add(L.OP_BN, 'bn', bnop(L.BN_FINALIZE))
-            f.add(L.OP_BN, 'bn', bnop(L.BN_APPLY))
+                f.add(L.OP_BN, 'bn', bnop(L.BN_FIN_APPLY))
+            else:
+                if training:
+                    f.add(L.OP_BN, 'bn', bnop(L.BN_STATS))
+                f.add(L.OP_BN, 'bn', bnop(L.BN_FINALIZE))
+                f.add(L.OP_BN, 'bn', bnop(L.BN_APPLY))
             recs.append(dict(kind='conv', key=key, x=cur, cin=ch, y=yb, c=cb, cout=cout, ks=ks, st=st,
                              act=s['act'], h=ho, w=wo, hin=h, win=w, bn=bn, bnop=bnop, mk=mk, ibn=ibn))
             P.bn_layers.append(bn)
@@ -281,11 +291,14 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
                 bnop = r['bnop']
                 bk.add(L.OP_BN, 'bn', bnop(L.BN_BWD_REDUCE, g=gcur, sums=Q.sums_b.data_ptr() + 8 * r['mk']['base'], Bb=Bb, gb=gb))
                 gbn = params_grad.get('bn%d' % r['ibn'])
-                if gbn is not None:
+                if gbn is not None and not fuse_bn():
                     o = bnop(L.BN_BWD_FINAL, sums=Q.sums_b.data_ptr() + 8 * r['mk']['base'], Bb=Bb, gb=gb)
                     o.dgamma, o.dbeta = gbn
                     bk.add(L.OP_BN, 'bn', o)
-                bk.add(L.OP_BN, 'bn', bnop(L.BN_BWD_APPLY, g=gcur, gx=gconv, sums=Q.sums_b.data_ptr() + 8 * r['mk']['base'], Bb=Bb, gb=gb))
+                o = bnop(L.BN_BWD_APPLY, g=gcur, gx=gconv, sums=Q.sums_b.data_ptr() + 8 * r['mk']['base'], Bb=Bb, gb=gb)
+                if gbn is not None and fuse_bn():
+                    o.dgamma, o.dbeta = gbn          # BWD_FINAL folded into the apply pass
+                bk.add(L.OP_BN, 'bn', o)
                 gpre = gconv
             else:
                 if r['act'] != L.ACT_NONE and not masked:

@@ -63,9 +63,67 @@ __global__ __launch_bounds__(256) void bn_pass_kernel(const esr_bn p, const int 
   // reference run as one launch); every per-channel array carries one [C] row per group
   const int ngrp = p.groups > 1 ? p.groups : 1, bpg = p.B / ngrp, grp = b / bpg;
   const double N = (double)bpg * p.H * p.W;
-  const float* const mean = p.mean + grp * p.C;
-  const float* const invstd = p.invstd + grp * p.C;
+  const float* mean = p.mean + grp * p.C;
+  const float* invstd = p.invstd + grp * p.C;
   double* const sums = p.sums + (int64_t)grp * 2 * p.C;
+  if constexpr (MODE == ESR_BN_FIN_APPLY) {
+    // FINALIZE folded into the APPLY pass (training): every workgroup forms the statistics of its own 16 channels
+    // from the sums (the FINALIZE arithmetic, so the numbers are the same); the workgroups at pixel chunk 0 of a
+    // group's first image also leave them in p.mean / p.invstd for the backward, and the one at image 0 applies the
+    // running-statistics updates of all groups in order
+    __shared__ float st_m[CPG], st_i[CPG];
+    if (threadIdx.x < CPG) {
+      const int c = g * CPG + threadIdx.x;
+      float m_ = 0.f, i_ = 0.f;
+      if (c < p.C) {
+        const double m = sums[c] / N;
+        double var = sums[p.C + c] / N - m * m;
+        if (var < 0) var = 0;
+        m_ = (float)m;
+        i_ = (float)(1.0 / sqrt(var + (double)p.eps));
+        if (blockIdx.x == 0 && b == grp * bpg) {
+          p.mean[grp * p.C + c] = m_;
+          p.invstd[grp * p.C + c] = i_;
+        }
+        if (blockIdx.x == 0 && b == 0) {
+          if (p.running_mean) {
+            float rm = p.running_mean[c], rv = p.running_var[c];
+            for (int q = 0; q < ngrp; ++q) {
+              const double* s = p.sums + (int64_t)q * 2 * p.C;
+              const double mq = s[c] / N;
+              double vq = s[p.C + c] / N - mq * mq;
+              if (vq < 0) vq = 0;
+              rm = (float)((1.0 - p.momentum) * rm + p.momentum * mq);
+              rv = (float)((1.0 - p.momentum) * rv + p.momentum * vq * (N / (N - 1.0)));
+            }
+            p.running_mean[c] = rm;
+            p.running_var[c] = rv;
+          }
+          if (p.num_batches_tracked && c == 0) *p.num_batches_tracked += ngrp;
+        }
+      }
+      st_m[threadIdx.x] = m_;
+      st_i[threadIdx.x] = i_;
+    }
+    __syncthreads();
+    mean = st_m - g * CPG;        // indexed by channel below
+    invstd = st_i - g * CPG;
+  }
+  if constexpr (MODE == ESR_BN_BWD_APPLY) {
+    // BWD_FINAL folded in: dgamma / dbeta from the sums of all groups, once per channel
+    if (p.dgamma && blockIdx.x == 0 && b == 0 && threadIdx.x < CPG) {
+      const int c = g * CPG + threadIdx.x;
+      if (c < p.C) {
+        double sg = 0, sb = 0;
+        for (int q = 0; q < ngrp; ++q) {
+          const double* s = p.sums + (int64_t)q * 2 * p.C;
+          sg += s[p.C + c]; sb += s[c];
+        }
+        p.dgamma[c] += (float)sg;
+        if (p.dbeta) p.dbeta[c] += (float)sb;
+      }
+    }
+  }
   for (int k = 0; k < ppt; ++k) {
   const int pix = (blockIdx.x * ppt + k) * 256 + threadIdx.x;
   const bool ok = pix < p.H * p.W;
@@ -75,7 +133,7 @@ __global__ __launch_bounds__(256) void bn_pass_kernel(const esr_bn p, const int 
     if (MODE == ESR_BN_STATS) {
 #pragma unroll
       for (int e = 0; e < CPG; ++e) { s0[e] += xv[e]; s1[e] += xv[e] * xv[e]; }
-    } else if (MODE == ESR_BN_APPLY) {
+    } else if (MODE == ESR_BN_APPLY || MODE == ESR_BN_FIN_APPLY) {
 #pragma unroll
       for (int e = 0; e < CPG; ++e) {
         const int c = g * CPG + e;
@@ -268,6 +326,10 @@ int bn_dispatch(const esr_bn& p, hipStream_t st) {
   switch (p.mode) {
     case ESR_BN_STATS: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_STATS>), rgrid, block, 0, st, p, ppt); break;
     case ESR_BN_APPLY: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_APPLY>), grid, block, 0, st, p, 1); break;
+    case ESR_BN_FIN_APPLY:
+      if (!p.training) { esr_set_error("esr_batchnorm: FIN_APPLY is a training-mode pass"); return ESR_ERR_INVALID; }
+      hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_FIN_APPLY>), grid, block, 0, st, p, 1);
+      break;
     case ESR_BN_BWD_REDUCE: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_BWD_REDUCE>), rgrid, block, 0, st, p, ppt); break;
     case ESR_BN_BWD_APPLY: hipLaunchKernelGGL((bn_pass_kernel<T, ESR_BN_BWD_APPLY>), grid, block, 0, st, p, 1); break;
     case ESR_BN_FINALIZE:

@@ -160,7 +160,7 @@ class WeightPack:
         idx = sorted({0, n // 3, (2 * n) // 3, n - 1})
         return (n,) + tuple(c[i][1].data_ptr() for i in idx) + tuple(c[i][2].data_ptr() for i in idx if c[i][2] is not None)
 
-    def ensure(self, stream, force=False):
+    def ensure(self, stream, force=False, record_sig=False):
         fp = self._ptr_fingerprint()
         if fp != getattr(self, '_fp', None):
             ptrs = tuple(p.data_ptr() for _, w, b in self.convs for p in (w, b) if p is not None)
@@ -170,7 +170,8 @@ class WeightPack:
                 self._sig = None
             self._fp = fp
         # training passes re-pack unconditionally (FusedAdam updates through raw pointers: no version bump to see)
-        sig = None if force else tuple(p._version for _, w, b in self.convs for p in (w, b) if p is not None)
+        # (record_sig: a forced pack whose result a later non-forced call may rely on — _PlannedModule.prepack)
+        sig = None if (force and not record_sig) else tuple(p._version for _, w, b in self.convs for p in (w, b) if p is not None)
         if force or sig != self._sig:
             self.ops.run(stream)
             with torch.no_grad():
@@ -769,6 +770,60 @@ def current_stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_concurrent_cache = {}
+
+
+def concurrent_streams(device, n, probe=True):
+    """n torch streams on `device` that really run NEXT TO the current stream and next to each other.  HIP maps streams
+    onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and two streams on one queue serialise; measured on
+    MI355X / ROCm 7.2 (tools/stream_probe.py): the FIRST stream a process creates shares its queue with the default
+    stream — the train step's "side" stream of round 3, whose D step therefore never overlapped the main stream's
+    work.  Probe: hold one workgroup on a (esr_debug_hold_cus, released as soon as the answer is known) and see whether
+    a tiny kernel on b completes meanwhile, both directions, against the current stream and the streams already
+    chosen.  Cached per (device, current stream).  probe=False: plain new streams."""
+    import time
+    dev = torch.device(device)
+    cur = torch.cuda.current_stream(dev)
+    key = (dev.index, cur.cuda_stream)
+    have = _concurrent_cache.setdefault(key, [])
+    if len(have) >= n:
+        return have[:n]
+    if not probe or torch.cuda.is_current_stream_capturing():
+        while len(have) < n:
+            have.append(torch.cuda.Stream(device=dev))
+        return have[:n]
+    words = torch.zeros(16, dtype=torch.int32).pin_memory()
+    p_release, p_started = C.c_void_p(words.data_ptr()), C.c_void_p(words.data_ptr() + 4)
+    x = torch.zeros(64, device=dev)
+
+    def runs_next_to(a, b):
+        # tiny kernel on b while one workgroup is held on a
+        torch.cuda.synchronize(dev)
+        words.zero_()
+        L.check(L.lib().esr_debug_hold_cus(1, p_release, 20, p_started, C.c_void_p(a.cuda_stream)), 'esr_debug_hold_cus')
+        t0 = time.perf_counter()
+        with torch.cuda.stream(b):
+            x.add_(1.0)
+        b.synchronize()
+        dt = time.perf_counter() - t0
+        words[0] = 1
+        torch.cuda.synchronize(dev)
+        return dt < 0.008
+
+    keep = []          # rejected candidates stay alive until the search ends (a freed stream's slot would be re-issued)
+    for _ in range(24):
+        if len(have) >= n:
+            break
+        cand = torch.cuda.Stream(device=dev)
+        if all(runs_next_to(o, cand) and runs_next_to(cand, o) for o in [cur] + have):
+            have.append(cand)
+        else:
+            keep.append(cand)
+    while len(have) < n:                         # nothing better found: serialising streams still give correct results
+        have.append(keep.pop() if keep else torch.cuda.Stream(device=dev))
+    return have[:n]
+
+
 class StreamOrder:
     """A module's launch plans own their activation buffers, packed weights and chain workspaces, so two inference
     calls of ONE module from two streams must not overlap (torch modules are stateless in that respect; a second
@@ -908,7 +963,7 @@ class DgradPack:
         self._ptrs = None
         self.ops = None
 
-    def ensure(self, stream, force=True):
+    def ensure(self, stream, force=True, record_sig=False):
         """force=False (a frozen eval-mode net, the VGG feature extractor): re-pack only when a parameter's
         storage or version changed, like WeightPack.ensure."""
         fp = (len(self.convs), len(self.gathers), len(self.ones)) + tuple(
@@ -959,7 +1014,7 @@ class DgradPack:
             ops.add(L.OP_PACK_BATCH, 'pack_batch', bp)
             self.ops, self._ptrs = ops, ptrs
             self._sig = None
-        sig = None if force else (tuple(w._version for _, w in self.convs)
+        sig = None if (force and not record_sig) else (tuple(w._version for _, w in self.convs)
                                   + tuple(pc[0]._version for _, _, pieces in self.gathers for pc in pieces)
                                   + tuple(w._version for _, _, w in self.ones))
         if force or sig != getattr(self, '_sig', None):

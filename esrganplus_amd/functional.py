@@ -248,7 +248,7 @@ class _RRDBNetFn(torch.autograd.Function):
         st = E.current_stream()
         wp = net._weights(dev)
         dp = net._dgrad_weights(dev)
-        dp.ensure(st)
+        dp.ensure(st, force=not net._dgrad_fresh())
         noise = bool(net.training)
         tp = _train_plan(net, wp, dp, B, H, W, dev, noise, zs is not None)
         ctx.lease = _PlanLease(tp)

@@ -19,6 +19,7 @@ import os
 import torch
 
 from . import dp as DP
+from . import engine as E
 from . import losses as LS
 from .optim import FusedAdam, DynamicLossScaler
 
@@ -48,22 +49,27 @@ class ESRGANPlusStep:
         self.log = {}
         self.fake_H = None
         self._steps = 0
-        # stream overlap of the step (ESR_TRAIN_OVERLAP): 0 = everything in sequence on the caller's stream;
-        # 1 = netF(var_H) under the generator's forward and the D step under the G backward (round 3);
-        # 2 (default) = additionally the G step's netD pass on a third stream next to its netF pass, forward AND
-        # backward (autograd runs a node's backward on the stream its forward ran on): both are chains of small
-        # launches that use a fraction of the CUs each
-        self.overlap = int(os.environ.get('ESR_TRAIN_OVERLAP', '2'))
+        # stream overlap of the step (ESR_TRAIN_OVERLAP): 0 = everything in sequence on the caller's stream (9.8 ms);
+        # 1 (default) = netF(var_H) and the D step on a second stream (8.9 ms); 2 = additionally the G step's netD
+        # pass on a third stream next to its netF pass, forward AND backward (autograd runs a node's backward on the
+        # stream its forward ran on).  Measured, round 4 (profiles/r04_experiments.md): more concurrency is NOT faster
+        # here — 2 costs 0.1-0.15 ms over 1, streams probed to be truly concurrent (engine.concurrent_streams,
+        # ESR_STREAM_PROBE=1) 0.4-0.9 ms, GPU_MAX_HW_QUEUES=8 3-5 ms: a persistent chain launch (128 lock-stepped
+        # workgroups exchanging halos) that shares the chip with other launches runs at the pace of its most-delayed
+        # tile, and the small launches slow each other 2-5x.  What mode 1 overlaps is what the default stream's
+        # hardware queue lets through.
+        self.overlap = int(os.environ.get('ESR_TRAIN_OVERLAP', '1'))
         # ESR_SHARED_D=0: the D step runs its own forward pair (round 3) instead of re-using the G step's pass
         self.shared_d = os.environ.get('ESR_SHARED_D', '1') != '0'
+        # ESR_PREPACK=0: every network packs its weights at the start of its next training forward (round 3)
+        self.prepack = os.environ.get('ESR_PREPACK', '1') != '0'
         self.overlap_d_step = self.overlap >= 1
 
     def _side(self, dev, which=0):
-        ss = self.__dict__.setdefault('_side_streams', {})
-        s = ss.get(which)
-        if s is None or s.device != dev:
-            s = ss[which] = torch.cuda.Stream(device=dev)
-        return s
+        # ESR_STREAM_PROBE=1: streams PROBED to run concurrently with the caller's stream and with each other
+        # (engine.concurrent_streams: the first stream a process creates shares the default stream's hardware queue);
+        # default: plain new streams, which measured faster (see `overlap` above)
+        return E.concurrent_streams(dev, 2, probe=os.environ.get('ESR_STREAM_PROBE', '0') == '1')[which]
 
     def _scale_t(self, dev):
         t = self.__dict__.get('_scale_tensor')
@@ -133,6 +139,7 @@ class ESRGANPlusStep:
         if ov >= 2:
             sideD = self._side(var_L.device, 1)
             sideD.wait_stream(main)
+            sideD.wait_stream(side)               # (netD's weight packs of the previous step's end: prepack)
             with torch.cuda.stream(sideD):
                 l_g_gan = d_pass()
         if ov >= 1:
@@ -198,6 +205,20 @@ class ESRGANPlusStep:
         self.optimizer_D.step(grad_scale=inv, scaler=self.scaler)
         if self.scaler:
             self.scaler.update()
+        if self.prepack and cuda:
+            # the next step's weight packs, now: the generator's forward copy on the main stream (the step starts with
+            # it anyway), everything that is only needed later — D's two packs, G's input-gradient operands — on the
+            # side stream, next to it and to the start of the next generator forward
+            netG.prepack(fwd=True, dgrad=False)
+            if ov >= 1:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    netD.prepack()
+                    netG.prepack(fwd=False, dgrad=True)
+                # (joined at the next step's `main.wait_stream(side)` in front of netF(fake_H): before any consumer)
+            else:
+                netD.prepack()
+                netG.prepack(fwd=False, dgrad=True)
         logs = dict(l_g_pix=l_g_pix, l_g_fea=l_g_fea, l_g_gan=l_g_gan, l_d_real=aux[2], l_d_fake=aux[3],
                     D_real=aux[0], D_fake=aux[1])
         if sync_log:      # the reference calls .item() on every loss each step (SRRaGAN_model.py:171-186)

@@ -234,6 +234,10 @@ typedef struct esr_unpermute {
  *   BWD_APPLY  gx = gamma*invstd*(g' - sum g'/N - xhat*sum(g' xhat)/N)   (eval: gamma*invstd*g') */
 enum esr_bn_mode { ESR_BN_STATS = 0, ESR_BN_FINALIZE = 1, ESR_BN_APPLY = 2, ESR_BN_BWD_REDUCE = 3,
                    ESR_BN_BWD_FINAL = 4, ESR_BN_BWD_APPLY = 5,
+                   ESR_BN_FIN_APPLY = 7,  /* training: FINALIZE and APPLY as ONE pass (every workgroup forms its channels'
+                                          statistics from the sums; mean / invstd / running statistics / num_batches_tracked
+                                          are written as FINALIZE would).  BWD_APPLY likewise performs BWD_FINAL when
+                                          dgamma is set */
                    ESR_BN_RESTAT = 6   /* training: apply the running-statistics (and num_batches_tracked) updates of
                                           ANOTHER forward call over the same batch from the sums still in place, groups in
                                           REVERSE order — the train step calls netD on (fake, real) and then, weights

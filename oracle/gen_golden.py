@@ -482,6 +482,69 @@ def gen_train_step():
     np.savez_compressed(os.path.join(OUT, 'train_step.npz'), **res)
 
 
+def gen_train_steps3():
+    """THREE iterations of the reference's training loop body (codes/train.py:97-106: ``update_learning_rate()`` —
+    the schedulers are stepped BEFORE the optimizers — then ``feed_data`` + ``optimize_parameters``) on the real
+    SRRaGANModel, nb=2, batch 4, MultiStepLR([1, 2], gamma 0.5), fresh data and noise per step: pins Adam's moments /
+    bias correction over several steps, the scheduler order, and the BatchNorm running statistics after 12 netD
+    forwards (4 per step, SRRaGAN_model.py:133-134,150-151)."""
+    install_vgg_stub(6)
+    sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+    RI.codes_arch()
+    from models import create_model
+    opt = {'model': 'srragan', 'scale': 4, 'gpu_ids': None, 'is_train': True,
+           'path': {'pretrain_model_G': None, 'pretrain_model_D': None},
+           'network_G': {'which_model_G': 'RRDB_net', 'norm_type': None, 'mode': 'CNA', 'nf': 64,
+                         'nb': 2, 'in_nc': 3, 'out_nc': 3, 'gc': 32, 'scale': 4},
+           'network_D': {'which_model_D': 'discriminator_vgg_128', 'norm_type': 'batch',
+                         'act_type': 'leakyrelu', 'mode': 'CNA', 'nf': 64, 'in_nc': 3},
+           'train': {'lr_G': 1e-4, 'weight_decay_G': 0, 'beta1_G': 0.9, 'lr_D': 1e-4,
+                     'weight_decay_D': 0, 'beta1_D': 0.9, 'lr_scheme': 'MultiStepLR',
+                     'lr_steps': [1, 2], 'lr_gamma': 0.5,
+                     'pixel_criterion': 'l1', 'pixel_weight': 0.01, 'feature_criterion': 'l1',
+                     'feature_weight': 1, 'gan_type': 'vanilla', 'gan_weight': 0.005,
+                     'D_update_ratio': None, 'D_init_iters': None}}
+    with RI.cuda_to_cpu():
+        model = create_model(opt)
+    sdG = synth.rrdbnet_state_dict(nb=2, seed=32)
+    sdD = synth.discriminator_state_dict(seed=33)
+    model.netG.load_state_dict(sdG, strict=True)
+    model.netD.load_state_dict(sdD, strict=True)
+    res = {}
+    import warnings
+    for it in range(1, 4):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')                  # "lr_scheduler.step() before optimizer.step()": the reference's order
+            model.update_learning_rate()
+        lr = synth.image_batch(70 + it, 4, 3, 32, 32, name='steps3.lr')
+        hr = synth.image_batch(80 + it, 4, 3, 128, 128, name='steps3.hr')
+        model.feed_data({'LR': lr, 'HR': hr})
+        z = draw_z(90 + it, RT.noise_shapes(lr.shape, 2, 'codes'), 'steps3.z')
+        with inject_z(z):
+            model.optimize_parameters(it)
+        log = model.get_current_log()
+        res['lr_%d' % it] = np.array([model.optimizer_G.param_groups[0]['lr'], model.optimizer_D.param_groups[0]['lr']])
+        res['log_%d' % it] = np.array([float(log[k]) for k in ('l_g_pix', 'l_g_fea', 'l_g_gan', 'l_d_real', 'l_d_fake',
+                                                              'D_real', 'D_fake')])
+        print('  step %d lr %s log %s' % (it, res['lr_%d' % it], res['log_%d' % it]))
+        res['fake_H_chk_%d' % it] = checks(model.fake_H)
+    g = dict(model.netG.named_parameters())
+    d = dict(model.netD.named_parameters())
+    res['G_chk'] = np.stack([checks(g[k]) for k in sdG.keys()])
+    res['D_chk'] = np.stack([checks(d[k]) for k in d.keys()])
+    res['G_delta_model.0.weight'] = npy(g['model.0.weight'] - sdG['model.0.weight'])
+    res['G_delta_model.1.sub.1.RDB2.conv3.0.bias'] = npy(g['model.1.sub.1.RDB2.conv3.0.bias'] - sdG['model.1.sub.1.RDB2.conv3.0.bias'])
+    res['D_delta_classifier.2.weight'] = npy(d['classifier.2.weight'] - sdD['classifier.2.weight'])
+    res['D_delta_features.3.weight'] = npy(d['features.3.weight'] - sdD['features.3.weight'])
+    bufs = dict(model.netD.named_buffers())
+    for k in ('features.3', 'features.15', 'features.27'):
+        res['rm_' + k] = npy(bufs[k + '.running_mean'])
+        res['rv_' + k] = npy(bufs[k + '.running_var'])
+    res['nbt'] = np.array([int(bufs[k]) for k in bufs if k.endswith('num_batches_tracked')])
+    print('  num_batches_tracked', res['nbt'])
+    np.savez_compressed(os.path.join(OUT, 'train_steps3.npz'), **res)
+
+
 def gen_psnr():
     sys.modules.setdefault('cv2', types.ModuleType('cv2'))
     RI._stub_torchvision()
@@ -592,7 +655,7 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['rdb', 'rrdbnet_small', 'rrdbnet_full', 'disc', 'disc_variants', 'vgg', 'train_step',
-                             'psnr', 'imresize', 'metrics', 'metrics_y', 'srresnet', 'rrdbnet_full_grad', 'disc_sn']
+                             'psnr', 'imresize', 'metrics', 'metrics_y', 'srresnet', 'rrdbnet_full_grad', 'disc_sn', 'train_steps3']
     for w in which:
         print('[gen_golden]', w)
         globals()['gen_' + w]()
