@@ -191,7 +191,11 @@ class _SeqNet(B._PlannedModule):
         wp = self._weights(dev)
         dp = None
         want_w = dual is not None or any(p.requires_grad for p in self.parameters())
-        if need_bwd:
+        # _per_call_weights (Discriminator_VGG_128_SN): the weights a backward needs are those of ITS forward, and a later
+        # forward rewrites the module's weight buffers (a new power iteration) before that backward runs — such plans own
+        # their input-gradient operands and head weights, snapshotted at forward time
+        own = need_bwd and getattr(self, '_per_call_weights', False)
+        if need_bwd and not own:
             dp = self._dgrad_weights(dev)
             dp.ensure(st, force=(bool(self.training) or want_w) and not self.__dict__.get('_weights_clean', False)
                       and not self._dgrad_fresh())
@@ -201,9 +205,14 @@ class _SeqNet(B._PlannedModule):
         pool = self._plans.setdefault(key, [])
         plan = next((p for p in pool if not p.busy), None)
         if plan is None:
+            head = self._head()
+            if own:
+                dp = self._new_dgrad_pack(dev)
+                head = {k: torch.empty_like(v) for k, v in head.items()} if head is not None else None
             plan = CN.build_seq_plan(self._spec(), wp, dp, self._pspec(), want_w, Bn, H, W, self.precision,
-                                     dev, training, need_bwd, self._input_affine(), self._head(),
+                                     dev, training, need_bwd, self._input_affine(), head,
                                      groups=groups, bwd_B=bwd_B if need_bwd else None, dual=dual)
+            plan.own_dp, plan.own_head = (dp, head) if own else (None, None)
             if E.use_graphs() and dual is None:
                 # hipGraph replay: the input lands in a fixed staging tensor (everything else these
                 # plans touch — outputs, upstream gradients, BN sums — already lives in fixed buffers)
@@ -212,6 +221,12 @@ class _SeqNet(B._PlannedModule):
                 plan.graph = True
             pool.append(plan)
         lease = CN._Lease(plan) if need_bwd else None
+        if own:
+            plan.own_dp.ensure(st, force=True)
+            if plan.own_head is not None:
+                with torch.no_grad():
+                    for k, v in self._head().items():
+                        plan.own_head[k].copy_(v)
         if training:
             plan.sums_f.zero_()
         if getattr(plan, 'graph', False):
@@ -411,6 +426,7 @@ class Discriminator_VGG_128_SN(_SeqNet):
     code in front of them, and autograd carries the plans' weight gradients through ``W / sigma`` to ``weight_orig``."""
 
     _has_bn = False
+    _per_call_weights = True
 
     def __init__(self):
         super().__init__()

@@ -337,16 +337,18 @@ class _PlannedModule(nn.Module):
             self._eye64 = eye
         return [('__eye', eye)]
 
+    def _new_dgrad_pack(self, device):
+        # dense-block convs get gather-form operands (one per channel slice); only the other
+        # convs (head / tail of the generator) are packed as plain transposes
+        convs = [(k, w) for k, w, _ in self._conv_list()
+                 if 'RDB' not in k and not k.startswith('rdb')] + self._dgrad_extra(device)
+        return E.DgradPack(convs, self.precision, device, self._dgrad_special(), self._dgrad_gathers())
+
     def _dgrad_weights(self, device):
         key = ('dgrad', self.precision, str(device))
         dp = self._wp.get(key)
         if dp is None:
-            # dense-block convs get gather-form operands (one per channel slice); only the other
-            # convs (head / tail of the generator) are packed as plain transposes
-            convs = [(k, w) for k, w, _ in self._conv_list()
-                     if 'RDB' not in k and not k.startswith('rdb')] + self._dgrad_extra(device)
-            dp = E.DgradPack(convs, self.precision, device, self._dgrad_special(), self._dgrad_gathers())
-            self._wp[key] = dp
+            dp = self._wp[key] = self._new_dgrad_pack(device)
         return dp
 
     def _subpix_keys(self):

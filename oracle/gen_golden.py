@@ -12,6 +12,7 @@ import types
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 import torch.nn as nn
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -245,6 +246,127 @@ def gen_rrdbnet_full_grad():
     np.savez_compressed(os.path.join(OUT, 'rrdbnet_full_grad.npz'), **res)
 
 
+class _Store16(torch.autograd.Function):
+    """fp16 STORAGE of a tensor, emulated: the value is rounded to fp16 where the fp16 path writes it to memory, and so
+    is the gradient that flows back through that point (times the loss scale, as the fp16 path keeps it)."""
+
+    @staticmethod
+    def forward(ctx, t, scale):
+        ctx.scale = scale
+        return t.half().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        s = ctx.scale
+        return (g * s).half().float() / s, None
+
+
+def rrdbnet_forward_fp16_storage(x, sd, nb, scale, z=None, variant='codes'):
+    """oracle.ref_torch.rrdbnet_forward with every tensor the fp16 path keeps in memory rounded to fp16 — packed
+    weights, block inputs / slices / outputs, head and tail activations — and fp32 accumulation inside each conv, which
+    is what v_mfma_f32_32x32x16_f16 does.  NOT the GPU kernels' summation order: an independent statement of "fp16
+    storage, fp32 accumulate" on the CPU.  z: the noise tensors of a training forward (None: eval)."""
+    st = lambda t: _Store16.apply(t, scale)
+    w = {k: (st(v) if k.endswith('.weight') else v) for k, v in sd.items()}      # biases stay fp32 (epilogue operands)
+    conv, lrelu = RT._conv, RT._lrelu
+    per = 3 if variant == 'codes' else 4
+    fea = st(conv(st(x), w, 'model.0'))
+    t = fea
+    for i in range(nb):
+        xr = t
+        for j in (1, 2, 3):
+            p = 'model.1.sub.%d.RDB%d' % (i, j)
+            xb = t
+            x1 = st(lrelu(conv(xb, w, p + '.conv1.0')))
+            x2 = st(lrelu(conv(torch.cat((xb, x1), 1), w, p + '.conv2.0')) + F.conv2d(xb, w[p + '.conv1x1.weight']))
+            x3 = st(lrelu(conv(torch.cat((xb, x1, x2), 1), w, p + '.conv3.0')))
+            x4 = st(lrelu(conv(torch.cat((xb, x1, x2, x3), 1), w, p + '.conv4.0')) + x2)
+            out = conv(torch.cat((xb, x1, x2, x3, x4), 1), w, p + '.conv5.0') * 0.2 + xb
+            out = RT.gaussian_noise(out, None if z is None else z[per * i + j - 1])
+            if j < 3:
+                t = st(out)
+            else:                                               # RDB3: the RRDB tail rides in the same epilogue
+                t = st(RT.gaussian_noise(out * 0.2 + xr, None if (z is None or per == 3) else z[per * i + 3]))
+    t = st(fea + conv(t, w, 'model.1.sub.%d' % nb))
+    for key in ('model.3', 'model.6'):
+        t = st(lrelu(conv(F.interpolate(t, scale_factor=2, mode='nearest'), w, key)))
+    t = st(lrelu(conv(t, w, 'model.8')))
+    return conv(t, w, 'model.10')
+
+
+def gen_rrdbnet_full_grad_fp16emu():
+    """How far does fp16 STORAGE alone move the nb = 23 parameter gradients from the fp32 reference's?  The restatement
+    with fp16-rounded tensors (rrdbnet_forward_fp16_storage, loss scale 2^17 as the GPU test uses) against the
+    imported reference's gradients in the GPU test's own metrics (relative L2, three random projections, the first 32
+    entries; eight tensors in full).  The committed numbers are what tests/test_gpu_backward.py derives its fp16
+    limits from (2 x these): the fp16 chains must sit where fp16 storage puts ANY implementation, not merely below a
+    hand-picked bound."""
+    import torch.nn.functional as F_  # noqa: F401
+    sd = synth.rrdbnet_state_dict(nb=23, seed=0, gain=0.5)
+    x = synth.image_batch(41, 1, 3, 128, 128, name='fullgrad.x')
+    gy = synth.normal_like(41, 'fullgrad.gy', (1, 3, 512, 512)) / (3 * 512 * 512)
+    keys = list(sd.keys())
+    ref = dict(np.load(os.path.join(OUT, 'rrdbnet_full_grad.npz')))
+    assert [str(k) for k in ref['keys']] == keys
+    S = 2.0 ** 17
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    y = rrdbnet_forward_fp16_storage(x, sdr, 23, S)
+    (y * gy).sum().backward()
+    ey = float(np.abs(npy(y)[0, :, :8, :8] - ref['y_head']).max())
+    errs = []
+    for row, k in zip(ref['probe'], keys):
+        got = sdr[k].grad.double().reshape(-1)
+        l2 = float(row[2])
+        e_l2 = abs(got.norm().item() - l2) / max(l2, 1e-30)
+        e_pr = 0.0
+        for i in range(3):
+            r = synth.normal_like(77, 'gproj.%s.%d' % (k, i), tuple(got.shape)).double()
+            e_pr = max(e_pr, abs((got * r).sum().item() - float(row[3 + i])) / max(l2, 1e-30))
+        n = min(32, got.numel())
+        head = row[6:6 + n]
+        e_hd = np.abs(got[:n].numpy() - head).max() / max(np.abs(head).max(), l2 / np.sqrt(got.numel()))
+        errs.append((e_l2, e_pr, e_hd))
+    errs = np.array(errs)
+    full_keys = [n[2:] for n in ref if n.startswith('g_')]
+    full = np.array([np.abs(npy(sdr[k].grad) - ref['g_' + k]).max() / np.abs(ref['g_' + k]).max() for k in full_keys])
+    print('  fp16-storage emulation vs fp32 reference: y_head err %.2e; worst (l2, proj, head) %s  mean %s'
+          % (ey, errs.max(0), errs.mean(0)))
+    for k, e in zip(full_keys, full):
+        print('  %-40s max|diff| / max|ref| = %.2e' % (k, e))
+    np.savez_compressed(os.path.join(OUT, 'rrdbnet_full_grad_fp16emu.npz'), worst=errs.max(0), mean=errs.mean(0),
+                        worst_key=np.array([keys[i] for i in errs.argmax(0)]), y_head_err=np.array(ey),
+                        full_keys=np.array(full_keys), full_err=full, loss_scale=np.array(S))
+
+
+def gen_rrdbnet_small_fp16emu():
+    """The fp16-storage emulation on the shape of tests/test_gpu_train_chain.py's oracle test (nb = 2, 2 x 3 x 24 x 40,
+    GaussianNoise ON, both network copies): relative L2 distance of every parameter gradient from the fp32
+    restatement's, same z.  Biases (sums with cancellation) sit at 4-5e-2 under fp16 storage whatever the
+    implementation; the GPU test takes its limits from these numbers."""
+    res = {}
+    nb, shape = 2, (2, 3, 24, 40)
+    sd = synth.rrdbnet_state_dict(nb=nb, seed=57)
+    x = synth.image_batch(57, *shape, name='o16.x')
+    gy = synth.normal_like(57, 'o16.gy', (shape[0], 3, 4 * shape[2], 4 * shape[3]))
+    for variant in ('codes', 'test_image'):
+        z = draw_z(58, RT.noise_shapes(shape, nb, variant), 'o16.z')
+        a = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ya = RT.rrdbnet_forward(x, a, nb, z, variant)
+        (ya * gy).sum().backward()
+        b = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        yb = rrdbnet_forward_fp16_storage(x, b, nb, 1.0, z, variant)
+        (yb * gy).sum().backward()
+        errs = np.array([((b[k].grad - a[k].grad).norm() / a[k].grad.norm()).item() for k in sd])
+        ey = ((ya - yb).abs().max() / (ya.max() - ya.min())).item()
+        keys = list(sd.keys())
+        print('  %s: output err / range %.2e, parameter-gradient rel L2: worst %.3e (%s), mean %.3e'
+              % (variant, ey, errs.max(), keys[int(errs.argmax())], errs.mean()))
+        res[variant + '_y'] = np.array(ey)
+        res[variant + '_worst'] = np.array(errs.max())
+        res[variant + '_mean'] = np.array(errs.mean())
+    np.savez_compressed(os.path.join(OUT, 'rrdbnet_small_fp16emu.npz'), **res)
+
+
 def gen_disc():
     sd = synth.discriminator_state_dict(seed=4)
     net = RI.build_discriminator()
@@ -327,6 +449,31 @@ def gen_disc_sn():
     with torch.no_grad():
         res['y_eval'] = npy(net(x))
     np.savez_compressed(os.path.join(OUT, 'disc_sn.npz'), **res)
+
+
+def gen_disc_sn_two():
+    """Discriminator_VGG_128_SN in the train step's call order (SRRaGAN_model.py:150-167): TWO training forwards — each
+    with its own power iteration, so each with its own normalised weights — and only then the backward of both.  Pins
+    that a call's backward uses the weights of ITS forward."""
+    sd = synth.discriminator_sn_state_dict(seed=8)
+    net = RI.build_discriminator_sn()
+    net.load_state_dict(sd, strict=True)
+    xa = synth.image_batch(8, 2, 3, 128, 128, name='dsn2.xa')
+    xb = synth.image_batch(9, 2, 3, 128, 128, name='dsn2.xb')
+    ga = synth.normal_like(8, 'dsn2.ga', (2, 1))
+    gb = synth.normal_like(9, 'dsn2.gb', (2, 1))
+    net.train()
+    xar = xa.clone().requires_grad_(True)
+    ya = net(xar)
+    yb = net(xb)
+    ((ya * ga).sum() + (yb * gb).sum()).backward()
+    params = dict(net.named_parameters())
+    res = {'ya': npy(ya), 'yb': npy(yb), 'gx_chk': checks(xar.grad), 'gx_sub8': npy(xar.grad)[:, :, ::8, ::8],
+           'keys': np.array(sorted(params.keys())),
+           'gchk': np.stack([checks(params[k].grad) for k in sorted(params.keys())])}
+    for k in ('conv0.weight_orig', 'conv9.bias', 'linear1.weight_orig', 'linear0.bias'):
+        res['g_' + k] = npy(params[k].grad)
+    np.savez_compressed(os.path.join(OUT, 'disc_sn_two.npz'), **res)
 
 
 def gen_disc_variants():
@@ -655,7 +802,7 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['rdb', 'rrdbnet_small', 'rrdbnet_full', 'disc', 'disc_variants', 'vgg', 'train_step',
-                             'psnr', 'imresize', 'metrics', 'metrics_y', 'srresnet', 'rrdbnet_full_grad', 'disc_sn', 'train_steps3']
+                             'psnr', 'imresize', 'metrics', 'metrics_y', 'srresnet', 'rrdbnet_full_grad', 'disc_sn', 'train_steps3', 'rrdbnet_full_grad_fp16emu', 'disc_sn_two', 'rrdbnet_small_fp16emu']
     for w in which:
         print('[gen_golden]', w)
         globals()['gen_' + w]()

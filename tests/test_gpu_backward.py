@@ -211,15 +211,30 @@ def test_full_depth_backward_at_bench_shape_vs_reference_golden(dev, golden, pre
     # gradient (a 16384-term sum with cancellation) by ~0.8/128 of its size per flipped pixel.  Hence per-tensor
     # bounds with room for a few flips and tight bounds on the means over the 700 tensors; a lost tile / block /
     # tap would show as tens of percent everywhere.
-    lim_w, lim_m = ((4e-3, 2.5e-2, 2.5e-2), (8e-4, 4e-3, 3e-3)) if prec == 'fp32' else ((8e-2, 0.5, 0.5), (1.2e-2, 0.11, 8e-2))
+    # fp16: the limits are DERIVED, not picked — tests/golden/rrdbnet_full_grad_fp16emu.npz holds the same metrics for
+    # a CPU restatement of "fp16 storage, fp32 accumulate" (oracle/gen_golden.py: rrdbnet_forward_fp16_storage: every
+    # tensor the fp16 path keeps in memory rounded to fp16, gradients too, loss scale 2^17) against the imported
+    # reference: worst (l2, proj, head) = (0.036, 0.249, 0.181), mean (0.0087, 0.064, 0.045) — fp16 storage alone puts
+    # ANY implementation there (LeakyReLU masks of pre-activations within fp16 rounding of zero flip).  The chains must
+    # stay within 2x of that emulation's worst case and 1.5x of its means (measured: 0.041 / 0.262 / 0.264, means
+    # 0.0064 / 0.067 / 0.048); each full tensor within 2x of the emulation's error on that tensor.
+    emu = dict(np.load('tests/golden/rrdbnet_full_grad_fp16emu.npz'))
+    if prec == 'fp32':
+        lim_w, lim_m = (4e-3, 2.5e-2, 2.5e-2), (8e-4, 4e-3, 3e-3)
+    else:
+        assert float(emu['loss_scale']) == S
+        lim_w, lim_m = tuple(2.0 * emu['worst']), tuple(1.5 * emu['mean'])
+        print('fp16 limits from the fp16-storage emulation: worst <= %s, mean <= %s' % (np.round(lim_w, 4), np.round(lim_m, 4)))
     assert worst['l2'][0] <= lim_w[0] and worst['proj'][0] <= lim_w[1] and worst['head'][0] <= lim_w[2], worst
     assert (mean <= np.array(lim_m)).all(), mean
+    emu_full = dict(zip([str(k) for k in emu['full_keys']], emu['full_err']))
     for k in [n[2:] for n in g if n.startswith('g_')]:
         want = g['g_' + k]
         got = (params[k].grad / (1.5 * S)).cpu().numpy()
         e = np.abs(got - want).max() / np.abs(want).max()
-        print('  %-40s max|diff| / max|ref| = %.2e' % (k, e))
-        assert e <= (6e-3 if prec == 'fp32' else 0.25), (k, e)
+        lim = 6e-3 if prec == 'fp32' else 2.0 * float(emu_full[k])
+        print('  %-40s max|diff| / max|ref| = %.2e  (limit %.2e)' % (k, e, lim))
+        assert e <= lim, (k, e, lim)
 
 
 @pytest.mark.parametrize('prec,tol', [('fp32', 2e-4), ('fp16', 4e-2)])

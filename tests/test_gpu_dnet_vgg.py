@@ -364,3 +364,40 @@ def test_discriminator_sn_matches_reference_golden(dev, golden):
     with torch.no_grad():
         ye = net(x)
     assert np.abs(ye.cpu().numpy() - g['y_eval']).max() <= 2e-4 * max(1.0, np.abs(g['y_eval']).max())
+
+
+def test_discriminator_sn_two_forwards_then_backward(dev, golden):
+    """The D step's call order (SRRaGAN_model.py:150-167): netD(real), netD(fake) — two training forwards, each with its
+    own power iteration and therefore its own W / sigma — and THEN the backward of both.  The first call's backward must
+    run on the weights its forward used (the module's weight buffers have been rewritten by the second call by then):
+    every parameter gradient and dL/dx of the first call against the imported reference (tests/golden/disc_sn_two.npz)."""
+    from esrganplus_amd import architecture as arch
+    g = golden('disc_sn_two')
+    net = arch.Discriminator_VGG_128_SN().to(dev)
+    net.load_state_dict(synth.discriminator_sn_state_dict(seed=8), strict=True)
+    xa = synth.image_batch(8, 2, 3, 128, 128, name='dsn2.xa').to(dev).requires_grad_(True)
+    xb = synth.image_batch(9, 2, 3, 128, 128, name='dsn2.xb').to(dev)
+    ga = synth.normal_like(8, 'dsn2.ga', (2, 1)).to(dev)
+    gb = synth.normal_like(9, 'dsn2.gb', (2, 1)).to(dev)
+    net.train()
+    ya = net(xa)
+    yb = net(xb)
+    assert np.abs(ya.detach().cpu().numpy() - g['ya']).max() <= 2e-4 * max(1.0, np.abs(g['ya']).max())
+    assert np.abs(yb.detach().cpu().numpy() - g['yb']).max() <= 2e-4 * max(1.0, np.abs(g['yb']).max())
+    ((ya * ga).sum() + (yb * gb).sum()).backward()
+    params = dict(net.named_parameters())
+    keys = [str(k) for k in g['keys']]
+    chk = np.stack([checks(params[k].grad) for k in keys])
+    rel = np.abs(chk - g['gchk']) / np.maximum(1e-3, np.abs(g['gchk'][:, 1:2]))
+    e_chk = np.abs(checks(xa.grad) - g['gx_chk']).max() / max(1.0, abs(g['gx_chk'][1]))
+    e_sub = np.abs(xa.grad.cpu().numpy()[:, :, ::8, ::8] - g['gx_sub8']).max() / max(1e-6, np.abs(g['gx_sub8']).max())
+    print('SN two forwards: dL/dx checks %.2e, sub8 %.2e; parameter checks worst %.2e (%s)'
+          % (e_chk, e_sub, rel.max(), keys[int(rel.argmax() // 3)]))
+    # (with the module-wide packs of round 3 — the first call's backward on the second call's weights — these read
+    # 1.7e-1 / 5.8e-1 and 4.4e-2 on the parameters; single pixels of a gradient whose maximum is 2e-5 move by a few
+    # 1e-3 of that maximum through LeakyReLU masks of pre-activations within fp32 rounding of zero)
+    assert e_chk <= 2e-3 and e_sub <= 1e-2, (e_chk, e_sub)
+    assert rel.max() <= 3e-3, (keys[int(rel.argmax() // 3)], rel.max())
+    for k in ('conv0.weight_orig', 'conv9.bias', 'linear1.weight_orig', 'linear0.bias'):
+        want = g['g_' + k]
+        assert np.abs(params[k].grad.cpu().numpy() - want).max() <= 3e-3 * max(1e-6, np.abs(want).max()), k
