@@ -29,6 +29,23 @@ PEAK_F16_TFLOPS = 2500.0               # MI355X dense fp16 MFMA (MI355X_MICROARC
 RDB_MAC_PER_PIXEL = 9 * 32 * (64 + 96 + 128 + 160) + 9 * 64 * 192 + 64 * 32
 
 
+def committed_traffic(kernel):
+    """(HBM bytes per launch, source note) of `kernel` from profiles/roofline_traffic.json — or (None, why) when the
+    row is missing or was measured on another version of the kernel's sources (its `source_sha` stamp differs)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import traffic_hashes as TH
+        tj = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')))
+        if kernel not in tj:
+            return None, None
+        if not TH.fresh(tj, kernel):
+            return None, 'profiles/roofline_traffic.json row is STALE (kernel sources changed since the PMC pass)'
+        return tj[kernel]['read_bytes'] + tj[kernel]['write_bytes'], \
+            'profiles/roofline_traffic.json (%s)' % tj.get('_source', 'rocprofv3 --pmc')
+    except (OSError, ValueError, KeyError, ImportError):
+        return None, None
+
+
 def conv_flops(c):
     """Algorithmic FLOPs of one fused-conv launch: 2 * MACs of the convolution(s) it replaces
     (true Cin/Cout, not the padded GEMM the kernel runs)."""
@@ -268,12 +285,7 @@ def generator_kernel_times(netG, lr, batch, size, reps=5):
         t_ms, f, n = agg[dom]
         ach = f / (t_ms * 1e-3) / 1e12
         traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')))
-            if dom in tj and batch == BATCH and size == LR:
-                traffic = tj[dom]['read_bytes'] + tj[dom]['write_bytes']
-        except (OSError, ValueError, KeyError):
-            pass
+        traffic = committed_traffic(dom)[0] if (batch == BATCH and size == LR) else None
         res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_F16_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
                            'launches_per_step': n // reps, 'avg_launch_us': round(t_ms / n * 1e3, 2),
@@ -592,15 +604,10 @@ def main():
         tot_ms = sum(a[0] for a in agg.values()) / reps
         t_ms, fl, n = agg[dom]
         ach = fl / (t_ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        try:      # PMC-measured HBM-side bytes per launch: NOT measured by this run — the committed summary of
-            #         separate rocprofv3 --pmc passes over this same command (MI355X_MICROARCH.md HBM section)
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')))
-            if dom in tj and args.batch == BATCH and args.lr == LR:
-                traffic = tj[dom]['read_bytes'] + tj[dom]['write_bytes']
-                traffic_src = 'profiles/roofline_traffic.json (%s)' % tj.get('_source', 'rocprofv3 --pmc')
-        except (OSError, ValueError, KeyError):
-            pass
+        # PMC-measured HBM-side bytes per launch: NOT measured by this run — the committed summary of separate
+        # rocprofv3 --pmc passes over this same command (MI355X_MICROARCH.md HBM section), quoted only while the
+        # kernel's sources are the ones it was measured on (tools/traffic_hashes.py)
+        traffic, traffic_src = committed_traffic(dom) if (args.batch == BATCH and args.lr == LR) else (None, None)
         res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_F16_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
                            'traffic_source': traffic_src,

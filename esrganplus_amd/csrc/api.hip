@@ -201,7 +201,9 @@ extern "C" int64_t esr_wgrad_workspace_elems(const esr_op* ops, int32_t n) {
 // ------------------------------------------------------------------------------------------------
 // hipGraph replay
 // ------------------------------------------------------------------------------------------------
-struct esr_graph_s { hipGraph_t graph; hipGraphExec_t exec; };
+struct esr_graph_s { hipGraph_t graph; hipGraphExec_t exec; bool has_chain; };
+int esr_chain_graph_before(hipStream_t st);             // rdb_fused.hip
+void esr_chain_graph_after(hipStream_t st, int cus);
 
 namespace {
 hipStream_t capture_stream() {
@@ -238,14 +240,28 @@ extern "C" int esr_graph_create(const esr_op* ops, int32_t n, esr_graph_t* out) 
   esr_graph_s* h = new esr_graph_s();
   h->graph = g;
   h->exec = x;
+  h->has_chain = false;
+  for (int i = 0; i < n; ++i)
+    if (ops[i].kind == ESR_OP_RDB_CHAIN || ops[i].kind == ESR_OP_RDB_CHAIN_BWD) h->has_chain = true;
   *out = h;
   return ESR_OK;
 }
 
 extern "C" int esr_graph_launch(esr_graph_t g, esr_stream_t stream) {
   if (!g || !g->exec) { esr_set_error("esr_graph_launch: invalid graph"); return ESR_ERR_INVALID; }
+  int cus = 0;
+  if (g->has_chain) {
+    // chain nodes replayed from a graph bypass chain_launch's bookkeeping: report an earlier abort here, and order the
+    // replay against chains in flight on other streams as one whole-GPU chain launch
+    if (esr_rdb_check_abort()) {
+      esr_set_error("esr_graph_launch: an earlier fused-chain launch aborted (a tile waited > 1 s for its neighbours: CUs held by other work?) — its results are invalid");
+      return ESR_ERR_LAUNCH;
+    }
+    cus = esr_chain_graph_before((hipStream_t)stream);
+  }
   const hipError_t e = hipGraphLaunch(g->exec, (hipStream_t)stream);
   if (e != hipSuccess) { esr_set_error("esr_graph_launch: %s", hipGetErrorString(e)); return ESR_ERR_LAUNCH; }
+  if (g->has_chain) esr_chain_graph_after((hipStream_t)stream, cus);
   return ESR_OK;
 }
 

@@ -274,6 +274,24 @@ int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, i
 }
 }  // namespace
 
+// For esr_graph_launch (api.hip): a captured op list with chain nodes replays them outside chain_launch — the replay as
+// a whole is ordered like ONE chain launch that needs every CU (before: wait for chains in flight on other streams;
+// after: recorded, so that later chain launches on other streams wait for it).
+int esr_chain_graph_before(hipStream_t st) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t pr;
+    static int cached[64] = {};
+    if (dev >= 0 && dev < 64) {
+      if (!cached[dev] && hipGetDeviceProperties(&pr, dev) == hipSuccess) cached[dev] = pr.multiProcessorCount;
+      if (cached[dev]) cus = cached[dev];
+    }
+  }
+  chain_order_before_launch(st, cus, cus);
+  return cus;
+}
+void esr_chain_graph_after(hipStream_t st, int cus) { chain_record_launch(st, cus); }
+
 extern "C" int esr_rdb_forward(const esr_rdb_chain* p, esr_stream_t stream) { return chain_launch(p, stream, "esr_rdb_forward", 0); }
 extern "C" int esr_rdb_backward(const esr_rdb_chain* p, esr_stream_t stream) { return chain_launch(p, stream, "esr_rdb_backward", 2); }
 

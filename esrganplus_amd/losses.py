@@ -57,8 +57,15 @@ class _L1Fn(torch.autograd.Function):
         return (ctx.grad * g if ctx.grad is not None else None), None, None
 
 
+def _as_f32(t):
+    # fp16 / bf16 operands (an autocast caller): upcast — autograd carries the gradient back through the cast
+    return t.float() if torch.is_tensor(t) and t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) else t
+
+
 def l1_loss(a, b, weight=1.0):
-    """``weight * F.l1_loss(a, b)``; the gradient flows to ``a`` only (``b`` is the target: var_H / real_fea)."""
+    """``weight * F.l1_loss(a, b)``; the gradient flows to ``a`` only (``b`` is the target: var_H / real_fea — a target
+    that requires a gradient is refused, not silently detached).  fp16 / bf16 operands are upcast."""
+    a, b = _as_f32(a), _as_f32(b)
     _check_operands('l1_loss', a, b)
     _require(a.shape == b.shape, 'l1_loss: shapes %s vs %s' % (tuple(a.shape), tuple(b.shape)))
     _require(not b.requires_grad, 'l1_loss: the target must not require a gradient')
@@ -151,6 +158,7 @@ def ragan_loss(x, y, x_is_real, y_is_real, weight=1.0, global_mean=False):
     """``weight * (BCE(x - mean(y), x_is_real) + BCE(y - mean(x), y_is_real)) / 2`` and the two means
     (returned as ``(loss, aux)`` with ``aux = [mean_x, mean_y, BCE_x, BCE_y]``, detached).  ``global_mean``: the means
     run over the batch of ALL ranks (data-parallel training; == the local batch on one rank)."""
+    x, y = _as_f32(x), _as_f32(y)
     _check_operands('ragan_loss', x, y)
     _require(x.numel() == y.numel(), 'ragan_loss: %d vs %d logits' % (x.numel(), y.numel()))
     fn = _RaGANGlobalFn if global_mean else _RaGANFn

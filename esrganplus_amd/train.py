@@ -103,8 +103,9 @@ class ESRGANPlusStep:
         # batch means of the relativistic terms: over ALL ranks when data-parallel (losses._RaGANGlobalFn: the fused
         # kernel + two scalar all-reduces), else inside the one fused loss launch
         mean = self.data_parallel
-        cuda = var_L.is_cuda
-        ov = self.overlap if cuda else 0
+        E.require_cuda(var_L, 'ESRGANPlusStep.step: var_L')      # (the networks and the fused losses have no CPU path)
+        cuda = True
+        ov = self.overlap
         # ---------------- G ----------------
         for p in netD.parameters():
             p.requires_grad = False

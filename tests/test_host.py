@@ -296,3 +296,20 @@ def test_flat_gradient_store_follows_autograd_accumulation_rules():
     net._deliver_flat_grads(a)
     assert torch.equal(params[3].grad, torch.ones_like(params[3]) + a.split([p.numel() for p in params])[3].view_as(params[3]))
     assert not net.mark_grads_stale()
+
+
+def test_committed_traffic_numbers_belong_to_the_current_kernels():
+    """bench.py quotes `roofline.traffic` from profiles/roofline_traffic.json (separate rocprofv3 --pmc passes): every
+    row must have been measured on the kernel sources in the tree (tools/traffic_hashes.py: sha256 over the files that
+    define the kernel) — editing a kernel without re-measuring its traffic fails here instead of shipping a stale
+    number."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import traffic_hashes as TH
+    tj = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')))
+    rows = [k for k in tj if not k.startswith('_')]
+    assert set(rows) <= set(TH.SOURCES), set(rows) - set(TH.SOURCES)
+    for k in rows:
+        assert tj[k]['read_bytes'] > 0 and tj[k]['write_bytes'] > 0
+        assert TH.fresh(tj, k), '%s: traffic was measured on other sources (re-run the PMC pass, then tools/traffic_hashes.py --update)' % k
