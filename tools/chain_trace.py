@@ -1,5 +1,5 @@
 """Per-phase timeline of the fused RDB-chain kernel (esr_rdb_chain.trace): where a tile's time goes.
-Usage: python tools/chain_trace.py [batch] [H] [W]"""
+Usage: python tools/chain_trace.py [batch] [H] [W] [rows per wave: 4 | 2 | 1]"""
 import sys
 import numpy as np
 import torch
@@ -9,6 +9,9 @@ from esrganplus_amd import architecture as arch, synth, _lib as L
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+ROWS = int(sys.argv[4]) if len(sys.argv) > 4 else 4       # rows per wave of the build that will run (ESR_RDB_ROWS forces it)
+import os
+os.environ['ESR_RDB_ROWS'] = str(ROWS)
 nb = 2
 dev = torch.device('cuda:0')
 net = arch.RRDBNet(3, 3, 64, nb).to(dev).eval().set_precision('fp16')
@@ -16,7 +19,7 @@ x = torch.rand(B, 3, H, W, device=dev)
 with torch.no_grad():
     net(x)
     plan = [p for p in net._plans.values() if p.chain_ops][0]
-    ntiles = B * ((H + 15) // 16) * ((W + 31) // 32)
+    ntiles = B * ((H + 4 * ROWS - 1) // (4 * ROWS)) * ((W + 31) // 32)
     tr = torch.zeros(ntiles * 64, dtype=torch.int64, device=dev)
     arr = plan.ops.array()
     arr[plan.chain_ops[0]].u.rdb_chain.trace = tr.data_ptr()
