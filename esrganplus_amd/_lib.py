@@ -45,7 +45,9 @@ class esr_conv(C.Structure):
                 ('nchw_out_c', C.c_int32), ('nchw_out', C.c_void_p),
                 ('debug_flags', C.c_int32), ('mask_cb_begin', C.c_int32), ('gamma', C.c_float),
                 ('layer3', C.c_uint32), ('z3', esr_g32), ('out3', esr_g32),
-                ('mask_act', C.c_int32), ('_pad2', C.c_int32), ('seed_dev', C.c_void_p)]
+                ('mask_act', C.c_int32), ('_pad2', C.c_int32), ('seed_dev', C.c_void_p),
+                ('ksplit', C.c_int32), ('stat_groups', C.c_int32), ('stat_C', C.c_int32), ('_pad3', C.c_int32),
+                ('split_ws', C.c_void_p), ('stat_sums', C.c_void_p)]
 
 
 class esr_pack(C.Structure):

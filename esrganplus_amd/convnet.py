@@ -34,6 +34,22 @@ class _Lease(object):
         self.release()
 
 
+def s2_ksplit(B, wo, ho, cin, cout, dt_e):
+    """K split of a 4x4/s2 conv that leaves a square map of 4 / 8 / 16 columns (the discriminators' deep layers:
+    include/esrgan_hip.h, esr_conv.ksplit): enough workgroups to fill the chip, at least two K steps each; 0 = the
+    plain one-image-per-tile launch (other shapes, fp32, ESR_S2_SPLIT=0)."""
+    if dt_e != L.ESR_F16 or wo != ho or wo not in (4, 8, 16) or B < 2 or os.environ.get('ESR_S2_SPLIT', '1') == '0':
+        return 0
+    nchunks = (cin + 15) // 16
+    per_tile = (32 // wo) * (2 if wo <= 4 else 1)
+    tyn = 1 if wo <= 4 else (wo + 7) // 8
+    base = ((B + per_tile - 1) // per_tile) * tyn * ((cout + 127) // 128)
+    k = 1
+    while k * 2 <= nchunks // 2 and k * 2 * base <= 256:
+        k *= 2
+    return k if k >= 2 else 0
+
+
 def _lin(mode, B_, I, O, act, **kw):
     o = L.esr_linear()
     o.mode, o.B, o.I, o.O, o.act = mode, B_, I, O, act
@@ -150,13 +166,29 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
         yb = _g32(P, B, cpad, ho, wo, dtype, dev)
         if bn is None:
             c = E._conv(dt_e, B, ho, wo, cur.view(0), ch, yb.view(0), e[key], s['act'], stride=st)
+            ksp = s2_ksplit(B, wo, ho, ch, cout, dt_e) if (st == 2 and ks == 4) else 0
+            if ksp:
+                ws = torch.empty(ksp * B * ho * wo * cpad, dtype=torch.float32, device=dev)
+                P.keep.append(ws)
+                c.ksplit, c.split_ws = ksp, ws.data_ptr()
             f.add_conv(c)
             recs.append(dict(kind='conv', key=key, x=cur, cin=ch, y=yb, c=None, cout=cout, ks=ks, st=st,
                              act=s['act'], h=ho, w=wo, hin=h, win=w, bn=None))
         else:
             cb = _g32(P, B, cpad, ho, wo, dtype, dev)
-            f.add_conv(E._conv(dt_e, B, ho, wo, cur.view(0), ch, cb.view(0), e[key], L.ACT_NONE, stride=st))
+            cv = E._conv(dt_e, B, ho, wo, cur.view(0), ch, cb.view(0), e[key], L.ACT_NONE, stride=st)
             base = ibn * 2 * maxc * groups
+            ksp = s2_ksplit(B, wo, ho, ch, cout, dt_e) if (st == 2 and ks == 4) else 0
+            stats_in_conv = False
+            if ksp:
+                # deep stride-2 layer: packed tiles + split K; its finishing pass also takes the BatchNorm statistics
+                ws = torch.empty(ksp * B * ho * wo * cpad, dtype=torch.float32, device=dev)
+                P.keep.append(ws)
+                cv.ksplit, cv.split_ws = ksp, ws.data_ptr()
+                if training and fuse_bn():
+                    cv.stat_sums, cv.stat_groups, cv.stat_C = P.sums_f.data_ptr() + 8 * base, groups, cout
+                    stats_in_conv = True
+            f.add_conv(cv)
             mk = dict(sums_f=P.sums_f.data_ptr() + 8 * base, base=base,
                       mean=stats.data_ptr() + 4 * base, invstd=stats.data_ptr() + 4 * (base + maxc * groups))
 
@@ -179,8 +211,10 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
                 o.running_mean, o.running_var = bn['rm'].data_ptr(), bn['rv'].data_ptr()
                 return o
             if training and fuse_bn():
-                # statistics pass, then ONE pass that finalizes and applies (ESR_BN_FIN_APPLY)
-                f.add(L.OP_BN, 'bn', bnop(L.BN_STATS))
+                # statistics pass (unless the conv's finishing pass took them), then ONE pass that finalizes and
+                # applies (ESR_BN_FIN_APPLY)
+                if not stats_in_conv:
+                    f.add(L.OP_BN, 'bn', bnop(L.BN_STATS))
                 f.add(L.OP_BN, 'bn', bnop(L.BN_FIN_APPLY))
             else:
                 if training:
@@ -328,6 +362,16 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
                             ks=4, stride=1, upsample=2)
             c.bias = None
             need_mask = prev is not None and prev['kind'] == 'conv' and prev['bn'] is None and prev['act'] != L.ACT_NONE
+            if r['st'] == 2 and r['ks'] == 4 and not need_mask and r['w'] <= 4:
+                # the transposed conv of the DEEPEST stride-2 layer (8x8 output): packed tiles + split K (esr_conv.ksplit),
+                # K = forward couts.  Only there: the fp32 slabs of the split grow with the OUTPUT map, and on the 16^2 /
+                # 32^2 outputs their write + read (67 MB per launch) costs more than the split saves (measured:
+                # 57 -> 102 us and 33 -> 100 us; profiles/r04_experiments.md)
+                ksp = s2_ksplit(Bb, r['w'], r['h'], cout, cin_, dt_e)
+                if ksp:
+                    ws = torch.empty(ksp * Bb * r['hin'] * r['win'] * ((cin_ + 31) // 32) * 32, dtype=torch.float32, device=dev)
+                    Q.keep.append(ws)
+                    c.ksplit, c.split_ws = ksp, ws.data_ptr()
             if need_mask:
                 c.mask, c.out2, c.mask_cb_begin = prev['y'].view(0, cin_), gx.view(0, cin_), 0
                 c.mask_act = prev['act']

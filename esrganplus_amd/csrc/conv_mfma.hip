@@ -223,17 +223,24 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
 // rounds re-copy an earlier window), weights before activations, so a counted
 // `s_waitcnt vmcnt(NLD)` leaves exactly the newest activation stage in flight.
 // ------------------------------------------------------------------------------------------------
-template <int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool PIPE_ = false, int RW = 4>
+template <int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool PIPE_ = false, int RW = 4, bool PACK_ = false>
 struct Geo {
   static constexpr int R = RW;      // output rows per wave (2: half-height tiles, twice the workgroups, for grids
                                     // far below one workgroup per CU — the LR-size training launches)
   static constexpr int NW = WR * WC * NCG;                               // waves per workgroup
   static constexpr int NT = NW * 64;
   static constexpr int TH = R * WR, TW = 32 * WC;                        // output tile
+  // PACK (4x4/s2 forward conv on maps of at most 16 output columns — the discriminator behind its third stride-2
+  // stage): the tile's 32 output columns are 2 / 4 / 8 IMAGES side by side (and, for 4-row maps, its two row groups
+  // two images on top of each other), each with its own halo in the staged tile: [pr][rows][pc][cols].  Sized for the
+  // worst case: 2 x 10 rows, 8 x 10 columns.  Always run with the K loop SPLIT over blockIdx.z (see launch_s2_packed).
+  static constexpr bool PACK = PACK_;
   // UPS == 3 (sub-pixel up-conv, KS == 2): the tile is counted in INPUT pixels; the 4 cout groups are the 4
   // output phases (dy, dx), each a 2x2 conv on the input shifted by (dy, dx)
-  static constexpr int IH = UPS == 3 ? TH + 2 : UPS ? TH / 2 + 2 : (TH - 1) * S + KS;       // staged input tile
-  static constexpr int IW = UPS == 3 ? TW + 2 : UPS ? TW / 2 + 2 : (TW - 1) * S + KS;
+  // (the transposed conv — UPS == 2, the input gradient of those layers — packs likewise: 8 / 4 / 2 images across the
+  //  tile's 64 output columns, two on top of each other for 8-row maps: 2 x 6 rows, 8 x 6 columns of input)
+  static constexpr int IH = PACK_ ? (UPS == 2 ? 12 : 20) : UPS == 3 ? TH + 2 : UPS ? TH / 2 + 2 : (TH - 1) * S + KS;       // staged input tile
+  static constexpr int IW = PACK_ ? (UPS == 2 ? 48 : 80) : UPS == 3 ? TW + 2 : UPS ? TW / 2 + 2 : (TW - 1) * S + KS;
   static constexpr int WIH = UPS == 3 ? R + 1 : UPS ? R / 2 + 2 : (R - 1) * S + KS;        // input rows one wave reads
   static constexpr int NSLOT = IH * IW * 2;                              // 16-byte slots (activations)
   static constexpr int NLD = (NSLOT + NT - 1) / NT;                      // activation DMA rounds
@@ -259,6 +266,9 @@ struct Geo {
   static constexpr int PAD = (KS - 1) / 2;
   static_assert(NW == 8 || NW == 4, "4 or 8 waves per workgroup");
   static_assert(UPS != 3 || (KS == 2 && S == 1 && NCG == 4 && WLDS && !HAS1X1), "sub-pixel up-conv: 2x2 taps, one cout group per phase");
+  static_assert(!PACK_ || (KS == 4 && S == 2 && UPS == 0 && WR == 2 && WC == 1 && !WLDS && !HAS1X1 && RW == 4) ||
+                    (KS == 4 && S == 1 && UPS == 2 && WR == 4 && WC == 2 && NCG == 1 && WLDS && !HAS1X1 && RW == 4),
+                "packed small maps: the 4x4/s2 conv and its transpose");
   static_assert(R * NCW <= 8, "accumulator budget");
   static_assert(LDS_BYTES <= LDS_BUDGET, "LDS budget");
 };
@@ -276,10 +286,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD, bool PIPE = false, int RW = 4>
+template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD, bool PIPE = false, int RW = 4, bool PACK = false>
 __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, const int block_x, const int grid_x,
-                                          const int block_y) {
-  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, PIPE, RW>;
+                                          const int block_y, const int block_z = 0) {
+  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, PIPE, RW, PACK>;
   static_assert(RW == 4 || (KS == 3 && S == 1 && UPS == 0), "half-height tiles: plain 3x3");
   static_assert(!PIPE || (KS == 3 && S == 1 && UPS == 0 && WLDS && NCG == 1), "pipelined K loop: 3x3/s1, LDS weights");
   constexpr int R = G::R;
@@ -303,7 +313,38 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
     const int nwg = grid_x, bid = block_x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+  int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+  // PACK: images per tile row (pc_n) / column (pr_n), this lane's image and column inside it
+  int pc_n = 1, pr_n = 1, ihs = G::IH, iws = G::IW, lane_pc = 0, lane_x = j, b_lane = 0;
+  if constexpr (PACK) {
+    t = block_x;                                       // (no XCD renumbering: a handful of tiles)
+    if constexpr (UPS == 2) {
+      // transposed conv: the tile is 16 rows x 64 columns of OUTPUT (p.H x p.W = 8 / 16 / 32 square); lane j is input
+      // column j of the tile's 32, its wave (wc) the output-column parity
+      const int wi = p.W >> 1;                         // input columns per image
+      pc_n = 32 / wi;
+      pr_n = p.H <= 8 ? 2 : 1;
+      const int tyn = pr_n == 2 ? 1 : (p.H + G::TH - 1) / G::TH;
+      b = (t / tyn) * (pc_n * pr_n);
+      tx = 0; ty = t % tyn;
+      ihs = pr_n == 2 ? (p.H >> 1) + 2 : G::TH / 2 + 2;
+      iws = wi + 2;
+      lane_pc = j / wi;
+      lane_x = j - lane_pc * wi;
+      b_lane = b + (pr_n == 2 ? (wr >> 1) * pc_n : 0) + lane_pc;
+    } else {
+      pc_n = 32 / p.W;                                   // p.W in {4, 8, 16}
+      pr_n = p.H <= 4 ? 2 : 1;
+      const int tyn = pr_n == 2 ? 1 : (p.H + G::TH - 1) / G::TH;     // tile rows per image
+      b = (t / tyn) * (pc_n * pr_n);                     // first image of this tile
+      tx = 0; ty = t % tyn;
+      ihs = pr_n == 2 ? (R - 1) * S + KS : G::IH;        // rows of one image's patch in the staged tile (10 | all)
+      iws = (p.W - 1) * S + KS;                          // columns of one image's patch
+      lane_pc = j / p.W;
+      lane_x = j - lane_pc * p.W;
+      b_lane = b + (pr_n == 2 ? wr * pc_n : 0) + lane_pc;
+    }
+  }
   const int cb0 = UPS == 3 ? block_y * NCW : (block_y * NCG + cg) * NCW;     // first 32-cout block of this wave
   const int pdy = UPS == 3 ? cg >> 1 : 0, pdx = UPS == 3 ? cg & 1 : 0;           // sub-pixel phase of this wave
   const int oy0 = ty * G::TH, ox0 = tx * G::TW;      // output tile origin (logical)
@@ -321,7 +362,17 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
     if (s >= G::NSLOT) s = G::NSLOT - 1;             // tail lanes: harmless re-copy into the padding
     const int row = s / (2 * G::IW), rem = s - row * 2 * G::IW;
     const int col = rem >> 1, hs = rem & 1, half = hs ^ ((col >> 3) & 1);
-    goff[i] = ((iy0 + row) * p.in.wp + ix0 + col) * 32 + half * 16;
+    if constexpr (PACK) {
+      // LDS (row, col) -> image (pr, pc) of the tile and the pixel inside its patch; slots outside every patch (and
+      // images past the batch) re-copy a valid pixel nobody reads
+      int pr = row / ihs, ry = row - pr * ihs, pc = col / iws, cx = col - pc * iws;
+      if (pr >= pr_n || pc >= pc_n) { pr = 0; pc = 0; ry = 0; cx = 0; }
+      int bi = b + pr * pc_n + pc;
+      if (bi >= p.B) bi = p.B - 1;
+      goff[i] = (bi - b) * (int)p.in.batch_stride + ((iy0 + ry) * p.in.wp + ix0 + cx) * 32 + half * 16;
+    } else {
+      goff[i] = ((iy0 + row) * p.in.wp + ix0 + col) * 32 + half * 16;
+    }
   }
   const char* in_b = (const char*)p.in.ptr + b * p.in.batch_stride;
   const int64_t in_gs = p.in.group_stride;
@@ -338,12 +389,30 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
                   : UPS == 3 ? (wc * 32 + j + pdx + kw)
                              : ((wc * 32 + j) * S + kw);
     colofs[kw] = col * 32 + ((h ^ ((col >> 3) & 1)) << 4) + (UPS == 3 ? wr * R + pdy : UPS ? wr * (R / 2) : wr * R * S) * G::IW * 32;
+    if constexpr (PACK) {
+      if constexpr (UPS == 2) {
+        const int pcol = lane_pc * iws + lane_x + ((wc + 1 - kw) >> 1) + 1;
+        const int prow = pr_n == 2 ? (wr >> 1) * ihs + (wr & 1) * (R / 2) : wr * (R / 2);
+        colofs[kw] = pcol * 32 + ((h ^ ((pcol >> 3) & 1)) << 4) + prow * G::IW * 32;
+      } else {
+        const int pcol = lane_pc * iws + lane_x * S + kw;            // this lane's image patch, column x * S + kw
+        colofs[kw] = pcol * 32 + ((h ^ ((pcol >> 3) & 1)) << 4) + (pr_n == 2 ? wr * ihs : wr * R * S) * G::IW * 32;
+      }
+    }
   }
 
   // ---- weights: packed [cout_block][chunk][tap][lane][16 B]
-  const int nchunks = p.cin_groups;
+  int nchunks = p.cin_groups;
   const int64_t w_cb_stride = (int64_t)nchunks * G::NTAP * 1024;
-  const char* const wbase = (const char*)p.w;
+  const char* wbase = (const char*)p.w;
+  if constexpr (PACK) {
+    // split K: this workgroup contracts input chunks [c0, c1) only (esr_conv.ksplit; partial sums to split_ws)
+    const int per = (nchunks + p.ksplit - 1) / p.ksplit, c0 = block_z * per;
+    const int c1 = c0 + per < nchunks ? c0 + per : nchunks;
+    in_b += (int64_t)c0 * p.in.group_stride;
+    wbase += (int64_t)c0 * G::NTAP * 1024;
+    nchunks = c1 > c0 ? c1 - c0 : 0;
+  }
   const int n1x1 = HAS1X1 ? p.n1x1_groups : 0;
   // LDS weight windows this wave copies each K step: window q = wave + 8*i (wrapping -> duplicate)
   const char* wsrc[G::WLD > 0 ? G::WLD : 1];
@@ -672,6 +741,29 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
   }
 
   // ---------------------------------------------------------------- epilogue
+  if constexpr (PACK) {
+    // partial sums of this K range, fp32: split_ws[split][image][oy][ox][cout] (cout padded to whole 32-blocks) — plain
+    // stores, one slab per split; the finishing launch adds the slabs up in split order (deterministic)
+    if (lane_pc >= pc_n || b_lane >= p.B) return;
+    const int CP = p.cout_blocks * 32;
+    const int oyb_ = UPS == 2 ? (pr_n == 2 ? (wr & 1) * R : oy0 + wr * R) : (pr_n == 2 ? 0 : oy0 + wr * R);
+    const int ox_ = UPS == 2 ? 2 * lane_x + wc : lane_x;
+    sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
+      constexpr int cw = decltype(CW)::value;
+      if (cb0 + cw >= p.cout_blocks) return;
+      float* const base = p.split_ws + ((int64_t)block_z * p.B + b_lane) * p.H * p.W * CP + (cb0 + cw) * 32 + 16 * h;
+      sfor<R>([&](auto RR) __attribute__((always_inline)) {
+        constexpr int r = decltype(RR)::value;
+        const int oy = oyb_ + r;
+        if (oy >= p.H) return;
+        const f32x16 a = accsel<r * NCW + cw>(acc);
+        float* const o = base + ((int64_t)oy * p.W + ox_) * CP;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f32x4*)(o + 4 * q) = f32x4{a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+      });
+    });
+    return;
+  }
   const int ox = UPS == 2 ? ox0 + 2 * j + wc : UPS == 3 ? 2 * (ox0 + wc * 32 + j) + pdx : ox0 + wc * 32 + j;
   if (ox >= p.W || (dbg & 1)) return;
   const int oyb = UPS == 3 ? 2 * (oy0 + wr * R) + pdy : oy0 + wr * R;
@@ -683,11 +775,110 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
   });
 }
 
-template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD, bool PIPE = false, int RW = 4>
+template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool BWD, bool PIPE = false, int RW = 4, bool PACK = false>
 __global__ __launch_bounds__(WR * WC * NCG * 64, 2) void conv_kernel(const esr_conv p) {
-  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, PIPE, RW>;
+  using G = Geo<KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, PIPE, RW, PACK>;
   __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
-  conv_body<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, BWD, PIPE, RW>(p, smem, blockIdx.x, gridDim.x, blockIdx.y);
+  conv_body<T, KS, S, UPS, WR, WC, NCG, NCW, WLDS, HAS1X1, BWD, PIPE, RW, PACK>(p, smem, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- the deep 4x4/s2 convs of the discriminators (maps of 4 / 8 / 16 output columns, 256-512 channels) ----------------
+// One image per 8x32 tile leaves these launches 50-94 % padding AND makes every tile's workgroup stream the layer's
+// whole weight tensor (128 workgroups x 2.1 MB = 268 MB of L2 -> register traffic for a 4 GFLOP layer: 137 us).  Packing
+// 2-16 images into a tile removes both, but leaves 8-32 workgroups with a serial K loop of 32 steps; so the packed
+// launch also SPLITS K over blockIdx.z — every workgroup contracts a few input chunks into an fp32 slab — and a
+// finishing launch adds the slabs up in split order, applies bias / activation, stores the fp16 G32 output and, when
+// asked, accumulates the BatchNorm statistics of that output (replacing the ESR_BN_STATS pass that would follow).
+template <typename T>
+__global__ __launch_bounds__(256) void s2_finish_kernel(const esr_conv p) {
+  // thread = (pixel, 16-channel group); grid (ceil(H W / 256), groups, B)
+  const int g = blockIdx.y, b = blockIdx.z;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = pix < p.H * p.W;
+  const int CP = p.cout_blocks * 32, c0 = g * 16;
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) v[e] = 0.f;
+  if (ok) {
+    for (int s = 0; s < p.ksplit; ++s) {
+      const float* q = p.split_ws + (((int64_t)s * p.B + b) * p.H * p.W + pix) * CP + c0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 a = *(const f32x4*)(q + 4 * k);
+        v[4 * k] += a[0]; v[4 * k + 1] += a[1]; v[4 * k + 2] += a[2]; v[4 * k + 3] += a[3];
+      }
+    }
+    half8 x, y;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float t = v[e] + (p.bias ? p.bias[c0 + e] : 0.f);
+      if (p.act == ESR_ACT_LRELU) t = fmaxf(t, t * ESR_LRELU_SLOPE);
+      else if (p.act == ESR_ACT_RELU) t = fmaxf(t, 0.f);
+      const _Float16 hq = (_Float16)t;
+      if (e < 8) x[e] = hq; else y[e - 8] = hq;
+      v[e] = (float)hq;                                  // the statistics see what the apply pass will read
+    }
+    if (g < p.out.ngroups) {
+      const int oy = pix / p.W, ox = pix - oy * p.W;
+      char* o = (char*)p.out.ptr + b * p.out.batch_stride + (int64_t)g * p.out.group_stride + ((int64_t)(oy + 1) * p.out.wp + ox + 1) * 32;
+      *(u32x4*)o = __builtin_bit_cast(u32x4, x);
+      *(u32x4*)(o + 16) = __builtin_bit_cast(u32x4, y);
+    }
+  }
+  if (!p.stat_sums) return;
+  // BatchNorm statistics (ESR_BN_STATS): per channel sum / sum of squares over the group's images -> fp64 atomics
+  float s0[16], s1[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { s0[e] = ok ? v[e] : 0.f; s1[e] = ok ? v[e] * v[e] : 0.f; }
+  __shared__ float red[4][2][16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0[e] += __shfl_xor(s0[e], o); s1[e] += __shfl_xor(s1[e], o); }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { red[wave][0][e] = s0[e]; red[wave][1][e] = s1[e]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int k = threadIdx.x >> 4, e = threadIdx.x & 15, c = c0 + e;
+    if (c < p.stat_C) {
+      const int ngrp = p.stat_groups > 1 ? p.stat_groups : 1, grp = b / (p.B / ngrp);
+      atomicAdd(p.stat_sums + (int64_t)grp * 2 * p.stat_C + k * p.stat_C + c,
+                (double)red[0][k][e] + red[1][k][e] + red[2][k][e] + red[3][k][e]);
+    }
+  }
+}
+
+// the transposed 4x4/s2 conv (esr_conv.upsample == 2: input gradient of those layers) on output maps of 8 / 16 / 32 columns
+template <typename T, int NCW>
+int launch_ts2_packed(const esr_conv& p, hipStream_t st) {
+  using G = Geo<4, 1, 2, 4, 2, 1, NCW, true, false, false, 4, true>;
+  const int per_tile = (64 / p.W) * (p.H <= 8 ? 2 : 1);
+  const int tyn = p.H <= 8 ? 1 : (p.H + G::TH - 1) / G::TH;
+  dim3 grid(((p.B + per_tile - 1) / per_tile) * tyn, (p.cout_blocks + NCW - 1) / NCW, p.ksplit);
+  hipLaunchKernelGGL((conv_kernel<T, 4, 1, 2, 4, 2, 1, NCW, true, false, false, false, 4, true>), grid, dim3(G::NT), 0, st, p);
+  int rc = esr_check_launch("conv_kernel (packed, split-K transposed 4x4/s2)");
+  if (rc) return rc;
+  dim3 fgrid((p.H * p.W + 255) / 256, p.cout_blocks * 2, p.B);
+  hipLaunchKernelGGL(s2_finish_kernel<T>, fgrid, dim3(256), 0, st, p);
+  return esr_check_launch("s2_finish_kernel");
+}
+
+template <typename T>
+int launch_s2_packed(const esr_conv& p, hipStream_t st) {
+  using G = Geo<4, 2, 0, 2, 1, 4, 1, false, false, false, 4, true>;
+  const int per_tile = (32 / p.W) * (p.H <= 4 ? 2 : 1);
+  const int tyn = p.H <= 4 ? 1 : (p.H + G::TH - 1) / G::TH;
+  dim3 grid(((p.B + per_tile - 1) / per_tile) * tyn, (p.cout_blocks + 3) / 4, p.ksplit);
+  hipLaunchKernelGGL((conv_kernel<T, 4, 2, 0, 2, 1, 4, 1, false, false, false, false, 4, true>), grid, dim3(G::NT), 0, st, p);
+  int rc = esr_check_launch("conv_kernel (packed, split-K 4x4/s2)");
+  if (rc) return rc;
+  dim3 fgrid((p.H * p.W + 255) / 256, p.cout_blocks * 2, p.B);
+  hipLaunchKernelGGL(s2_finish_kernel<T>, fgrid, dim3(256), 0, st, p);
+  return esr_check_launch("s2_finish_kernel");
 }
 
 template <typename T, int KS, int S, int UPS, int WR, int WC, int NCG, int NCW, bool WLDS, bool HAS1X1, bool PIPE = false, int RW = 4>
@@ -765,6 +956,15 @@ int dispatch(const esr_conv& p, hipStream_t st) {
   if (has1) { esr_set_error("conv: fused 1x1 only with 3x3/s1"); return ESR_ERR_UNSUPPORTED; }
   if (p.ks == 4 && p.stride == 1 && p.upsample == 2) {
     if ((p.H | p.W) & 1) { esr_set_error("conv: transposed stride-2 needs even output size"); return ESR_ERR_INVALID; }
+    if (p.ksplit > 1) {
+      if (sizeof(T) != 2 || !(p.W == 8 || p.W == 16 || p.W == 32) || p.H != p.W || !p.split_ws || !p.out.ptr || p.res1.ptr ||
+          p.res2.ptr || p.aux_out.ptr || p.mask.ptr || p.out3.ptr || p.noise_mode != ESR_NOISE_OFF || p.nchw_out_c > 0 ||
+          p.alpha != 1.0f || p.ksplit > p.cin_groups || p.bias || p.act != ESR_ACT_NONE || p.stat_sums) {
+        esr_set_error("conv: ksplit (transposed) needs a plain fp16 layer on an 8 / 16 / 32-column square output map");
+        return ESR_ERR_UNSUPPORTED;
+      }
+      return cbk == 1 ? launch_ts2_packed<T, 1>(p, st) : launch_ts2_packed<T, 2>(p, st);
+    }
     return cbk == 1 ? launch<T, 4, 1, 2, 4, 2, 1, 1, true, false>(p, st) : launch<T, 4, 1, 2, 4, 2, 1, 2, true, false>(p, st);
   }
   if (p.ks == 3 && p.stride == 1 && p.upsample == 1) {
@@ -782,6 +982,16 @@ int dispatch(const esr_conv& p, hipStream_t st) {
     // discriminator's first stride-2 conv) half of those would idle: 2 row x 2 column x 2 cout groups on an 8x64 tile
     static const bool wide = [] { const char* e = getenv("ESR_S2_WIDE"); return !e || atoi(e) != 0; }();
     if (wide && cbk <= 2 && p.W > 32) return launch<T, 4, 2, 0, 2, 2, 2, 1, false, false>(p, st);
+    if (p.ksplit > 1) {
+      // packed small maps + split K (launch_s2_packed): the caller sized split_ws for it (esr_conv_split_ws_floats)
+      if (sizeof(T) != 2 || !(p.W == 4 || p.W == 8 || p.W == 16) || p.H != p.W || !p.split_ws || !p.out.ptr || p.res1.ptr ||
+          p.res2.ptr || p.aux_out.ptr || p.mask.ptr || p.out3.ptr || p.noise_mode != ESR_NOISE_OFF || p.nchw_out_c > 0 ||
+          p.alpha != 1.0f || p.ksplit > p.cin_groups) {
+        esr_set_error("conv: ksplit needs a plain fp16 4x4/s2 layer on a 4 / 8 / 16-column square map");
+        return ESR_ERR_UNSUPPORTED;
+      }
+      return launch_s2_packed<T>(p, st);
+    }
     return launch<T, 4, 2, 0, 2, 1, 4, 1, false, false>(p, st);
   }
   if (p.ks == 1 && p.stride == 1 && !p.upsample) {
@@ -799,6 +1009,7 @@ extern "C" int esr_conv_forward(const esr_conv* p, esr_stream_t stream) {
     return ESR_ERR_INVALID;
   }
   if (p->mask.ptr && !p->out2.ptr) { esr_set_error("esr_conv_forward: mask without out2"); return ESR_ERR_INVALID; }
+  if (p->stat_sums && p->ksplit <= 1) { esr_set_error("esr_conv_forward: stat_sums rides on the split-K finishing pass (ksplit > 1)"); return ESR_ERR_INVALID; }
 
   hipStream_t st = (hipStream_t)stream;
   if (p->dtype == ESR_F16) return dispatch<_Float16>(*p, st);

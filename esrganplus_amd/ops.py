@@ -7,7 +7,7 @@ from . import _lib as L
 
 
 def conv2d(x, weight, bias=None, stride=1, act=None, upsample=False, precision='fp32',
-           residual=None, alpha=1.0, subpix=False):
+           residual=None, alpha=1.0, subpix=False, ksplit=0, stats=None):
     """act(conv2d(x, weight, bias, stride, padding=(k-1)//2)) [* alpha + residual] — the
     conv_block of block.py:125-151 (optionally on a nearest-x2 upsampled input, block.py:315-322;
     subpix: that up-conv in its 4-phase 2x2 form, esr_conv.upsample == 3)."""
@@ -38,6 +38,12 @@ def conv2d(x, weight, bias=None, stride=1, act=None, upsample=False, precision='
     c = E._conv(dt_e, B, Ho, Wo, xin.view(0), Cin, out.view(0), wp.entries['c'], a, stride=stride,
                 upsample=1 if upsample else 0)
     keep = []
+    if ksplit > 1:         # esr_conv.ksplit: packed tiles + split K (4x4/s2 on small square maps); stats: [groups] fp64 sums
+        ws = torch.empty(ksplit * B * Ho * Wo * ((Cout + 31) // 32) * 32, dtype=torch.float32, device=dev)
+        c.ksplit, c.split_ws = ksplit, ws.data_ptr()
+        keep.append(ws)
+        if stats is not None:
+            c.stat_sums, c.stat_groups, c.stat_C = stats.data_ptr(), stats.shape[0], Cout
     if residual is not None:
         r = residual.detach().contiguous().float()
         rb = E.G32(B, ((Cout + 31) // 32) * 32, Ho, Wo, precision, dev)

@@ -106,6 +106,17 @@ typedef struct esr_conv {
   int32_t _pad2;
   const uint64_t* seed_dev; /* non-NULL: the Philox seed is read from DEVICE memory at run time (so a
                                captured graph can be replayed with a fresh seed); overrides `seed` */
+  /* ---- round 4: the discriminators' deep 4x4/s2 convs (architecture.py:87-129: features.14 / .20 / .26 — fp16, square
+   * maps of 4 / 8 / 16 output columns, plain layer: bias [+ act], one G32 output).  ksplit > 1: several images share a
+   * tile and the K loop is split over ksplit workgroups per tile; each writes an fp32 slab of split_ws
+   * ([ksplit][B][H][W][cout_blocks * 32] floats) and a finishing launch of the same call adds the slabs up in split
+   * order (deterministic), applies bias / act and stores `out`.  stat_sums (optional): that pass also accumulates the
+   * BatchNorm statistics of the stored output exactly as ESR_BN_STATS would (sums[grp][c] += x, sums[grp][C + c] +=
+   * x^2, groups = stat_groups, C = stat_C; the caller zeroes stat_sums), so the BatchNorm that follows starts at
+   * ESR_BN_FIN_APPLY.  ksplit <= 1: off. */
+  int32_t ksplit, stat_groups, stat_C, _pad3;
+  float* split_ws;
+  double* stat_sums;
 } esr_conv;
 
 /* Weight packing: OIHW fp32 master (the nn.Parameter the reference keeps, e.g. state-dict key
@@ -635,7 +646,7 @@ int esr_graph_destroy(esr_graph_t g);
 int esr_run_ops_timed(const esr_op* ops, int32_t n, esr_stream_t stream, float* ms_out);
 
 const char* esr_last_error(void);
-int esr_abi_version(void);   /* 3 (round 3: esr_ragan_loss.mode / sums / ext, ...; 2 = round 2: esr_bn.groups / num_batches_tracked,
+int esr_abi_version(void);   /* 4 (round 4: esr_conv.ksplit / split_ws / stat_sums, ESR_BN_FIN_APPLY / ESR_BN_RESTAT); 3 (round 3: esr_ragan_loss.mode / sums / ext, ...; 2 = round 2: esr_bn.groups / num_batches_tracked,
                                 esr_l1_loss, esr_ragan_loss, ESR_OPF_SIDE_FREE) */
 size_t esr_sizeof_op(void);
 

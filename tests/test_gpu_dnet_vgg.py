@@ -401,3 +401,50 @@ def test_discriminator_sn_two_forwards_then_backward(dev, golden):
     for k in ('conv0.weight_orig', 'conv9.bias', 'linear1.weight_orig', 'linear0.bias'):
         want = g['g_' + k]
         assert np.abs(params[k].grad.cpu().numpy() - want).max() <= 3e-3 * max(1e-6, np.abs(want).max()), k
+
+
+@pytest.mark.parametrize('case', [(512, 512, 4, 32, 8), (512, 256, 8, 16, 4), (256, 128, 16, 9, 2), (64, 96, 4, 3, 2), (160, 64, 8, 5, 4)])
+def test_transposed_stride2_conv_packed_split_k(dev, case):
+    """Input gradient of the discriminator's deep 4x4/s2 convs (esr_conv.upsample == 2 on 8 / 16 / 32-column output
+    maps): with esr_conv.ksplit the tile holds several images and the K loop (the forward conv's output channels) is
+    split over workgroups, finished in split order.  Against autograd's conv_transpose2d on the fp16-rounded operands,
+    against the one-image-per-tile launch (<= 1 fp16 ulp: summation order only), bit-identical run to run; batches that
+    do not fill the last tile, forward input channels that do not fill the last 32-block."""
+    from esrganplus_amd import engine as E, _lib as L
+    co, ci, H, B, ksplit = case                     # forward conv: ci -> co, output H x H; its input gradient is 2H x 2H
+    g = np.random.default_rng(co + ci + H + B)
+    w = torch.from_numpy(g.standard_normal((co, ci, 4, 4), dtype=np.float32)) * (1.0 / np.sqrt(co * 4))
+    gy = torch.from_numpy(g.standard_normal((B, co, H, H), dtype=np.float32))
+    ref = torch.nn.functional.conv_transpose2d(gy.half().float(), w.half().float(), stride=2, padding=1)
+    wd = w.to(dev)
+    dp = E.DgradPack([('c', wd)], 'fp16', dev, {'c': {'ts2': True}})
+    st = E.current_stream()
+    dp.ensure(st)
+    outs = []
+    for ks_ in (ksplit, ksplit, 0):
+        gin = E.G32(B, co, H, H, 'fp16', dev)
+        gout = E.G32(B, ((ci + 31) // 32) * 32, 2 * H, 2 * H, 'fp16', dev)
+        ops = L.OpList()
+        gyd = gy.to(dev)
+        out = torch.empty(B, ci, 2 * H, 2 * H, device=dev)
+        lo = L.esr_layout()
+        lo.dtype, lo.to_g32, lo.B, lo.C, lo.H, lo.W, lo.nchw, lo.g32 = L.ESR_F16, 1, B, co, H, H, gyd.data_ptr(), gin.view(0, co)
+        ops.add(L.OP_LAYOUT, 'layout', lo)
+        c = E._conv(L.ESR_F16, B, 2 * H, 2 * H, gin.view(0), co, gout.view(0, ci), dp.entries['c'], L.ACT_NONE,
+                    ks=4, stride=1, upsample=2)
+        c.bias = None
+        ws = None
+        if ks_:
+            ws = torch.empty(ks_ * B * 4 * H * H * ((ci + 31) // 32) * 32, dtype=torch.float32, device=dev)
+            c.ksplit, c.split_ws = ks_, ws.data_ptr()
+        ops.add_conv(c)
+        lo2 = L.esr_layout()
+        lo2.dtype, lo2.to_g32, lo2.B, lo2.C, lo2.H, lo2.W, lo2.nchw, lo2.g32 = L.ESR_F16, 0, B, ci, 2 * H, 2 * H, out.data_ptr(), gout.view(0, ci)
+        ops.add(L.OP_LAYOUT, 'layout', lo2)
+        ops.run(st)
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    scale = max(1.0, ref.abs().max().item())
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0] - ref).abs().max().item() <= 2e-3 * scale
+    assert (outs[0] - outs[2]).abs().max().item() <= 2.0 ** -10 * scale

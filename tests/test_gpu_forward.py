@@ -60,6 +60,37 @@ def test_single_conv(dev, case, precision):
     assert (y - ref).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize('case', [(64, 96, 32, 5, 2), (128, 128, 16, 9, 4), (256, 160, 8, 19, 8), (32, 32, 8, 2, 2),
+                                  (512, 512, 8, 32, 16), (512, 512, 16, 32, 8), (256, 256, 32, 32, 4)])
+def test_stride2_conv_packed_split_k(dev, case):
+    """The discriminator's deep 4x4/s2 convs (architecture.py:87-129: features.14 / .20 / .26 leave 16- / 8- / 4-column
+    maps): esr_conv.ksplit packs 2-16 images into a tile, splits the K loop over workgroups (fp32 slabs) and finishes in
+    a second launch that also takes the BatchNorm statistics of the stored output.  Against torch's conv2d on the
+    fp16-rounded operands (fp32 accumulation either way: 2e-3 of the output scale), against the one-image-per-tile
+    launch (same fp16 output up to the summation order: <= 1 fp16 ulp), bit-identical run to run (plain-store slabs
+    added in split order), statistics == sums over the stored fp16 values; batches that do not fill the last tile."""
+    from esrganplus_amd import ops
+    cin, cout, hin, B, ksplit = case
+    g = np.random.default_rng(cin + cout + hin + B)
+    x = torch.from_numpy(g.standard_normal((B, cin, hin, hin), dtype=np.float32))
+    w = torch.from_numpy(g.standard_normal((cout, cin, 4, 4), dtype=np.float32)) / np.sqrt(cin * 16)
+    b = torch.from_numpy(g.standard_normal(cout, dtype=np.float32))
+    ref = torch.nn.functional.conv2d(x.half().float(), w.half().float(), b, stride=2, padding=1)
+    groups = 2 if B % 2 == 0 else 1
+    stats = torch.zeros(groups, 2 * cout, dtype=torch.float64, device=dev)
+    y = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), stride=2, precision='fp16', ksplit=ksplit, stats=stats).cpu()
+    y2 = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), stride=2, precision='fp16', ksplit=ksplit).cpu()
+    y1 = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), stride=2, precision='fp16').cpu()
+    assert y.shape == ref.shape == (B, cout, hin // 2, hin // 2)
+    assert torch.equal(y, y2)
+    assert (y - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    assert (y - y1).abs().max().item() <= 2.0 ** -10 * max(1.0, ref.abs().max().item())
+    st = stats.cpu()
+    yg = y.double().reshape(groups, B // groups, cout, -1)
+    assert torch.allclose(st[:, :cout], yg.sum(dim=(1, 3)), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(st[:, cout:], (yg * yg).sum(dim=(1, 3)), rtol=1e-6, atol=1e-6)
+
+
 SUBPIX_CASES = [
     # cin, cout, act, (B, H_in, W_in): upconv_blcok (block.py:315-322) in its 4-phase 2x2 form
     (64, 64, 'leakyrelu', (1, 12, 20)),      # ragged: 12x20 input is not a multiple of the 8x32 tile
