@@ -71,7 +71,8 @@ class esr_wgrad(C.Structure):
 class esr_layout(C.Structure):
     _fields_ = [('dtype', C.c_int32), ('to_g32', C.c_int32), ('B', C.c_int32), ('C', C.c_int32),
                 ('H', C.c_int32), ('W', C.c_int32), ('nchw', C.c_void_p), ('g32', esr_g32),
-                ('use_affine', C.c_int32), ('mean_c', C.c_float * 4), ('inv_std_c', C.c_float * 4)]
+                ('use_affine', C.c_int32), ('mean_c', C.c_float * 4), ('inv_std_c', C.c_float * 4),
+                ('accumulate', C.c_int32), ('_pad', C.c_int32)]
 
 
 class esr_noise_fill(C.Structure):
@@ -167,7 +168,8 @@ class esr_rdb_chain(C.Structure):
 
 class esr_l1_loss(C.Structure):
     _fields_ = [('a', C.c_void_p), ('b', C.c_void_p), ('grad_a', C.c_void_p), ('loss', C.c_void_p),
-                ('scratch', C.c_void_p), ('n', C.c_int64), ('weight', C.c_float), ('_pad', C.c_int32)]
+                ('scratch', C.c_void_p), ('n', C.c_int64), ('weight', C.c_float), ('grad_scale', C.c_float),
+                ('grad_scale_dev', C.c_void_p)]
 
 
 class esr_ragan_loss(C.Structure):
@@ -175,7 +177,8 @@ class esr_ragan_loss(C.Structure):
                 ('loss', C.c_void_p), ('mean_x', C.c_void_p), ('mean_y', C.c_void_p),
                 ('bce_x', C.c_void_p), ('bce_y', C.c_void_p), ('n', C.c_int32),
                 ('tx', C.c_float), ('ty', C.c_float), ('weight', C.c_float),
-                ('mode', C.c_int32), ('_pad', C.c_int32), ('sums', C.c_void_p), ('ext', C.c_void_p)]
+                ('mode', C.c_int32), ('grad_scale', C.c_float), ('sums', C.c_void_p), ('ext', C.c_void_p),
+                ('grad_scale_dev', C.c_void_p)]
 
 
 class esr_img_metrics(C.Structure):

@@ -387,7 +387,8 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
         aff = None
         if input_affine is not None:
             aff = (input_affine[0], input_affine[1])
-        _layout(bk, dt_e, 0, Bb, cin0, gcur, nchw_ptr=Q.gx_tensor.data_ptr(), affine=aff)
+        Q.gx_op = _layout(bk, dt_e, 0, Bb, cin0, gcur, nchw_ptr=Q.gx_tensor.data_ptr(), affine=aff)
+        Q.has_bn = nbn > 0
         Q.wgrad_arena = E.attach_wgrad_arena(bk, dev, exclusive=True)
         return Q
 
@@ -418,6 +419,8 @@ def _run_pass(Q, graph, gy, n_total, want_gx, needs):
     if graph:
         Q.bwd.graph_launch(st)
     else:
+        lo = Q.bwd.array()[Q.gx_op].u.layout
+        lo.nchw, lo.accumulate = Q.gx_tensor.data_ptr(), 0
         Q.bwd.run(st)
     gx = None
     if want_gx:
@@ -433,6 +436,24 @@ def _run_pass(Q, graph, gy, n_total, want_gx, needs):
                 grads[i] = flat[off:off + numel].view(shape)
             off += numel
     return gx, grads
+
+
+def run_pass_into(Q, gx_into=None, accumulate=False):
+    """The hand-written train step's face of a backward pass: the upstream gradient is ALREADY in Q.gy_tensor (the loss
+    kernel wrote it there), the input gradient goes to ``gx_into`` (NCHW fp32; ``accumulate``: added to what it holds)
+    or is dropped into the pass's own buffer, the parameter gradients stay in Q.grad_flat (OIHW order of the plan's
+    parameter list).  No copies, no clones."""
+    st = E.current_stream()
+    if getattr(Q, 'has_bn', True):
+        Q.sums_b.zero_()
+    if Q.grad_flat is not None:
+        Q.grad_flat.zero_()
+        if Q.tapmajor is not None:
+            Q.tapmajor.tm.zero_()
+    lo = Q.bwd.array()[Q.gx_op].u.layout
+    lo.nchw = (gx_into if gx_into is not None else Q.gx_tensor).data_ptr()
+    lo.accumulate = 1 if (accumulate and gx_into is not None) else 0
+    Q.bwd.run(st)
 
 
 class SeqNetFn(torch.autograd.Function):

@@ -190,7 +190,8 @@ __global__ void from_g32_kernel(const esr_layout p) {
     if (c < p.C) {
       float f = (float)v[e];
       if (p.use_affine && c < 4) f *= p.inv_std_c[c];   // adjoint of (x - mean) * inv_std
-      p.nchw[(((int64_t)b * p.C + c) * p.H + y) * p.W + x] = f;
+      float* const o = p.nchw + (((int64_t)b * p.C + c) * p.H + y) * p.W + x;
+      *o = p.accumulate ? *o + f : f;
     }
   }
 }

@@ -12,7 +12,7 @@ namespace {
 __global__ __launch_bounds__(256) void l1_loss_kernel(const esr_l1_loss p) {
   const int64_t stride = (int64_t)gridDim.x * 256 * 4;
   double s = 0.0;
-  const float gw = p.weight / (float)p.n;
+  const float gw = p.weight / (float)p.n * (p.grad_scale != 0.f ? p.grad_scale : 1.f) * (p.grad_scale_dev ? *p.grad_scale_dev : 1.f);
   // 16-byte vector accesses only when all three pointers allow them (a view with an odd storage offset takes the
   // scalar path: same sums, same order per thread)
   const bool vec = (((uintptr_t)p.a | (uintptr_t)p.b | (uintptr_t)p.grad_a) & 15) == 0;
@@ -123,10 +123,11 @@ __global__ __launch_bounds__(256) void ragan_loss_kernel(const esr_ragan_loss p)
   }
   // d loss / d x_i = hw/n [ (sigmoid(z1_i) - tx) - (sum_j (sigmoid(z2_j) - ty)) / N ]: the second term is the mean's share
   // (N and the sum run over all ranks in mode 3 — every rank's loss sees the mean, gradients are averaged over ranks)
+  const float gs = hw * inv * (p.grad_scale != 0.f ? p.grad_scale : 1.f) * (p.grad_scale_dev ? *p.grad_scale_dev : 1.f);
   for (int i = threadIdx.x; i < p.n; i += 256) {
     const float z1 = p.x[i] - my, z2 = p.y[i] - mx;
-    if (p.grad_x) p.grad_x[i] = hw * inv * ((sigmoidf(z1) - p.tx) - t[3] * ninv_glob);
-    if (p.grad_y) p.grad_y[i] = hw * inv * ((sigmoidf(z2) - p.ty) - t[2] * ninv_glob);
+    if (p.grad_x) p.grad_x[i] = gs * ((sigmoidf(z1) - p.tx) - t[3] * ninv_glob);
+    if (p.grad_y) p.grad_y[i] = gs * ((sigmoidf(z2) - p.ty) - t[2] * ninv_glob);
   }
 }
 

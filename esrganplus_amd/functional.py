@@ -281,6 +281,45 @@ class _RRDBNetFn(torch.autograd.Function):
         return (gx, None, None, None) + tuple(grads)
 
 
+class TrainPass:
+    """State of one RRDBNet training forward outside autograd (train.ESRGANPlusStep's hand-written step)."""
+    __slots__ = ('lease', 'seed', 'noise', 'explicit', 'sync')
+
+
+def rrdbnet_train_forward(net, x, z=None):
+    """RRDBNet.forward in training form (every activation the backward needs is kept) WITHOUT an autograd node:
+    returns (y, state) for ``rrdbnet_train_backward``.  Same plans, same launches as ``_RRDBNetFn``."""
+    xin = _prep_input(x, 'input')
+    B, C_, H, W = xin.shape
+    if C_ != net.in_nc:
+        raise ValueError('expected %d input channels, got %d' % (net.in_nc, C_))
+    dev = xin.device
+    st = E.current_stream()
+    noise = bool(net.training)
+    per = 4 if net.variant == 'test_image' else 3
+    zs = _zs_list(z, per * net.nb, (B, 64, H, W), dev) if noise else None
+    wp = net._weights(dev)
+    dp = net._dgrad_weights(dev)
+    dp.ensure(st, force=not net._dgrad_fresh())
+    tp = _train_plan(net, wp, dp, B, H, W, dev, noise, zs is not None)
+    s = TrainPass()
+    s.lease = _PlanLease(tp)
+    s.seed = _draw_seed() if (noise and zs is None) else 0
+    s.noise, s.explicit, s.sync = noise, zs is not None, getattr(net, '_grad_sync', None)
+    return _train_forward(tp, xin, st, s.seed, zs), s
+
+
+def rrdbnet_train_backward(net, s, gy):
+    """The backward of ``rrdbnet_train_forward``: parameter gradients into the module's flat store (every parameter's
+    ``.grad`` = its view of it, block._PlannedModule._deliver_flat_grads); dL/dx is not formed."""
+    tp = s.lease.tp
+    if tp is None:
+        raise RuntimeError('rrdbnet_train_backward called twice on one forward')
+    _train_backward(tp, gy, E.current_stream(), s.noise, s.explicit, s.seed, False, s.sync)
+    net._deliver_flat_grads(tp.grad_flat)
+    s.lease.release()
+
+
 def _block_train_plan(mod, kind, wp, dp, B, H, W, dev, noise, explicit):
     key = ('train', kind, B, H, W, mod.precision, noise, explicit, wp.generation, str(dev))
     pool = mod._plans.setdefault(key, [])

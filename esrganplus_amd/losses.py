@@ -62,6 +62,74 @@ def _as_f32(t):
     return t.float() if torch.is_tensor(t) and t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) else t
 
 
+def _scale_args(p, grad_scale, scale_dev):
+    p.grad_scale = float(grad_scale)
+    if scale_dev is not None:
+        p.grad_scale_dev = scale_dev.data_ptr()
+
+
+def l1_raw(a, b, weight, grad_out=None, grad_scale=1.0, scale_dev=None):
+    """One launch, no autograd: ``(weight * mean|a - b|, grad)`` with ``grad = grad_scale [* scale_dev[0]] * weight *
+    sign(a - b) / n`` written into ``grad_out`` (a contiguous fp32 tensor of a's size — e.g. the buffer a backward launch
+    list reads its upstream gradient from) or not formed at all (``grad_out=None``).  The hand-written train step
+    (train.ESRGANPlusStep) calls the losses this way; ``l1_loss`` is the autograd face of the same kernel."""
+    a_, b_ = a.detach().contiguous(), b.detach().contiguous()
+    _check_operands('l1_raw', a_, b_)
+    _require(a_.shape == b_.shape, 'l1_raw: shapes %s vs %s' % (tuple(a_.shape), tuple(b_.shape)))
+    loss = torch.empty((), dtype=torch.float32, device=a_.device)
+    p = L.esr_l1_loss()
+    p.a, p.b, p.loss, p.n, p.weight = a_.data_ptr(), b_.data_ptr(), loss.data_ptr(), a_.numel(), float(weight)
+    if grad_out is not None:
+        _require(grad_out.is_contiguous() and grad_out.dtype == torch.float32 and grad_out.numel() == a_.numel(), 'l1_raw: grad_out')
+        p.grad_a = grad_out.data_ptr()
+    p.scratch = _dev_scratch(a_.device).data_ptr()
+    _scale_args(p, grad_scale, scale_dev)
+    L.check(L.lib().esr_l1_loss_forward(C.byref(p), C.c_void_p(E.current_stream())), 'esr_l1_loss_forward')
+    return loss
+
+
+def ragan_raw(x, y, x_is_real, y_is_real, weight, grad_x=None, grad_y=None, grad_scale=1.0, scale_dev=None,
+              global_mean=False):
+    """The relativistic-average GAN term without autograd: ``(loss, aux)`` as ``ragan_loss``; the gradients w.r.t. the
+    logits, times ``grad_scale [* scale_dev[0]]``, are written into ``grad_x`` / ``grad_y`` (contiguous fp32, n floats;
+    None: not formed).  ``global_mean``: the batch means run over all ranks (two scalar all-reduces between the launches,
+    as ``_RaGANGlobalFn``)."""
+    import torch.distributed as dist
+    x_, y_ = x.detach().contiguous().view(-1), y.detach().contiguous().view(-1)
+    _check_operands('ragan_raw', x_, y_)
+    _require(x_.numel() == y_.numel(), 'ragan_raw: %d vs %d logits' % (x_.numel(), y_.numel()))
+    dev = x_.device
+    st = C.c_void_p(E.current_stream())
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    out = torch.empty(4, dtype=torch.float32, device=dev)        # mean(x), mean(y), BCE_x, BCE_y
+    p = L.esr_ragan_loss()
+    p.x, p.y, p.n = x_.data_ptr(), y_.data_ptr(), x_.numel()
+    p.tx, p.ty, p.weight = (1.0 if x_is_real else 0.0), (1.0 if y_is_real else 0.0), float(weight)
+    p.loss, p.mean_x, p.mean_y = loss.data_ptr(), out.data_ptr(), out.data_ptr() + 4
+    p.bce_x, p.bce_y = out.data_ptr() + 8, out.data_ptr() + 12
+    _scale_args(p, grad_scale, scale_dev)
+    gx = grad_x.data_ptr() if grad_x is not None else None
+    gy = grad_y.data_ptr() if grad_y is not None else None
+    if not (global_mean and dist.is_initialized() and dist.get_world_size() > 1):
+        p.grad_x, p.grad_y = gx, gy
+        L.check(L.lib().esr_ragan_loss_forward(C.byref(p), st), 'esr_ragan_loss_forward')
+        return loss, out
+    ext = torch.zeros(5, dtype=torch.float32, device=dev)       # sum x, sum y, n | D1, D2 (all ranks)
+    ext[2] = float(x_.numel())
+    p.mode, p.sums = 1, ext.data_ptr()
+    L.check(L.lib().esr_ragan_loss_forward(C.byref(p), st), 'esr_ragan_loss_forward')
+    dist.all_reduce(ext[0:3])
+    dsum = torch.zeros(2, dtype=torch.float32, device=dev)
+    p.mode, p.sums, p.ext = 2, dsum.data_ptr(), ext.data_ptr()
+    L.check(L.lib().esr_ragan_loss_forward(C.byref(p), st), 'esr_ragan_loss_forward')
+    if gx is not None or gy is not None:
+        dist.all_reduce(dsum)
+        ext[3:5] = dsum
+        p.mode, p.grad_x, p.grad_y = 3, gx, gy
+        L.check(L.lib().esr_ragan_loss_forward(C.byref(p), st), 'esr_ragan_loss_forward')
+    return loss, out
+
+
 def l1_loss(a, b, weight=1.0):
     """``weight * F.l1_loss(a, b)``; the gradient flows to ``a`` only (``b`` is the target: var_H / real_fea — a target
     that requires a gradient is refused, not silently detached).  fp16 / bf16 operands are upcast."""

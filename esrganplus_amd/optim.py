@@ -109,10 +109,12 @@ class FusedAdam(torch.optim.Optimizer):
         return st['stage']
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, scaler=None):
+    def step(self, closure=None, grad_scale=1.0, scaler=None, flat_grad=None):
         """``grad_scale`` multiplies every gradient on the fly (1/loss_scale under static loss scaling).
         ``scaler`` (DynamicLossScaler): the gradients are checked for inf / nan first and the whole update is
-        skipped on the device when one is found; otherwise they are divided by the current scale."""
+        skipped on the device when one is found; otherwise they are divided by the current scale.
+        ``flat_grad`` (single parameter group): the gradients of all parameters as ONE fp32 tensor in parameter order —
+        what a fused backward plan leaves behind — instead of the parameters' ``.grad`` (which need not be set)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -120,10 +122,15 @@ class FusedAdam(torch.optim.Optimizer):
         stream = E.current_stream()
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group['params'] if p.requires_grad]
-            if not params or not any(p.grad is not None for p in params):
+            if not params or (flat_grad is None and not any(p.grad is not None for p in params)):
                 continue
             st = self._group_state(gi, params)
-            flat = self._flat_grad(st, params)
+            if flat_grad is not None:
+                if len(self.param_groups) != 1 or flat_grad.numel() != st['total'] or flat_grad.dtype != torch.float32:
+                    raise L.HipExtensionError('FusedAdam.step(flat_grad=...): one parameter group, %d fp32 elements' % st['total'])
+                flat = flat_grad
+            else:
+                flat = self._flat_grad(st, params)
             st['step'] += 1                 # steps ATTEMPTED (== applied without a scaler)
             b1, b2 = group['betas']
             slot = 0

@@ -63,6 +63,11 @@ class ESRGANPlusStep:
         self.shared_d = os.environ.get('ESR_SHARED_D', '1') != '0'
         # ESR_PREPACK=0: every network packs its weights at the start of its next training forward (round 3)
         self.prepack = os.environ.get('ESR_PREPACK', '1') != '0'
+        # ESR_TRAIN_MANUAL=0: the step is written with autograd (losses as autograd Functions, torch.autograd.backward
+        # over the three networks' nodes: ~100 glue launches — clones, gradient copies / sums, zero fills — and their
+        # host time per step).  Default: the same launch lists driven directly (`_step_manual`), when the networks
+        # allow it (`_manual_ok`)
+        self.manual = os.environ.get('ESR_TRAIN_MANUAL', '1') != '0'
         self.overlap_d_step = self.overlap >= 1
 
     def _side(self, dev, which=0):
@@ -95,15 +100,142 @@ class ESRGANPlusStep:
                 'exposed_ms_per_step': (self.exG.exposed_ms() + self.exD.exposed_ms()) / n,
                 'exposed_ms_per_step_G': self.exG.exposed_ms() / n, 'exposed_ms_per_step_D': self.exD.exposed_ms() / n}
 
+    def _manual_ok(self):
+        netG, netD, netF = self.netG, self.netD, self.netF
+        return (self.manual and self.shared_d and getattr(netD, '_shared_ok', False) and netD.training
+                and getattr(netG, 'flat_param_grads', False) and hasattr(netG, '_convs') and hasattr(netF, '_run_forward')
+                and all(p.requires_grad for p in netG._convs()[1]) and all(p.requires_grad for p in netD.parameters()))
+
+    def _step_manual(self, var_L, var_H, var_ref, z, sync_log):
+        """optimize_parameters (SRRaGAN_model.py:113-168) as a hand-written forward / backward over the networks'
+        launch lists — no autograd graph.  The same kernels in the same order as the autograd form of ``step`` (which
+        stays for networks this path does not cover, and as the A/B reference: tests run both against the reference's
+        golden steps); what disappears is the glue between them:
+          * every loss kernel writes its gradient straight into the buffer the next backward list reads
+            (losses.l1_raw / ragan_raw: the loss scale rides in the kernel);
+          * dL/d fake_H = d l_pix + d l_fea + d l_gan is never summed by a launch: the pixel loss writes the buffer, the
+            last layout ops of netF's and netD's input-gradient passes ADD into it (esr_layout.accumulate);
+          * netD's parameter gradients stay in its plan's flat buffer (the parameters' .grad are persistent views of
+            it), RRDBNet's go to its flat store: both optimizers consume them without a copy."""
+        from . import functional as Fn
+        from . import convnet as CN
+        netG, netD, netF = self.netG, self.netD, self.netF
+        dev = var_L.device
+        S = float(self.loss_scale)
+        sdev = self.scaler.state if self.scaler else None          # state[0] = the dynamic loss scale (device)
+        mean = self.data_parallel
+        ov = self.overlap
+        n = var_L.shape[0]
+        main = torch.cuda.current_stream()
+        side = self._side(dev, 0) if ov >= 1 else None
+        if not netG.mark_grads_stale():
+            self.optimizer_G.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            if ov >= 1:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    real_fea = netF._run_forward(var_H, need_bwd=False)[0]
+                real_fea.record_stream(main)
+            fake, stG = Fn.rrdbnet_train_forward(netG, var_L, z)
+            self.fake_H = fake
+            gy = self.__dict__.get('_gy')
+            if gy is None or gy.shape != fake.shape or gy.device != fake.device:
+                gy = self._gy = torch.empty_like(fake)
+            l_g_pix = LS.l1_raw(fake, var_H, self.l_pix_w, grad_out=gy, grad_scale=S, scale_dev=sdev)
+            if ov >= 1:
+                main.wait_stream(side)
+            else:
+                real_fea = netF._run_forward(var_H, need_bwd=False)[0]
+            fake_fea, leaseF = netF._run_forward(fake, need_bwd=True)
+            PF = leaseF.plan
+            l_g_fea = LS.l1_raw(fake_fea, real_fea, self.l_fea_w, grad_out=PF.gy_tensor, grad_scale=S, scale_dev=sdev)
+            # ONE netD forward for the step's four calls (forward_shared): groups (fake, real)
+            out, leaseD = netD._run_forward(torch.cat([fake, var_ref]), need_bwd=True, groups=2 if netD._has_bn else 1, dual=n)
+            PD = leaseD.plan
+            pg, pr = out[:n], out[n:]
+            # G step: BCE(pred_d_real - mean(pred_g_fake), 0) + BCE(pred_g_fake - mean(pred_d_real), 1), gradient to the fake half
+            l_g_gan, _ = LS.ragan_raw(pr, pg, False, True, self.l_gan_w, grad_x=None, grad_y=PD.second.gy_tensor,
+                                      grad_scale=S, scale_dev=sdev, global_mean=mean)
+
+            def d_step():
+                # D step (SRRaGAN_model.py:143-168): the second pair of calls sees the first pair's values
+                if PD.restat is not None and PD.restat.ops:
+                    PD.restat.run(E.current_stream())
+                gyt = PD.gy_tensor                                # plan order [fake; real]
+                l_d, aux = LS.ragan_raw(pr, pg, True, False, 1.0, grad_x=gyt[n:], grad_y=gyt[:n],
+                                        grad_scale=S, scale_dev=sdev, global_mean=mean)
+                CN.run_pass_into(PD)
+                views = PD.__dict__.get('_param_views')
+                if views is None:
+                    views, off = [], 0
+                    for numel, shape in PD.grad_views:
+                        views.append(PD.grad_flat[off:off + numel].view(shape))
+                        off += numel
+                    PD._param_views = views
+                    PD._param_list = [t for _, t in netD._pspec()]
+                for p_, v in zip(PD._param_list, views):
+                    p_.grad = v
+                self.exD.start()
+                return aux
+
+            # the D step is enqueued BEFORE the main stream's backward (after it: 8.88 vs 8.57 ms — it then runs under
+            # the G backward chain, and a chain that shares the chip slows down more than the overlap saves)
+            d_first = True
+            if ov >= 1:
+                side.wait_stream(main)
+                if d_first:
+                    with torch.cuda.stream(side):
+                        aux = d_step()
+            # dL/d fake_H: + d l_gan (netD, first pair) + d l_fea (netF), added by the passes' last layout ops
+            CN.run_pass_into(PD.second, gx_into=gy, accumulate=True)
+            CN.run_pass_into(PF, gx_into=gy, accumulate=True)
+            Fn.rrdbnet_train_backward(netG, stG, gy)
+            self.exG.start()
+            if ov >= 1:
+                if not d_first:
+                    with torch.cuda.stream(side):
+                        aux = d_step()
+                main.wait_stream(side)
+            else:
+                aux = d_step()
+            leaseF.release()
+            leaseD.release()
+            inv = 1.0 / self.loss_scale
+            self.exG.wait()
+            self.optimizer_G.step(grad_scale=inv, scaler=self.scaler)
+            self.exD.wait()
+            self.optimizer_D.step(grad_scale=inv, scaler=self.scaler)
+            if self.scaler:
+                self.scaler.update()
+            if self.prepack:
+                netG.prepack(fwd=True, dgrad=False)
+                if ov >= 1:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        netD.prepack()
+                        netG.prepack(fwd=False, dgrad=True)
+                else:
+                    netD.prepack()
+                    netG.prepack(fwd=False, dgrad=True)
+        logs = dict(l_g_pix=l_g_pix, l_g_fea=l_g_fea, l_g_gan=l_g_gan, l_d_real=aux[2], l_d_fake=aux[3],
+                    D_real=aux[0], D_fake=aux[1])
+        if sync_log:
+            self.log = {k: float(v) for k, v in logs.items()}
+        else:
+            self.log = logs
+        return self.log
+
     def step(self, var_L, var_H, var_ref=None, z=None, sync_log=True):
         """One optimisation step (SRRaGAN_model.py:113-168)."""
         netG, netD, netF = self.netG, self.netD, self.netF
         var_ref = var_H if var_ref is None else var_ref
         self._steps += 1
+        E.require_cuda(var_L, 'ESRGANPlusStep.step: var_L')      # (the networks and the fused losses have no CPU path)
+        if self._manual_ok():
+            return self._step_manual(var_L, var_H, var_ref, z, sync_log)
         # batch means of the relativistic terms: over ALL ranks when data-parallel (losses._RaGANGlobalFn: the fused
         # kernel + two scalar all-reduces), else inside the one fused loss launch
         mean = self.data_parallel
-        E.require_cuda(var_L, 'ESRGANPlusStep.step: var_L')      # (the networks and the fused losses have no CPU path)
         cuda = True
         ov = self.overlap
         # ---------------- G ----------------

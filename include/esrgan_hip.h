@@ -185,6 +185,10 @@ typedef struct esr_layout {
                           norm, architecture.py:304-305) */
   float mean_c[4];
   float inv_std_c[4];
+  int32_t accumulate;  /* to_g32 == 0 only: nchw += value instead of nchw = value (round 4: the input gradients of netF
+                          and netD land in the buffer that already holds the pixel loss's, SRRaGAN_model.py:124-140:
+                          dL/d fake_H = d l_pix + d l_fea + d l_gan without add launches) */
+  int32_t _pad;
 } esr_layout;
 
 /* Philox-4x32-7 + Box-Muller N(0,1) fill (csrc/common.h), NCHW fp32 — the exact z the fused noise epilogue uses for
@@ -369,7 +373,10 @@ typedef struct esr_l1_loss {
   float* loss;                 /* 1 float */
   double* scratch;             /* 2 doubles, zero */
   int64_t n;
-  float weight; int32_t _pad;
+  float weight;
+  float grad_scale;            /* round 4: grad_a is additionally multiplied by this (the loss scale of the fp16 path: the
+                                  loss itself stays unscaled); 0 = 1 */
+  const float* grad_scale_dev; /* non-NULL: multiplied in as well, read on the device (dynamic loss scaling, esr_amp state[0]) */
 } esr_l1_loss;
 
 typedef struct esr_ragan_loss {
@@ -386,9 +393,11 @@ typedef struct esr_ragan_loss {
    *   mode 2  means = ext[0]/ext[2], ext[1]/ext[2] (global sums, global count): loss, mean_x/y, bce_x/y and
    *           sums[0..1] = {sum_i sigmoid(x_i - mean y) - tx,  sum_i sigmoid(y_i - mean x) - ty}
    *   mode 3  grad_x / grad_y from the global means and ext[3..4] = those two sums over all ranks         */
-  int32_t mode, _pad;
+  int32_t mode;
+  float grad_scale;                    /* round 4: grad_x / grad_y times this (loss scale); 0 = 1 */
   float* sums;                         /* 2 floats (modes 1, 2) */
   const float* ext;                    /* 5 floats (modes 2, 3) */
+  const float* grad_scale_dev;         /* non-NULL: multiplied in as well, read on the device */
 } esr_ragan_loss;
 
 typedef struct esr_img_metrics {

@@ -53,14 +53,17 @@ def test_optimize_parameters_step_matches_reference():
     assert np.mean(np.sign(dd) == np.sign(g['D_delta_classifier.2.weight'])) >= 0.97
 
 
-@pytest.mark.parametrize('knobs', [{}, {'ESR_SHARED_D': '0', 'ESR_TRAIN_OVERLAP': '0', 'ESR_FLAT_GRADS': '0', 'ESR_FUSE_BN': '0'}])
+@pytest.mark.parametrize('knobs', [{}, {'ESR_TRAIN_MANUAL': '0'},
+                                   {'ESR_TRAIN_MANUAL': '0', 'ESR_SHARED_D': '0', 'ESR_TRAIN_OVERLAP': '0', 'ESR_FLAT_GRADS': '0',
+                                    'ESR_FUSE_BN': '0', 'ESR_S2_SPLIT': '0'}])
 def test_three_training_iterations_match_the_reference(monkeypatch, knobs):
     """Three iterations of the reference's loop body (codes/train.py:97-106) — MultiStepLR([1, 2]) stepped BEFORE the
     optimizers, fresh data and noise per step — against the imported SRRaGANModel (tests/golden/train_steps3.npz,
     oracle/gen_golden.py: gen_train_steps3): the seven logged losses per step, the learning rates, the weights after
     the third Adam step (moments + bias correction over steps), and the discriminator's BatchNorm buffers after its 12
-    training forwards.  Runs the production step (shared netD forward, stream overlap, flat gradient store, fused
-    BatchNorm passes) and the plain one (every knob off)."""
+    training forwards.  Runs the production step (hand-written forward / backward over the launch lists, shared netD forward, stream overlap,
+    flat gradient store, fused BatchNorm passes, split-K deep convs), the same through autograd, and the plain one
+    (every knob off)."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     from esrganplus_amd import architecture as arch, train
