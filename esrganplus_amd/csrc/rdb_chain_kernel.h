@@ -74,18 +74,33 @@ constexpr int NSLOT = IH * IW * 2;          // 16-byte slots of one activation s
 constexpr int NLD = (NSLOT + NT - 1) / NT;  // DMA rounds per stage (5)
 constexpr int ASLOT = NLD * NT * 16;        // 20480
 constexpr int AR = 4;                       // activation slots: all stages of a 64-channel fp16 input are resident
-constexpr int WSLOT = 18 * 1024;            // weight unit (6 blocks x 3 kh fragments)
-constexpr int WR = 4;                       // weight ring depth (3 units ahead)
+// ESR_FAT: the unit runner of the small-tile builds (run_units_fat below).  With one row per wave a unit is 6..15
+// MFMAs (0.08..0.2 us): a fragment read covers ONE MFMA and the unit boundary (barrier, DMA set-up) comes every few
+// hundred cycles, so the fragments of unit i+1 are read while unit i's MFMAs issue, and the weight ring is deeper
+// (the 4-row tile leaves the LDS room: 8 slots of 15 fragments, requests 6 units ahead).
+#ifndef ESR_FAT
+#define ESR_FAT (ESR_R == 1)
+#endif
+constexpr bool FAT = ESR_FAT != 0;
+constexpr int WSLOT = FAT ? 15 * 1024 : 18 * 1024;   // weight unit (fp16 schedule: <= 15 fragments; fp32 phases: 6 blocks x 3 kh)
+constexpr int WR = FAT ? 8 : 4;             // weight ring depth
+#ifndef ESR_AH
+#define ESR_AH (ESR_FAT ? 6 : 3)
+#endif
+constexpr int AH = ESR_AH;                  // a unit's weights are requested AH units ahead (<= WR - 1; FAT: <= WR - 2)
+static_assert(AH >= 3 && AH <= (FAT ? WR - 2 : WR - 1), "weight ring lead");
 constexpr int WOFF = AR * ASLOT;
 constexpr int LDS_CTRL = WOFF + WR * WSLOT;   // two control words behind the rings
 constexpr int LDS_BIAS = LDS_CTRL + 64;        // fp16 path: the block's 192 biases (fp32)
 constexpr int LDS_FLAGS = LDS_BIAS + 192 * 4;  // fp16 path: the neighbours' flags as wave 0 last fetched them (64 words)
 constexpr int LDS_HALO = LDS_FLAGS + 256;      // fp16 path: per thread {source, destination} offset of its halo slot
-constexpr int LDS_BYTES = LDS_HALO + NT * 8;   // 158784
+constexpr int LDS_NBR = LDS_HALO + NT * 8;     // fp16 path: per lane of wave 0, the byte offset (in the workspace) of the flag it fetches
+constexpr int LDS_BYTES = LDS_NBR + 256;       // 159040
 constexpr int MASK_SLICE = 512 * R;            // bytes of one slice's masks of a tile: [wave][lane][R rows x u16]
 constexpr int MASK_TILE = 4 * MASK_SLICE;
 constexpr int LDS_MASK = LDS_BYTES;            // backward: two buffers of LeakyReLU masks (one dense slice each)
 constexpr int LDS_BYTES_BWD = LDS_MASK + 2 * MASK_SLICE;
+static_assert(LDS_BYTES_BWD <= 160 * 1024, "LDS budget");
 constexpr int NHALO = 2 * 2 * IW + 2 * 2 * TH;  // 16-byte slots of the 1-pixel halo ring of one stage (200)
 constexpr int WS_HDR = 16;                  // workspace words before the per-tile flags
 enum { WS_TICKET = 0, WS_ABORT = 1 };
@@ -579,8 +594,23 @@ template <typename T, bool BW = false> struct Sched {
   //   top(i): before unit i, units i+1 and i+2 were requested since;
   //   mid(i): opening unit i+1 inside unit i's last step: unit i+2, and unit i+3's first steps(i)-1 requests.
   static constexpr int steps(int i) { return nkw(at(i)) * nblk(at(i)); }
-  static constexpr int wait_top(int i, bool has_next) { return (nf_at(i + 1, has_next) >> 2) + (nf_at(i + 2, has_next) >> 2); }
+  static constexpr int wait_top(int i, bool has_next) {
+    int n = 0;
+    for (int k = 1; k < AH; ++k) n += nf_at(i + k, has_next) >> 2;
+    return n;
+  }
+  // FAT runner: at the top of unit i the NEXT unit's weights must have landed (they are read while unit i's MFMAs
+  // issue); requested since: units i+2 .. i+AH-1 (during units i+2-AH .. i-1)
+  static constexpr int wait_fat(int i, bool has_next) {
+    int n = 0;
+    for (int k = 2; k < AH; ++k) n += nf_at(i + k, has_next) >> 2;
+    return n;
+  }
+  // .. strict form: nothing but the requests issued during unit i-1 may still be in flight (the epilogue's stores in
+  // front of unit i-1 have landed)
+  static constexpr int wait_fat_strict(int i, bool has_next) { return nf_at(i - 1 + AH, has_next) >> 2; }
   static constexpr int wait_mid(int i, bool has_next) {
+    static_assert(FAT || AH == 3, "wait_mid counts a lead of 3 units");
     const int part = nf_at(i + 3, has_next) >> 2, done = steps(i) - 1;
     return (nf_at(i + 2, has_next) >> 2) + (part < done ? part : done);
   }
@@ -731,7 +761,16 @@ struct WStream {
   const char* w;       // this block's fused weight stream
   const char* wnext;   // the next block's (nullptr: none)
   int ring;            // ring slot of this block's unit 0
+  uint64_t* dbg;       // ESR_ABL & 32: time stamps of the traced segment's unit boundaries (measurement builds)
 };
+#ifndef ESR_DBG_SEG
+#define ESR_DBG_SEG 4        // first unit of the traced segment (forward schedule: 4 = bulk_1)
+#endif
+template <int I0> __device__ __forceinline__ void dbg_stamp(const WStream& s, int k) {
+  if constexpr ((ESR_ABL & 32) && I0 == ESR_DBG_SEG) {
+    if (s.dbg && threadIdx.x == 0) s.dbg[k] = __builtin_amdgcn_s_memtime();
+  }
+}
 template <typename T, int A, int B> __device__ __forceinline__ void wait_units(const WStream& s) {
   if constexpr (A == B) wait_vm<A>();
   else { if (s.wnext) wait_vm<A>(); else wait_vm<B>(); }
@@ -744,7 +783,7 @@ template <typename T, int A, int B> __device__ __forceinline__ void wait_units(c
 struct Ahead { const char* src; char* dst; int cnt; };
 template <typename S, int I>
 __device__ __forceinline__ Ahead ahead_of(const WStream& s, const Tile& t, char* smem, uint32_t lane16) {
-  constexpr int J = I + 3;
+  constexpr int J = I + AH;
   constexpr bool wrap = J >= S::N;
   constexpr UDesc dj = S::at(wrap ? J - S::N : J);
   const int start = (t.wave * dj.nf) >> 2;
@@ -757,25 +796,229 @@ __device__ __forceinline__ Ahead ahead_of(const WStream& s, const Tile& t, char*
 }
 // SURE = requests every wave issues unconditionally (nf >> 2 of a unit of this block; none when the unit may
 // belong to a next block that does not exist)
-template <int I_, int SURE = 0> __device__ __forceinline__ void issue_one(const Ahead& a) {
-  if constexpr (I_ < 4) {
+// MAXC = the most any wave issues (ceil(nf / 4)): the slots behind it cost no test
+template <int I_, int SURE = 0, int MAXC = 4> __device__ __forceinline__ void issue_one(const Ahead& a) {
+  if constexpr (I_ < 4 && I_ < MAXC) {
     if (I_ < SURE || I_ < a.cnt)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a.src,
                                        (__attribute__((address_space(3))) void*)a.dst, 16, I_ * 1024, 0);
   }
 }
 template <typename S, int I> constexpr int sure_ahead() {
-  return (I + 3 >= S::N || (ESR_ABL & 1)) ? 0 : (S::at(I + 3).nf >> 2);
+  return (I + AH >= S::N || (ESR_ABL & 1)) ? 0 : (S::at(I + AH).nf >> 2);
+}
+template <typename S, int I> constexpr int most_ahead() {
+  return (ESR_ABL & 1) ? 0 : (S::at(I + AH >= S::N ? I + AH - S::N : I + AH).nf + 3) >> 2;
 }
 // units [I0, I1) of the schedule, back to back.  `hook(I)` runs inside unit I after the barrier that opens
 // unit I+1 (every wave has waited for everything older than unit I+2's requests by then).
-struct NoHook { template <typename X> __device__ __forceinline__ void operator()(X) const {} };
+struct NoHook { template <typename X, typename P> __device__ __forceinline__ void operator()(X, P) const {} };
+// Phases of hook(I, PH) — the hand-off work that rides on unit I of a bulk.  PH_ALL: everything, behind the barrier
+// that opens unit I+1 (unit_steps runner).  FAT runner: PH_START in front of unit I's MFMAs, PH_END behind them (in
+// front of the DMA wait + barrier), PH_TOP behind that barrier, PH_IN behind MFMA 2 of unit I+1 — LDS words a phase
+// needs are requested one phase earlier, so that nothing waits for an LDS round trip with the matrix pipe idle.
+enum { PH_ALL = 9, PH_START = 0, PH_END = 1, PH_TOP = 2, PH_IN = 3 };
+template <int P> using PhC = std::integral_constant<int, P>;
 // TRAIL: barrier after the last unit.  The slot of a segment's last unit is next written by the request of a unit
 // that runs behind the NEXT segment's opening barrier, so the barrier is only needed where the code that follows
 // writes LDS the last unit reads (the block tail's own-pixel writes over x4's slots).
+// ---- FAT runner (ESR_FAT) -----------------------------------------------------------------------------
+// A unit's MFMAs in issue order: (column tap, input row, kh, cout block) — per accumulator the same (kw, kh) order as
+// unit_steps, so the builds agree bit for bit; consecutive MFMAs go to different accumulators wherever the unit has
+// more than one (a dependent accumulate issues later than an independent one).
+template <int NKW, int NBLK> struct FatShape {
+  static constexpr int NA = NKW * NBLK * 3, NB = NKW * (R + 2), NR = NA + NB, NM = NA * R;
+  struct Tab {
+    int a[NM], b[NM], kwi[NM], ir[NM], kh[NM], bi[NM];   // per MFMA: its fragments and coordinates
+    int ra[NM], rb[NM];                                  // refill issued behind MFMA m: A fragment / B fragment index (-1: none)
+    int qa[NA], qb[NB];                                  // position of a fragment's refill in the unit's refill order
+    int before[NM + 1];                                  // refills issued behind MFMAs 0 .. m-1
+    int allow[2][NM];                                    // lgkmcnt in front of MFMA m ([1]: this unit refills too)
+    bool wait[2][NM];                                    // .. and whether a wait is needed at all
+    int ord0[NR], own0[NM][2], allow0[2][NM];            // the segment's first unit (reads its own fragments): see make()
+    bool wait0[2][NM], bad;
+  };
+  static constexpr int P0 = 8;
+  static constexpr Tab make() {
+    Tab t{};
+    int m = 0;
+    for (int kwi = 0; kwi < NKW; ++kwi)
+      for (int ir = 0; ir < R + 2; ++ir)
+        for (int kh = 0; kh < 3; ++kh) {
+          const int r = ir - kh;
+          if (r < 0 || r >= R) continue;
+          for (int bi = 0; bi < NBLK; ++bi) {
+            t.a[m] = (kwi * NBLK + bi) * 3 + kh; t.b[m] = kwi * (R + 2) + ir;
+            t.kwi[m] = kwi; t.ir[m] = ir; t.kh[m] = kh; t.bi[m] = bi;
+            ++m;
+          }
+        }
+    int q = 0;
+    for (int i = 0; i < NM; ++i) {
+      t.before[i] = q;
+      bool la = true, lb = true;                         // last reader of its fragments?
+      for (int j = i + 1; j < NM; ++j) { if (t.a[j] == t.a[i]) la = false; if (t.b[j] == t.b[i]) lb = false; }
+      t.ra[i] = la ? t.a[i] : -1; t.rb[i] = lb ? t.b[i] : -1;
+      if (la) t.qa[t.a[i]] = q++;
+      if (lb) t.qb[t.b[i]] = q++;
+    }
+    t.before[NM] = q;
+    // In-order return: `lgkmcnt(c)` proves every read but the last c issued has landed.  In front of MFMA i of a unit
+    // whose fragments were refilled during the previous unit (NR reads, positions qa / qb), issued since the later of
+    // its two fragments: the rest of that unit's refills and, when this unit refills for the next one, before[i].
+    for (int nx = 0; nx < 2; ++nx) {
+      int proven = -1;                                   // refill position known to have landed
+      for (int i = 0; i < NM; ++i) {
+        const int pa = t.qa[t.a[i]], pb = t.qb[t.b[i]], pos = pa > pb ? pa : pb;
+        int c = (NR - 1 - pos) + (nx ? t.before[i] : 0);
+        if (c > 15) c = 15;
+        t.allow[nx][i] = c;
+        t.wait[nx][i] = pos > proven;
+        if (pos > proven) proven = NR + (nx ? t.before[i] : 0) - c - 1;
+      }
+    }
+    // The segment's FIRST unit reads its own fragments, in consumption order (ord0; P0 of them ahead of the first MFMA,
+    // two more behind every MFMA — the LDS takes 4 cycles per wave and read, all at once they would keep the matrix
+    // pipe waiting for ~300 cycles) and starts its MFMAs as they land.  The issue sequence is simulated here: in
+    // front of MFMA i, issued since the later of its two reads = everything behind it.
+    {
+      int q0 = 0, seen_a[NA] = {}, seen_b[NB] = {};
+      for (int i = 0; i < NM; ++i) {
+        if (!seen_b[t.b[i]]) { seen_b[t.b[i]] = 1; t.ord0[q0++] = NA + t.b[i]; }
+        if (!seen_a[t.a[i]]) { seen_a[t.a[i]] = 1; t.ord0[q0++] = t.a[i]; }
+      }
+      for (int nx = 0; nx < 2; ++nx) {
+        int pos[NR] = {}, issued = 0, next = 0, proven = -1;
+        for (int f = 0; f < NR; ++f) pos[f] = -1;
+        for (; next < P0 && next < NR; ++next) pos[t.ord0[next]] = issued++;
+        for (int i = 0; i < NM; ++i) {
+          const int pa = pos[t.a[i]], pb = pos[NA + t.b[i]], need = pa > pb ? pa : pb;
+          if (pa < 0 || pb < 0) t.bad = true;
+          int c = issued - 1 - need;
+          if (c > 15) c = 15;
+          t.allow0[nx][i] = c;
+          t.wait0[nx][i] = need > proven;
+          if (need > proven) proven = issued - c - 1;
+          for (int k = 0; k < 2; ++k) {
+            t.own0[i][k] = next < NR ? t.ord0[next] : -1;
+            if (next < NR) pos[t.ord0[next++]] = issued++;
+          }
+          if (nx) issued += (t.ra[i] >= 0) + (t.rb[i] >= 0);
+        }
+        if (next < NR) t.bad = true;
+      }
+    }
+    return t;
+  }
+  static constexpr Tab tab = make();
+};
+// the registers of a fragment pass through a statement in front of their MFMA: the wait itself, or nothing
+template <int C> __device__ __forceinline__ void lds_wait2(u32x4& a, u32x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(C));
+}
+__device__ __forceinline__ void lds_tie2(u32x4& a, u32x4& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+
+// units [I0, I1) — one segment, all of one shape — back to back.  The fragments of a unit sit in registers before
+// its first MFMA: the first unit reads its own (one exposed LDS round trip per segment), every later one was read
+// during its predecessor, each register refilled right behind its last reader.  Top of unit i: its DMA wait (unit
+// i+1's weights) + barrier + hook(i-1); the ring slot a request of unit i overwrites was last READ during unit
+// i+AH-WR-1 <= i-3 and consumed by every wave before the barrier that opened unit i-1.
+template <typename S, int I0, int I1, bool STRICT0, bool TRAIL, typename HOOK>
+__device__ __forceinline__ void run_units_fat(Acc24& acc, const WStream& s, char* smem, const Tile& t, HOOK&& hook) {
+  using T = typename S::Elem;
+  constexpr UDesc d0 = S::at(I0);
+  constexpr int NKW = S::nkw(d0), NBLK = S::nblk(d0), BLK0 = S::blk0(d0);
+  using F = FatShape<NKW, NBLK>;
+  static_assert(F::NM >= 4, "a unit carries up to four weight requests per wave");
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
+  const int lane = t.lane();
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  const int colofs[3] = {Tile::colofs(lane, 0), Tile::colofs(lane, 1), Tile::colofs(lane, 2)};
+  u32x4 fa[F::NA], fb[F::NB];
+  dbg_stamp<I0>(s, 0);
+  wait_units<T, S::wait_fat(I0, true), S::wait_fat(I0, false)>(s);      // the first two units' weights
+  __builtin_amdgcn_s_barrier();
+  dbg_stamp<I0>(s, 1);
+  const uint32_t lrow0 = lds_rows + S::slot(d0) * ASLOT;
+  const uint32_t lw0 = lds0 + WOFF + ((s.ring + I0) & (WR - 1)) * WSLOT + lane16;
+  {
+    static_assert(!F::tab.bad, "first-unit read schedule");
+    sfor<(F::P0 < F::NR ? F::P0 : F::NR)>([&](auto QI) __attribute__((always_inline)) {
+      constexpr int f = F::tab.ord0[decltype(QI)::value];
+      if constexpr (f >= F::NA) lds_read16<((f - F::NA) % (R + 2)) * IW * 32>(fb[f - F::NA], lrow0 + colofs[NKW == 3 ? (f - F::NA) / (R + 2) : d0.kw]);
+      else lds_read16<f * 1024>(fa[f], lw0);
+    });
+  }
+  dbg_stamp<I0>(s, 2);
+  sfor<I1 - I0>([&](auto II) __attribute__((always_inline)) {
+    constexpr int I = I0 + decltype(II)::value;
+    constexpr UDesc d = S::at(I);
+    constexpr bool NXT = I + 1 < I1;
+    constexpr UDesc dn = S::at(NXT ? I + 1 : I);
+    static_assert(S::nkw(d) == NKW && S::nblk(d) == NBLK && S::blk0(d) == BLK0, "one shape per segment");
+    constexpr bool FIRST = d.P == 1 && d.c == 0 && d.kw == 0;
+    const uint32_t lrn = lds_rows + S::slot(dn) * ASLOT;
+    const uint32_t lbn[3] = {lrn + colofs[NKW == 3 ? 0 : dn.kw], lrn + colofs[1], lrn + colofs[2]};
+    const uint32_t lwn = lds0 + WOFF + ((s.ring + I + 1) & (WR - 1)) * WSLOT + lane16;
+    const Ahead ah = ahead_of<S, I>(s, t, smem, lane16);
+    if constexpr (NXT) hook(std::integral_constant<int, I>{}, PhC<PH_START>{});
+    sfor<F::NM>([&](auto MI) __attribute__((always_inline)) {
+      constexpr int m = decltype(MI)::value;
+      constexpr int a = F::tab.a[m], b = F::tab.b[m], blk = BLK0 + F::tab.bi[m], r = F::tab.ir[m] - F::tab.kh[m];
+      if constexpr (I > I0 && F::tab.wait[NXT][m] && !(ESR_ABL & 6)) lds_wait2<F::tab.allow[NXT][m]>(fa[a], fb[b]);
+      else if constexpr (I == I0 && F::tab.wait0[NXT][m]) lds_wait2<F::tab.allow0[NXT][m]>(fa[a], fb[b]);
+      else lds_tie2(fa[a], fb[b]);
+      mma_cls<T, acc_in_agpr(blk), FIRST && F::tab.kwi[m] == 0 && F::tab.kh[m] == 0 && blk < 4>(acc_br<blk, r>(acc), fa[a], fb[b]);
+      if constexpr (I == I0) {
+        sfor<2>([&](auto KI) __attribute__((always_inline)) {
+          constexpr int f = F::tab.own0[m][decltype(KI)::value];
+          if constexpr (f >= F::NA) lds_read16<((f - F::NA) % (R + 2)) * IW * 32>(fb[f - F::NA], lrow0 + colofs[NKW == 3 ? (f - F::NA) / (R + 2) : d0.kw]);
+          else if constexpr (f >= 0) lds_read16<f * 1024>(fa[f], lw0);
+        });
+      }
+      if constexpr (NXT) {
+        if constexpr (F::tab.ra[m] >= 0 && !(ESR_ABL & 2)) lds_read16<F::tab.ra[m] * 1024>(fa[F::tab.ra[m]], lwn);
+        if constexpr (F::tab.rb[m] >= 0 && !(ESR_ABL & 4))
+          lds_read16<(F::tab.rb[m] % (R + 2)) * IW * 32>(fb[F::tab.rb[m]], lbn[F::tab.rb[m] / (R + 2)]);
+      }
+      // the wave's (up to four) weight requests, spread over the unit: the LDS-DMA path takes 64 bytes per cycle and
+      // CU (tools/experiments/issue_probe.hip: one 1 KB request per wave and MFMA doubles the MFMA's time, one per four
+      // costs 7 %) — four waves requesting behind four consecutive MFMAs stall on it
+      if constexpr (m == 2 && I > I0) hook(std::integral_constant<int, I - 1>{}, PhC<PH_IN>{});
+      {
+        constexpr int MC = most_ahead<S, I>();
+        constexpr int k = MC ? (m * MC + F::NM - 1) / F::NM : 0;       // the k-th request sits behind MFMA k NM / MC
+        if constexpr (MC > 0 && k < MC && m == k * F::NM / MC) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_one<k, sure_ahead<S, I>(), MC>(ah);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    });
+    if constexpr (NXT) {
+      // top of unit I+1: its successor's weights, the barrier, hook(I)
+      hook(std::integral_constant<int, I>{}, PhC<PH_END>{});
+      if constexpr (!(ESR_ABL & 256)) {
+        if constexpr (STRICT0 && I == I0) wait_units<T, S::wait_fat_strict(I + 1, true), S::wait_fat_strict(I + 1, false)>(s);
+        else wait_units<T, S::wait_fat(I + 1, true), S::wait_fat(I + 1, false)>(s);
+      }
+      dbg_stamp<I0>(s, 3 + 3 * (I - I0));
+      if constexpr (!(ESR_ABL & 128)) __builtin_amdgcn_s_barrier();
+      dbg_stamp<I0>(s, 4 + 3 * (I - I0));
+      if constexpr (!(ESR_ABL & 512)) hook(std::integral_constant<int, I>{}, PhC<PH_TOP>{});
+      dbg_stamp<I0>(s, 5 + 3 * (I - I0));
+    } else {
+      dbg_stamp<I0>(s, 3 + 3 * (I - I0));
+    }
+  });
+  if constexpr (TRAIL) __builtin_amdgcn_s_barrier();
+}
+
 template <typename S, int I0, int I1, bool STRICT0 = false, bool TRAIL = true, typename HOOK = NoHook>
 __device__ __forceinline__ void run_units_s(Acc24& acc, const WStream& s, char* smem, const Tile& t, HOOK&& hook = NoHook{}) {
   using T = typename S::Elem;
+  if constexpr (FAT) { run_units_fat<S, I0, I1, STRICT0, TRAIL>(acc, s, smem, t, hook); return; }
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
   UFrags f;
@@ -797,10 +1040,12 @@ __device__ __forceinline__ void run_units_s(Acc24& acc, const WStream& s, char* 
     const Ahead ah = ahead_of<S, I>(s, t, smem, lane16);
     auto issue = [&](auto SI) __attribute__((always_inline)) { issue_one<decltype(SI)::value, sure_ahead<S, I>()>(ah); };
     auto mid = [&]() __attribute__((always_inline)) {
+      if constexpr (!(ESR_ABL & 256)) {
       if constexpr (STRICT0 && I == I0) wait_units<T, S::wait_mid_strict(I, true), S::wait_mid_strict(I, false)>(s);
       else wait_units<T, S::wait_mid(I, true), S::wait_mid(I, false)>(s);   // the next unit's weights
-      __builtin_amdgcn_s_barrier();        // next unit visible to all waves; all waves past this unit's LDS reads
-      hook(std::integral_constant<int, I>{});
+      }
+      if constexpr (!(ESR_ABL & 128)) __builtin_amdgcn_s_barrier();        // next unit visible to all waves; all waves past this unit's LDS reads
+      if constexpr (!(ESR_ABL & 512)) hook(std::integral_constant<int, I>{}, PhC<PH_ALL>{});
     };
     unit_steps<T, S::blk0(d), S::nblk(d), NKW, (d.P == 1 && d.c == 0 && d.kw == 0), (I > I0), (I + 1 < I1), S::parity(I0, I)>(
         acc, f, lb, lw, lbn, lwn, issue, mid);
@@ -995,6 +1240,36 @@ __device__ __forceinline__ void poll_check(unsigned epoch, char* smem, const Til
   const bool ok = __all(lds_peek(lds0 + LDS_FLAGS + lane * 4) >= epoch);
   const unsigned tag = ok ? epoch : 0u;
   if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + LDS_CTRL + 32), "v"(tag) : "memory");
+}
+
+// The same hand-off in the phases of the FAT runner (PH_*): every LDS word is requested one phase before it is used.
+// State that crosses phases (VGPRs that live for one unit).
+struct PollRegs { unsigned nbr, flag, tag, hsrc; };
+__device__ __forceinline__ void lds_req32(unsigned& d, uint32_t addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(d) : "v"(addr)); }
+// words requested at least one unit (>= 6 fragment reads) ago
+__device__ __forceinline__ void lds_old(unsigned& d) { asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(d)); }
+// the byte offset of the flag a lane of wave 0 fetches (lanes 0..7: its neighbour; the others and absent neighbours:
+// the tile's own flag, which is up) — once per tile, by wave 0
+__device__ __forceinline__ void stage_nbr(int tile, char* smem, const Tile& t) {
+  const int lane = t.lane();
+  int nbr = tile;
+  if (lane < 8) {
+    const int k = lane < 4 ? lane : lane + 1;
+    const int ny = t.ty + k / 3 - 1, nx = t.tx + k % 3 - 1;
+    if (ny >= 0 && ny < t.tiles_y && nx >= 0 && nx < t.tiles_x) nbr = (t.b * t.tiles_y + ny) * t.tiles_x + nx;
+  }
+  *(volatile int*)(smem + LDS_NBR + lane * 4) = (WS_HDR + nbr) * 4;
+}
+__device__ __forceinline__ void poll_issue_at(unsigned* ws, unsigned off, char* smem) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)ws + off),
+                                   (__attribute__((address_space(3))) void*)(smem + LDS_FLAGS), 4, 0, 16);
+}
+// wave 0, in front of the barrier: all neighbours up -> the tag every wave reads behind it
+__device__ __forceinline__ void poll_tag(unsigned flag, unsigned epoch, uint32_t lds0, const Tile& t) {
+  const bool ok = __all(flag >= epoch);
+  const unsigned tag = ok ? epoch : 0u;
+  if (t.lane() == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + LDS_CTRL + 32), "v"(tag) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // ---- epilogue of one finished 32-cout block ---------------------------------------------------------
@@ -1425,6 +1700,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       t.halo(hsrc, hdst);
       *(volatile int*)(smem + LDS_HALO + t.tid() * 8) = hsrc;
       *(volatile int*)(smem + LDS_HALO + t.tid() * 8 + 4) = hdst;
+      if (FAT && t.wave == 0) stage_nbr(tile, smem, t);
     }
     const ImgView dense = img_view(p.dense, t.b);
     const char* const dense_b = (const char*)p.dense.ptr + (int64_t)t.b * p.dense.batch_stride;
@@ -1464,6 +1740,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
     for (int rb = 0; rb < p.n_blocks; ++rb) {
       const esr_rdb_block& blk = p.blocks[rb];
       ev = rb == 1 ? 0 : -1;
+      ws_.dbg = ((ESR_ABL & 32) && rb == 1 && q.trace) ? q.trace + (int64_t)tile * 64 + 32 : nullptr;
       trace_ev(q, tile, ev);
       const char* const w = uniform_ptr(blk.w);
       const char* const xin_b = (const char*)blk.x_in.ptr + (int64_t)t.b * blk.x_in.batch_stride;
@@ -1504,8 +1781,34 @@ if constexpr (DIR == 2) {
         };
         int early = 0;
         HaloRegs<CF::KD> hq;
-        auto bulk_hook = [&](auto IDX, auto FIRST_, auto END_, int g0, int next_slice, int next_buf) __attribute__((always_inline)) {
+        PollRegs pr;
+        auto bulk_hook = [&](auto IDX, auto PH, auto FIRST_, auto END_, int g0, int next_slice, int next_buf) __attribute__((always_inline)) {
           constexpr int I = decltype(IDX)::value, rel = I - decltype(FIRST_)::value, left = decltype(END_)::value - 1 - I;
+          constexpr int ph = decltype(PH)::value;
+          if constexpr (ph != PH_ALL) {
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+            if constexpr (rel == 0 && ph == PH_TOP) {
+              if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (next_slice >= 0) mask_dma(next_slice, next_buf);
+            }
+            if constexpr (left == 4) {
+              if constexpr (ph == PH_START) { if (t.wave == 0) lds_req32(pr.nbr, lds0 + LDS_NBR + t.lane() * 4); }
+              if constexpr (ph == PH_TOP) { if (t.wave == 0) { lds_old(pr.nbr); poll_issue_at(ws, pr.nbr, smem); } }
+            }
+            if constexpr (left == 1) {
+              if constexpr (ph == PH_START) { if (t.wave == 0) lds_req32(pr.flag, lds0 + LDS_FLAGS + t.lane() * 4); }
+              if constexpr (ph == PH_END) { if (t.wave == 0) { lds_old(pr.flag); poll_tag(pr.flag, epoch, lds0, t); } }
+              if constexpr (ph == PH_TOP) {
+                lds_req32(pr.tag, lds0 + LDS_CTRL + 32);
+                lds_req32(pr.hsrc, lds0 + LDS_HALO + t.tid() * 8);
+              }
+              if constexpr (ph == PH_IN) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr.tag), "+v"(pr.hsrc));
+                early = __builtin_amdgcn_readfirstlane((int)(pr.tag == epoch));
+                if (early) halo_issue<CF::KD>(dblk, g0, (int)pr.hsrc, hq);
+              }
+            }
+          } else
           if constexpr (rel == 0) {
             if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (next_slice >= 0) mask_dma(next_slice, next_buf);       // (every wave is past the epilogue that read this buffer)
@@ -1534,8 +1837,8 @@ if constexpr (DIR == 2) {
         mask_dma(3, 0);                      // a4's masks (first epilogue), a3's (second)
         mask_dma(2, 1);
         if (rb == 0) {
-          sfor<3>([&](auto UI) __attribute__((always_inline)) {
-            const Ahead ah = ahead_of<S, decltype(UI)::value - 3>(ws_, t, smem, (uint32_t)t.lane() * 16u);
+          sfor<AH>([&](auto UI) __attribute__((always_inline)) {
+            const Ahead ah = ahead_of<S, decltype(UI)::value - AH>(ws_, t, smem, (uint32_t)t.lane() * 16u);
             sfor<4>([&](auto X) __attribute__((always_inline)) { issue_one<decltype(X)::value>(ah); });
           });
           sfor<CF::KX>([&](auto CI) __attribute__((always_inline)) {
@@ -1559,7 +1862,7 @@ if constexpr (DIR == 2) {
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open(acc);
-        run_units_s<S, S::first(U_BULK, 1), S::end(U_BULK, 1), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 1)>{}, std::integral_constant<int, S::end(U_BULK, 1)>{}, 0, 1, 0); });
+        run_units_s<S, S::first(U_BULK, 1), S::end(U_BULK, 1), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 1)>{}, std::integral_constant<int, S::end(U_BULK, 1)>{}, 0, 1, 0); });
         seg_close(acc);
         trace_ev(q, tile, ev);
         __builtin_amdgcn_s_barrier();          // every wave done reading g_t in slots 0, 1
@@ -1579,7 +1882,7 @@ if constexpr (DIR == 2) {
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open(acc);
-        run_units_s<S, S::first(U_BULK, 2), S::end(U_BULK, 2), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 2)>{}, std::integral_constant<int, S::end(U_BULK, 2)>{}, CF::KD, 0, 1); });
+        run_units_s<S, S::first(U_BULK, 2), S::end(U_BULK, 2), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 2)>{}, std::integral_constant<int, S::end(U_BULK, 2)>{}, CF::KD, 0, 1); });
         seg_close(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(CF::KD, 2)) return;
@@ -1597,7 +1900,7 @@ if constexpr (DIR == 2) {
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open<3>(acc);
-        run_units_s<S, S::first(U_BULK, 3), S::end(U_BULK, 3), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD, -1, 0); });
+        run_units_s<S, S::first(U_BULK, 3), S::end(U_BULK, 3), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD, -1, 0); });
         seg_close<3>(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(2 * CF::KD, 0)) return;
@@ -1612,7 +1915,7 @@ if constexpr (DIR == 2) {
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open<4>(acc);
-        run_units_s<S, S::first(U_BULK, 4), S::end(U_BULK, 4), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD, -1, 0); });
+        run_units_s<S, S::first(U_BULK, 4), S::end(U_BULK, 4), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD, -1, 0); });
         seg_close<4>(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(3 * CF::KD, 2)) return;
@@ -1649,8 +1952,33 @@ if constexpr (DIR == 2) {
         // the bulk instead.
         int early = 0;
         HaloRegs<CF::KD> hq;
-        auto bulk_hook = [&](auto IDX, auto FIRST_, auto END_, int g0) __attribute__((always_inline)) {
+        PollRegs pr;
+        auto bulk_hook = [&](auto IDX, auto PH, auto FIRST_, auto END_, int g0) __attribute__((always_inline)) {
           constexpr int I = decltype(IDX)::value, rel = I - decltype(FIRST_)::value, left = decltype(END_)::value - 1 - I;
+          constexpr int ph = decltype(PH)::value;
+          if constexpr (ph != PH_ALL) {
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+            if constexpr (rel == 0 && ph == PH_TOP) {
+              if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if constexpr (left == 4 && !(ESR_ABL & 64)) {
+              if constexpr (ph == PH_START) { if (t.wave == 0) lds_req32(pr.nbr, lds0 + LDS_NBR + t.lane() * 4); }
+              if constexpr (ph == PH_TOP) { if (t.wave == 0) { lds_old(pr.nbr); poll_issue_at(ws, pr.nbr, smem); } }
+            }
+            if constexpr (left == 1 && !(ESR_ABL & 64)) {
+              if constexpr (ph == PH_START) { if (t.wave == 0) lds_req32(pr.flag, lds0 + LDS_FLAGS + t.lane() * 4); }
+              if constexpr (ph == PH_END) { if (t.wave == 0) { lds_old(pr.flag); poll_tag(pr.flag, epoch, lds0, t); } }
+              if constexpr (ph == PH_TOP) {
+                lds_req32(pr.tag, lds0 + LDS_CTRL + 32);
+                lds_req32(pr.hsrc, lds0 + LDS_HALO + t.tid() * 8);
+              }
+              if constexpr (ph == PH_IN) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr.tag), "+v"(pr.hsrc));
+                early = __builtin_amdgcn_readfirstlane((int)(pr.tag == epoch));
+                if (early) halo_issue<CF::KD>(dblk, g0, (int)pr.hsrc, hq);
+              }
+            }
+          } else
           if constexpr (rel == 0) {
             if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           } else if constexpr (left == 4 && !(ESR_ABL & 64)) {
@@ -1680,8 +2008,8 @@ if constexpr (DIR == 2) {
         if (rb == 0) {
           // the chain's input comes from another launch: stage all of x (with halo) by DMA, and start
           // the weight stream (its first three units)
-          sfor<3>([&](auto UI) __attribute__((always_inline)) {
-            const Ahead ah = ahead_of<S, decltype(UI)::value - 3>(ws_, t, smem, (uint32_t)t.lane() * 16u);
+          sfor<AH>([&](auto UI) __attribute__((always_inline)) {
+            const Ahead ah = ahead_of<S, decltype(UI)::value - AH>(ws_, t, smem, (uint32_t)t.lane() * 16u);
             sfor<4>([&](auto X) __attribute__((always_inline)) { issue_one<decltype(X)::value>(ah); });
           });
           sfor<CF::KX>([&](auto CI) __attribute__((always_inline)) {
@@ -1708,7 +2036,7 @@ if constexpr (DIR == 2) {
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open(acc);
-        run_units<T, S::first(U_BULK, 1), S::end(U_BULK, 1), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 1)>{}, std::integral_constant<int, S::end(U_BULK, 1)>{}, 0); });
+        run_units<T, S::first(U_BULK, 1), S::end(U_BULK, 1), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 1)>{}, std::integral_constant<int, S::end(U_BULK, 1)>{}, 0); });
         seg_close(acc);
         trace_ev(q, tile, ev);
         // ---------------- P = conv1x1(x) from the resident x; then x1 may take x's slots
@@ -1733,7 +2061,7 @@ if constexpr (DIR == 2) {
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open(acc);
-        run_units<T, S::first(U_BULK, 2), S::end(U_BULK, 2), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 2)>{}, std::integral_constant<int, S::end(U_BULK, 2)>{}, CF::KD); });
+        run_units<T, S::first(U_BULK, 2), S::end(U_BULK, 2), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 2)>{}, std::integral_constant<int, S::end(U_BULK, 2)>{}, CF::KD); });
         seg_close(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(CF::KD, 2)) return;
@@ -1749,7 +2077,7 @@ if constexpr (DIR == 2) {
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open<3>(acc);
-        run_units<T, S::first(U_BULK, 3), S::end(U_BULK, 3), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD); });
+        run_units<T, S::first(U_BULK, 3), S::end(U_BULK, 3), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD); });
         seg_close<3>(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(2 * CF::KD, 0)) return;
@@ -1767,7 +2095,7 @@ if constexpr (DIR == 2) {
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open<4>(acc);
-        run_units<T, S::first(U_BULK, 4), S::end(U_BULK, 4), true, false>(acc, ws_, smem, t, [&](auto IDX) __attribute__((always_inline)) { bulk_hook(IDX, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD); });
+        run_units<T, S::first(U_BULK, 4), S::end(U_BULK, 4), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD); });
         seg_close<4>(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(3 * CF::KD, 2)) return;

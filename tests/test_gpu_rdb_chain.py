@@ -401,21 +401,29 @@ def test_starved_chain_launch_is_reported_at_the_next_call(dev):
         del bad
 
 
-def _concurrent_stream(dev, words, p_release, p_started):
-    """A stream whose kernels run NEXT TO the current stream's (HIP maps streams onto a few hardware queues; one that
-    shares the current stream's queue would put the chain behind the hold kernel instead of beside it)."""
+def _concurrent_stream(dev, words, p_release, p_started, work=None):
+    """A stream whose kernels run NEXT TO the work's (HIP maps streams onto a few hardware queues; one that shares a
+    queue with the current stream — or with a side stream the library runs weight gradients on — would put that work
+    behind the hold kernel instead of beside it).  work(): what has to run next to the stream (default: a tiny kernel on
+    the current stream)."""
     import ctypes as C
     import time
     from esrganplus_amd import _lib as L
+    if work is None:
+        work = lambda: torch.zeros(1, device=dev).item()
+    keep = []
     for _ in range(8):
         cand = torch.cuda.Stream()
+        keep.append(cand)
+        torch.cuda.synchronize()
         words.zero_()
         L.check(L.lib().esr_debug_hold_cus(1, p_release, 200, p_started, C.c_void_p(cand.cuda_stream)), 'esr_debug_hold_cus')
         t0 = time.perf_counter()
-        torch.zeros(1, device=dev).item()
+        work()
+        torch.cuda.current_stream().synchronize()
         dt = time.perf_counter() - t0
         words[0] = 1
-        cand.synchronize()
+        torch.cuda.synchronize()
         if dt < 0.1:
             return cand
     return None
@@ -495,6 +503,10 @@ def test_chains_make_progress_next_to_a_resident_kernel(dev):
         return y.detach(), torch.cat([p.grad.reshape(-1) for p in tnet.parameters()])
 
     (y0, g0), t_free = free(fb, 5)
+    # (the backward also runs weight gradients on the library's side streams: the hold kernel must not sit in THEIR queue)
+    side = _concurrent_stream(dev, words, p_release, p_started, work=fb)
+    if side is None:
+        pytest.skip('no stream that runs concurrently with the training pass')
     (y1, g1), t_held = held(fb, 5)
     assert L.lib().esr_rdb_check_abort() == 0
     assert torch.equal(y1, y0) and torch.equal(g1, g0)
