@@ -813,11 +813,13 @@ template <typename S, int I> constexpr int most_ahead() {
 // units [I0, I1) of the schedule, back to back.  `hook(I)` runs inside unit I after the barrier that opens
 // unit I+1 (every wave has waited for everything older than unit I+2's requests by then).
 struct NoHook { template <typename X, typename P> __device__ __forceinline__ void operator()(X, P) const {} };
-// Phases of hook(I, PH) — the hand-off work that rides on unit I of a bulk.  PH_ALL: everything, behind the barrier
-// that opens unit I+1 (unit_steps runner).  FAT runner: PH_START in front of unit I's MFMAs, PH_END behind them (in
-// front of the DMA wait + barrier), PH_TOP behind that barrier, PH_IN behind MFMA 2 of unit I+1 — LDS words a phase
-// needs are requested one phase earlier, so that nothing waits for an LDS round trip with the matrix pipe idle.
-enum { PH_ALL = 9, PH_START = 0, PH_END = 1, PH_TOP = 2, PH_IN = 3 };
+// Phases of hook(I, PH) — the hand-off work that rides on unit I of a bulk: PH_START in front of unit I's MFMAs,
+// PH_END in front of the DMA wait + barrier that opens unit I+1, PH_TOP behind that barrier, PH_IN a few MFMAs into
+// unit I+1 (FAT runner: behind its MFMA 2; unit_steps runner: in front of unit I+1, i.e. behind the six MFMAs that
+// follow the barrier).  The LDS words a phase needs are requested one phase earlier, so that nothing waits for an LDS
+// round trip with the matrix pipe idle (round 4: the wave-0 hooks cost 3.5 % of a block on 16-row tiles, 15 % on 4-row
+// tiles — address arithmetic from spilled SGPRs and ds_read + lgkmcnt(0) pairs behind the barrier).
+enum { PH_START = 0, PH_END = 1, PH_TOP = 2, PH_IN = 3 };
 template <int P> using PhC = std::integral_constant<int, P>;
 // TRAIL: barrier after the last unit.  The slot of a segment's last unit is next written by the request of a unit
 // that runs behind the NEXT segment's opening barrier, so the barrier is only needed where the code that follows
@@ -923,7 +925,7 @@ __device__ __forceinline__ void lds_tie2(u32x4& a, u32x4& b) { asm volatile("" :
 // during its predecessor, each register refilled right behind its last reader.  Top of unit i: its DMA wait (unit
 // i+1's weights) + barrier + hook(i-1); the ring slot a request of unit i overwrites was last READ during unit
 // i+AH-WR-1 <= i-3 and consumed by every wave before the barrier that opened unit i-1.
-template <typename S, int I0, int I1, bool STRICT0, bool TRAIL, typename HOOK>
+template <typename S, int I0, int I1, bool STRICT0, bool TRAIL, bool PREW, typename HOOK>
 __device__ __forceinline__ void run_units_fat(Acc24& acc, const WStream& s, char* smem, const Tile& t, HOOK&& hook) {
   using T = typename S::Elem;
   constexpr UDesc d0 = S::at(I0);
@@ -937,7 +939,7 @@ __device__ __forceinline__ void run_units_fat(Acc24& acc, const WStream& s, char
   const int colofs[3] = {Tile::colofs(lane, 0), Tile::colofs(lane, 1), Tile::colofs(lane, 2)};
   u32x4 fa[F::NA], fb[F::NB];
   dbg_stamp<I0>(s, 0);
-  wait_units<T, S::wait_fat(I0, true), S::wait_fat(I0, false)>(s);      // the first two units' weights
+  if constexpr (!PREW) wait_units<T, S::wait_fat(I0, true), S::wait_fat(I0, false)>(s);      // the first two units' weights
   __builtin_amdgcn_s_barrier();
   dbg_stamp<I0>(s, 1);
   const uint32_t lrow0 = lds_rows + S::slot(d0) * ASLOT;
@@ -1015,18 +1017,28 @@ __device__ __forceinline__ void run_units_fat(Acc24& acc, const WStream& s, char
   if constexpr (TRAIL) __builtin_amdgcn_s_barrier();
 }
 
-template <typename S, int I0, int I1, bool STRICT0 = false, bool TRAIL = true, typename HOOK = NoHook>
+// PREW: the wait for the segment's first weights already happened (prewait_units, in front of the epilogue whose stores
+// would otherwise stand between those requests and the allowed count: vmcnt retires in order)
+template <typename S, int I0> __device__ __forceinline__ void prewait_units(const WStream& s) {
+  using T = typename S::Elem;
+  if constexpr (FAT) wait_units<T, S::wait_fat(I0, true), S::wait_fat(I0, false)>(s);
+  else wait_units<T, S::wait_top(I0, true), S::wait_top(I0, false)>(s);
+}
+template <typename S, int I0, int I1, bool STRICT0 = false, bool TRAIL = true, bool PREW = false, typename HOOK = NoHook>
 __device__ __forceinline__ void run_units_s(Acc24& acc, const WStream& s, char* smem, const Tile& t, HOOK&& hook = NoHook{}) {
   using T = typename S::Elem;
-  if constexpr (FAT) { run_units_fat<S, I0, I1, STRICT0, TRAIL>(acc, s, smem, t, hook); return; }
+  if constexpr (FAT) { run_units_fat<S, I0, I1, STRICT0, TRAIL, PREW>(acc, s, smem, t, hook); return; }
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lds_rows = lds0 + t.wave * (R * IW * 32);
   UFrags f;
   const int lane = t.lane();
   const uint32_t lane16 = (uint32_t)lane * 16u;
   const int colofs[3] = {Tile::colofs(lane, 0), Tile::colofs(lane, 1), Tile::colofs(lane, 2)};
-  wait_units<T, S::wait_top(I0, true), S::wait_top(I0, false)>(s);      // the first unit's weights
+  dbg_stamp<I0>(s, 0);
+  if constexpr (!PREW) wait_units<T, S::wait_top(I0, true), S::wait_top(I0, false)>(s);      // the first unit's weights
   __builtin_amdgcn_s_barrier();
+  dbg_stamp<I0>(s, 1);
+  dbg_stamp<I0>(s, 2);
   sfor<I1 - I0>([&](auto II) __attribute__((always_inline)) {
     constexpr int I = I0 + decltype(II)::value;
     constexpr UDesc d = S::at(I);
@@ -1039,22 +1051,28 @@ __device__ __forceinline__ void run_units_s(Acc24& acc, const WStream& s, char* 
     const uint32_t lwn = lds0 + WOFF + ((s.ring + I + 1) & (WR - 1)) * WSLOT + lane16;
     const Ahead ah = ahead_of<S, I>(s, t, smem, lane16);
     auto issue = [&](auto SI) __attribute__((always_inline)) { issue_one<decltype(SI)::value, sure_ahead<S, I>()>(ah); };
+    if constexpr (I > I0) hook(std::integral_constant<int, I - 1>{}, PhC<PH_IN>{});
+    if constexpr (I + 1 < I1) hook(std::integral_constant<int, I>{}, PhC<PH_START>{});
     auto mid = [&]() __attribute__((always_inline)) {
+      hook(std::integral_constant<int, I>{}, PhC<PH_END>{});
       if constexpr (!(ESR_ABL & 256)) {
       if constexpr (STRICT0 && I == I0) wait_units<T, S::wait_mid_strict(I, true), S::wait_mid_strict(I, false)>(s);
       else wait_units<T, S::wait_mid(I, true), S::wait_mid(I, false)>(s);   // the next unit's weights
       }
+      dbg_stamp<I0>(s, 3 + 3 * (I - I0));
       if constexpr (!(ESR_ABL & 128)) __builtin_amdgcn_s_barrier();        // next unit visible to all waves; all waves past this unit's LDS reads
-      if constexpr (!(ESR_ABL & 512)) hook(std::integral_constant<int, I>{}, PhC<PH_ALL>{});
+      dbg_stamp<I0>(s, 4 + 3 * (I - I0));
+      if constexpr (!(ESR_ABL & 512)) hook(std::integral_constant<int, I>{}, PhC<PH_TOP>{});
+      dbg_stamp<I0>(s, 5 + 3 * (I - I0));
     };
     unit_steps<T, S::blk0(d), S::nblk(d), NKW, (d.P == 1 && d.c == 0 && d.kw == 0), (I > I0), (I + 1 < I1), S::parity(I0, I)>(
         acc, f, lb, lw, lbn, lwn, issue, mid);
   });
   if constexpr (TRAIL) __builtin_amdgcn_s_barrier();            // every wave done with the last unit's slots
 }
-template <typename T, int I0, int I1, bool STRICT0 = false, bool TRAIL = true, typename HOOK = NoHook>
+template <typename T, int I0, int I1, bool STRICT0 = false, bool TRAIL = true, bool PREW = false, typename HOOK = NoHook>
 __device__ __forceinline__ void run_units(Acc24& acc, const WStream& s, char* smem, const Tile& t, HOOK&& hook = NoHook{}) {
-  run_units_s<Sched<T>, I0, I1, STRICT0, TRAIL>(acc, s, smem, t, hook);
+  run_units_s<Sched<T>, I0, I1, STRICT0, TRAIL, PREW>(acc, s, smem, t, hook);
 }
 
 // P = conv1x1(x) from the resident x stages (slots 0..KX-1); its fragments are one unit of the weight
@@ -1214,40 +1232,26 @@ __device__ __forceinline__ bool wait_neighbours(unsigned* ws, unsigned epoch, ch
 }
 
 // Non-blocking form for the bulks (wave 0 only): the 8 flags are fetched by LDS-DMA into LDS_FLAGS — no
-// register result, hence nothing to wait for — and looked at two units later with plain LDS reads: a flag that
+// register result, hence nothing to wait for — and looked at some units later with plain LDS reads: a flag that
 // has not landed yet simply still shows its older (smaller) value and sends the tile through the blocking
 // poll after the bulk.  LDS accesses here are inline asm: hipcc orders a visible LDS access after every
 // LDS-DMA in flight with `vmcnt(0)`, which would drain the weight stream.
-__device__ __forceinline__ void poll_issue(unsigned* ws, int tile, char* smem, const Tile& t) {
-  const int lane = t.lane();
-  int nbr = tile;                                         // no neighbour: the tile's own flag (already up)
-  if (lane < 8) {
-    const int k = lane < 4 ? lane : lane + 1;
-    const int ny = t.ty + k / 3 - 1, nx = t.tx + k % 3 - 1;
-    if (ny >= 0 && ny < t.tiles_y && nx >= 0 && nx < t.tiles_x) nbr = (t.b * t.tiles_y + ny) * t.tiles_x + nx;
-  }
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws + WS_HDR + nbr),
-                                   (__attribute__((address_space(3))) void*)(smem + LDS_FLAGS), 4, 0, 16);
-}
-__device__ __forceinline__ unsigned lds_peek(uint32_t addr) {
-  unsigned v;
-  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-__device__ __forceinline__ void poll_check(unsigned epoch, char* smem, const Tile& t) {
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int lane = t.lane();
-  const bool ok = __all(lds_peek(lds0 + LDS_FLAGS + lane * 4) >= epoch);
-  const unsigned tag = ok ? epoch : 0u;
-  if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + LDS_CTRL + 32), "v"(tag) : "memory");
-}
-
-// The same hand-off in the phases of the FAT runner (PH_*): every LDS word is requested one phase before it is used.
+// The hand-off in the phases of the unit runners (PH_*): every LDS word is requested one phase before it is used.
 // State that crosses phases (VGPRs that live for one unit).
 struct PollRegs { unsigned nbr, flag, tag, hsrc; };
 __device__ __forceinline__ void lds_req32(unsigned& d, uint32_t addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(d) : "v"(addr)); }
-// words requested at least one unit (>= 6 fragment reads) ago
-__device__ __forceinline__ void lds_old(unsigned& d) { asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(d)); }
+// a word requested one phase ago.  FAT runner: at least six fragment reads were issued behind it (in-order return);
+// unit_steps runner: nothing is in flight at the places that ask (its steps drain their reads)
+__device__ __forceinline__ void lds_old(unsigned& d) {
+  if constexpr (FAT) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(d));
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d));
+}
+// the two words of PH_TOP, asked for in PH_IN.  unit_steps runner: the last step requested the next unit's first six
+// fragments behind them (and R - 1 more): leave those in flight
+__device__ __forceinline__ void lds_old2(unsigned& a, unsigned& b) {
+  if constexpr (FAT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
+  else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a), "+v"(b));
+}
 // the byte offset of the flag a lane of wave 0 fetches (lanes 0..7: its neighbour; the others and absent neighbours:
 // the tile's own flag, which is up) — once per tile, by wave 0
 __device__ __forceinline__ void stage_nbr(int tile, char* smem, const Tile& t) {
@@ -1700,7 +1704,7 @@ __global__ __launch_bounds__(NT, 1) void rdb_chain_kernel(const esr_rdb_chain p,
       t.halo(hsrc, hdst);
       *(volatile int*)(smem + LDS_HALO + t.tid() * 8) = hsrc;
       *(volatile int*)(smem + LDS_HALO + t.tid() * 8 + 4) = hdst;
-      if (FAT && t.wave == 0) stage_nbr(tile, smem, t);
+      if (t.wave == 0) stage_nbr(tile, smem, t);
     }
     const ImgView dense = img_view(p.dense, t.b);
     const char* const dense_b = (const char*)p.dense.ptr + (int64_t)t.b * p.dense.batch_stride;
@@ -1785,41 +1789,27 @@ if constexpr (DIR == 2) {
         auto bulk_hook = [&](auto IDX, auto PH, auto FIRST_, auto END_, int g0, int next_slice, int next_buf) __attribute__((always_inline)) {
           constexpr int I = decltype(IDX)::value, rel = I - decltype(FIRST_)::value, left = decltype(END_)::value - 1 - I;
           constexpr int ph = decltype(PH)::value;
-          if constexpr (ph != PH_ALL) {
-            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-            if constexpr (rel == 0 && ph == PH_TOP) {
-              if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (next_slice >= 0) mask_dma(next_slice, next_buf);
-            }
-            if constexpr (left == 4) {
-              if constexpr (ph == PH_START) { if (t.wave == 0) lds_req32(pr.nbr, lds0 + LDS_NBR + t.lane() * 4); }
-              if constexpr (ph == PH_TOP) { if (t.wave == 0) { lds_old(pr.nbr); poll_issue_at(ws, pr.nbr, smem); } }
-            }
-            if constexpr (left == 1) {
-              if constexpr (ph == PH_START) { if (t.wave == 0) lds_req32(pr.flag, lds0 + LDS_FLAGS + t.lane() * 4); }
-              if constexpr (ph == PH_END) { if (t.wave == 0) { lds_old(pr.flag); poll_tag(pr.flag, epoch, lds0, t); } }
-              if constexpr (ph == PH_TOP) {
-                lds_req32(pr.tag, lds0 + LDS_CTRL + 32);
-                lds_req32(pr.hsrc, lds0 + LDS_HALO + t.tid() * 8);
-              }
-              if constexpr (ph == PH_IN) {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr.tag), "+v"(pr.hsrc));
-                early = __builtin_amdgcn_readfirstlane((int)(pr.tag == epoch));
-                if (early) halo_issue<CF::KD>(dblk, g0, (int)pr.hsrc, hq);
-              }
-            }
-          } else
-          if constexpr (rel == 0) {
+          const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+          if constexpr (rel == 0 && ph == PH_TOP) {
             if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (next_slice >= 0) mask_dma(next_slice, next_buf);       // (every wave is past the epilogue that read this buffer)
-          } else if constexpr (left == 4) {
-            if (t.wave == 0) poll_issue(ws, tile, smem, t);
-          } else if constexpr (left == 2) {
-            if (t.wave == 0) poll_check(epoch, smem, t);
-          } else if constexpr (left == 1) {
-            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-            early = __builtin_amdgcn_readfirstlane((int)(lds_peek(lds0 + LDS_CTRL + 32) == epoch));
-            if (early) halo_issue<CF::KD>(dblk, g0, (int)lds_peek(lds0 + LDS_HALO + t.tid() * 8), hq);
+          }
+          if constexpr (left == 4) {
+            if constexpr (ph == PH_START) { if (t.wave == 0) lds_req32(pr.nbr, lds0 + LDS_NBR + t.lane() * 4); }
+            if constexpr (ph == PH_TOP) { if (t.wave == 0) { lds_old(pr.nbr); poll_issue_at(ws, pr.nbr, smem); } }
+          }
+          if constexpr (left == 1) {
+            if constexpr (ph == PH_START) { if (t.wave == 0) lds_req32(pr.flag, lds0 + LDS_FLAGS + t.lane() * 4); }
+            if constexpr (ph == PH_END) { if (t.wave == 0) { lds_old(pr.flag); poll_tag(pr.flag, epoch, lds0, t); } }
+            if constexpr (ph == PH_TOP) {
+              lds_req32(pr.tag, lds0 + LDS_CTRL + 32);
+              lds_req32(pr.hsrc, lds0 + LDS_HALO + t.tid() * 8);
+            }
+            if constexpr (ph == PH_IN) {
+              lds_old2(pr.tag, pr.hsrc);
+              early = __builtin_amdgcn_readfirstlane((int)(pr.tag == epoch));
+              if (early) halo_issue<CF::KD>(dblk, g0, (int)pr.hsrc, hq);
+            }
           }
         };
         auto finish_halo = [&](int g0, int slot0) __attribute__((always_inline)) -> bool {
@@ -1856,13 +1846,14 @@ if constexpr (DIR == 2) {
         run_units_s<S, S::first(U_CRIT, 1), S::end(U_CRIT, 1), false, false>(acc, ws_, smem, t);
         seg_close(acc);
         trace_ev(q, tile, ev);
+        prewait_units<S, S::first(U_BULK, 1)>(ws_);     // bulk_1's first weights, in front of the epilogue's stores
         mfma_drain();
         RowsRaw<T> s1;
         epilogue_bwd<T, 0, 2>(acc, q, dblk, 0, t, smem, 0, &s1, 0);
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open(acc);
-        run_units_s<S, S::first(U_BULK, 1), S::end(U_BULK, 1), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 1)>{}, std::integral_constant<int, S::end(U_BULK, 1)>{}, 0, 1, 0); });
+        run_units_s<S, S::first(U_BULK, 1), S::end(U_BULK, 1), true, false, true>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 1)>{}, std::integral_constant<int, S::end(U_BULK, 1)>{}, 0, 1, 0); });
         seg_close(acc);
         trace_ev(q, tile, ev);
         __builtin_amdgcn_s_barrier();          // every wave done reading g_t in slots 0, 1
@@ -1877,12 +1868,13 @@ if constexpr (DIR == 2) {
         run_units_s<S, S::first(U_CRIT, 2), S::end(U_CRIT, 2), false, false>(acc, ws_, smem, t);
         seg_close(acc);
         trace_ev(q, tile, ev);
+        prewait_units<S, S::first(U_BULK, 2)>(ws_);     // bulk_2's first weights, in front of the epilogue's stores
         mfma_drain();
         epilogue_bwd<T, 1, 1>(acc, q, dblk, 1, t, smem, 2, nullptr, 1);
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open(acc);
-        run_units_s<S, S::first(U_BULK, 2), S::end(U_BULK, 2), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 2)>{}, std::integral_constant<int, S::end(U_BULK, 2)>{}, CF::KD, 0, 1); });
+        run_units_s<S, S::first(U_BULK, 2), S::end(U_BULK, 2), true, false, true>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 2)>{}, std::integral_constant<int, S::end(U_BULK, 2)>{}, CF::KD, 0, 1); });
         seg_close(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(CF::KD, 2)) return;
@@ -1894,13 +1886,14 @@ if constexpr (DIR == 2) {
         trace_ev(q, tile, ev);
         { OneT one;
           load_1x1t<S>(one, ws_, smem, t);
+          prewait_units<S, S::first(U_BULK, 3)>(ws_);     // bulk_3's first weights, in front of the epilogue's stores
           mfma_drain();
           epilogue_bwd<T, 2, 1, true>(acc, q, dblk, 2, t, smem, 0, nullptr, 0, &aux, &one);
           seg_close(acc); }                 // (the epilogue's own MFMAs into g_x)
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open<3>(acc);
-        run_units_s<S, S::first(U_BULK, 3), S::end(U_BULK, 3), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD, -1, 0); });
+        run_units_s<S, S::first(U_BULK, 3), S::end(U_BULK, 3), true, false, true>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD, -1, 0); });
         seg_close<3>(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(2 * CF::KD, 0)) return;
@@ -1910,12 +1903,13 @@ if constexpr (DIR == 2) {
         run_units_s<S, S::first(U_CRIT, 4), S::end(U_CRIT, 4), false, false>(acc, ws_, smem, t);
         seg_close<3>(acc);
         trace_ev(q, tile, ev);
+        prewait_units<S, S::first(U_BULK, 4)>(ws_);     // bulk_4's first weights, in front of the epilogue's stores
         mfma_drain();
         epilogue_bwd<T, 3, 1>(acc, q, dblk, 3, t, smem, 2, nullptr, 1);
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open<4>(acc);
-        run_units_s<S, S::first(U_BULK, 4), S::end(U_BULK, 4), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD, -1, 0); });
+        run_units_s<S, S::first(U_BULK, 4), S::end(U_BULK, 4), true, false, true>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD, -1, 0); });
         seg_close<4>(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(3 * CF::KD, 2)) return;
@@ -1956,39 +1950,26 @@ if constexpr (DIR == 2) {
         auto bulk_hook = [&](auto IDX, auto PH, auto FIRST_, auto END_, int g0) __attribute__((always_inline)) {
           constexpr int I = decltype(IDX)::value, rel = I - decltype(FIRST_)::value, left = decltype(END_)::value - 1 - I;
           constexpr int ph = decltype(PH)::value;
-          if constexpr (ph != PH_ALL) {
-            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-            if constexpr (rel == 0 && ph == PH_TOP) {
-              if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if constexpr (left == 4 && !(ESR_ABL & 64)) {
-              if constexpr (ph == PH_START) { if (t.wave == 0) lds_req32(pr.nbr, lds0 + LDS_NBR + t.lane() * 4); }
-              if constexpr (ph == PH_TOP) { if (t.wave == 0) { lds_old(pr.nbr); poll_issue_at(ws, pr.nbr, smem); } }
-            }
-            if constexpr (left == 1 && !(ESR_ABL & 64)) {
-              if constexpr (ph == PH_START) { if (t.wave == 0) lds_req32(pr.flag, lds0 + LDS_FLAGS + t.lane() * 4); }
-              if constexpr (ph == PH_END) { if (t.wave == 0) { lds_old(pr.flag); poll_tag(pr.flag, epoch, lds0, t); } }
-              if constexpr (ph == PH_TOP) {
-                lds_req32(pr.tag, lds0 + LDS_CTRL + 32);
-                lds_req32(pr.hsrc, lds0 + LDS_HALO + t.tid() * 8);
-              }
-              if constexpr (ph == PH_IN) {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr.tag), "+v"(pr.hsrc));
-                early = __builtin_amdgcn_readfirstlane((int)(pr.tag == epoch));
-                if (early) halo_issue<CF::KD>(dblk, g0, (int)pr.hsrc, hq);
-              }
-            }
-          } else
-          if constexpr (rel == 0) {
+          const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+          if constexpr (rel == 0 && ph == PH_TOP) {
             if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else if constexpr (left == 4 && !(ESR_ABL & 64)) {
-            if (t.wave == 0) poll_issue(ws, tile, smem, t);
-          } else if constexpr (left == 2 && !(ESR_ABL & 64)) {
-            if (t.wave == 0) poll_check(epoch, smem, t);
-          } else if constexpr (left == 1 && !(ESR_ABL & 64)) {
-            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-            early = __builtin_amdgcn_readfirstlane((int)(lds_peek(lds0 + LDS_CTRL + 32) == epoch));
-            if (early) halo_issue<CF::KD>(dblk, g0, (int)lds_peek(lds0 + LDS_HALO + t.tid() * 8), hq);
+          }
+          if constexpr (left == 4 && !(ESR_ABL & 64)) {
+            if constexpr (ph == PH_START) { if (t.wave == 0) lds_req32(pr.nbr, lds0 + LDS_NBR + t.lane() * 4); }
+            if constexpr (ph == PH_TOP) { if (t.wave == 0) { lds_old(pr.nbr); poll_issue_at(ws, pr.nbr, smem); } }
+          }
+          if constexpr (left == 1 && !(ESR_ABL & 64)) {
+            if constexpr (ph == PH_START) { if (t.wave == 0) lds_req32(pr.flag, lds0 + LDS_FLAGS + t.lane() * 4); }
+            if constexpr (ph == PH_END) { if (t.wave == 0) { lds_old(pr.flag); poll_tag(pr.flag, epoch, lds0, t); } }
+            if constexpr (ph == PH_TOP) {
+              lds_req32(pr.tag, lds0 + LDS_CTRL + 32);
+              lds_req32(pr.hsrc, lds0 + LDS_HALO + t.tid() * 8);
+            }
+            if constexpr (ph == PH_IN) {
+              lds_old2(pr.tag, pr.hsrc);
+              early = __builtin_amdgcn_readfirstlane((int)(pr.tag == epoch));
+              if (early) halo_issue<CF::KD>(dblk, g0, (int)pr.hsrc, hq);
+            }
           }
         };
         // after the bulk: the halo of stage g0 into slots slot0..
@@ -2030,13 +2011,14 @@ if constexpr (DIR == 2) {
         seg_close(acc);
         trace_ev(q, tile, ev);
         lds_bias(smem, 0, t, bb);
+        prewait_units<S, S::first(U_BULK, 1)>(ws_);     // bulk_1's first weights, in front of the epilogue's stores
         mfma_drain();
         RowsRaw<T> x1, x2;
         epilogue<T, 0, 0, 2, true, TR>(acc, q, bs, bb, dblk, 0, 0, nullptr, nullptr, false, t, smem, 0, &x1, 0.f, true, mbase, 0);     // x1 (kept: x still occupies its slots)
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open(acc);
-        run_units<T, S::first(U_BULK, 1), S::end(U_BULK, 1), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 1)>{}, std::integral_constant<int, S::end(U_BULK, 1)>{}, 0); });
+        run_units<T, S::first(U_BULK, 1), S::end(U_BULK, 1), true, false, true>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 1)>{}, std::integral_constant<int, S::end(U_BULK, 1)>{}, 0); });
         seg_close(acc);
         trace_ev(q, tile, ev);
         // ---------------- P = conv1x1(x) from the resident x; then x1 may take x's slots
@@ -2056,12 +2038,13 @@ if constexpr (DIR == 2) {
         seg_close(acc);
         trace_ev(q, tile, ev);
         lds_bias(smem, 32, t, bb);
+        prewait_units<S, S::first(U_BULK, 2)>(ws_);     // bulk_2's first weights, in front of the epilogue's stores
         mfma_drain();
         epilogue<T, 1, 1, 1, true, TR>(acc, q, bs, bb, dblk, 1, 0, nullptr, nullptr, false, t, smem, 2, nullptr, 0.f, true, mbase, 1);       // x2
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open(acc);
-        run_units<T, S::first(U_BULK, 2), S::end(U_BULK, 2), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 2)>{}, std::integral_constant<int, S::end(U_BULK, 2)>{}, CF::KD); });
+        run_units<T, S::first(U_BULK, 2), S::end(U_BULK, 2), true, false, true>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 2)>{}, std::integral_constant<int, S::end(U_BULK, 2)>{}, CF::KD); });
         seg_close(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(CF::KD, 2)) return;
@@ -2072,12 +2055,13 @@ if constexpr (DIR == 2) {
         seg_close(acc);
         trace_ev(q, tile, ev);
         lds_bias(smem, 64, t, bb);
+        prewait_units<S, S::first(U_BULK, 3)>(ws_);     // bulk_3's first weights, in front of the epilogue's stores
         mfma_drain();
         epilogue<T, 2, 0, 1, true, TR>(acc, q, bs, bb, dblk, 2, 0, nullptr, nullptr, false, t, smem, 0, nullptr, 0.f, true, mbase, 2);       // x3
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open<3>(acc);
-        run_units<T, S::first(U_BULK, 3), S::end(U_BULK, 3), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD); });
+        run_units<T, S::first(U_BULK, 3), S::end(U_BULK, 3), true, false, true>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 3)>{}, std::integral_constant<int, S::end(U_BULK, 3)>{}, 2 * CF::KD); });
         seg_close<3>(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(2 * CF::KD, 0)) return;
@@ -2089,13 +2073,14 @@ if constexpr (DIR == 2) {
         trace_ev(q, tile, ev);
         lds_bias(smem, 96, t, bb);
         lds_get_rows(smem, 2, x2.q, t);   // x2's own pixels still sit in the slots x4 is about to take
+        prewait_units<S, S::first(U_BULK, 4)>(ws_);     // bulk_4's first weights, in front of the epilogue's stores
         mfma_drain();
         epilogue<T, 3, 2, 1, true, TR>(acc, q, bs, bb, dblk, 3, 0, &x2, nullptr, false, t, smem, 2, nullptr, 0.f, true, mbase, 3);           // x4 (+ x2)
         RowsRaw<T> tx0, tx1, tr0, tr1;
         ++epoch;
         trace_ev(q, tile, ev);
         seg_open<4>(acc);
-        run_units<T, S::first(U_BULK, 4), S::end(U_BULK, 4), true, false>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD); });
+        run_units<T, S::first(U_BULK, 4), S::end(U_BULK, 4), true, false, true>(acc, ws_, smem, t, [&](auto IDX, auto PH) __attribute__((always_inline)) { bulk_hook(IDX, PH, std::integral_constant<int, S::first(U_BULK, 4)>{}, std::integral_constant<int, S::end(U_BULK, 4)>{}, 3 * CF::KD); });
         seg_close<4>(acc);
         trace_ev(q, tile, ev);
         if (!finish_halo(3 * CF::KD, 2)) return;
