@@ -77,7 +77,7 @@ constexpr int AR = 4;                       // activation slots: all stages of a
 // ESR_FAT: the unit runner of the small-tile builds (run_units_fat below).  With one row per wave a unit is 6..15
 // MFMAs (0.08..0.2 us): a fragment read covers ONE MFMA and the unit boundary (barrier, DMA set-up) comes every few
 // hundred cycles, so the fragments of unit i+1 are read while unit i's MFMAs issue, and the weight ring is deeper
-// (the 4-row tile leaves the LDS room: 8 slots of 15 fragments, requests 6 units ahead).
+// (the 4-row tile leaves the LDS room: 8 slots of 15 fragments, requests 4 units ahead).
 #ifndef ESR_FAT
 #define ESR_FAT (ESR_R == 1)
 #endif
@@ -85,7 +85,7 @@ constexpr bool FAT = ESR_FAT != 0;
 constexpr int WSLOT = FAT ? 15 * 1024 : 18 * 1024;   // weight unit (fp16 schedule: <= 15 fragments; fp32 phases: 6 blocks x 3 kh)
 constexpr int WR = FAT ? 8 : 4;             // weight ring depth
 #ifndef ESR_AH
-#define ESR_AH (ESR_FAT ? 6 : 3)
+#define ESR_AH (ESR_FAT ? 4 : 3)     // (block at 16 x 32^2 with a lead of 3 / 4 / 5 / 6 units: 22.6 / 20.8 / 21.1 / 21.7 us)
 #endif
 constexpr int AH = ESR_AH;                  // a unit's weights are requested AH units ahead (<= WR - 1; FAT: <= WR - 2)
 static_assert(AH >= 3 && AH <= (FAT ? WR - 2 : WR - 1), "weight ring lead");
@@ -840,7 +840,10 @@ template <int NKW, int NBLK> struct FatShape {
     int ord0[NR], own0[NM][2], allow0[2][NM];            // the segment's first unit (reads its own fragments): see make()
     bool wait0[2][NM], bad;
   };
-  static constexpr int P0 = 8;
+#ifndef ESR_P0
+#define ESR_P0 8
+#endif
+  static constexpr int P0 = ESR_P0;
   static constexpr Tab make() {
     Tab t{};
     int m = 0;
