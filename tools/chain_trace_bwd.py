@@ -1,13 +1,17 @@
 """Per-phase timeline of the BACKWARD chain (esr_rdb_backward, trace): as tools/chain_trace.py.
-Usage: python tools/chain_trace_bwd.py [noise 0/1]"""
+Usage: python tools/chain_trace_bwd.py [noise 0/1] [H] [W] [rows per wave 4 | 2 | 1]"""
 import sys, os
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from esrganplus_amd import architecture as arch, synth, _lib as L
 
-B, H, W, nb = 16, 128, 128, 2
+B, nb = 16, 2
 noise = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+ROWS = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+os.environ['ESR_RDB_ROWS'] = str(ROWS)
 dev = torch.device('cuda:0')
 net = arch.RRDBNet(3, 3, 64, nb).to(dev).train(bool(noise)).set_precision('fp16')
 x = torch.rand(B, 3, H, W, device=dev)
@@ -15,7 +19,7 @@ y = net(x)
 y.sum().backward()
 pool = [v for k, v in net._plans.items() if isinstance(v, list)][0]
 tp = pool[0]
-ntiles = B * ((H + 15) // 16) * ((W + 31) // 32)
+ntiles = B * ((H + 4 * ROWS - 1) // (4 * ROWS)) * ((W + 31) // 32)
 tr = torch.zeros(ntiles * 64, dtype=torch.int64, device=dev)
 arr = tp.bwd.array()
 arr[tp.bwd_chain_ops[0]].u.rdb_chain.trace = tr.data_ptr()
