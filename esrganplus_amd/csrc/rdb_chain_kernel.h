@@ -289,6 +289,24 @@ template <> struct Ch16<_Float16> {
     __builtin_amdgcn_raw_buffer_store_b128(q[0], t.r, off, 0, 16);
     __builtin_amdgcn_raw_buffer_store_b128(q[1], t.r, off + 16, 0, 16);
   }
+  // The same 64 bytes per pixel pair of lanes, ROW-CONTIGUOUS: lane (pixel j, group h) holds the 32 bytes of its pixel
+  // in group h, so store_packed's two instructions each fill half of every 32-byte sector (16 bytes per lane, 32 apart)
+  // — and these are write-through stores: 13.5 GB reached memory per training-forward launch for 6.9 GB of slices
+  // (PMC WRITE_SIZE, profiles/r04_fwdbwd_pmc_summary.txt).  One v_permlane32_swap per dword exchanges the upper
+  // half-wave's first 16 bytes with the lower half-wave's second 16: afterwards lanes 0..31 / 32..63 hold bytes 0..15 /
+  // 16..31 of the 32 pixels of ONE group, and each instruction stores a whole 1 KB group row.  pixoff: the offset of
+  // the lane's own pixel (both lanes of a pair: the same pixel j), or the out-of-range offset for a dropped pixel.
+  static __device__ __forceinline__ void store_packed_rows(const ImgView& t, int cb, int h, int pixoff, const u32x4 (&q)[2]) {
+    u32x4 a = q[0], b = q[1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const auto r = __builtin_amdgcn_permlane32_swap(a[i], b[i], false, false);
+      a[i] = r[0]; b[i] = r[1];
+    }
+    const int off = pixoff + h * 16;           // (an out-of-range pixoff stays out of range: + 16 at most)
+    __builtin_amdgcn_raw_buffer_store_b128(a, t.r, (2 * cb) * t.gs + off, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(b, t.r, (2 * cb + 1) * t.gs + off, 0, 16);
+  }
   struct Raw { u32x4 q[2]; };
   static __device__ __forceinline__ void load(const ImgView& t, int cb, int h, int pixoff, Raw& r) {
     const int off = (2 * cb + h) * t.gs + pixoff;
@@ -1450,7 +1468,7 @@ __device__ __forceinline__ void epilogue(Acc24& acc, const PT& p, const BlkS& bl
       // tile's border pixels are stored — 82 % fewer bytes through the lock-stepped store bursts
       const bool edge = TRAIN || (MODE == 3 && full_store) || p.save_dense || tj == 0 || tj == TW - 1 || (t.wave == 0 && r == 0) ||
                         (t.wave == NT / 64 - 1 && r == R - 1);
-      C16::store_packed(out, (inside && edge) ? out_cb : 0, th, (inside && edge) ? po : (int)0x80000000u, q.q);
+      C16::store_packed_rows(out, (inside && edge) ? out_cb : 0, th, (inside && edge) ? po : (int)0x80000000u, q.q);
       // beyond the image: the zero padding (only tiles that stick out of the image have such pixels: one scalar test)
       if (ragged && !live) { q.q[0] = u32x4{0, 0, 0, 0}; q.q[1] = u32x4{0, 0, 0, 0}; }
       if constexpr (LW & 1) lds_put_row(smem, slot0 + th, r, q.q, own_px, own_swz);
@@ -1559,7 +1577,7 @@ __device__ __forceinline__ void epilogue_bwd(Acc24& acc, const PT& p, const ImgV
       typename C16::Raw q;
       C16::pack(raw, q.q);
       if (ragged && !inside) { q.q[0] = u32x4{0, 0, 0, 0}; q.q[1] = u32x4{0, 0, 0, 0}; }
-      C16::store_packed(*aux, inside ? 0 : 0, th, inside ? po : (int)0x80000000u, q.q);
+      C16::store_packed_rows(*aux, 0, th, inside ? po : (int)0x80000000u, q.q);
       mma_f16_after_valu<acc_in_agpr(4)>(acc_br<4, r>(acc), one->a[0], q.q[0]);
       mma_f16_after_valu<acc_in_agpr(4)>(acc_br<4, r>(acc), one->a[1], q.q[1]);
       mma_f16_after_valu<acc_in_agpr(5)>(acc_br<5, r>(acc), one->a[2], q.q[0]);
@@ -1571,7 +1589,7 @@ __device__ __forceinline__ void epilogue_bwd(Acc24& acc, const PT& p, const ImgV
     for (int e = 0; e < 16; ++e) v[e] = a[e] * (((bits >> (15 - e)) & 1u) ? ESR_LRELU_SLOPE : 1.0f);   // lrelu'(a): 0.2 where a < 0 (block.py:12)
     typename C16::Raw q;
     C16::pack(v, q.q);
-    C16::store_packed(out, inside ? out_cb : 0, th, inside ? po : (int)0x80000000u, q.q);
+    C16::store_packed_rows(out, inside ? out_cb : 0, th, inside ? po : (int)0x80000000u, q.q);
     if (ragged && !inside) { q.q[0] = u32x4{0, 0, 0, 0}; q.q[1] = u32x4{0, 0, 0, 0}; }
     if constexpr (LW & 1) lds_put_row(smem, slot0 + th, r, q.q, own_px, own_swz);
     if constexpr (LW & 2) keep->q[r] = q;
@@ -1620,7 +1638,7 @@ __device__ __forceinline__ void tail_bwd(Acc24& acc, const PT& p, const BlkS& bl
       }
       typename C16::Raw qa;
       C16::pack(v, qa.q);
-      C16::store_packed(out_a, inside ? ch_cb : 0, th, inside ? po : (int)0x80000000u, qa.q);
+      C16::store_packed_rows(out_a, inside ? ch_cb : 0, th, inside ? po : (int)0x80000000u, qa.q);
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] *= 0.2f;
     }
@@ -1632,7 +1650,7 @@ __device__ __forceinline__ void tail_bwd(Acc24& acc, const PT& p, const BlkS& bl
     }
     typename C16::Raw q;
     C16::pack(v, q.q);
-    C16::store_packed(out, inside ? ch_cb : 0, th, inside ? po : (int)0x80000000u, q.q);
+    C16::store_packed_rows(out, inside ? ch_cb : 0, th, inside ? po : (int)0x80000000u, q.q);
     if (ragged && !inside) { q.q[0] = u32x4{0, 0, 0, 0}; q.q[1] = u32x4{0, 0, 0, 0}; }
     lds_put_row(smem, slot0 + th, r, q.q, own_px, own_swz);
     // the next block's g_x accumulators start at its g_t (= this output as stored): d(0.2 conv5 + x)/dx = 1
