@@ -153,6 +153,23 @@ __device__ __forceinline__ void mma_cls(f32x16& acc, const u32x4& a, const u32x4
     }
   }
 }
+// fp16 MFMA with the counted LDS wait for its fragments INSIDE the statement (WAITC < 0: none).  hipcc pads every
+// asm statement that follows another one defining VGPRs (a wait or tie statement, a fragment read) with `s_nop 0`; one
+// wave per SIMD pays an issue slot for each — 370 per block of the 4-row build before this.
+template <bool AGPR, bool FIRST, int WAITC>
+__device__ __forceinline__ void mma_w(f32x16& acc, const u32x4& a, const u32x4& b) {
+  if constexpr (WAITC >= 0) {
+    if constexpr (FIRST) {
+      if constexpr (AGPR) asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b), "n"(WAITC));
+      else asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b), "n"(WAITC));
+    } else {
+      if constexpr (AGPR) asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "n"(WAITC));
+      else asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b), "n"(WAITC));
+    }
+  } else {
+    mma_cls<_Float16, AGPR, FIRST>(acc, a, b);
+  }
+}
 // >= 18 wait states: covers "XDL write VGPR -> VALU / VMEM read or write" for 8- and 16-pass MFMAs
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
@@ -989,10 +1006,9 @@ __device__ __forceinline__ void run_units_fat(Acc24& acc, const WStream& s, char
     sfor<F::NM>([&](auto MI) __attribute__((always_inline)) {
       constexpr int m = decltype(MI)::value;
       constexpr int a = F::tab.a[m], b = F::tab.b[m], blk = BLK0 + F::tab.bi[m], r = F::tab.ir[m] - F::tab.kh[m];
-      if constexpr (I > I0 && F::tab.wait[NXT][m] && !(ESR_ABL & 6)) lds_wait2<F::tab.allow[NXT][m]>(fa[a], fb[b]);
-      else if constexpr (I == I0 && F::tab.wait0[NXT][m]) lds_wait2<F::tab.allow0[NXT][m]>(fa[a], fb[b]);
-      else lds_tie2(fa[a], fb[b]);
-      mma_cls<T, acc_in_agpr(blk), FIRST && F::tab.kwi[m] == 0 && F::tab.kh[m] == 0 && blk < 4>(acc_br<blk, r>(acc), fa[a], fb[b]);
+      constexpr int WC = (I > I0 && F::tab.wait[NXT][m] && !(ESR_ABL & 6)) ? F::tab.allow[NXT][m]
+                         : (I == I0 && F::tab.wait0[NXT][m]) ? F::tab.allow0[NXT][m] : -1;
+      mma_w<acc_in_agpr(blk), FIRST && F::tab.kwi[m] == 0 && F::tab.kh[m] == 0 && blk < 4, WC>(acc_br<blk, r>(acc), fa[a], fb[b]);
       if constexpr (I == I0) {
         sfor<2>([&](auto KI) __attribute__((always_inline)) {
           constexpr int f = F::tab.own0[m][decltype(KI)::value];

@@ -375,24 +375,34 @@ def test_starved_chain_launch_is_reported_at_the_next_call(dev):
                 break
         if side is None:
             pytest.skip('no stream that runs concurrently with the current one')
-        words.zero_()
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        L.check(L.lib().esr_debug_hold_cus(cus - 1, p_release, 4000, p_started, C.c_void_p(side.cuda_stream)), 'esr_debug_hold_cus')
-        for _ in range(300):                              # every hold workgroup is resident before the chain arrives
-            if int(words[1]) == cus - 1:
+        # Workgroups are dealt round-robin to the 8 XCDs and wait for a CU of THEIR XCD: a tile starts (and then spins
+        # for its neighbours) only if one of the three tiles is dealt to the XCD with the free CU — otherwise all three
+        # wait behind the hold kernel and run normally once it gives up.  Where the dealing starts depends on the
+        # launches before it: try with the dealer rotated by one XCD per attempt.
+        ws_abort, spun = 0, 0.0
+        for attempt in range(8):
+            words.zero_()
+            L.check(L.lib().esr_debug_hold_cus(cus - 1, p_release, 2500, p_started, C.c_void_p(side.cuda_stream)), 'esr_debug_hold_cus')
+            for _ in range(300):                          # every hold workgroup is resident before the chain arrives
+                if int(words[1]) == cus - 1:
+                    break
+                time.sleep(0.01)
+            assert int(words[1]) == cus - 1
+            t0 = time.perf_counter()
+            bad = net(x)                                  # one CU left: a tile spins for its neighbours, then aborts
+            torch.cuda.current_stream().synchronize()
+            spun = time.perf_counter() - t0
+            words[0] = 1                                  # lets the hold workgroups go (they also give up after 2.5 s)
+            torch.cuda.synchronize()
+            ws_abort = int(_chain_plans(net)[0].chain_ws[1].item())
+            if ws_abort == 1:
                 break
-            time.sleep(0.01)
-        assert int(words[1]) == cus - 1
-        t0 = time.perf_counter()
-        bad = net(x)                                      # one CU left: tile 0 spins for its neighbours, then aborts
-        torch.cuda.current_stream().synchronize()
-        spun = time.perf_counter() - t0
-        words[0] = 1                                      # lets the hold workgroups go (they also give up after 4 s)
-        torch.cuda.synchronize()
-        ws_abort = int(_chain_plans(net)[0].chain_ws[1].item())
-        # (spun is 1 s when the free CU's XCD is the one the spinning tile was dispatched to and up to the 4 s of the
-        # hold kernel otherwise: workgroups are dealt round-robin to the 8 XCDs and wait for a CU of THEIR XCD)
-        assert ws_abort == 1 and spun > 0.9, ('the launch was not starved', ws_abort, spun)
+            assert L.lib().esr_rdb_check_abort() == 0 and torch.equal(bad, good)     # it waited, then ran normally
+            torch.zeros(1, device=dev).add_(1)            # one more workgroup: the dealer moves on by one XCD
+        if ws_abort != 1:
+            pytest.skip('no tile was dealt to the XCD with the free CU in 8 attempts')
+        assert spun > 0.9, ('the launch was not starved', ws_abort, spun)
         with pytest.raises(L.HipExtensionError, match='aborted'):
             net(x)
         again = net(x)
