@@ -68,6 +68,12 @@ class ESRGANPlusStep:
         # host time per step).  Default: the same launch lists driven directly (`_step_manual`), when the networks
         # allow it (`_manual_ok`)
         self.manual = os.environ.get('ESR_TRAIN_MANUAL', '1') != '0'
+        # netF(fake): forward, feature loss and input-gradient pass on the SIDE stream, next to netD's forward and its
+        # G-step pass on the main stream (both hang off fake_H only; their two contributions to dL/d fake_H meet in one add)
+        self.netf_side = os.environ.get('ESR_TRAIN_NETF_SIDE', '1') == '1'
+        self.d_when = os.environ.get('ESR_TRAIN_DSTEP', 'last')       # 'first' | 'mid' | 'last': see _step_manual
+        self.order = os.environ.get('ESR_TRAIN_ORDER', 'main_first')  # host enqueue order of netD's forward vs netF(fake)
+        self.tail_side = os.environ.get('ESR_TRAIN_TAIL_SIDE', '1') == '1'
         self.overlap_d_step = self.overlap >= 1
 
     def _side(self, dev, which=0):
@@ -142,20 +148,56 @@ class ESRGANPlusStep:
             if gy is None or gy.shape != fake.shape or gy.device != fake.device:
                 gy = self._gy = torch.empty_like(fake)
             l_g_pix = LS.l1_raw(fake, var_H, self.l_pix_w, grad_out=gy, grad_scale=S, scale_dev=sdev)
-            if ov >= 1:
-                main.wait_stream(side)
+            nf_side = self.netf_side and ov >= 1
+            box = {}
+
+            def netf_fake():
+                fake_fea, leaseF = netF._run_forward(fake, need_bwd=True)
+                PF = leaseF.plan
+                box['leaseF'], box['PF'] = leaseF, PF
+                box['l_g_fea'] = LS.l1_raw(fake_fea, real_fea, self.l_fea_w, grad_out=PF.gy_tensor, grad_scale=S, scale_dev=sdev)
+
+            def netd_fwd():
+                ev = self.__dict__.get('_ev_tail')
+                if ev is not None:
+                    main.wait_event(ev)                       # the previous step's D step, D's Adam and packs (side stream)
+                # ONE netD forward for the step's four calls (forward_shared): groups (fake, real)
+                out, leaseD = netD._run_forward(torch.cat([fake, var_ref]), need_bwd=True, groups=2 if netD._has_bn else 1, dual=n)
+                PD = leaseD.plan
+                if side is not None:
+                    out.record_stream(side)                   # (the D step reads it there)
+                box['leaseD'], box['PD'], box['pg'], box['pr'] = leaseD, PD, out[:n], out[n:]
+                # G step: BCE(pred_d_real - mean(pred_g_fake), 0) + BCE(pred_g_fake - mean(pred_d_real), 1), gradient to the fake half
+                box['l_g_gan'], _ = LS.ragan_raw(out[n:], out[:n], False, True, self.l_gan_w, grad_x=None, grad_y=PD.second.gy_tensor,
+                                                 grad_scale=S, scale_dev=sdev, global_mean=mean)
+
+            if nf_side:
+                # netF(fake) — forward, feature loss, input-gradient pass — on the side stream next to netD's forward and
+                # G-step pass on the main stream.  The HOST enqueues the main stream's netD forward first (it is the longer
+                # chain: the G backward hangs off it); the two input gradients meet in one add.
+                gy2 = self.__dict__.get('_gy2')
+                if gy2 is None or gy2.shape != fake.shape or gy2.device != fake.device:
+                    gy2 = self._gy2 = torch.empty_like(fake)
+                side.wait_stream(main)                        # fake_H
+                fake.record_stream(side)
+                if self.order == 'main_first':
+                    netd_fwd()
+                with torch.cuda.stream(side):
+                    netf_fake()
+                    CN.run_pass_into(box['PF'], gx_into=gy2, accumulate=False)
+                    ev_f = torch.cuda.Event()
+                    ev_f.record(side)
+                if self.order != 'main_first':
+                    netd_fwd()
             else:
-                real_fea = netF._run_forward(var_H, need_bwd=False)[0]
-            fake_fea, leaseF = netF._run_forward(fake, need_bwd=True)
-            PF = leaseF.plan
-            l_g_fea = LS.l1_raw(fake_fea, real_fea, self.l_fea_w, grad_out=PF.gy_tensor, grad_scale=S, scale_dev=sdev)
-            # ONE netD forward for the step's four calls (forward_shared): groups (fake, real)
-            out, leaseD = netD._run_forward(torch.cat([fake, var_ref]), need_bwd=True, groups=2 if netD._has_bn else 1, dual=n)
-            PD = leaseD.plan
-            pg, pr = out[:n], out[n:]
-            # G step: BCE(pred_d_real - mean(pred_g_fake), 0) + BCE(pred_g_fake - mean(pred_d_real), 1), gradient to the fake half
-            l_g_gan, _ = LS.ragan_raw(pr, pg, False, True, self.l_gan_w, grad_x=None, grad_y=PD.second.gy_tensor,
-                                      grad_scale=S, scale_dev=sdev, global_mean=mean)
+                if ov >= 1:
+                    main.wait_stream(side)
+                else:
+                    real_fea = netF._run_forward(var_H, need_bwd=False)[0]
+                netf_fake()
+                netd_fwd()
+            leaseF, PF, l_g_fea = box['leaseF'], box['PF'], box['l_g_fea']
+            leaseD, PD, pg, pr, l_g_gan = box['leaseD'], box['PD'], box['pg'], box['pr'], box['l_g_gan']
 
             def d_step():
                 # D step (SRRaGAN_model.py:143-168): the second pair of calls sees the first pair's values
@@ -178,55 +220,105 @@ class ESRGANPlusStep:
                 self.exD.start()
                 return aux
 
-            # the D step is enqueued BEFORE the main stream's backward (after it: 8.88 vs 8.57 ms — it then runs under
-            # the G backward chain, and a chain that shares the chip slows down more than the overlap saves)
-            d_first = True
+            # When the host enqueues the D step (~60 launches, ~0.5-1 ms of host time during which the main stream gets
+            # nothing new).  Round 4, same box, ms per step with netF(fake) on the main / side stream: 'first' (before
+            # the main stream's backward passes) 8.03 / 7.92, 'mid' 8.05 / 7.92, 'last' (behind the G backward's launch:
+            # it then runs under the backward chain) 8.35 / 7.57.
+            # Where the HOST enqueues it matters as much: the D step is ~60 launches (~1 ms of host time) during which the
+            # main stream gets nothing new.  'mid': the main stream's netD / netF input-gradient passes (two C calls,
+            # ~0.9 ms of GPU work) go out first and run while the host enqueues the D step; the G backward follows.
+            d_when = self.d_when
             if ov >= 1:
                 side.wait_stream(main)
-                if d_first:
+                if d_when == 'first':
                     with torch.cuda.stream(side):
                         aux = d_step()
             # dL/d fake_H: + d l_gan (netD, first pair) + d l_fea (netF), added by the passes' last layout ops
             CN.run_pass_into(PD.second, gx_into=gy, accumulate=True)
-            CN.run_pass_into(PF, gx_into=gy, accumulate=True)
+            if nf_side:
+                main.wait_event(ev_f)
+                gy.add_(gy2)
+            else:
+                CN.run_pass_into(PF, gx_into=gy, accumulate=True)
+            if ov >= 1 and d_when == 'mid':
+                with torch.cuda.stream(side):
+                    aux = d_step()
             Fn.rrdbnet_train_backward(netG, stG, gy)
             self.exG.start()
             if ov >= 1:
-                if not d_first:
+                if d_when == 'last':
                     with torch.cuda.stream(side):
                         aux = d_step()
-                main.wait_stream(side)
             else:
                 aux = d_step()
             leaseF.release()
             leaseD.release()
             inv = 1.0 / self.loss_scale
-            self.exG.wait()
-            self.optimizer_G.step(grad_scale=inv, scaler=self.scaler)
-            self.exD.wait()
-            self.optimizer_D.step(grad_scale=inv, scaler=self.scaler)
-            if self.scaler:
-                self.scaler.update()
-            if self.prepack:
-                netG.prepack(fwd=True, dgrad=False)
+            # The step's tail.  tail_side (static loss scale): the main stream only carries what the NEXT generator forward
+            # waits for — G's Adam and the pack of its forward weights; the D step's end, D's Adam, D's packs and G's
+            # input-gradient packs stay on the side stream, and the main stream meets them again (ev_tail) in front of the
+            # next netD forward.
+            # Only in the pipelined form of the call (sync_log=False: the caller reads nothing before `finish()` / a device
+            # synchronisation); the default call returns with everything ordered on the current stream.
+            tail_side = ov >= 1 and self.tail_side and self.scaler is None and not sync_log
+            if not tail_side:
                 if ov >= 1:
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
+                    main.wait_stream(side)
+                self.exG.wait()
+                self.optimizer_G.step(grad_scale=inv, scaler=self.scaler)
+                self.exD.wait()
+                self.optimizer_D.step(grad_scale=inv, scaler=self.scaler)
+                if self.scaler:
+                    self.scaler.update()
+                if self.prepack:
+                    netG.prepack(fwd=True, dgrad=False)
+                    if ov >= 1:
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            netD.prepack()
+                            netG.prepack(fwd=False, dgrad=True)
+                    else:
                         netD.prepack()
                         netG.prepack(fwd=False, dgrad=True)
-                else:
-                    netD.prepack()
-                    netG.prepack(fwd=False, dgrad=True)
+                if ov >= 1:
+                    self._ev_tail = torch.cuda.Event()
+                    self._ev_tail.record(side)
+            else:
+                self.exG.wait()
+                self.optimizer_G.step(grad_scale=inv, scaler=None)
+                if self.prepack:
+                    netG.prepack(fwd=True, dgrad=False)
+                side.wait_stream(main)                        # G's new weights (its input-gradient packs read them)
+                with torch.cuda.stream(side):
+                    self.exD.wait()
+                    self.optimizer_D.step(grad_scale=inv, scaler=None)
+                    if self.prepack:
+                        netD.prepack()
+                        netG.prepack(fwd=False, dgrad=True)
+                    self._ev_tail = torch.cuda.Event()
+                    self._ev_tail.record(side)
         logs = dict(l_g_pix=l_g_pix, l_g_fea=l_g_fea, l_g_gan=l_g_gan, l_d_real=aux[2], l_d_fake=aux[3],
                     D_real=aux[0], D_fake=aux[1])
         if sync_log:
+            if ov >= 1:
+                main.wait_stream(side)
             self.log = {k: float(v) for k, v in logs.items()}
         else:
             self.log = logs
         return self.log
 
+    def finish(self):
+        """Orders what a pipelined step (``step(..., sync_log=False)``) left on the side stream — the end of the D
+        step, D's Adam, the weight packs — in front of the current stream: call it (or synchronise the device) before
+        reading the networks' parameters, buffers or the logged losses after such a step."""
+        ev = self.__dict__.get('_ev_tail')
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def step(self, var_L, var_H, var_ref=None, z=None, sync_log=True):
-        """One optimisation step (SRRaGAN_model.py:113-168)."""
+        """One optimisation step (SRRaGAN_model.py:113-168).  sync_log=False: the pipelined form for training loops —
+        the logged losses stay device tensors and the step's discriminator-side tail may still be in flight on the side
+        stream when the call returns (the next step, ``finish()`` and a device synchronisation order it)."""
         netG, netD, netF = self.netG, self.netD, self.netF
         var_ref = var_H if var_ref is None else var_ref
         self._steps += 1

@@ -53,7 +53,7 @@ def test_optimize_parameters_step_matches_reference():
     assert np.mean(np.sign(dd) == np.sign(g['D_delta_classifier.2.weight'])) >= 0.97
 
 
-@pytest.mark.parametrize('knobs', [{}, {'ESR_TRAIN_MANUAL': '0'},
+@pytest.mark.parametrize('knobs', [{}, {'PIPELINED': '1'}, {'ESR_TRAIN_NETF_SIDE': '0', 'ESR_TRAIN_DSTEP': 'first'}, {'ESR_TRAIN_MANUAL': '0'},
                                    {'ESR_TRAIN_MANUAL': '0', 'ESR_SHARED_D': '0', 'ESR_TRAIN_OVERLAP': '0', 'ESR_FLAT_GRADS': '0',
                                     'ESR_FUSE_BN': '0', 'ESR_S2_SPLIT': '0'}])
 def test_three_training_iterations_match_the_reference(monkeypatch, knobs):
@@ -64,8 +64,10 @@ def test_three_training_iterations_match_the_reference(monkeypatch, knobs):
     training forwards.  Runs the production step (hand-written forward / backward over the launch lists, shared netD forward, stream overlap,
     flat gradient store, fused BatchNorm passes, split-K deep convs), the same through autograd, and the plain one
     (every knob off)."""
+    pipelined = knobs.get('PIPELINED') == '1'      # step(sync_log=False) + finish(): the D-side tail stays on the side stream
     for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
+        if k != 'PIPELINED':
+            monkeypatch.setenv(k, v)
     from esrganplus_amd import architecture as arch, train
     from oracle import ref_torch as RT
     monkeypatch.setattr(arch._RRDBNetBase, 'flat_param_grads', knobs.get('ESR_FLAT_GRADS', '1') != '0')
@@ -83,6 +85,7 @@ def test_three_training_iterations_match_the_reference(monkeypatch, knobs):
     scheds = [torch.optim.lr_scheduler.MultiStepLR(o, [1, 2], 0.5) for o in (st.optimizer_G, st.optimizer_D)]
     import warnings
     keys = ('l_g_pix', 'l_g_fea', 'l_g_gan', 'l_d_real', 'l_d_fake', 'D_real', 'D_fake')
+    logs = []
     for it in range(1, 4):
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
@@ -94,13 +97,18 @@ def test_three_training_iterations_match_the_reference(monkeypatch, knobs):
         hr = synth.image_batch(80 + it, 4, 3, 128, 128, name='steps3.hr').to(dev)
         z = [synth.normal_like(90 + it, 'steps3.z.%d' % i, s).to(dev)
              for i, s in enumerate(RT.noise_shapes(lr.shape, 2, 'codes'))]
-        log = st.step(lr, hr, z=z)
-        got = np.array([log[k] for k in keys])
+        if pipelined:                                   # three steps back to back, nothing read in between
+            logs.append(dict(st.step(lr, hr, z=z, sync_log=False)))
+        else:
+            logs.append(st.step(lr, hr, z=z))
+        assert np.abs(checks(st.fake_H.detach()) - g['fake_H_chk_%d' % it]).max() <= 2e-3 * np.abs(g['fake_H_chk_%d' % it]).max()
+    st.finish()
+    for it in range(1, 4):
+        got = np.array([float(logs[it - 1][k]) for k in keys])
         ref = g['log_%d' % it]
         print('step %d  hip %s\n        ref %s' % (it, got, ref))
         # (steps 2 and 3 run on weights that already differ in the last bits: 5e-4 of the value, 2e-4 absolute)
         assert np.all(np.abs(got - ref) <= 5e-4 * np.maximum(1.0, np.abs(ref))), (it, got - ref)
-        assert np.abs(checks(st.fake_H.detach()) - g['fake_H_chk_%d' % it]).max() <= 2e-3 * np.abs(g['fake_H_chk_%d' % it]).max()
     pg, pd = dict(netG.named_parameters()), dict(netD.named_parameters())
     chk = np.stack([checks(pg[k]) for k in sdG.keys()])
     assert np.abs(chk - g['G_chk']).max() <= 2e-3 * np.abs(g['G_chk']).max()
