@@ -223,7 +223,8 @@ def train_object(args, world, rank, dev, dist, steps, warmup, kernels=True):
            'tflops': round(fl / dt / 1e12, 1), 'frac_of_f16_mfma_peak': round(fl / dt / 1e12 / PEAK_F16_TFLOPS, 4),
            'steps': steps, 'warmup': warmup,
            'what': 'full ESRGAN+ train step (RRDBNet nb=23 noise on + Discriminator_VGG_128 + VGG19[:35] feature loss, '
-                   'Adam x2, loss scale 1024), batch %d of 32x32 LR -> 128x128 HR, %s (BASELINE configs[2])'
+                   'Adam x2, loss scale 1024), batch %d of 32x32 LR -> 128x128 HR, %s (BASELINE configs[2]); pipelined calls '
+                   '(step(sync_log=False): nothing read back between steps), K steps to a device synchronise'
                    % (tb, args.precision)}
     if kernels and args.precision == 'fp16':
         k = generator_kernel_times(st.netG, lr, tb, 32)
