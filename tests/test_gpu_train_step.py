@@ -437,3 +437,37 @@ def test_weight_gradients_are_bit_identical_run_to_run(dev, prec):
         (netD(xd) * gd).sum().backward()
         runs.append(torch.cat([p.grad.reshape(-1) for p in netD.parameters()]).clone())
     assert torch.equal(runs[0], runs[1])
+
+
+def test_pipelined_steps_equal_synchronised_steps_bit_for_bit():
+    """step(sync_log=False) leaves the discriminator-side tail (end of the D step, D's Adam, weight packs) on the side
+    stream and enqueues the D step behind the G backward; step() orders everything on the current stream.  Same
+    kernels, same order per stream, deterministic reductions: after 12 steps from the same start the two loops must hold
+    the same weights, moments and BatchNorm buffers BIT FOR BIT — a missing wait between the streams shows up here."""
+    from esrganplus_amd import architecture as arch, train
+    dev = torch.device('cuda:0')
+    sdG, sdD = synth.rrdbnet_state_dict(nb=2, seed=41), synth.discriminator_state_dict(seed=42)
+
+    def run(pipelined):
+        torch.manual_seed(1234)
+        netG = arch.RRDBNet(3, 3, 64, 2).to(dev).train().set_precision('fp16')
+        netD = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision('fp16')
+        netF = arch.VGGFeatureExtractor(34, False, True, dev).to(dev).eval().set_precision('fp16')
+        netG.load_state_dict(sdG, strict=True)
+        netD.load_state_dict(sdD, strict=True)
+        netF.load_state_dict(synth.vgg19_state_dict(6, 34), strict=False)
+        st = train.ESRGANPlusStep(netG, netD, netF, loss_scale=1024.0)
+        for it in range(12):
+            lr = synth.image_batch(500 + it, 4, 3, 32, 32, name='pipe.lr').to(dev)
+            hr = synth.image_batch(600 + it, 4, 3, 128, 128, name='pipe.hr').to(dev)
+            st.step(lr, hr, sync_log=not pipelined)
+        st.finish()
+        torch.cuda.synchronize()
+        out = {'G.' + k: v.detach().clone() for k, v in netG.state_dict().items()}
+        out.update({'D.' + k: v.detach().clone() for k, v in netD.state_dict().items()})
+        return out
+
+    a, b = run(False), run(True)
+    assert a.keys() == b.keys()
+    bad = [k for k in a if not torch.equal(a[k], b[k])]
+    assert not bad, bad[:8]
