@@ -98,6 +98,62 @@ template <int MODE, int NACC, int DMAEVERY = 1> void run(const char* name, const
   printf("%-58s %7.2f ns / MFMA   %7.1f s_memtime ticks / MFMA\n", name, ms * 1e6 / n, cyc / n);
 }
 
+
+// MODE 10: the 4-row chain's inner loop in miniature — per MFMA: its own A fragment (refilled in place), every 4th
+// MFMA a streaming 1 KB LDS-DMA, a counted wait and EXTRA vector instructions (address code, spill reloads) — run by 4
+// waves (one per SIMD) or by 8 waves (two per SIMD, each half the MFMAs): what a second wave per SIMD would hide.
+template <int NW, int EXTRA>
+__global__ __launch_bounds__(NW * 64) void probe2(const char* w, uint64_t* out, int iters) {
+  __shared__ __attribute__((aligned(16))) char smem[96 * 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x16 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  u32x4 b = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+  u32x4 fa[6] = {b, b, b, b, b, b};
+  const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (threadIdx.x & 255) * 16;
+  char* dst = smem + 64 * 1024 + wave * 1024;
+  const char* stream = w + wave * 1024 + lane * 16;
+  int x = lane;
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    if ((it & 63) == 0) stream = w + wave * 1024 + lane * 16;
+    sfor<48>([&](auto MI) __attribute__((always_inline)) {
+      constexpr int m = decltype(MI)::value;
+      asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fa[m % 6]));
+      mma(acc[m % 3], fa[m % 6], b);
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[m % 6]) : "v"(lds), "n"((m % 8) * 4096));
+      if constexpr (m % 4 == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)stream, (__attribute__((address_space(3))) void*)dst, 16, (m % 4) * 1024, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        stream += NW * 1024;
+      }
+#pragma unroll
+      for (int e = 0; e < EXTRA; ++e) asm volatile("v_add_u32 %0, %0, 1" : "+v"(x));
+      if constexpr (m % 16 == 15) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      if constexpr (m % 12 == 11) __builtin_amdgcn_s_barrier();
+    });
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  float s = acc[0][0] + acc[1][0] + acc[2][0];
+  if (s == 123.f && x == 7 && fa[0][0] + fa[1][0] + fa[2][0] + fa[3][0] + fa[4][0] + fa[5][0] == 1) out[blockIdx.x] = 0;
+}
+template <int NW, int EXTRA> void run2(const char* name, const char* w, uint64_t* out) {
+  const int iters = 200 * 4 / NW, grid = 128;          // the same MFMAs per SIMD
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((probe2<NW, EXTRA>), dim3(grid), dim3(NW * 64), 0, 0, w, out, iters);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((probe2<NW, EXTRA>), dim3(grid), dim3(NW * 64), 0, 0, w, out, iters);
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  const double n = 48.0 * 200;                          // MFMAs per SIMD
+  printf("%-58s %7.2f ns / MFMA of the SIMD\n", name, ms * 1e6 / n);
+}
+
 int main() {
   char* w; uint64_t* out;
   hipMalloc(&w, 64 << 20); hipMemset(w, 0, 64 << 20); hipMalloc(&out, 8 * 1024);
@@ -122,5 +178,11 @@ int main() {
   run<9, 6, 1>("6 acc, A refilled 1 MFMA behind its reader", w, out);
   run<9, 6, 2>("6 acc, A refilled 2 MFMAs behind its reader", w, out);
   run<9, 6, 3>("6 acc, A refilled 3 MFMAs behind its reader", w, out);
+  run2<4, 0>("inner loop, 4 waves, no extra instructions", w, out);
+  run2<8, 0>("inner loop, 8 waves (2 per SIMD), no extra", w, out);
+  run2<4, 3>("inner loop, 4 waves, 3 extra VALU per MFMA", w, out);
+  run2<8, 3>("inner loop, 8 waves, 3 extra VALU per MFMA", w, out);
+  run2<4, 6>("inner loop, 4 waves, 6 extra VALU per MFMA", w, out);
+  run2<8, 6>("inner loop, 8 waves, 6 extra VALU per MFMA", w, out);
   return 0;
 }
