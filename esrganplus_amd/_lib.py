@@ -118,6 +118,14 @@ class esr_unpermute(C.Structure):
 ADAM_BLOCK_ELEMS = 4096
 
 
+class esr_adam_entry(C.Structure):     # rows of esr_adam.entries (optim.py builds them as an int64[n, 3] array)
+    _fields_ = [('p', C.c_void_p), ('goff', C.c_int64), ('n', C.c_int64)]
+
+
+class esr_adam_block(C.Structure):     # rows of esr_adam.blocks (int32[n, 2])
+    _fields_ = [('entry', C.c_int32), ('first', C.c_int32)]
+
+
 class esr_adam(C.Structure):
     _fields_ = [('entries', C.c_void_p), ('blocks', C.c_void_p), ('nblocks', C.c_int32), ('_pad', C.c_int32),
                 ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),

@@ -239,6 +239,7 @@ class _PlannedModule(nn.Module):
         replica = super()._replicate_for_data_parallel()
         replica.__dict__['_conv_cache'] = None
         replica.__dict__['_gstore'] = None
+        replica.__dict__.pop('_grad_proxy', None)     # its weights are non-leaf copies: per-tensor gradient outputs
         replica.__dict__['_wp'] = {}
         replica.__dict__['_plans'] = {}
         replica.__dict__['_force_repack'] = True
@@ -314,6 +315,15 @@ class _PlannedModule(nn.Module):
             return False
         gs['stale'] = True
         return True
+
+    def _flush_stale_grads(self):
+        """A backward through the per-tensor autograd route ADDS into `.grad` (AccumulateGrad): a store that was only
+        marked stale — `mark_grads_stale()` stood in for `zero_grad()` — must really be zeroed first, or the old
+        gradients pile up (a parameter frozen after the first step, `flat_param_grads` switched off)."""
+        gs = self.__dict__.get('_gstore')
+        if gs is not None and gs['stale']:
+            gs['flat'].zero_()
+            gs['stale'] = False
 
     def _conv_list(self):
         raise NotImplementedError

@@ -368,6 +368,11 @@ class _BlockFn(torch.autograd.Function):
         return (gx if ctx.needs_input_grad[0] else None, None, None, None, None) + tuple(grads)
 
 
+def _flat_grad_route(net, params):
+    """True when the backward may hand the parameter gradients over as ONE flat buffer (`_deliver_flat_grads`)."""
+    return bool(net.flat_param_grads) and all(p.requires_grad and p.is_leaf for p in params)
+
+
 def run_rrdbnet(net, x, z=None):
     """RRDBNet.forward (architecture.py:76-78) on the HIP path."""
     if x.dim() == 4 and x.shape[0] == 0:          # empty batch: torch returns an empty result
@@ -381,11 +386,15 @@ def run_rrdbnet(net, x, z=None):
         per = 4 if net.variant == 'test_image' else 3
         zs = _zs_list(z, per * net.nb, (B, 64, H, W), x.device) if net.training else None
         params = net._convs()[1]
-        if net.flat_param_grads and all(p.requires_grad for p in params):
+        # the flat route assigns `.grad` itself, which only means something on LEAF parameters: under a multi-device
+        # nn.DataParallel (networks.py:105-107) a replica's weights are Broadcast outputs, and their gradient has to
+        # travel back through autograd to the originals -> per-tensor outputs
+        if _flat_grad_route(net, params):
             proxy = net.__dict__.get('_grad_proxy')
             if proxy is None or proxy.device != x.device:
                 proxy = net.__dict__['_grad_proxy'] = torch.zeros(1, device=x.device, requires_grad=True)
             return _RRDBNetFn.apply(x, net, zs, proxy)
+        net._flush_stale_grads()
         return _RRDBNetFn.apply(x, net, zs, None, *params)
     xin = _prep_input(x, 'input')
     B, C_, H, W = xin.shape

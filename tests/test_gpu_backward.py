@@ -256,3 +256,27 @@ def test_rrdbnet_input_gradient_only(dev, golden, prec, tol):
     err = np.abs(x.grad.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
     assert err <= tol, err
     assert all(p.grad is None for p in net.parameters())
+
+
+def test_data_parallel_replica_hands_gradients_back_to_the_original(dev):
+    """networks.py:105-107 wraps the generator in nn.DataParallel: a replica's weights are Broadcast outputs (non-leaf),
+    so its backward must return per-tensor gradients that autograd carries back to the ORIGINAL parameters (ADVICE r04:
+    the flat-gradient route assigned `.grad` on the copies and the originals got nothing)."""
+    from esrganplus_amd import architecture as arch
+    nb = 1
+    sd = synth.rrdbnet_state_dict(nb=nb, seed=5)
+    x = synth.image_batch(4, 2, 3, 16, 24, name='dp.x').to(dev)
+    gy = synth.normal_like(4, 'dp.gy', (2, 3, 64, 96)).to(dev)
+
+    def grads(replicated):
+        net = arch.RRDBNet(3, 3, 64, nb).to(dev).eval()
+        net.load_state_dict(sd, strict=True)
+        run = torch.nn.parallel.replicate(net, [0])[0] if replicated else net
+        if replicated:
+            assert all(not p.is_leaf for p in run._convs()[1])
+        (run(x) * gy).sum().backward()
+        return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    ref, got = grads(False), grads(True)
+    assert len(ref) == len(got) == len(sd)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k

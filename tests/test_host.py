@@ -150,24 +150,71 @@ def test_data_parallel_replica_does_not_inherit_caches():
     assert net.__dict__['_conv_cache'] is not None and 'x' in net._plans
 
 
+def test_data_parallel_replica_takes_the_per_tensor_gradient_route():
+    """nn.DataParallel's replicas hold NON-LEAF copies of the weights (Broadcast outputs); assigning `.grad`
+    on them (the flat route) would drop G's gradients.  The flat route is only taken on leaf parameters, and a store that
+    was marked stale is zeroed before a per-tensor backward adds into it."""
+    import torch
+    from esrganplus_amd import architecture as arch, functional as F_
+    net = arch.RRDBNet(3, 3, 64, 1)
+    assert net.flat_param_grads and F_._flat_grad_route(net, net._convs()[1])
+    net.__dict__['_grad_proxy'] = torch.zeros(1, requires_grad=True)
+    rep = net._replicate_for_data_parallel()
+    assert '_grad_proxy' not in rep.__dict__ and '_grad_proxy' in net.__dict__
+    copies = [p * 1.0 for p in net._convs()[1]]                     # what replicate() swaps in: requires_grad, not leaf
+    assert all(c.requires_grad and not c.is_leaf for c in copies)
+    assert not F_._flat_grad_route(net, copies)
+    frozen = net._convs()[1]
+    frozen[3].requires_grad_(False)
+    assert not F_._flat_grad_route(net, frozen)
+    frozen[3].requires_grad_(True)
+    gs = net._grad_store(torch.device('cpu'))
+    gs['flat'].fill_(2.0)
+    for p_, v in zip(gs['params'], gs['views']):
+        p_.grad = v
+    assert net.mark_grads_stale() and gs['stale']
+    net._flush_stale_grads()
+    assert not gs['stale'] and float(gs['flat'].abs().sum()) == 0.0 and float(frozen[0].grad.abs().sum()) == 0.0
+
+
 def test_header_is_plain_c_and_structs_match_ctypes(tmp_path):
-    """include/esrgan_hip.h must be consumable from C (the boundary is a C ABI) and every struct the
-    Python binding mirrors must have the size the C compiler gives it."""
+    """include/esrgan_hip.h must be consumable from C (the boundary is a C ABI) and EVERY struct it declares must
+    have a ctypes mirror in _lib.py with the size AND the field offsets the C compiler gives it.  The struct list
+    is read from the header, so a struct added there without a mirror fails here."""
     import ctypes as C
+    import re
     import subprocess
     from esrganplus_amd import _lib as L
     hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'esrgan_hip.h')
     subprocess.check_call(['gcc', '-std=c99', '-fsyntax-only', '-x', 'c', hdr])
-    names = ['esr_g32', 'esr_conv', 'esr_pack', 'esr_pack_batch', 'esr_layout', 'esr_noise_fill', 'esr_wgrad',
-             'esr_unpermute', 'esr_bn', 'esr_pool', 'esr_linear', 'esr_adam', 'esr_resample', 'esr_op']
+    names = re.findall(r'^typedef struct (esr_\w+) \{', open(hdr).read(), flags=re.M)
+    assert len(names) >= 26 and {'esr_rdb_block', 'esr_rdb_chain', 'esr_rdb_wgrad', 'esr_rdb_wgrad_block', 'esr_l1_loss',
+                                 'esr_ragan_loss', 'esr_img_metrics', 'esr_amp', 'esr_frag_gather',
+                                 'esr_unperm_entry', 'esr_op'} <= set(names), names
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, 'structs of the header without a ctypes mirror: %s' % missing
+    prints = []
+    for n in names:
+        prints.append('printf("%s . %%zu\\n", sizeof(%s));' % (n, n))
+        for f in getattr(L, n)._fields_:
+            cname = f[0][:-1] if f[0].endswith('_') and not f[0].startswith('_') else f[0]   # in_ -> in
+            prints.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (n, f[0], n, cname))
     src = tmp_path / 'sz.c'
-    src.write_text('#include <stdio.h>\n#include "%s"\nint main(void){%s return 0;}\n' % (
-        hdr, ''.join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names)))
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void){%s return 0;}\n'
+                   % (hdr, '\n'.join(prints)))
     exe = tmp_path / 'sz'
     subprocess.check_call(['gcc', '-std=c99', str(src), '-o', str(exe)])
-    out = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
-    for n in names:
-        assert int(out[n]) == C.sizeof(getattr(L, n)), (n, out[n], C.sizeof(getattr(L, n)))
+    seen = 0
+    for line in subprocess.check_output([str(exe)]).decode().splitlines():
+        n, f, v = line.split()
+        st = getattr(L, n)
+        got = C.sizeof(st) if f == '.' else getattr(st, f).offset
+        assert int(v) == got, (n, f, int(v), got)
+        seen += 1
+    assert seen == len(prints)
+    # the members of the op union are exactly the header's
+    union_c = re.search(r'typedef struct esr_op \{.*?union \{(.*?)\} u;', open(hdr).read(), flags=re.S).group(1)
+    assert re.findall(r'(\w+);', union_c) == [f[0] for f in L._op_union._fields_]
 
 
 def test_committed_bench_line_follows_the_contract():
