@@ -87,6 +87,7 @@ class _RRDBNetBase(B._PlannedModule):
         """x: NCHW float32 in [0,1] on the MI355X -> [B, out_nc, 4H, 4W] float32.
         ``z`` (training mode only): explicit N(0,1) tensors, one [B,64,H,W] per noise layer in
         execution order, for bit-parity tests; default = fused Philox stream."""
+        self._join_pending()
         return run_rrdbnet(self, x, z)
 
 
@@ -242,6 +243,7 @@ class _SeqNet(B._PlannedModule):
         return y, lease
 
     def forward(self, x):
+        self._join_pending()
         need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         if not need:
             return self._run_forward(x, need_bwd=False)[0]
@@ -256,6 +258,7 @@ class _SeqNet(B._PlannedModule):
         detached."""
         if a.shape != b.shape:
             raise ValueError('forward_pair: the two batches must have one shape')
+        self._join_pending()
         n = a.shape[0]
         x = torch.cat([a, b])
         wantp = any(p.requires_grad for p in self.parameters())
@@ -287,6 +290,7 @@ class _SeqNet(B._PlannedModule):
             raise RuntimeError('forward_shared: a training-mode pass whose first operand requires a gradient')
         if a.shape != b.shape:
             raise ValueError('forward_shared: the two batches must have one shape')
+        self._join_pending()
         holder = []
         y = CN.SharedFirstFn.apply(a, b, self, holder)
         n = a.shape[0]

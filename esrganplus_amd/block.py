@@ -202,6 +202,21 @@ class _PlannedModule(nn.Module):
                 object.__setattr__(mod, '_weights_clean', False)
         return _Ctx()
 
+    # ---- work a training loop left in flight on ANOTHER stream (train.ESRGANPlusStep's pipelined form keeps the end of
+    # the D step, D's Adam and the weight packs on its side stream): the public entry points order it in front of the
+    # caller's stream, so a validation forward / a checkpoint between two pipelined steps sees finished weights ----
+    def _defer_to(self, event):
+        self.__dict__['_pending_ev'] = event
+
+    def _join_pending(self):
+        ev = self.__dict__.pop('_pending_ev', None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def state_dict(self, *a, **k):
+        self._join_pending()
+        return super().state_dict(*a, **k)
+
     def set_precision(self, precision):
         """'fp32': v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain) — the <=1e-3 parity path.
         'fp16': fp16 storage + v_mfma_f32_32x32x16_f16 with fp32 accumulation — the fast path."""
@@ -239,6 +254,7 @@ class _PlannedModule(nn.Module):
         replica = super()._replicate_for_data_parallel()
         replica.__dict__['_conv_cache'] = None
         replica.__dict__['_gstore'] = None
+        replica.__dict__.pop('_pending_ev', None)
         replica.__dict__.pop('_grad_proxy', None)     # its weights are non-leaf copies: per-tensor gradient outputs
         replica.__dict__['_wp'] = {}
         replica.__dict__['_plans'] = {}
@@ -392,7 +408,8 @@ class _PlannedModule(nn.Module):
             wp = E.WeightPack(self._conv_list(), self.precision, device, self._subpix_keys())
             self._wp[key] = wp
         clean = self.__dict__.get('_weights_clean', False) or self.__dict__.pop('_prepacked_fwd', False)
-        wp.ensure(E.current_stream(), force=self._force_repack or (self.training and not clean))
+        wp.ensure(E.current_stream(), force=self._force_repack or (self.training and not clean),
+                  full=self._force_repack)
         self._force_repack = False
         return wp
 

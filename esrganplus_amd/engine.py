@@ -160,9 +160,15 @@ class WeightPack:
         idx = sorted({0, n // 3, (2 * n) // 3, n - 1})
         return (n,) + tuple(c[i][1].data_ptr() for i in idx) + tuple(c[i][2].data_ptr() for i in idx if c[i][2] is not None)
 
-    def ensure(self, stream, force=False, record_sig=False):
+    FULL_CHECK_EVERY = 64     # calls between full pointer comparisons (an unsampled parameter re-pointed by hand:
+    #                            `p.data = t`, per-layer re-init, load_state_dict(assign=True) — ADVICE r04)
+
+    def ensure(self, stream, force=False, record_sig=False, full=False):
+        """full=True (the module saw load_state_dict / _apply / replicate): compare EVERY parameter's storage, not the
+        sampled fingerprint; the same happens on every FULL_CHECK_EVERY-th call."""
         fp = self._ptr_fingerprint()
-        if fp != getattr(self, '_fp', None):
+        self._calls = getattr(self, '_calls', 0) + 1
+        if full or self._calls % self.FULL_CHECK_EVERY == 0 or fp != getattr(self, '_fp', None):
             ptrs = tuple(p.data_ptr() for _, w, b in self.convs for p in (w, b) if p is not None)
             if ptrs != self._ptrs:
                 self._rebuild()
@@ -970,7 +976,9 @@ class DgradPack:
             lst[i][-1].data_ptr() if torch.is_tensor(lst[i][-1]) else lst[i][-1][0][0].data_ptr()
             for lst in (self.convs, self.gathers, self.ones) if lst for i in sorted({0, len(lst) // 2, len(lst) - 1}))
         ptrs = self._ptrs
-        if fp != getattr(self, '_fp', None):      # (sampled storages first, as WeightPack.ensure)
+        self._calls = getattr(self, '_calls', 0) + 1
+        if (self._calls % WeightPack.FULL_CHECK_EVERY == 0
+                or fp != getattr(self, '_fp', None)):      # (sampled storages first, as WeightPack.ensure)
             ptrs = tuple(w.data_ptr() for _, w in self.convs) + tuple(
                 pc[0].data_ptr() for _, _, pieces in self.gathers for pc in pieces) + tuple(w.data_ptr() for _, _, w in self.ones)
             self._fp = fp

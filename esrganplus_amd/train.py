@@ -58,7 +58,7 @@ class ESRGANPlusStep:
         # workgroups exchanging halos) that shares the chip with other launches runs at the pace of its most-delayed
         # tile, and the small launches slow each other 2-5x.  What mode 1 overlaps is what the default stream's
         # hardware queue lets through.
-        self.overlap = int(os.environ.get('ESR_TRAIN_OVERLAP', '1'))
+        self.overlap = self._knob_int('ESR_TRAIN_OVERLAP', '1', (0, 1, 2))
         # ESR_SHARED_D=0: the D step runs its own forward pair (round 3) instead of re-using the G step's pass
         self.shared_d = os.environ.get('ESR_SHARED_D', '1') != '0'
         # ESR_PREPACK=0: every network packs its weights at the start of its next training forward (round 3)
@@ -71,10 +71,22 @@ class ESRGANPlusStep:
         # netF(fake): forward, feature loss and input-gradient pass on the SIDE stream, next to netD's forward and its
         # G-step pass on the main stream (both hang off fake_H only; their two contributions to dL/d fake_H meet in one add)
         self.netf_side = os.environ.get('ESR_TRAIN_NETF_SIDE', '1') == '1'
-        self.d_when = os.environ.get('ESR_TRAIN_DSTEP', 'last')       # 'first' | 'mid' | 'last': see _step_manual
-        self.order = os.environ.get('ESR_TRAIN_ORDER', 'main_first')  # host enqueue order of netD's forward vs netF(fake)
+        self.d_when = self._knob('ESR_TRAIN_DSTEP', 'last', ('first', 'mid', 'last'))       # see _step_manual
+        # host enqueue order of netD's forward vs netF(fake)
+        self.order = self._knob('ESR_TRAIN_ORDER', 'main_first', ('main_first', 'side_first'))
         self.tail_side = os.environ.get('ESR_TRAIN_TAIL_SIDE', '1') == '1'
         self.overlap_d_step = self.overlap >= 1
+
+    @staticmethod
+    def _knob(name, default, allowed):
+        v = os.environ.get(name, default)
+        if v not in allowed:          # (a misspelt ESR_TRAIN_DSTEP used to mean: the D step never runs)
+            raise ValueError('%s=%r: expected one of %s' % (name, v, ', '.join(allowed)))
+        return v
+
+    @classmethod
+    def _knob_int(cls, name, default, allowed):
+        return int(cls._knob(name, default, tuple(str(a) for a in allowed)))
 
     def _side(self, dev, which=0):
         # ESR_STREAM_PROBE=1: streams PROBED to run concurrently with the caller's stream and with each other
@@ -122,7 +134,8 @@ class ESRGANPlusStep:
           * dL/d fake_H = d l_pix + d l_fea + d l_gan is never summed by a launch: the pixel loss writes the buffer, the
             last layout ops of netF's and netD's input-gradient passes ADD into it (esr_layout.accumulate);
           * netD's parameter gradients stay in its plan's flat buffer (the parameters' .grad are persistent views of
-            it), RRDBNet's go to its flat store: both optimizers consume them without a copy."""
+            it: FusedAdam reads them in place); RRDBNet's leave the backward as one flat buffer and reach its module-owned
+            store with ONE 67 MB device copy (`_deliver_flat_grads`), which FusedAdam then reads in place."""
         from . import functional as Fn
         from . import convnet as CN
         netG, netD, netF = self.netG, self.netD, self.netF
@@ -283,6 +296,7 @@ class ESRGANPlusStep:
                 if ov >= 1:
                     self._ev_tail = torch.cuda.Event()
                     self._ev_tail.record(side)
+                    self._defer_networks(self._ev_tail)
             else:
                 self.exG.wait()
                 self.optimizer_G.step(grad_scale=inv, scaler=None)
@@ -297,6 +311,7 @@ class ESRGANPlusStep:
                         netG.prepack(fwd=False, dgrad=True)
                     self._ev_tail = torch.cuda.Event()
                     self._ev_tail.record(side)
+                self._defer_networks(self._ev_tail)
         logs = dict(l_g_pix=l_g_pix, l_g_fea=l_g_fea, l_g_gan=l_g_gan, l_d_real=aux[2], l_d_fake=aux[3],
                     D_real=aux[0], D_fake=aux[1])
         if sync_log:
@@ -306,6 +321,20 @@ class ESRGANPlusStep:
         else:
             self.log = logs
         return self.log
+
+    def _defer_networks(self, ev):
+        # the networks' PUBLIC entry points (forward / forward_pair / state_dict) order this event in front of their
+        # caller's stream (block._PlannedModule._join_pending): a validation forward or a checkpoint between two steps
+        # sees the finished optimizer updates and weight packs without the loop having to call finish()
+        for net in (self.netG, self.netD):
+            if hasattr(net, '_defer_to'):
+                net._defer_to(ev)
+
+    def state_dict(self):
+        """The two optimizers' states (base_model.py:65-74 `save_training_state`), ordered behind whatever a pipelined
+        step left in flight."""
+        self.finish()
+        return {'optimizers': [self.optimizer_G.state_dict(), self.optimizer_D.state_dict()]}
 
     def finish(self):
         """Orders what a pipelined step (``step(..., sync_log=False)``) left on the side stream — the end of the D

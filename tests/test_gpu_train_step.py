@@ -471,3 +471,49 @@ def test_pipelined_steps_equal_synchronised_steps_bit_for_bit():
     assert a.keys() == b.keys()
     bad = [k for k in a if not torch.equal(a[k], b[k])]
     assert not bad, bad[:8]
+
+
+def test_networks_join_a_pipelined_steps_tail_at_their_public_entry_points(monkeypatch):
+    """after step(sync_log=False) the D step's end, D's Adam and the weight packs are still on the side
+    stream.  Without finish(), a validation forward / a checkpoint taken on the CURRENT stream right after the call must
+    still see the finished update: the networks' forward / state_dict order that tail in front of their caller's stream
+    (block._PlannedModule._join_pending).  Also: a misspelt schedule knob is refused instead of silently dropping the D step."""
+    from esrganplus_amd import architecture as arch, train
+    dev = torch.device('cuda:0')
+    sdG, sdD = synth.rrdbnet_state_dict(nb=1, seed=51), synth.discriminator_state_dict(seed=52)
+
+    def run(explicit_finish):
+        netG = arch.RRDBNet(3, 3, 64, 1).to(dev).train().set_precision('fp16')
+        netD = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision('fp16')
+        netF = arch.VGGFeatureExtractor(34, False, True, dev).to(dev).eval().set_precision('fp16')
+        netG.load_state_dict(sdG, strict=True)
+        netD.load_state_dict(sdD, strict=True)
+        netF.load_state_dict(synth.vgg19_state_dict(6, 34), strict=False)
+        st = train.ESRGANPlusStep(netG, netD, netF, loss_scale=1024.0)
+        for it in range(3):
+            lr = synth.image_batch(700 + it, 4, 3, 32, 32, name='join.lr').to(dev)
+            hr = synth.image_batch(800 + it, 4, 3, 128, 128, name='join.hr').to(dev)
+            st.step(lr, hr, sync_log=False)
+        assert netD.__dict__.get('_pending_ev') is not None and netG.__dict__.get('_pending_ev') is not None
+        if explicit_finish:
+            st.finish()
+            torch.cuda.synchronize()
+        # no finish(): the reads below are on the current stream, the tail is on the side stream
+        sd = {k: v.detach().clone() for k, v in netD.state_dict().items()}
+        if not explicit_finish:
+            assert netD.__dict__.get('_pending_ev') is None
+        netD.eval()
+        with torch.no_grad():
+            y = netD(hr).clone()
+        opt = st.state_dict()['optimizers'][1]['state']
+        m = {k: v['exp_avg'].detach().clone() for k, v in opt.items()}
+        torch.cuda.synchronize()
+        return sd, y, m
+
+    (sa, ya, ma), (sb, yb, mb) = run(True), run(False)
+    assert all(torch.equal(sa[k], sb[k]) for k in sa) and torch.equal(ya, yb)
+    assert ma.keys() == mb.keys() and all(torch.equal(ma[k], mb[k]) for k in ma)
+    monkeypatch.setenv('ESR_TRAIN_DSTEP', 'lsat')
+    with pytest.raises(ValueError):
+        train.ESRGANPlusStep(arch.RRDBNet(3, 3, 64, 1), arch.Discriminator_VGG_128(3, 64),
+                             arch.VGGFeatureExtractor(34, False, True, torch.device('cpu')))
