@@ -231,7 +231,7 @@ EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_p
            'esr_abi_version', 'esr_sizeof_op', 'esr_rdb_forward', 'esr_rdb_workspace_bytes', 'esr_rdb_weight_stream_bytes',
            'esr_rdb_max_tiles_per_image', 'esr_gather_fragments', 'esr_image_metrics', 'esr_wgrad_workspace_elems',
            'esr_l1_loss_forward', 'esr_ragan_loss_forward', 'esr_rdb_wgrad_run', 'esr_rdb_wgrad_workspace_elems', 'esr_rdb_backward',
-           'esr_rdb_mask_bytes', 'esr_rdb_check_abort', 'esr_debug_hold_cus']
+           'esr_rdb_mask_bytes', 'esr_rdb_check_abort', 'esr_debug_hold_cus', 'esr_debug_device_alias', 'esr_debug_chain_order_waits']
 
 _lib = None
 _lock = threading.Lock()
@@ -279,6 +279,8 @@ def lib():
         L.esr_rdb_weight_stream_bytes.argtypes = [C.c_int32]
         L.esr_rdb_mask_bytes.restype = C.c_size_t
         L.esr_rdb_mask_bytes.argtypes = [C.c_int32] * 3
+        L.esr_debug_chain_order_waits.restype = C.c_uint64
+        L.esr_debug_device_alias.argtypes = [C.c_int32]
         L.esr_rdb_wgrad_workspace_elems.restype = C.c_int64
         L.esr_rdb_wgrad_workspace_elems.argtypes = [C.c_int32] * 4
         for name, st in (('esr_conv_forward', esr_conv), ('esr_pack_conv_weights', esr_pack),

@@ -181,6 +181,10 @@ class _SeqNet(B._PlannedModule):
     def _dgrad_special(self):
         return {s['conv']: {'ts2': True} for s in self._spec() if 'conv' in s and s['stride'] == 2}
 
+    def _wants_param_grads(self):
+        # by attribute access (`_pspec`), not `parameters()`: that is empty on a nn.DataParallel replica
+        return any(t.requires_grad for _, t in self._pspec())
+
     def _run_forward(self, x, need_bwd, groups=1, bwd_B=None, dual=None):
         E.require_cuda(x, 'input')
         xin = x.detach().contiguous().float()
@@ -191,7 +195,7 @@ class _SeqNet(B._PlannedModule):
         st = E.current_stream()
         wp = self._weights(dev)
         dp = None
-        want_w = dual is not None or any(p.requires_grad for p in self.parameters())
+        want_w = dual is not None or self._wants_param_grads()
         # _per_call_weights (Discriminator_VGG_128_SN): the weights a backward needs are those of ITS forward, and a later
         # forward rewrites the module's weight buffers (a new power iteration) before that backward runs — such plans own
         # their input-gradient operands and head weights, snapshotted at forward time
@@ -244,7 +248,7 @@ class _SeqNet(B._PlannedModule):
 
     def forward(self, x):
         self._join_pending()
-        need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        need = torch.is_grad_enabled() and (x.requires_grad or self._wants_param_grads())
         if not need:
             return self._run_forward(x, need_bwd=False)[0]
         return CN.SeqNetFn.apply(x, self, *[t for _, t in self._pspec()])
@@ -261,7 +265,7 @@ class _SeqNet(B._PlannedModule):
         self._join_pending()
         n = a.shape[0]
         x = torch.cat([a, b])
-        wantp = any(p.requires_grad for p in self.parameters())
+        wantp = self._wants_param_grads()
         need = torch.is_grad_enabled() and (x.requires_grad or wantp)
         groups = 2 if self._has_bn else 1
         if not need:

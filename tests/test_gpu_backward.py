@@ -280,3 +280,22 @@ def test_data_parallel_replica_hands_gradients_back_to_the_original(dev):
     assert len(ref) == len(got) == len(sd)
     for k in ref:
         assert torch.equal(ref[k], got[k]), k
+
+
+def test_data_parallel_discriminator_replica_hands_gradients_back(dev):
+    """The same for networks.py:136-137 (netD under nn.DataParallel): a replica's `parameters()` is empty, its weights
+    are non-leaf attributes; the plan must still see that they want gradients and autograd must carry them back."""
+    from esrganplus_amd import architecture as arch
+    sd = synth.discriminator_state_dict(seed=9)
+    x = synth.image_batch(5, 2, 3, 128, 128, name='dpd.x').to(dev)
+
+    def grads(replicated):
+        net = arch.Discriminator_VGG_128(3, 64).to(dev).train()
+        net.load_state_dict(sd, strict=True)
+        run = torch.nn.parallel.replicate(net, [0])[0] if replicated else net
+        run(x).sum().backward()
+        return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    ref, got = grads(False), grads(True)
+    assert len(ref) == len(got) == len(list(arch.Discriminator_VGG_128(3, 64).parameters()))
+    for k in ref:
+        assert torch.allclose(ref[k], got[k], rtol=1e-5, atol=1e-6), k
