@@ -49,7 +49,6 @@
 // launches and requires bit-equal results run to run.
 #pragma once
 #include <cstdlib>
-#include <atomic>
 #include <mutex>
 
 #include "mfma_tile.h"
@@ -2227,19 +2226,16 @@ if constexpr (DIR == 2) {
 }
 
 // ---- host-side helpers shared by the three translation units
-// CUs of the CURRENT device (cached per device: a process may drive several — nn.DataParallel)
+int g_num_cus = 0;
+std::once_flag g_cu_once;
 int num_cus() {
-  static std::atomic<int> cached[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
-  int v = cached[dev].load(std::memory_order_relaxed);
-  if (v <= 0) {
+  std::call_once(g_cu_once, [] {
+    int dev = 0;
     hipDeviceProp_t prop;
-    v = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
-    if (v <= 0) v = 256;
-    cached[dev].store(v, std::memory_order_relaxed);
-  }
-  return v;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
+    if (g_num_cus <= 0) g_num_cus = 256;
+  });
+  return g_num_cus;
 }
 
 }  // namespace

@@ -31,6 +31,21 @@ int esr_bookkeeping_device() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0) { (void)hipGetLastError(); dev = 0; }
   return dev % ESR_MAX_DEV;
 }
+// CUs of the CURRENT device, cached per device (rdb_chain_kernel.h's num_cus() caches the first device's count per
+// process; a process may drive several devices)
+static int num_cus_dev() {
+  static std::atomic<int> cached[ESR_MAX_DEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ESR_MAX_DEV) { (void)hipGetLastError(); return 256; }
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v <= 0) {
+    hipDeviceProp_t prop;
+    v = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+    if (v <= 0) v = 256;
+    cached[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 extern "C" int esr_debug_device_alias(int32_t alias) {
   const int old = t_dev_alias;
   t_dev_alias = alias;
@@ -200,7 +215,7 @@ extern "C" size_t esr_rdb_mask_bytes(int32_t B, int32_t H, int32_t W) {
   return (size_t)B * ((H + 15) / 16) * ((W + TW - 1) / TW) * 8192;
 }
 
-extern "C" int esr_rdb_max_tiles_per_image(void) { return num_cus(); }
+extern "C" int esr_rdb_max_tiles_per_image(void) { return num_cus_dev(); }
 
 namespace {
 int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, int want_mode) {
@@ -239,7 +254,7 @@ int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, i
       return ESR_ERR_INVALID;
     }
   }
-  const int cus = num_cus();
+  const int cus = num_cus_dev();
   const int rows = rows_per_wave(p, cus);
   const int tiles_x = (p->W + TW - 1) / TW, tiles_y = (p->H + 4 * rows - 1) / (4 * rows);
   const int tpi = tiles_x * tiles_y, ntiles = tpi * p->B;
