@@ -226,6 +226,18 @@ def train_object(args, world, rank, dev, dist, steps, warmup, kernels=True):
                    'Adam x2, loss scale 1024), batch %d of 32x32 LR -> 128x128 HR, %s (BASELINE configs[2]); pipelined calls '
                    '(step(sync_log=False): nothing read back between steps), K steps to a device synchronise'
                    % (tb, args.precision)}
+    # the reference's loop reads seven .item()s per step (SRRaGAN_model.py:171-186): the same step with the default,
+    # synchronous call (everything ordered on the current stream, the losses read back as floats every step)
+    st.finish()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        st.step(lr, hr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st.step(lr, hr)
+    torch.cuda.synchronize()
+    res['ms_per_step_sync_log'] = round((time.perf_counter() - t0) / steps * 1e3, 3)
     if kernels and args.precision == 'fp16':
         k = generator_kernel_times(st.netG, lr, tb, 32)
         if k:
@@ -322,6 +334,30 @@ def dp_train_object(args, world, rank, dev, dist, steps=20, warmup=3):
                     '(BASELINE configs[3])' % tb}
 
 
+def dp_gtrain_object(args, world, rank, dev, dist, steps=5, warmup=2):
+    """BASELINE configs[4] at world > 1: the mixed-tile generator step (16x128^2 + 8x192^2 + 4x256^2 LR per rank and step,
+    noise on, L1, Adam) data-parallel over the process group — G's gradients all-reduced in buckets INSIDE each bucket's
+    backward (per RRDB), three exchanges of 67.4 MB per step — next to this process's own no-exchange figure: per-bucket
+    ms, bytes all-reduced, the time the compute stream spent blocked on the exchanges (HIP events around the waits)."""
+    dt1, per1, lr_pix = measure_gtrain(args, world, rank, dev, dist, steps, warmup, data_parallel=False)
+    torch.cuda.empty_cache()
+    rep = {}
+    dtn, pern, _ = measure_gtrain(args, world, rank, dev, dist, steps, warmup, data_parallel=True, report=rep)
+    t = torch.tensor([rep['exposed_ms_per_step']], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    f = gtrain_fields(dtn, pern, lr_pix, world)
+    return {'n_ranks': dist.get_world_size(), 'backend': dist.get_backend(),
+            'ms_per_step': f['ms_per_step'], 'ms_per_step_no_exchange': round(dt1 * 1e3, 3),
+            'value': f['value'], 'unit': 'HR-Mpix/s', 'scaling': 'weak',
+            'buckets_ms': {k: v['ms'] for k, v in f['buckets'].items()},
+            'buckets_ms_no_exchange': {'%dx%d^2' % b: round(ms, 3) for b, ms in zip(GTRAIN_BUCKETS, per1)},
+            'allreduce_bytes_per_step': int(rep['bytes_per_step']), 'allreduce_calls_per_step': rep['calls_per_step'],
+            'expected_allreduce_bytes_per_step': 4 * rep['n_params'] * len(GTRAIN_BUCKETS),
+            'exposed_comm_ms_per_step': round(float(t.item()), 3), 'steps': steps, 'warmup': warmup,
+            'what': 'nESRGAN+ generator (noise on) fwd+bwd+Adam, L1 loss, 16x128^2 + 8x192^2 + 4x256^2 LR tiles per rank and '
+                    'step, fp16, gradients all-reduced per bucket inside the backward (BASELINE configs[4])'}
+
+
 def train_bench(args, world, rank, dev, dist):
     """BASELINE configs[2]/[3]: full ESRGAN+ train step (RRDBNet + Discriminator_VGG_128 + VGG19
     feature loss, Adam x2; train_ESRGANplus.json), per-GPU batch 16 of 32x32 LR -> 128x128 HR, data
@@ -350,24 +386,29 @@ def train_bench(args, world, rank, dev, dist):
 GTRAIN_BUCKETS = ((16, 128), (8, 192), (4, 256))
 
 
-def measure_gtrain(args, world, rank, dev, dist, steps, warmup):
+def measure_gtrain(args, world, rank, dev, dist, steps, warmup, data_parallel=None, report=None):
     """BASELINE configs[4]: the noise-injection generator in TRAIN mode (noise
     on), forward + backward + Adam with an L1 pixel loss, on mixed LR tiles bucketed by size
     (128/192/256 -> HR 512/768/1024).  The reference's discriminators only accept HR 96/128/192
     crops, so at these sizes there is no GAN step to reproduce: generator-only, as SURVEY.md reads it.
     One bench "step" = one optimizer iteration per bucket (16x128^2, 8x192^2, 4x256^2 LR per GPU: ~45 GB of saved
     activations, sized for 288 GB HBM).  Returns (seconds per step, per-bucket ms from HIP events, lr pixels)."""
-    from esrganplus_amd import architecture as arch, synth, dp as DP, losses as LS
+    from esrganplus_amd import architecture as arch, synth, dp as DP, losses as LS, functional as Fn
     prec = args.precision
+    dp_on = (world > 1) if data_parallel is None else bool(data_parallel)
     netG = arch.RRDBNet(3, 3, 64, NB).to(dev).train().set_precision(prec)
     netG.load_state_dict(synth.rrdbnet_state_dict(NB, 0, gain=0.5))
-    if world > 1:
+    if dp_on:
         DP.broadcast_parameters(netG)
     from esrganplus_amd.optim import FusedAdam
     opt = FusedAdam(netG.parameters(), lr=1e-4, betas=(0.9, 0.999))
-    ex = DP.GradExchange(netG)
-    scale = torch.full((), 1024.0 if prec == 'fp16' else 1.0, dtype=torch.float32, device=dev)
-    inv = 1.0 / float(scale)
+    ex = DP.GradExchange(netG, enabled=dp_on, measure=dp_on)
+    S = 1024.0 if prec == 'fp16' else 1.0
+    scale = torch.full((), S, dtype=torch.float32, device=dev)
+    inv = 1.0 / S
+    # ESR_GTRAIN_MANUAL=0: the bucket loop through autograd (netG(lr), losses.l1_loss, torch.autograd.backward) — the
+    # same launch lists plus ~290 torch glue launches per step; default: driven directly, as train.ESRGANPlusStep does
+    manual = os.environ.get('ESR_GTRAIN_MANUAL', '1') != '0' and netG.flat_param_grads
     buckets = []
     for k, (n, sz) in enumerate(GTRAIN_BUCKETS):
         lr = synth.image_batch(400 + 10 * rank + k, n, 3, sz, sz, name='bench.glr').to(dev)
@@ -376,18 +417,29 @@ def measure_gtrain(args, world, rank, dev, dist, steps, warmup):
     lr_pix = sum(l.shape[0] * l.shape[2] * l.shape[3] for l, _ in buckets)
     marks = []
 
+    gys = [torch.empty_like(h) for _, h in buckets] if manual else None
+
     def step(timed=False):
-        for lr, hr in buckets:
+        for k, (lr, hr) in enumerate(buckets):
             if timed:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 marks.append(e)
-            opt.zero_grad(set_to_none=True)
-            loss = LS.l1_loss(netG(lr), hr)
-            torch.autograd.backward([loss], [scale])
+            if not netG.mark_grads_stale():
+                opt.zero_grad(set_to_none=True)
+            if manual:
+                with torch.no_grad():
+                    fake, stG = Fn.rrdbnet_train_forward(netG, lr)
+                    loss = LS.l1_raw(fake, hr, 1.0, grad_out=gys[k], grad_scale=S)     # loss + its gradient: one launch
+                    del fake
+                    Fn.rrdbnet_train_backward(netG, stG, gys[k])
+            else:
+                loss = LS.l1_loss(netG(lr), hr)
+                torch.autograd.backward([loss], [scale])
             ex.start()
             ex.wait()
             opt.step(grad_scale=inv)
+            netG.prepack(fwd=True, dgrad=True)           # the next bucket's weight packs, right behind the update
         if timed:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
@@ -397,12 +449,17 @@ def measure_gtrain(args, world, rank, dev, dist, steps, warmup):
     for _ in range(max(warmup, 1)):
         step()
     _sync_all(dist)
+    ex.reset_counters()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step(True)
     torch.cuda.synchronize()
     elapsed = _max_over_ranks(time.perf_counter() - t0, dist, dev)
     assert torch.isfinite(loss).all()
+    if report is not None:
+        report.update(calls_per_step=ex.calls / steps, bytes_per_step=ex.bytes / steps,
+                      exposed_ms_per_step=ex.exposed_ms() / steps, manual=bool(manual),
+                      n_params=sum(p.numel() for p in netG.parameters()))
     nbk = len(buckets) + 1
     per = [0.0] * len(buckets)
     for s_ in range(steps):
@@ -422,6 +479,7 @@ def gtrain_fields(dt, per, lr_pix, world=1):
                                    'frac_of_f16_mfma_peak': round(fl / (ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
                                    'tiles_16x32_per_image': tiles, 'workgroups': n * tiles}
     return {'ms_per_step': round(dt * 1e3, 3), 'value': round(world * 16 * lr_pix / 1e6 / dt, 3), 'unit': 'HR-Mpix/s',
+            'buckets_per_gpu_step': ' + '.join('%dx%d^2' % b for b in GTRAIN_BUCKETS),
             'tflops_per_gpu': round(step_flops / dt / 1e12, 1),
             'frac_of_f16_mfma_peak': round(step_flops / dt / 1e12 / PEAK_F16_TFLOPS, 4), 'buckets': bk}
 
@@ -452,18 +510,20 @@ def fwd_bwd_probe(args, dev, steps=20):
     the forward headline, not instead of it (north_star's roofline target is on the forward).  Carries its own
     `roofline` object: the three fused dense-block kernels (training forward chain, backward chain, weight
     gradients) timed with HIP events on the launch stream, the slowest of them named as the dominant kernel."""
-    import torch.nn.functional as F
-    from esrganplus_amd import architecture as arch, synth
+    from esrganplus_amd import architecture as arch, synth, losses as LS
     netG = arch.RRDBNet(3, 3, 64, NB).to(dev).train().set_precision('fp16')
     netG.load_state_dict(synth.rrdbnet_state_dict(NB, 0, gain=0.5))
     lr = synth.image_batch(300, args.batch, 3, args.lr, args.lr, name='bench.fb.lr').to(dev)
     hr = synth.image_batch(301, args.batch, 3, 4 * args.lr, 4 * args.lr, name='bench.fb.hr').to(dev)
 
+    scale = torch.full((), 1024.0, dtype=torch.float32, device=dev)
+
     def step():
-        for q in netG.parameters():
-            q.grad = None
-        loss = F.l1_loss(netG(lr), hr)
-        (loss * 1024.0).backward()
+        if not netG.mark_grads_stale():
+            for q in netG.parameters():
+                q.grad = None
+        loss = LS.l1_loss(netG(lr), hr)                  # the library's loss kernel (csrc/loss_kernels.hip), one launch
+        torch.autograd.backward([loss], [scale])
         return loss
 
     for _ in range(3):
@@ -504,10 +564,15 @@ def main():
                     help="'forward' = BASELINE configs[1] (the headline metric); 'train' = configs[2]/[3]: "
                          'full ESRGAN+ step, batch 16 of 32x32 LR per GPU, DP over RCCL; '
                          "'gtrain' = configs[4]: noise-on generator fwd+bwd+Adam on mixed 128/192/256 LR tiles")
+    ap.add_argument('--gtrain-buckets', default=','.join('%dx%d' % b for b in GTRAIN_BUCKETS),
+                    help='configs[4] buckets as COUNTxLR_SIZE per GPU and step (default: the benchmarked 16x128,8x192,4x256; '
+                         'smaller ones only for dry runs with several ranks on one GPU)')
     ap.add_argument('--precision', choices=['fp16', 'fp32'], default='fp16')
     ap.add_argument('--train-batch', type=int, default=16,
                     help="--mode train: LR tiles per GPU per step (the reference's config uses 16)")
     args = ap.parse_args()
+    global GTRAIN_BUCKETS
+    GTRAIN_BUCKETS = tuple(tuple(int(v) for v in b.split('x')) for b in args.gtrain_buckets.split(','))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -646,8 +711,11 @@ def main():
         net = None
         torch.cuda.empty_cache()
         dpo = dp_train_object(args, world, rank, dev, dist, steps=args.dp_steps)
+        torch.cuda.empty_cache()
+        dpg = dp_gtrain_object(args, world, rank, dev, dist, steps=max(2, args.dp_steps // 4))
         if rank == 0:
             res['dp_train'] = dpo
+            res['dp_gtrain'] = dpg
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -483,6 +483,7 @@ def test_networks_join_a_pipelined_steps_tail_at_their_public_entry_points(monke
     sdG, sdD = synth.rrdbnet_state_dict(nb=1, seed=51), synth.discriminator_state_dict(seed=52)
 
     def run(explicit_finish):
+        torch.manual_seed(4321)                       # (the Philox seeds of the noise layers are drawn from torch's generator)
         netG = arch.RRDBNet(3, 3, 64, 1).to(dev).train().set_precision('fp16')
         netD = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision('fp16')
         netF = arch.VGGFeatureExtractor(34, False, True, dev).to(dev).eval().set_precision('fp16')
