@@ -549,6 +549,7 @@ def fwd_bwd_probe(args, dev, steps=20):
 
 
 def main():
+    global GTRAIN_BUCKETS
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -571,7 +572,6 @@ def main():
     ap.add_argument('--train-batch', type=int, default=16,
                     help="--mode train: LR tiles per GPU per step (the reference's config uses 16)")
     args = ap.parse_args()
-    global GTRAIN_BUCKETS
     GTRAIN_BUCKETS = tuple(tuple(int(v) for v in b.split('x')) for b in args.gtrain_buckets.split(','))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
