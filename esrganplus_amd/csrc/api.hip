@@ -1,6 +1,7 @@
 // api.hip — error plumbing, geometry helper and the op-list runner of libesrgan_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <mutex>
 
 #include "common.h"
@@ -46,18 +47,22 @@ extern "C" void esr_g32_dims(int32_t H, int32_t W, int32_t* Hp, int32_t* Wp) {
 }
 
 // Side streams for ESR_OPF_SIDE runs: one non-blocking stream + two fork/join event pairs (+ NFREE streams for the
-// free runs) per (device, CALLER STREAM), created on first use — the only device resources the library ever owns.
-// Keyed by the caller's stream, not only by the device: the fork / join events are re-recorded by every esr_run_ops
-// call, so two threads driving two networks on two streams of one device must not share them (an event re-recorded
-// by the other thread between this thread's record and its wait would order the side run after the wrong work).
+// free runs) per DEVICE, created on first use — the only device resources the library ever owns.  Callers on several
+// streams / threads of one device share them: a fork is {record the event on the caller's stream, make the side stream
+// wait for it}, done under the state's mutex so that no other caller re-records the event in between (a join event
+// re-recorded by another caller only makes this caller wait for more of the in-order side stream: safe).
+// ESR_SIDE_PER_STREAM=1 gives every caller stream its own set instead: measured SLOWER on the train step (7.75 vs
+// 7.24 ms: more streams in flight, see train.py on stream counts), kept as a knob.
 int esr_bookkeeping_device();                    // rdb_fused.hip
 namespace {
 constexpr int NFREE = 3;   // streams for ESR_OPF_SIDE_FREE runs (independent weight gradients, several at once)
-struct SideState { hipStream_t owner; hipStream_t stream; hipEvent_t fork[2], join[2]; hipStream_t xs[NFREE]; hipEvent_t xfork, xjoin[NFREE]; SideState* next; };
+struct SideState { std::mutex mu; hipStream_t owner; hipStream_t stream; hipEvent_t fork[2], join[2]; hipStream_t xs[NFREE]; hipEvent_t xfork, xjoin[NFREE]; SideState* next; };
 SideState* side_state(hipStream_t owner) {
   static std::mutex mu;
   static SideState* per_dev[64] = {};
   const int dev = esr_bookkeeping_device();
+  static const bool per_stream = [] { const char* e = getenv("ESR_SIDE_PER_STREAM"); return e && atoi(e) != 0; }();
+  if (!per_stream) owner = nullptr;              // default: one side state per device
   std::lock_guard<std::mutex> lk(mu);
   for (SideState* s = per_dev[dev]; s; s = s->next)
     if (s->owner == owner) return s;
@@ -121,8 +126,11 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
           SideState* ss = side_state((hipStream_t)stream);
           if (!ss) return ESR_ERR_LAUNCH;
           const int q = nfree % NFREE;
-          ESR_HIP(hipEventRecord(ss->xfork, (hipStream_t)stream));
-          ESR_HIP(hipStreamWaitEvent(ss->xs[q], ss->xfork, 0));
+          {
+            std::lock_guard<std::mutex> lk(ss->mu);
+            ESR_HIP(hipEventRecord(ss->xfork, (hipStream_t)stream));
+            ESR_HIP(hipStreamWaitEvent(ss->xs[q], ss->xfork, 0));
+          }
           rc = esr_conv_wgrad_multi(run, m, (esr_stream_t)ss->xs[q]);
           ESR_HIP(hipEventRecord(ss->xjoin[q], ss->xs[q]));
           ++nfree;
@@ -133,8 +141,11 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
           if (!ss) return ESR_ERR_LAUNCH;
           hipStream_t main_st = (hipStream_t)stream;
           if (nside > 0) ESR_HIP(hipStreamWaitEvent(main_st, ss->join[(nside - 1) & 1], 0));
-          ESR_HIP(hipEventRecord(ss->fork[nside & 1], main_st));
-          ESR_HIP(hipStreamWaitEvent(ss->stream, ss->fork[nside & 1], 0));
+          {
+            std::lock_guard<std::mutex> lk(ss->mu);
+            ESR_HIP(hipEventRecord(ss->fork[nside & 1], main_st));
+            ESR_HIP(hipStreamWaitEvent(ss->stream, ss->fork[nside & 1], 0));
+          }
           rc = esr_conv_wgrad_multi(run, m, (esr_stream_t)ss->stream);
           ESR_HIP(hipEventRecord(ss->join[nside & 1], ss->stream));
           ++nside;
@@ -162,8 +173,11 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
         if (!ss) return ESR_ERR_LAUNCH;
         hipStream_t main_st = (hipStream_t)stream;
         if (nside > 0) ESR_HIP(hipStreamWaitEvent(main_st, ss->join[(nside - 1) & 1], 0));
-        ESR_HIP(hipEventRecord(ss->fork[nside & 1], main_st));
-        ESR_HIP(hipStreamWaitEvent(ss->stream, ss->fork[nside & 1], 0));
+        {
+          std::lock_guard<std::mutex> lk(ss->mu);
+          ESR_HIP(hipEventRecord(ss->fork[nside & 1], main_st));
+          ESR_HIP(hipStreamWaitEvent(ss->stream, ss->fork[nside & 1], 0));
+        }
         rc = esr_rdb_wgrad_run(&ops[i].u.rdb_wgrad, (esr_stream_t)ss->stream);
         ESR_HIP(hipEventRecord(ss->join[nside & 1], ss->stream));
         ++nside;

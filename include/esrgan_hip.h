@@ -614,9 +614,11 @@ int esr_rdb_check_abort(void);
  * that has started adds 1 to *started (optional). */
 int esr_debug_hold_cus(int32_t n_workgroups, const uint32_t* release, uint32_t max_ms, uint32_t* started, esr_stream_t stream);
 /* Library state and devices.  What the library keeps between calls — the chain launches in flight (the ordering above),
- * the abort word, the side streams of ESR_OPF_SIDE runs — is keyed by the CURRENT DEVICE of the calling thread (the side
- * streams additionally by the caller's stream): nn.DataParallel's one-thread-per-device replicas (networks.py:105-107)
- * never wait for, or report the aborts of, each other's devices.
+ * the abort word, the side streams of ESR_OPF_SIDE runs — is keyed by the CURRENT DEVICE of the calling thread:
+ * nn.DataParallel's one-thread-per-device replicas (networks.py:105-107) never wait for, or report the aborts of, each
+ * other's devices.  Callers on several threads / streams of ONE device share that device's side streams; their fork
+ * (event record + wait) is atomic under a per-device mutex, so the sharing is safe (ESR_SIDE_PER_STREAM=1: one set of
+ * side streams per caller stream instead — measured slower).
  * Diagnostics for tests on a one-GPU box: esr_debug_device_alias makes the CALLING THREAD's bookkeeping use `alias` in
  * place of hipGetDevice() (alias < 0: back to the real device; returns the previous alias); launches still go to the
  * real device.  esr_debug_chain_order_waits: cross-stream event waits the chain ordering has inserted so far. */
