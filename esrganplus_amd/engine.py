@@ -865,6 +865,18 @@ class StreamOrder:
         self.last = cur.cuda_stream
 
 
+def bwd_chain_split(B, H, W, nb):
+    """Launches the fused backward chain of a training plan is cut into (runs of whole RRDBs; 1 = one launch).  More
+    than one only when the chain's grid leaves at least half of the CUs idle (4-row tiles, at most cus / 2 of them):
+    the weight gradients of a run then execute under the next run's chain.  ESR_BWD_SPLIT = n forces n (1: off)."""
+    env = os.environ.get('ESR_BWD_SPLIT')
+    if env is not None:
+        return max(1, min(int(env), nb))
+    cus = L.lib().esr_rdb_max_tiles_per_image()
+    tiles4 = B * ((H + 3) // 4) * ((W + 31) // 32)
+    return min(4, nb) if 2 * tiles4 <= cus else 1
+
+
 def use_rdb_wgrad():
     """fp16 training plans: the six weight gradients of a dense block as ONE esr_rdb_wgrad pass over its saved
     concat buffer and gradient concat (csrc/rdb_wgrad.hip) instead of six esr_conv_wgrad problems
@@ -1495,20 +1507,16 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         ws_bytes = L.lib().esr_rdb_workspace_bytes(B, H, W)
         bws = torch.zeros((ws_bytes + 3) // 4, dtype=torch.int32, device=device)
         TP.bufs.extend([bblk_t, bws])
-        ch = L.esr_rdb_chain()
-        ch.dtype, ch.B, ch.H, ch.W, ch.mode = dt_e, B, H, W, 2
-        ch.n_blocks, ch.noise_mode, ch.sigma, ch.save_dense = len(border), L.NOISE_OFF, SIGMA, 1
-        ch.dense = Qs[0].view(64, 128)
-        ch.blocks, ch.workspace, ch.workspace_bytes = bblk_t.data_ptr(), bws.data_ptr(), ws_bytes
-        TP.bwd_chain_ops.append(Bk.add(L.OP_RDB_CHAIN_BWD, 'rdb_chain', ch))
-        TP.bwd_chain_ws = bws
-        # weight gradients: one pass over all blocks — or, data-parallel, one per RRDB so that each RRDB's slice of the
-        # flat gradient buffer goes to its all-reduce while the next pass runs
-        groups = [wblocks] if not segmented else [wblocks[k:k + nj] for k in range(0, len(wblocks), nj)]
-        n_max = max(len(g_) for g_ in groups)
-        warena = torch.empty(int(L.lib().esr_rdb_wgrad_workspace_elems(B, H, W, n_max)), dtype=torch.float32, device=device)
-        TP.bufs.append(warena)
-        for gi, grp in enumerate(groups):
+        def chain_op(k0, k1):
+            ch = L.esr_rdb_chain()
+            ch.dtype, ch.B, ch.H, ch.W, ch.mode = dt_e, B, H, W, 2
+            ch.n_blocks, ch.noise_mode, ch.sigma, ch.save_dense = k1 - k0, L.NOISE_OFF, SIGMA, 1
+            ch.dense = Qs[k0].view(64, 128)
+            ch.blocks = bblk_t.data_ptr() + k0 * C.sizeof(L.esr_rdb_block)
+            ch.workspace, ch.workspace_bytes = bws.data_ptr(), ws_bytes
+            TP.bwd_chain_ops.append(Bk.add(L.OP_RDB_CHAIN_BWD, 'rdb_chain', ch))
+
+        def wgrad_op(grp, arena, flags=0):
             arr_ = (L.esr_rdb_wgrad_block * len(grp))(*grp)
             wt = torch.frombuffer(bytearray(bytes(arr_)), dtype=torch.uint8).to(device)
             TP.bufs.append(wt)
@@ -1516,10 +1524,37 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             rw.dtype, rw.B, rw.H, rw.W = dt_e, B, H, W
             rw.n_blocks, rw.tap_major, rw.scale5, rw.scale = len(grp), 1, 0.2, 1.0
             rw.blocks = wt.data_ptr()
-            rw.partial, rw.partial_elems = warena.data_ptr(), warena.numel()
-            Bk.add(L.OP_RDB_WGRAD, 'rdb_wgrad', rw)
-            if segmented:
-                close_segment(['model.1.sub.%d' % (nb - 1 - gi)])
+            rw.partial, rw.partial_elems = arena.data_ptr(), arena.numel()
+            Bk.add(L.OP_RDB_WGRAD, 'rdb_wgrad', rw, flags=flags)
+
+        TP.bwd_chain_ws = bws
+        nsplit = 1 if segmented else bwd_chain_split(B, H, W, nb)
+        if nsplit > 1:
+            # Small grids (the reference's training crops: 16 x 32^2 LR = 128 four-row tiles on 256 CUs): the chain leaves
+            # half of the chip idle and the weight gradients — 0.7 ms behind a 1.9 ms chain — sit on the step's critical
+            # path.  The chain runs as `nsplit` launches over runs of whole RRDBs, and the weight gradients of a run go
+            # to the SIDE stream right behind its chain launch: they execute on the idle CUs under the next run's chain
+            # (block n reads its g_t from Qs[n], which the previous launch's last block wrote: launch boundaries are
+            # free of semantics).  Only the last run's weight gradients are left behind the chain.
+            per_run = (nb + nsplit - 1) // nsplit
+            warena = torch.empty(int(L.lib().esr_rdb_wgrad_workspace_elems(B, H, W, per_run * nj)), dtype=torch.float32, device=device)
+            TP.bufs.append(warena)
+            for r0 in range(0, nb, per_run):
+                k0, k1 = r0 * nj, min(nb, r0 + per_run) * nj
+                chain_op(k0, k1)
+                wgrad_op(wblocks[k0:k1], warena, flags=_SIDE)
+        else:
+            chain_op(0, len(border))
+            # weight gradients: one pass over all blocks — or, data-parallel, one per RRDB so that each RRDB's slice of the
+            # flat gradient buffer goes to its all-reduce while the next pass runs
+            groups = [wblocks] if not segmented else [wblocks[k:k + nj] for k in range(0, len(wblocks), nj)]
+            n_max = max(len(g_) for g_ in groups)
+            warena = torch.empty(int(L.lib().esr_rdb_wgrad_workspace_elems(B, H, W, n_max)), dtype=torch.float32, device=device)
+            TP.bufs.append(warena)
+            for gi, grp in enumerate(groups):
+                wgrad_op(grp, warena)
+                if segmented:
+                    close_segment(['model.1.sub.%d' % (nb - 1 - gi)])
     for i in range(nb - 1 if not chain else -1, -1, -1):
         for j in range(nj - 1, -1, -1):
             bf, ax = S[i][j], AUX[i][j]

@@ -182,3 +182,34 @@ def test_fp16_noise_on_training_chains_match_the_oracle(dev, monkeypatch, cls_na
     assert ey <= 2e-3, ey
     assert worst <= lw, (wk, worst, lw)
     assert np.mean(errs) <= lm, (np.mean(errs), lm)
+
+
+@pytest.mark.parametrize('cls_name', ['RRDBNet', 'RRDB_Net'])
+def test_backward_chain_split_into_runs_is_bit_identical(dev, monkeypatch, cls_name):
+    """Training crops (16 x 32^2 LR: 128 four-row tiles) run the fused backward as several chain launches over runs of
+    RRDBs, each followed by its weight-gradient pass on the side stream under the next run's chain
+    (engine.bwd_chain_split).  Launch boundaries carry no semantics: every gradient equals the one-launch form bit for
+    bit, noise on (same Philox key)."""
+    from esrganplus_amd import architecture as arch
+    nb = 5
+    sd = synth.rrdbnet_state_dict(nb=nb, seed=71, gain=0.7)
+    x = synth.image_batch(71, 16, 3, 32, 32, name='split.x').to(dev)
+    gy = synth.normal_like(72, 'split.gy', (16, 3, 128, 128)).to(dev)
+    res = {}
+    for split in ('1', '4', '5', 'auto'):
+        if split == 'auto':
+            monkeypatch.delenv('ESR_BWD_SPLIT', raising=False)
+        else:
+            monkeypatch.setenv('ESR_BWD_SPLIT', split)
+        net = getattr(arch, cls_name)(3, 3, 64, nb).to(dev).train().set_precision('fp16')
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(99)
+        (net(x) * gy).sum().backward()
+        torch.cuda.synchronize()
+        tps = [tp for pool in net._plans.values() if isinstance(pool, list) for tp in pool if getattr(tp, 'bwd_chain_ops', None)]
+        assert len(tps) == 1
+        res[split] = (len(tps[0].bwd_chain_ops), {k: p.grad.clone() for k, p in net.named_parameters()})
+    assert res['1'][0] == 1 and res['4'][0] == 3 and res['5'][0] == 5 and res['auto'][0] == 3     # runs of ceil(5 / 4) = 2 RRDBs
+    for split in ('4', '5', 'auto'):
+        bad = [k for k, g in res['1'][1].items() if not torch.equal(g, res[split][1][k])]
+        assert not bad, (split, bad[:6])
