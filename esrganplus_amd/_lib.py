@@ -208,7 +208,8 @@ class esr_rdb_wgrad_block(C.Structure):
 class esr_rdb_wgrad(C.Structure):
     _fields_ = [('dtype', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
                 ('n_blocks', C.c_int32), ('tap_major', C.c_int32), ('scale5', C.c_float), ('scale', C.c_float),
-                ('blocks', C.c_void_p), ('partial', C.c_void_p), ('partial_elems', C.c_int64)]
+                ('blocks', C.c_void_p), ('partial', C.c_void_p), ('partial_elems', C.c_int64),
+                ('max_workgroups', C.c_int32), ('_pad', C.c_int32)]
 
 
 class _op_union(C.Union):

@@ -126,7 +126,57 @@ struct KArgs {
   int strips, igroups, ipw;       // column strips per image, image groups, images per task
   int ntasks;                     // per block: 4 sets x strips x igroups
   int64_t slot_stride;            // floats per slot (SLOT_ELEMS rounded up to 4)
+  int total;                      // tasks of the launch (n_blocks x ntasks): workgroup w runs w, w + grid, w + 2 grid, ...
+  uint32_t* pace;                 // NULL, or one step counter per workgroup (zero at launch): see Pace
 };
+
+// ---- lock step of the four sets of a chunk (round 5) ------------------------------------------------------------------
+// The four workgroups that run the four channel sets of one (block, image group, column strip) read the same rows of
+// S and Q: set A, C, D all stage x and x1, B, C, D stage x2, A and B stage g_t ... 24 staged 32-channel blocks for 13
+// distinct ones.  They sit on ONE XCD (workgroup ids 8 apart) and start together, but nothing kept them together: PMC
+// showed 23.7 GB fetched per launch at 16 x 128^2 for 15 GB of operands, L2 hit rate 0.22 (profiles/r04).  Now the grid
+// is persistent (every workgroup resident for the whole launch, striding over the tasks) and a workgroup starts row
+// step s only when its three siblings have started step s - 1: the later readers of a row find it in the XCD's L2.
+// Protocol, one lane of wave 0: publish the own step count (relaxed, agent scope), look at the siblings' counts that
+// were LOADED DURING THE PREVIOUS STEP (those loads retire under the step's vmcnt(0): no extra latency on the common
+// path), spin on fresh loads only when one is behind — bounded: a sibling that does not show up within ~60 us (another
+// kernel holds its CU) switches the lock step off for the rest of this workgroup's launch.  Speed only: every
+// workgroup computes the same sums whatever the others do.
+struct Pace {
+  uint32_t* mine;                 // this workgroup's counter (NULL: lock step off)
+  const uint32_t* sib[3];
+  uint32_t count;                 // steps this workgroup has started
+  uint32_t seen[3];               // the siblings' counts as loaded during the previous step
+};
+__device__ __forceinline__ uint32_t pace_load(const uint32_t* q) {
+  return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pace_step(Pace& pc) {
+  // called by wave 0 only, in front of the step's barrier
+  if (!pc.mine) return;
+  const uint32_t c = ++pc.count;
+  if (threadIdx.x == 0) __hip_atomic_store(pc.mine, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool behind = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) behind |= pc.seen[k] + 1u < c;
+  if (__builtin_amdgcn_readfirstlane((int)behind)) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+      uint32_t lo = 0xFFFFFFFFu;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const uint32_t v = pace_load(pc.sib[k]); lo = v < lo ? v : lo; }
+      if (lo + 1u >= c) break;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 6000ull) { pc.mine = nullptr; return; }     // 100 MHz: 60 us
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+}
+__device__ __forceinline__ void pace_prefetch(Pace& pc) {
+  // behind the barrier: the loads land under this step's MFMAs and are covered by the next step's vmcnt(0)
+  if (!pc.mine) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) pc.seen[k] = pace_load(pc.sib[k]);
+}
 
 // one step of one wave: output rows 0..3 of the step against in-rows 0..5 (ring pairs p0, p1, p2).
 // NIB_ROW / NGB_ROW: bytes of one in-row / g-row image of the set (compile time: every fragment address is
@@ -195,7 +245,7 @@ __device__ __forceinline__ void step_mma(Acc9& acc, float& bsum, const bool want
 }
 
 template <int SET>
-__device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const int chunk, char* const smem) {
+__device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const int chunk, char* const smem, Pace& pc) {
   constexpr SetDesc sd = kSets[SET];
   constexpr int nib = sd.nib, ngb = sd.ngb;
   constexpr int PAIRB = pair_bytes(nib), GQB = gquad_bytes(ngb);
@@ -314,7 +364,9 @@ __device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const 
     issue_gquad(0);
     for (int t = 0; t < T; ++t) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // batch t (issued a whole step ago) has landed
+      if (wave == 0) pace_step(pc);                // lock step with the chunk's other sets (a late sibling: bounded spin)
       __builtin_amdgcn_s_barrier();                // ... for every wave; every wave is done reading step t - 1
+      if (wave == 0) pace_prefetch(pc);
       if (t + 1 < T) {
         issue_pair(2 * t + 3);
         issue_pair(2 * t + 4);
@@ -358,21 +410,37 @@ __device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const 
 __global__ __launch_bounds__(NTH, 2) void rdb_wgrad_kernel(const KArgs ka) {
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   // ---- task decode: linear id -> (block, chunk, set) with a chunk's four sets on ONE XCD (ids 8 apart: the
-  // dispatcher places workgroup b on XCD b % 8), close in time, so that what two sets both stage (conv5's two
+  // dispatcher places workgroup b on XCD b % 8) and in lock step (Pace), so that what two sets both stage (conv5's two
   // halves share g_t; sets A, C, D share x) is an L2 hit for the later ones.  Speed only.
+  // Persistent grid: workgroup w runs tasks w, w + grid, ... — with grid a multiple of 32 a workgroup keeps its XCD, its
+  // set and its three siblings (w with bits 3, 4 changed) for the whole launch.
   const int per_block = ka.ntasks;
-  const int blk = blockIdx.x / per_block;
-  const int l = blockIdx.x - blk * per_block;
   const int nchunk = ka.strips * ka.igroups;
   const int full = (nchunk / 8) * 32;                    // tasks in complete groups of 8 chunks
-  int chunk, set;
-  if (l < full) { const int grp = l >> 5, w = l & 31; chunk = grp * 8 + (w & 7); set = w >> 3; }
-  else { const int rem = nchunk & 7, w = l - full; chunk = (nchunk / 8) * 8 + w % rem; set = w / rem; }
-  switch (set) {
-    case 0: wgrad_set<0>(ka, blk, chunk, smem); break;
-    case 1: wgrad_set<1>(ka, blk, chunk, smem); break;
-    case 2: wgrad_set<2>(ka, blk, chunk, smem); break;
-    default: wgrad_set<3>(ka, blk, chunk, smem); break;
+  Pace pc;
+  pc.mine = nullptr;
+  pc.count = 0;
+  pc.seen[0] = pc.seen[1] = pc.seen[2] = 0;
+  if (ka.pace) {                                          // (host: only when every task sits in a complete group)
+    const int w = blockIdx.x, me = (w >> 3) & 3;
+    pc.mine = ka.pace + w;
+    int k = 0;
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx)
+      if (sidx != me) pc.sib[k++] = ka.pace + ((w & ~24) | (sidx << 3));
+  }
+  for (int task = blockIdx.x; task < ka.total; task += gridDim.x) {
+    const int blk = task / per_block;
+    const int l = task - blk * per_block;
+    int chunk, set;
+    if (l < full) { const int grp = l >> 5, w = l & 31; chunk = grp * 8 + (w & 7); set = w >> 3; }
+    else { const int rem = nchunk & 7, w = l - full; chunk = (nchunk / 8) * 8 + w % rem; set = w / rem; }
+    switch (set) {
+      case 0: wgrad_set<0>(ka, blk, chunk, smem, pc); break;
+      case 1: wgrad_set<1>(ka, blk, chunk, smem, pc); break;
+      case 2: wgrad_set<2>(ka, blk, chunk, smem, pc); break;
+      default: wgrad_set<3>(ka, blk, chunk, smem, pc); break;
+    }
   }
 }
 
@@ -421,12 +489,29 @@ int images_per_task(int B, int strips, int n_blocks) {
 
 }  // namespace
 
-extern "C" int64_t esr_rdb_wgrad_workspace_elems(int32_t B, int32_t H, int32_t W, int32_t n_blocks) {
-  if (B <= 0 || H <= 0 || W <= 0 || n_blocks <= 0) return 0;
+constexpr int PACE_WORDS = 1024;            // step counters of the persistent grid (one per workgroup, <= CUs), behind the slots
+
+static int64_t slot_floats(int32_t B, int32_t W, int32_t n_blocks) {
   const int strips = (W + 31) / 32;
   const int ipw = images_per_task(B, strips, n_blocks);
   const int igroups = (B + ipw - 1) / ipw;
   return (int64_t)n_blocks * strips * igroups * ((SLOT_ELEMS + 3) & ~3);
+}
+
+extern "C" int64_t esr_rdb_wgrad_workspace_elems(int32_t B, int32_t H, int32_t W, int32_t n_blocks) {
+  if (B <= 0 || H <= 0 || W <= 0 || n_blocks <= 0) return 0;
+  return slot_floats(B, W, n_blocks) + PACE_WORDS;
+}
+
+static int wgrad_cus() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+  if (!cached[dev]) {
+    hipDeviceProp_t pr;
+    cached[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+  }
+  return cached[dev];
 }
 
 extern "C" int esr_rdb_wgrad_run(const esr_rdb_wgrad* p, esr_stream_t stream) {
@@ -448,7 +533,29 @@ extern "C" int esr_rdb_wgrad_run(const esr_rdb_wgrad* p, esr_stream_t stream) {
     return ESR_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(rdb_wgrad_kernel, dim3((unsigned)(p->n_blocks * ka.ntasks)), dim3(NTH), 0, st, ka);
+  // persistent grid: one workgroup per CU (145 KB of LDS each), or p->max_workgroups of them when the caller wants the
+  // rest of the chip left to something else (the train plan runs a pass next to the following backward-chain launch);
+  // a multiple of 32 keeps every workgroup on its XCD and with its set (see the kernel)
+  ka.total = p->n_blocks * ka.ntasks;
+  static const int env_grid = [] { const char* e = getenv("ESR_RDB_WGRAD_GRID"); return e ? atoi(e) : 0; }();     // 0: persistent; < 0: one workgroup per task (round 4)
+  int grid = wgrad_cus();
+  if (p->max_workgroups > 0 && p->max_workgroups < grid) grid = p->max_workgroups;
+  if (env_grid > 0) grid = env_grid;
+  if (grid >= 32) grid &= ~31;
+  if (grid > ka.total || env_grid < 0) grid = ka.total;
+  // lock step of a chunk's four sets (Pace): every task in a complete group of 8 chunks, the grid a multiple of 32 so
+  // that siblings stay siblings, more than one task per workgroup's worth of rows to keep together
+  static const bool pace_on = [] { const char* e = getenv("ESR_RDB_WGRAD_PACE"); return !e || atoi(e) != 0; }();
+  const int nchunk = ka.strips * ka.igroups;
+  ka.pace = nullptr;
+  if (pace_on && nchunk % 8 == 0 && grid % 32 == 0 && grid <= PACE_WORDS && grid < ka.total + 1 && env_grid >= 0) {
+    ka.pace = (uint32_t*)(p->partial + slot_floats(p->B, p->W, p->n_blocks));
+    if (hipMemsetAsync(ka.pace, 0, (size_t)grid * sizeof(uint32_t), st) != hipSuccess) {
+      esr_set_error("esr_rdb_wgrad_run: hipMemsetAsync failed");
+      return ESR_ERR_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(rdb_wgrad_kernel, dim3((unsigned)grid), dim3(NTH), 0, st, ka);
   int rc = esr_check_launch("rdb_wgrad_kernel");
   if (rc) return rc;
   const int64_t total = (int64_t)p->n_blocks * SLOT_ELEMS;

@@ -1516,7 +1516,7 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             ch.workspace, ch.workspace_bytes = bws.data_ptr(), ws_bytes
             TP.bwd_chain_ops.append(Bk.add(L.OP_RDB_CHAIN_BWD, 'rdb_chain', ch))
 
-        def wgrad_op(grp, arena, flags=0):
+        def wgrad_op(grp, arena, flags=0, max_wg=0):
             arr_ = (L.esr_rdb_wgrad_block * len(grp))(*grp)
             wt = torch.frombuffer(bytearray(bytes(arr_)), dtype=torch.uint8).to(device)
             TP.bufs.append(wt)
@@ -1525,6 +1525,7 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             rw.n_blocks, rw.tap_major, rw.scale5, rw.scale = len(grp), 1, 0.2, 1.0
             rw.blocks = wt.data_ptr()
             rw.partial, rw.partial_elems = arena.data_ptr(), arena.numel()
+            rw.max_workgroups = max_wg
             Bk.add(L.OP_RDB_WGRAD, 'rdb_wgrad', rw, flags=flags)
 
         TP.bwd_chain_ws = bws
@@ -1539,10 +1540,14 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             per_run = (nb + nsplit - 1) // nsplit
             warena = torch.empty(int(L.lib().esr_rdb_wgrad_workspace_elems(B, H, W, per_run * nj)), dtype=torch.float32, device=device)
             TP.bufs.append(warena)
+            cus = L.lib().esr_rdb_max_tiles_per_image()
+            spare = max(32, cus - B * ((H + 3) // 4) * ((W + 31) // 32))     # CUs the chain's grid leaves free
             for r0 in range(0, nb, per_run):
                 k0, k1 = r0 * nj, min(nb, r0 + per_run) * nj
                 chain_op(k0, k1)
-                wgrad_op(wblocks[k0:k1], warena, flags=_SIDE)
+                # every run but the last shares the chip with the next run's chain: its pass keeps to the spare CUs
+                # (a persistent grid of that many workgroups) so that the chain's workgroups find theirs free
+                wgrad_op(wblocks[k0:k1], warena, flags=_SIDE, max_wg=spare if k1 < len(border) else 0)
         else:
             chain_op(0, len(border))
             # weight gradients: one pass over all blocks — or, data-parallel, one per RRDB so that each RRDB's slice of the

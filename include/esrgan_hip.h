@@ -528,8 +528,13 @@ typedef struct esr_rdb_wgrad {
   float scale5;             /* 0.2: g_a5 = 0.2 g_t (block.py:267) */
   float scale;              /* applied to every gradient (1.0) */
   const esr_rdb_wgrad_block* blocks;   /* DEVICE array */
-  float* partial;           /* esr_rdb_wgrad_workspace_elems() floats: per-task partial sums, reduced in a fixed order */
+  float* partial;           /* esr_rdb_wgrad_workspace_elems() floats: per-task partial sums, reduced in a fixed order
+                               (+ the step counters that keep the four channel sets of a row band in lock step) */
   int64_t partial_elems;
+  int32_t max_workgroups;   /* 0: the pass takes every CU (persistent grid, one workgroup per CU); n > 0: at most n
+                               workgroups — the caller runs the pass NEXT TO other work (the train plan: a run of RRDBs'
+                               weight gradients on the side stream under the next run's backward chain) */
+  int32_t _pad;
 } esr_rdb_wgrad;
 
 enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_NOISE_FILL = 4,
@@ -666,7 +671,7 @@ int esr_graph_destroy(esr_graph_t g);
 int esr_run_ops_timed(const esr_op* ops, int32_t n, esr_stream_t stream, float* ms_out);
 
 const char* esr_last_error(void);
-int esr_abi_version(void);   /* 4 (round 4: esr_conv.ksplit / split_ws / stat_sums, ESR_BN_FIN_APPLY / ESR_BN_RESTAT); 3 (round 3: esr_ragan_loss.mode / sums / ext, ...; 2 = round 2: esr_bn.groups / num_batches_tracked,
+int esr_abi_version(void);   /* 5 (round 5: esr_rdb_wgrad.max_workgroups, esr_debug_device_alias / esr_debug_chain_order_waits); 4 (round 4: esr_conv.ksplit / split_ws / stat_sums, ESR_BN_FIN_APPLY / ESR_BN_RESTAT); 3 (round 3: esr_ragan_loss.mode / sums / ext, ...; 2 = round 2: esr_bn.groups / num_batches_tracked,
                                 esr_l1_loss, esr_ragan_loss, ESR_OPF_SIDE_FREE) */
 size_t esr_sizeof_op(void);
 
