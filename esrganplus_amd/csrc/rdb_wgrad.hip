@@ -130,13 +130,14 @@ struct KArgs {
   uint32_t* pace;                 // NULL, or one step counter per workgroup (zero at launch): see Pace
 };
 
-// ---- lock step of the four sets of a chunk (round 5) ------------------------------------------------------------------
+// ---- lock step of the four sets of a chunk (round 5; an EXPERIMENT, off by default: ESR_RDB_WGRAD_PACE=1) -----------
 // The four workgroups that run the four channel sets of one (block, image group, column strip) read the same rows of
 // S and Q: set A, C, D all stage x and x1, B, C, D stage x2, A and B stage g_t ... 24 staged 32-channel blocks for 13
-// distinct ones.  They sit on ONE XCD (workgroup ids 8 apart) and start together, but nothing kept them together: PMC
-// showed 23.7 GB fetched per launch at 16 x 128^2 for 15 GB of operands, L2 hit rate 0.22 (profiles/r04).  Now the grid
-// is persistent (every workgroup resident for the whole launch, striding over the tasks) and a workgroup starts row
-// step s only when its three siblings have started step s - 1: the later readers of a row find it in the XCD's L2.
+// distinct ones.  They sit on ONE XCD (workgroup ids 8 apart) and start together, but nothing keeps them together: PMC
+// shows 22.9 GB fetched per launch at 16 x 128^2 for 15 GB of operands, L2 hit rate 0.30.  With the lock step the grid is
+// persistent (every workgroup resident for the whole launch, striding over the tasks) and a workgroup starts row step s
+// only when its three siblings have started step s - 1: the later readers of a row find it in the XCD's L2 (FETCH 16.4
+// GB, hit rate 0.53) — and the launch takes 17 % LONGER (see esr_rdb_wgrad_run): the bytes were not the bound.
 // Protocol, one lane of wave 0: publish the own step count (relaxed, agent scope), look at the siblings' counts that
 // were LOADED DURING THE PREVIOUS STEP (those loads retire under the step's vmcnt(0): no extra latency on the common
 // path), spin on fresh loads only when one is behind — bounded: a sibling that does not show up within ~60 us (another
@@ -533,22 +534,28 @@ extern "C" int esr_rdb_wgrad_run(const esr_rdb_wgrad* p, esr_stream_t stream) {
     return ESR_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;
-  // persistent grid: one workgroup per CU (145 KB of LDS each), or p->max_workgroups of them when the caller wants the
-  // rest of the chip left to something else (the train plan runs a pass next to the following backward-chain launch);
-  // a multiple of 32 keeps every workgroup on its XCD and with its set (see the kernel)
+  // Grid.  Default: one workgroup per task (the hardware deals tasks to CUs as they free up).  Persistent forms — every
+  // workgroup strides over the tasks — when the caller caps the workgroups (p->max_workgroups: the train plan runs a pass
+  // NEXT TO the following backward-chain launch and leaves that launch its CUs), with ESR_RDB_WGRAD_GRID=n, and for the
+  // lock step of a chunk's four sets (ESR_RDB_WGRAD_PACE=1, see Pace).  Measured at 69 blocks x 16 x 128^2 (round 5,
+  // tools/pmc_wgrad.sh): one workgroup per task 9.32 ms, FETCH 22.9 GB, L2 hit 0.30; persistent 9.38 ms, 25.9 GB, 0.20;
+  // persistent + lock step 11.05 ms, FETCH 16.4 GB, L2 hit 0.53 — the lock step removes the re-reads and the kernel gets
+  // SLOWER: it is bound by its L2 -> LDS staging and the step barrier, not by HBM bytes, and in lock step every chunk
+  // runs at the pace of its slowest set (C stages 7 channel blocks per row step, B 5).  Hence off by default.
   ka.total = p->n_blocks * ka.ntasks;
-  static const int env_grid = [] { const char* e = getenv("ESR_RDB_WGRAD_GRID"); return e ? atoi(e) : 0; }();     // 0: persistent; < 0: one workgroup per task (round 4)
-  int grid = wgrad_cus();
-  if (p->max_workgroups > 0 && p->max_workgroups < grid) grid = p->max_workgroups;
-  if (env_grid > 0) grid = env_grid;
-  if (grid >= 32) grid &= ~31;
-  if (grid > ka.total || env_grid < 0) grid = ka.total;
-  // lock step of a chunk's four sets (Pace): every task in a complete group of 8 chunks, the grid a multiple of 32 so
-  // that siblings stay siblings, more than one task per workgroup's worth of rows to keep together
-  static const bool pace_on = [] { const char* e = getenv("ESR_RDB_WGRAD_PACE"); return !e || atoi(e) != 0; }();
+  static const int env_grid = [] { const char* e = getenv("ESR_RDB_WGRAD_GRID"); return e ? atoi(e) : 0; }();
+  static const bool pace_on = [] { const char* e = getenv("ESR_RDB_WGRAD_PACE"); return e && atoi(e) != 0; }();
+  int grid = ka.total;
+  if (p->max_workgroups > 0 || env_grid > 0 || pace_on) {
+    grid = wgrad_cus();
+    if (p->max_workgroups > 0 && p->max_workgroups < grid) grid = p->max_workgroups;
+    if (env_grid > 0) grid = env_grid;
+    if (grid >= 32) grid &= ~31;                 // a multiple of 32 keeps every workgroup on its XCD and with its set
+    if (grid > ka.total) grid = ka.total;
+  }
   const int nchunk = ka.strips * ka.igroups;
   ka.pace = nullptr;
-  if (pace_on && nchunk % 8 == 0 && grid % 32 == 0 && grid <= PACE_WORDS && grid < ka.total + 1 && env_grid >= 0) {
+  if (pace_on && nchunk % 8 == 0 && grid % 32 == 0 && grid <= PACE_WORDS) {
     ka.pace = (uint32_t*)(p->partial + slot_floats(p->B, p->W, p->n_blocks));
     if (hipMemsetAsync(ka.pace, 0, (size_t)grid * sizeof(uint32_t), st) != hipSuccess) {
       esr_set_error("esr_rdb_wgrad_run: hipMemsetAsync failed");
