@@ -874,7 +874,7 @@ def bwd_chain_split(B, H, W, nb):
         return max(1, min(int(env), nb))
     cus = L.lib().esr_rdb_max_tiles_per_image()
     tiles4 = B * ((H + 3) // 4) * ((W + 31) // 32)
-    return min(4, nb) if 2 * tiles4 <= cus else 1
+    return min(2, nb) if 2 * tiles4 <= cus else 1      # (train step, same box: 1 run 7.09 ms, 2 runs 7.01, 4 runs 7.06)
 
 
 def use_rdb_wgrad():

@@ -209,7 +209,7 @@ def test_backward_chain_split_into_runs_is_bit_identical(dev, monkeypatch, cls_n
         tps = [tp for pool in net._plans.values() if isinstance(pool, list) for tp in pool if getattr(tp, 'bwd_chain_ops', None)]
         assert len(tps) == 1
         res[split] = (len(tps[0].bwd_chain_ops), {k: p.grad.clone() for k, p in net.named_parameters()})
-    assert res['1'][0] == 1 and res['4'][0] == 3 and res['5'][0] == 5 and res['auto'][0] == 3     # runs of ceil(5 / 4) = 2 RRDBs
+    assert res['1'][0] == 1 and res['4'][0] == 3 and res['5'][0] == 5 and res['auto'][0] == 2     # '4': runs of ceil(5 / 4) = 2 RRDBs
     for split in ('4', '5', 'auto'):
         bad = [k for k, g in res['1'][1].items() if not torch.equal(g, res[split][1][k])]
         assert not bad, (split, bad[:6])
