@@ -37,6 +37,7 @@ def require_cuda(t, what):
 
 # ESR_SIDE=0: weight-gradient runs on the launch stream instead of the side stream (A/B)
 _SIDE = L.OPF_SIDE if os.environ.get('ESR_SIDE', '1') != '0' else 0
+_SIDE_FREE = L.OPF_SIDE_FREE if os.environ.get('ESR_TAIL_WGRAD_FREE', '1') != '0' else 0     # (A/B knob, round 5)
 
 class G32:
     """[B][ngroups][Hp][Wp][cpg] activation buffer with a physical zero halo."""
@@ -772,6 +773,29 @@ def attach_wgrad_arena(oplist, device, exclusive=False):
     return arena
 
 
+def attach_free_wgrad_regions(oplist, device):
+    """ESR_OPF_SIDE_FREE weight-gradient ops of a list whose other wgrad ops share one arena (attach_wgrad_arena): they
+    are in flight together, so each gets a partial region of its own.  Returns the tensor that holds them (or None)."""
+    if not deterministic_wgrad():
+        return None
+    arr = oplist.array()
+    needs = []
+    for i, o in enumerate(oplist.ops):
+        if o.kind == L.OP_WGRAD and (o.flags & L.OPF_SIDE_FREE):
+            n = L.lib().esr_wgrad_workspace_elems(C.cast(C.byref(arr[i]), C.c_void_p), 1)
+            needs.append((o, (int(n) + 63) // 64 * 64))
+    total = sum(n for _, n in needs)
+    if total <= 0:
+        return None
+    arena = torch.empty(total, dtype=torch.float32, device=device)
+    off = 0
+    for o, n in needs:
+        o.u.wgrad.partial, o.u.wgrad.partial_elems = (arena.data_ptr() + 4 * off, n) if n else (None, 0)
+        off += n
+    oplist._arr = None
+    return arena
+
+
 def current_stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -1368,9 +1392,13 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         if deferred is not None:
             deferred.append(wg)      # emitted as one run at the end of the block (one batched launch)
         else:
-            # head / tail convs: their gradient and input buffers are written once per backward pass,
-            # so these launches too can run next to the main chain
-            Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=_SIDE)
+            # head / tail convs: their gradient and input buffers are written once per backward pass and their slots of
+            # the gradient buffer are read only behind the list's unpermute, so these launches run next to the main
+            # chain WITHOUT ordering among themselves (ESR_OPF_SIDE_FREE: up to three in flight, each with its own
+            # partial region — attach_free_wgrad_regions).  Round 5: as ordered side runs the main stream waited for
+            # run k - 1 before forking run k — at training crops a 70 us weight gradient per 25 us dgrad conv, i.e.
+            # the tail's backward took 0.4 ms of the step's critical path instead of 0.15
+            Bk.add(L.OP_WGRAD, 'wgrad', wg, flags=(_SIDE | _SIDE_FREE) if _SIDE else 0)
 
     if block:
         GY = buf(64)
@@ -1681,4 +1709,5 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
         c.nchw_out_c = in_nc
         TP.gx_op = add_b(c)
     TP.wgrad_arena = attach_wgrad_arena(Bk, device)
+    TP.wgrad_free_arena = attach_free_wgrad_regions(Bk, device)
     return TP
