@@ -22,6 +22,7 @@ OP_CONV, OP_PACK, OP_LAYOUT, OP_NOISE_FILL, OP_WGRAD, OP_BN, OP_POOL, OP_LINEAR,
 OP_RDB_CHAIN, OP_FRAG_GATHER, OP_RDB_WGRAD, OP_RDB_CHAIN_BWD = 11, 12, 13, 14
 BN_STATS, BN_FINALIZE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_FINAL, BN_BWD_APPLY, BN_RESTAT, BN_FIN_APPLY = 0, 1, 2, 3, 4, 5, 6, 7
 NO_LAYER = 0xFFFFFFFF
+POOL_FWD, POOL_BWD, POOL_SHUFFLE, POOL_UNSHUFFLE = 0, 1, 2, 3      # esr_pool.mode
 
 
 class esr_g32(C.Structure):

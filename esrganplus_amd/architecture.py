@@ -110,49 +110,6 @@ class RRDB_Net(_RRDBNetBase):
         self._build(in_nc, out_nc, nf, nb, upscale, norm_type, act_type, mode, upsample_mode, True)
 
 
-class SRResNet(nn.Module):
-    """architecture.py:13-44 of the reference (networks.py:88-91 builds it with act 'relu', upsample_mode
-    'pixelshuffle'; train_SRResNet.json:39-43: norm_type null, mode CNA, nb 16).  Not planned as a whole like
-    RRDBNet: a chain of ``Conv2dHIP`` modules (every conv, forward and backward, on the HIP kernels) with torch glue
-    for ReLU, the residual adds and nn.PixelShuffle / nn.Upsample.  Same state-dict keys as the reference."""
-
-    def __init__(self, in_nc, out_nc, nf, nb, upscale=4, norm_type=None, act_type='relu', mode='CNA', res_scale=1,
-                 upsample_mode='upconv'):
-        super().__init__()
-        if norm_type or mode != 'CNA':
-            raise NotImplementedError('HIP SRResNet: norm_type null, mode CNA (train_SRResNet.json:40-41)')
-        n_upscale = 1 if upscale == 3 else int(math.log(upscale, 2))
-        fea_conv = B.conv_block(in_nc, nf, kernel_size=3, norm_type=None, act_type=None, hip=True)
-        blocks = [B.ResNetBlock(nf, nf, nf, norm_type=None, act_type=act_type, mode=mode, res_scale=res_scale)
-                  for _ in range(nb)]
-        LR_conv = B.conv_block(nf, nf, kernel_size=3, norm_type=None, act_type=None, mode=mode, hip=True)
-        if upsample_mode == 'upconv':
-            up = lambda *a, **k: B.upconv_blcok(*a, hip=True, **k)
-        elif upsample_mode == 'pixelshuffle':
-            up = B.pixelshuffle_block
-        else:
-            raise NotImplementedError('upsample mode [{:s}] is not found'.format(upsample_mode))
-        if upscale == 3:
-            if upsample_mode == 'upconv':
-                raise NotImplementedError('x3 upconv is outside the kernels (nearest x2 only)')
-            upsampler = [up(nf, nf, 3, act_type=act_type)]
-        else:
-            upsampler = [up(nf, nf, act_type=act_type) for _ in range(n_upscale)]
-        HR_conv0 = B.conv_block(nf, nf, kernel_size=3, norm_type=None, act_type=act_type, hip=True)
-        HR_conv1 = B.conv_block(nf, out_nc, kernel_size=3, norm_type=None, act_type=None, hip=True)
-        self.model = B.sequential(fea_conv, B.ShortcutBlock(B.sequential(*blocks, LR_conv)), *upsampler,
-                                  HR_conv0, HR_conv1)
-
-    def set_precision(self, precision):
-        for m in self.modules():
-            if isinstance(m, Conv2dHIP):
-                m.set_precision(precision)
-        return self
-
-    def forward(self, x):
-        return self.model(x)
-
-
 # =================================================================================================
 # Discriminator_VGG_128 and VGGFeatureExtractor (the rest of the ESRGAN+ train step)
 # =================================================================================================
@@ -579,3 +536,106 @@ class Conv2dHIP(_SeqNet, nn.Conv2d):
         if self.bias is not None:
             ps.append(('conv.bias', self.bias))
         return ps
+
+
+class SRResNet(_SeqNet):
+    """architecture.py:13-44 of the reference (networks.py:88-91 builds it with act 'relu', upsample_mode
+    'pixelshuffle'; train_SRResNet.json:39-43: norm_type null, mode CNA, nb 16).  Same module tree and state-dict keys
+    as the reference.  Round 5: planned as a WHOLE — one forward and one backward launch list per input shape
+    (convnet.build_seq_plan), one autograd node — instead of a chain of per-conv modules with torch glue: ReLU and the
+    ResNetBlock / ShortcutBlock residual adds are conv epilogues (block.py:199-232, 84-86), nearest-x2 up-sampling is
+    folded into the conv's load (block.py:315-322), nn.PixelShuffle(2) is one index-remapping launch whose ReLU rides
+    in the producing conv's epilogue (block.py:299-312; ReLU commutes with the shuffle), the backward mirrors it
+    (skip gradients enter the dgrad convs as epilogue residuals).  x3 (PixelShuffle(3)) keeps the per-conv modules."""
+
+    _has_bn = False
+
+    def __init__(self, in_nc, out_nc, nf, nb, upscale=4, norm_type=None, act_type='relu', mode='CNA', res_scale=1,
+                 upsample_mode='upconv'):
+        super().__init__()
+        if norm_type or mode != 'CNA':
+            raise NotImplementedError('HIP SRResNet: norm_type null, mode CNA (train_SRResNet.json:40-41)')
+        if act_type not in ('relu', None):
+            raise NotImplementedError('HIP SRResNet: act_type relu (networks.py:88-91)')
+        n_upscale = 1 if upscale == 3 else int(math.log(upscale, 2))
+        self._planned = upscale != 3              # x3: per-conv modules + torch glue (nn.PixelShuffle(3))
+        hip = not self._planned
+        fea_conv = B.conv_block(in_nc, nf, kernel_size=3, norm_type=None, act_type=None, hip=hip)
+        blocks = [B.ResNetBlock(nf, nf, nf, norm_type=None, act_type=act_type, mode=mode, res_scale=res_scale, hip=hip)
+                  for _ in range(nb)]
+        LR_conv = B.conv_block(nf, nf, kernel_size=3, norm_type=None, act_type=None, mode=mode, hip=hip)
+        if upsample_mode == 'upconv':
+            up = lambda *a, **k: B.upconv_blcok(*a, hip=hip, **k)
+        elif upsample_mode == 'pixelshuffle':
+            up = lambda *a, **k: B.pixelshuffle_block(*a, hip=hip, **k)
+        else:
+            raise NotImplementedError('upsample mode [{:s}] is not found'.format(upsample_mode))
+        if upscale == 3:
+            if upsample_mode == 'upconv':
+                raise NotImplementedError('x3 upconv is outside the kernels (nearest x2 only)')
+            upsampler = [up(nf, nf, 3, act_type=act_type)]
+        else:
+            upsampler = [up(nf, nf, act_type=act_type) for _ in range(n_upscale)]
+        HR_conv0 = B.conv_block(nf, nf, kernel_size=3, norm_type=None, act_type=act_type, hip=hip)
+        HR_conv1 = B.conv_block(nf, out_nc, kernel_size=3, norm_type=None, act_type=None, hip=hip)
+        self.model = B.sequential(fea_conv, B.ShortcutBlock(B.sequential(*blocks, LR_conv)), *upsampler,
+                                  HR_conv0, HR_conv1)
+        self.in_nc, self.out_nc, self.nf, self.nb = in_nc, out_nc, nf, nb
+        self.n_upscale, self.upsample_mode, self.res_scale = n_upscale, upsample_mode, float(res_scale)
+        self.act = L.ACT_RELU if act_type == 'relu' else L.ACT_NONE
+        self._init_planned()
+
+    def set_precision(self, precision):
+        super().set_precision(precision)
+        for m in self.modules():
+            if isinstance(m, Conv2dHIP):
+                m.set_precision(precision)
+        return self
+
+    def _named_convs(self):
+        return [('model.' + n, m) for n, m in self.model.named_modules() if isinstance(m, nn.Conv2d)]
+
+    def _conv_list(self):
+        return [(k, m.weight, m.bias) for k, m in self._named_convs()]
+
+    def _pspec(self):
+        ps = []
+        for k, m in self._named_convs():
+            ps += [(k + '.weight', m.weight), (k + '.bias', m.bias)]
+        return ps
+
+    def _dgrad_special(self):
+        if self.upsample_mode != 'upconv':
+            return {}
+        convs = self._named_convs()
+        return {k: {'ups': True} for k, _ in convs[2 + 2 * self.nb:2 + 2 * self.nb + self.n_upscale]}
+
+    def _spec(self):
+        convs = self._named_convs()
+        assert len(convs) == 4 + 2 * self.nb + self.n_upscale
+
+        def cv(i, act, **kw):
+            k, m = convs[i]
+            return dict({'conv': k, 'cin': m.in_channels, 'cout': m.out_channels, 'ks': 3, 'stride': 1, 'act': act,
+                         'bn': None}, **kw)
+        spec = [cv(0, L.ACT_NONE), {'save': 'fea'}]
+        for i in range(self.nb):
+            # ResNetBlock (block.py:229-232): x + res_scale * conv1(act(conv0(x)))
+            spec += [{'save': 'b%d' % i}, cv(1 + 2 * i, self.act), cv(2 + 2 * i, L.ACT_NONE, res='b%d' % i, alpha=self.res_scale)]
+        spec.append(cv(1 + 2 * self.nb, L.ACT_NONE, res='fea', alpha=1.0))        # ShortcutBlock: x + sub(x)
+        for u in range(self.n_upscale):
+            i = 2 + 2 * self.nb + u
+            if self.upsample_mode == 'upconv':
+                spec.append(cv(i, self.act, ups=True))
+            else:
+                spec += [cv(i, self.act), {'shuffle': 2}]
+        i = 2 + 2 * self.nb + self.n_upscale
+        spec += [cv(i, self.act), cv(i + 1, L.ACT_NONE)]
+        return spec
+
+    def forward(self, x):
+        if not self._planned:
+            return self.model(x)
+        return super().forward(x)
+
+

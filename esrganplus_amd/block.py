@@ -106,13 +106,14 @@ def upconv_blcok(in_nc, out_nc, upscale_factor=2, kernel_size=3, stride=1, bias=
 
 
 def pixelshuffle_block(in_nc, out_nc, upscale_factor=2, kernel_size=3, stride=1, bias=True,
-                       pad_type='zero', norm_type=None, act_type='relu'):
+                       pad_type='zero', norm_type=None, act_type='relu', hip=True):
     """block.py:299-312: conv to out_nc * r^2 channels (HIP conv, ``Conv2dHIP``) -> nn.PixelShuffle(r) -> act.
-    Keys as the reference: ``0.weight`` / ``0.bias`` (the shuffle and the activation hold no parameters)."""
+    Keys as the reference: ``0.weight`` / ``0.bias`` (the shuffle and the activation hold no parameters).
+    hip=False: parameter holders only (inside a network that is planned as a whole: architecture.SRResNet)."""
     if norm_type:
         raise NotImplementedError('pixelshuffle_block with a norm layer is not used by the reference configs')
     conv = conv_block(in_nc, out_nc * (upscale_factor ** 2), kernel_size, stride, bias=bias, pad_type=pad_type,
-                      norm_type=None, act_type=None, hip=True)
+                      norm_type=None, act_type=None, hip=hip)
     return sequential(conv, nn.PixelShuffle(upscale_factor), act(act_type) if act_type else None)
 
 
@@ -121,14 +122,15 @@ class ResNetBlock(nn.Module):
     convs on the HIP kernels (``Conv2dHIP``)."""
 
     def __init__(self, in_nc, mid_nc, out_nc, kernel_size=3, stride=1, dilation=1, groups=1, bias=True,
-                 pad_type='zero', norm_type=None, act_type='relu', mode='CNA', res_scale=1):
+                 pad_type='zero', norm_type=None, act_type='relu', mode='CNA', res_scale=1, hip=True):
         super().__init__()
         if norm_type or mode != 'CNA':
             raise NotImplementedError('HIP ResNetBlock: mode CNA without a norm layer (train_SRResNet.json:40-41)')
+        # hip=False: parameter holders only (inside a network that is planned as a whole: architecture.SRResNet)
         conv0 = conv_block(in_nc, mid_nc, kernel_size, stride, dilation, groups, bias, pad_type, None, act_type,
-                           mode, hip=True)
+                           mode, hip=hip)
         conv1 = conv_block(mid_nc, out_nc, kernel_size, stride, dilation, groups, bias, pad_type, None, None,
-                           mode, hip=True)
+                           mode, hip=hip)
         self.res = sequential(conv0, conv1)
         self.res_scale = res_scale
 

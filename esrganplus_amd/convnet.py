@@ -122,6 +122,11 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
 
        spec: list of dicts, in execution order:
          {'conv': key, 'cin', 'cout', 'ks', 'stride', 'act': ACT_*, 'bn': None | dict(weight,bias,rm,rv)}
+             optional (round 5, SRResNet: architecture.py:13-44, block.py:199-232,299-322 as ONE launch plan):
+             'ups': True        nearest x2 up-sampling folded into the conv's load (upconv_blcok)
+             'res': tag, 'alpha': a    out = conv(x) * a + saved[tag]   (ResNetBlock / ShortcutBlock adds, in the epilogue)
+         {'save': tag}          the current tensor is a residual source (no launch)
+         {'shuffle': 2}         nn.PixelShuffle(2) (its ReLU rides in the producing conv's epilogue: it commutes)
          {'pool': True}
        head: None | dict(w1,b1,w2,b2) — flatten + Linear(.,100) + LeakyReLU + Linear(100,1)
        pspec: [(name, tensor)] in autograd-argument order; names '<convkey>.weight|bias',
@@ -148,7 +153,23 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
     cur, ch, h, w = xin, cin0, H, W
     recs = []          # per layer record for the backward
     ibn = 0
+    saved = {}
     for s in spec:
+        if 'save' in s:
+            saved[s['save']] = (cur, ch)
+            recs.append(dict(kind='save', tag=s['save']))
+            continue
+        if 'shuffle' in s:
+            if s['shuffle'] != 2 or ch % (4 * cpg):
+                raise L.HipExtensionError('pixel shuffle: factor 2 on a multiple of %d channels' % (4 * cpg))
+            y = _g32(P, B, ch // 4, 2 * h, 2 * w, dtype, dev)
+            pl = L.esr_pool()
+            pl.dtype, pl.mode, pl.B, pl.C, pl.H, pl.W = dt_e, L.POOL_SHUFFLE, B, ch // 4, h, w
+            pl.x, pl.y = cur.view(0, ch), y.view(0, ch // 4)
+            f.add(L.OP_POOL, 'pool', pl)
+            recs.append(dict(kind='shuffle', x=cur, y=y, ch=ch // 4, h=h, w=w))
+            cur, ch, h, w = y, ch // 4, 2 * h, 2 * w
+            continue
         if 'pool' in s:
             y = _g32(P, B, ch, h // 2, w // 2, dtype, dev)
             pl = L.esr_pool()
@@ -162,10 +183,19 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
         pad = (ks - 1) // 2
         ho, wo = (h + 2 * pad - ks) // st + 1, (w + 2 * pad - ks) // st + 1
         bn = s.get('bn')
+        ups, res = bool(s.get('ups')), s.get('res')
+        if (ups or res is not None) and (bn is not None or ks != 3 or st != 1 or (res is not None and s['act'] != L.ACT_NONE)):
+            raise L.HipExtensionError('conv %s: up-sampling / residual epilogues are for plain 3x3 stride-1 convs' % key)
+        if ups:
+            ho, wo = 2 * h, 2 * w
         cpad = ((cout + 31) // 32) * 32
         yb = _g32(P, B, cpad, ho, wo, dtype, dev)
         if bn is None:
-            c = E._conv(dt_e, B, ho, wo, cur.view(0), ch, yb.view(0), e[key], s['act'], stride=st)
+            c = E._conv(dt_e, B, ho, wo, cur.view(0), ch, yb.view(0), e[key], s['act'], stride=st, upsample=1 if ups else 0)
+            if res is not None:
+                src, src_ch = saved[res]
+                assert src_ch == cout and (src.H, src.W) == (ho, wo), 'residual source of %s has another shape' % key
+                c.res1, c.alpha = src.view(0, cout), float(s.get('alpha', 1.0))
             ksp = s2_ksplit(B, wo, ho, ch, cout, dt_e) if (st == 2 and ks == 4) else 0
             if ksp:
                 ws = torch.empty(ksp * B * ho * wo * cpad, dtype=torch.float32, device=dev)
@@ -173,7 +203,8 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
                 c.ksplit, c.split_ws = ksp, ws.data_ptr()
             f.add_conv(c)
             recs.append(dict(kind='conv', key=key, x=cur, cin=ch, y=yb, c=None, cout=cout, ks=ks, st=st,
-                             act=s['act'], h=ho, w=wo, hin=h, win=w, bn=None))
+                             act=s['act'], h=ho, w=wo, hin=h, win=w, bn=None, ups=ups, res=res,
+                             alpha=float(s.get('alpha', 1.0))))
         else:
             cb = _g32(P, B, cpad, ho, wo, dtype, dev)
             cv = E._conv(dt_e, B, ho, wo, cur.view(0), ch, cb.view(0), e[key], L.ACT_NONE, stride=st)
@@ -307,19 +338,49 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
 
         # gcur_masked: True when gcur already is the gradient w.r.t. the producing conv's pre-activation
         masked = head is not None and head_masks
+        skips = {}       # residual tag -> gradient buffers that flow back to the saved tensor over the skip
+
+        def before(li):
+            """(the layer in front of recs[li] in execution order, the residual tags saved in between)"""
+            k, tags = li - 1, []
+            while k >= 0 and recs[k]['kind'] == 'save':
+                tags.append(recs[k]['tag'])
+                k -= 1
+            return (recs[k] if k >= 0 else None), tags
+
         for li in range(len(recs) - 1, -1, -1):
             r = recs[li]
+            if r['kind'] == 'save':
+                continue
+            if r['kind'] == 'shuffle':
+                prev, tags = before(li)
+                if tags:
+                    raise L.HipExtensionError('a residual source right in front of a pixel shuffle is not supported')
+                gx = g32q(4 * r['ch'], r['h'], r['w'])
+                pl = L.esr_pool()
+                pl.dtype, pl.mode, pl.B, pl.C, pl.H, pl.W = dt_e, L.POOL_UNSHUFFLE, Bb, r['ch'], r['h'], r['w']
+                pl.x, pl.g, pl.gx = r['x'].view(0, 4 * r['ch']), gcur.view(0, r['ch']), gx.view(0, 4 * r['ch'])
+                act_prev = prev['act'] if (prev and prev['kind'] == 'conv' and prev['bn'] is None) else L.ACT_NONE
+                if act_prev not in (L.ACT_NONE, L.ACT_RELU):
+                    raise L.HipExtensionError('pixel shuffle behind a LeakyReLU conv: only ReLU / no activation')
+                pl.relu_mask = 1 if act_prev == L.ACT_RELU else 0
+                bk.add(L.OP_POOL, 'pool', pl)
+                gcur, masked = gx, bool(pl.relu_mask)
+                continue
             if r['kind'] == 'pool':
                 gx = g32q(r['ch'], r['h'] * 2, r['w'] * 2)
                 pl = L.esr_pool()
                 pl.dtype, pl.mode, pl.B, pl.C, pl.H, pl.W = dt_e, 1, Bb, r['ch'], r['h'], r['w']
                 pl.x, pl.y, pl.g, pl.gx = r['x'].view(0, r['ch']), r['y'].view(0, r['ch']), gcur.view(0, r['ch']), gx.view(0, r['ch'])
-                prev = recs[li - 1] if li > 0 else None
+                prev = before(li)[0]
                 pl.relu_mask = 1 if (prev and prev['kind'] == 'conv' and prev['act'] == L.ACT_RELU and prev['bn'] is None) else 0
                 bk.add(L.OP_POOL, 'pool', pl)
                 gcur, masked = gx, bool(pl.relu_mask)
                 continue
             cout, cin_ = r['cout'], r['cin']
+            alpha = r.get('alpha', 1.0) if r.get('res') is not None else 1.0
+            if r.get('res') is not None:
+                skips.setdefault(r['res'], []).append(gcur)       # d(out)/d(saved) = 1: the skip carries gcur as it is
             if r['bn'] is not None:
                 gconv = g32q(((cout + 31) // 32) * 32, r['h'], r['w'])
                 bnop = r['bnop']
@@ -342,10 +403,10 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
             gw = params_grad.get(r['key'])
             if gw is not None:
                 wg = L.esr_wgrad()
-                wg.dtype, wg.ks, wg.stride, wg.upsample = dt_e, r['ks'], r['st'], 0
+                wg.dtype, wg.ks, wg.stride, wg.upsample = dt_e, r['ks'], r['st'], 1 if r.get('ups') else 0
                 wg.B, wg.H, wg.W, wg.cout, wg.cin = Bb, r['h'], r['w'], cout, cin_
                 wg.g, wg.in_ = gpre.view(0, cout), r['x'].view(0, cin_)
-                wg.dw, wg.dbias, wg.scale = gw[0], gw[1], 1.0
+                wg.dw, wg.dbias, wg.scale = gw[0], gw[1], alpha
                 if Q.tapmajor is not None and r['ks'] in (3, 4):
                     wg.dw, wg.tap_major = Q.tapmajor.slot(poff[r['key'] + '.weight'], cout, cin_, r['ks'] ** 2), 1
                 # every layer owns its gradient buffers, so the weight gradient can run on the side stream
@@ -353,9 +414,15 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
                 # (no waits between these runs, several in flight: ESR_OPF_SIDE_FREE; each gets its own partial region)
                 bk.add(L.OP_WGRAD, 'wgrad', wg, flags=L.OPF_SIDE | L.OPF_SIDE_FREE)
             # input gradient
-            prev = recs[li - 1] if li > 0 else None
+            prev, tags = before(li)
+            resid = [g_ for t_ in tags for g_ in skips.get(t_, [])]
+            if len(resid) > 2:
+                raise L.HipExtensionError('more than two skip connections end at the input of %s' % r['key'])
             gx = g32q(((cin_ + cpg - 1) // cpg) * cpg, r['hin'], r['win'])
-            if r['st'] == 1:
+            if r.get('ups'):
+                # adjoint of (nearest x2 + 3x3 conv): a 4x4 / stride-2 conv over the gradient (esr_pack.ups_dgrad operand)
+                c = E._conv(dt_e, Bb, r['hin'], r['win'], gpre.view(0), cout, None, de[r['key']], L.ACT_NONE, ks=4, stride=2)
+            elif r['st'] == 1:
                 c = E._conv(dt_e, Bb, r['hin'], r['win'], gpre.view(0), cout, None, de[r['key']], L.ACT_NONE)
             else:
                 c = E._conv(dt_e, Bb, r['hin'], r['win'], gpre.view(0), cout, None, de[r['key']], L.ACT_NONE,
@@ -372,6 +439,11 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
                     ws = torch.empty(ksp * Bb * r['hin'] * r['win'] * ((cin_ + 31) // 32) * 32, dtype=torch.float32, device=dev)
                     Q.keep.append(ws)
                     c.ksplit, c.split_ws = ksp, ws.data_ptr()
+            c.alpha = alpha                                   # (backward epilogue: v = acc * alpha [+ res1] [+ res2])
+            if resid:
+                c.res1 = resid[0].view(0, cin_)
+                if len(resid) > 1:
+                    c.res2, c.beta = resid[1].view(0, cin_), 1.0
             if need_mask:
                 c.mask, c.out2, c.mask_cb_begin = prev['y'].view(0, cin_), gx.view(0, cin_), 0
                 c.mask_act = prev['act']

@@ -271,6 +271,44 @@ __global__ __launch_bounds__(256) void pool_kernel(const esr_pool p) {
   }
 }
 
+// nn.PixelShuffle(2) (block.py:299-312) on G32 tensors: out[b][c][2y+i][2x+j] = in[b][4c + 2i + j][y][x].  One thread per
+// (low-res pixel, high-res channel group): the group's CPG channels at the four output pixels are the 4 CPG channels of
+// four consecutive low-res groups.  INV: the gradient's way back (gx[4c + 2i + j][y][x] = g[c][2y+i][2x+j]), optionally
+// masked by the ReLU of the conv that produced the shuffled tensor (p.x = that conv's stored output).
+template <typename T, bool INV>
+__global__ __launch_bounds__(256) void shuffle_kernel(const esr_pool p) {
+  constexpr int CPG = DT<T>::CPG;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y, b = blockIdx.z;
+  if (pix >= p.H * p.W) return;
+  const int y = pix / p.W, x = pix % p.W;
+  float lo[4][CPG], hi[4][CPG];
+  if (!INV) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ld16<T>((const char*)p.x.ptr + pix_off(p.x, b, 4 * g + q, y, x), lo[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < CPG; ++e) { const int cl = q * CPG + e; hi[cl & 3][cl >> 2] = lo[q][e]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st16<T>((char*)p.y.ptr + pix_off(p.y, b, g, 2 * y + (q >> 1), 2 * x + (q & 1)), hi[q]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ld16<T>((const char*)p.g.ptr + pix_off(p.g, b, g, 2 * y + (q >> 1), 2 * x + (q & 1)), hi[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (p.relu_mask) ld16<T>((const char*)p.x.ptr + pix_off(p.x, b, 4 * g + q, y, x), lo[q]);
+      float o[CPG];
+#pragma unroll
+      for (int e = 0; e < CPG; ++e) {
+        const int cl = q * CPG + e;
+        o[e] = (!p.relu_mask || lo[q][e] > 0.f) ? hi[cl & 3][cl >> 2] : 0.f;
+      }
+      st16<T>((char*)p.gx.ptr + pix_off(p.gx, b, 4 * g + q, y, x), o);
+    }
+  }
+}
+
 // y[b][o] = act(sum_i x[b][i] w[o][i] + bias[o]) — one block per (o, b)
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const esr_linear p) {
   const int o = blockIdx.x, b = blockIdx.y;
@@ -366,6 +404,21 @@ extern "C" int esr_maxpool2(const esr_pool* p, esr_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   const int cpg = p->dtype == ESR_F16 ? 16 : 8;
   dim3 grid((p->H * p->W + 255) / 256, (p->C + cpg - 1) / cpg, p->B), block(256);
+  if (p->mode == 2 || p->mode == 3) {
+    // nn.PixelShuffle(2) / its adjoint: C = channels of the HIGH-resolution tensor, H x W = the LOW-resolution size
+    if (p->C % cpg != 0 || (p->mode == 2 ? !p->y.ptr : (!p->g.ptr || !p->gx.ptr))) {
+      esr_set_error("esr_maxpool2 (pixel shuffle): C must be a multiple of the channel group, operands must be set");
+      return ESR_ERR_INVALID;
+    }
+    if (p->dtype == ESR_F16) {
+      if (p->mode == 2) hipLaunchKernelGGL((shuffle_kernel<_Float16, false>), grid, block, 0, st, *p);
+      else hipLaunchKernelGGL((shuffle_kernel<_Float16, true>), grid, block, 0, st, *p);
+    } else if (p->dtype == ESR_F32) {
+      if (p->mode == 2) hipLaunchKernelGGL((shuffle_kernel<float, false>), grid, block, 0, st, *p);
+      else hipLaunchKernelGGL((shuffle_kernel<float, true>), grid, block, 0, st, *p);
+    } else { esr_set_error("esr_maxpool2: bad dtype"); return ESR_ERR_INVALID; }
+    return esr_check_launch("shuffle_kernel");
+  }
   if (p->dtype == ESR_F16) {
     if (p->mode == 0) hipLaunchKernelGGL((pool_kernel<_Float16, 0>), grid, block, 0, st, *p);
     else hipLaunchKernelGGL((pool_kernel<_Float16, 1>), grid, block, 0, st, *p);

@@ -278,7 +278,11 @@ typedef struct esr_bn {
 } esr_bn;
 
 /* MaxPool2d(2,2) (torchvision VGG19 cfg 'E', architecture.py:287-298).  mode 0: y = pool(x);
- * mode 1: gx = route g to the FIRST maximum of each 2x2 window (torch semantics). */
+ * mode 1: gx = route g to the FIRST maximum of each 2x2 window (torch semantics).
+ * Round 5 — the same struct carries nn.PixelShuffle(2) (pixelshuffle_block, block.py:299-312; SRResNet's upsampler):
+ * mode 2: y[b][c][2h+i][2w+j] = x[b][4c + 2i + j][h][w]   (C = channels of y, H x W = size of x; C % channel group == 0)
+ * mode 3: its adjoint, gx[b][4c + 2i + j][h][w] = g[b][c][2h+i][2w+j], with relu_mask: times ReLU'(x) of the conv that
+ *         produced x (the activation behind the shuffle commutes with it, so it rides in the conv's epilogue). */
 typedef struct esr_pool {
   int32_t dtype, mode;
   int32_t B, C, H, W;           /* OUTPUT (pooled) size */

