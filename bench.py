@@ -297,8 +297,9 @@ def generator_kernel_times(netG, lr, batch, size, reps=5):
         dom = max(fused, key=lambda k: agg[k][0])
         t_ms, f, n = agg[dom]
         ach = f / (t_ms * 1e-3) / 1e12
-        traffic = None
-        traffic = committed_traffic(dom)[0] if (batch == BATCH and size == LR) else None
+        # committed PMC rows: the bench shape (profile_fwdbwd.sh) and the train step's shape (tools/pmc_train.sh)
+        traffic = committed_traffic(dom)[0] if (batch == BATCH and size == LR) else (
+            committed_traffic(dom + '@train')[0] if (batch == 16 and size == 32) else None)
         res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_F16_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
                            'launches_per_step': n // reps, 'avg_launch_us': round(t_ms / n * 1e3, 2),

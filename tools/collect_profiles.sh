@@ -5,7 +5,7 @@
 set -e
 TAG=${1:-r04}
 G=gpurun_out; P=profiles
-cp $G/${TAG}_bench_train.json $G/${TAG}_bench_gtrain.json $G/${TAG}_fwd_pmc_summary.txt $G/${TAG}_fwdbwd_pmc_summary.txt $P/
+cp $G/${TAG}_bench.json $G/${TAG}_bench_train.json $G/${TAG}_bench_gtrain.json $G/${TAG}_fwd_pmc_summary.txt $G/${TAG}_fwdbwd_pmc_summary.txt $P/
 cp $G/prof_${TAG}/trace/trace_kernel_stats.csv $P/${TAG}_fwd_kernel_stats.csv
 cp $G/prof_${TAG}_fwdbwd/trace/trace_kernel_stats.csv $P/${TAG}_fwdbwd_kernel_stats.csv
 cp $G/prof_${TAG}_train/train/train_kernel_stats.csv $P/${TAG}_train_kernel_stats.csv

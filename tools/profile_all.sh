@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box: everything profiles/<tag>_* is made from.  Usage: tools/profile_all.sh r03
-TAG=${1:-r03}
+TAG=${1:-r05}
 O=$GRAFT_REPO_ROOT/gpurun_out
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python bench.py --mode train --steps 30 --warmup 5 > $O/${TAG}_bench_train.json 2>> $O/${TAG}_bench.err

@@ -14,6 +14,8 @@ CSRC = os.path.join(ROOT, 'esrganplus_amd', 'csrc')
 CHAIN = ('rdb_chain_kernel.h', 'mfma_tile.h', 'common.h')
 CONV = ('conv_mfma.hip', 'mfma_tile.h', 'common.h')
 SOURCES = {'rdb_chain': CHAIN, 'rdb_chain_train': CHAIN, 'rdb_chain_bwd': CHAIN, 'rdb_wgrad': ('rdb_wgrad.hip', 'common.h'),
+           # the same kernels at the train step's shape (16 x 32^2 LR crops, 4-row tiles; tools/pmc_train.sh)
+           'rdb_chain_train@train': CHAIN, 'rdb_chain_bwd@train': CHAIN, 'rdb_wgrad@train': ('rdb_wgrad.hip', 'common.h'),
            'conv3x3_c32': CONV, 'conv3x3_c64': CONV, 'upconv_subpix_c64': CONV}
 
 

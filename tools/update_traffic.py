@@ -20,10 +20,15 @@ def parse(path):
         m = re.search(r'HBM-side read ~ ([\d.]+) MB .* write ~ ([\d.]+) MB', l)
         if m and cur: out[cur] = (float(m.group(1)), float(m.group(2)))
     return out
-S = {k: parse('profiles/%s_%s_pmc_summary.txt' % (tag, k)) for k in ('fwd', 'fwdbwd')}
+import os
+if os.path.exists('profiles/%s_train_pmc_summary.txt' % tag):      # tools/pmc_train.sh: the train step's shape
+    ROWS.update({'rdb_chain_train@train': ('train', 'rdb_chain<f16,train-forward>'), 'rdb_chain_bwd@train': ('train', 'rdb_chain<f16,backward>'),
+                 'rdb_wgrad@train': ('train', 'rdb_wgrad_kernel')})
+S = {k: parse('profiles/%s_%s_pmc_summary.txt' % (tag, k)) for k in ('fwd', 'fwdbwd', 'train') if os.path.exists('profiles/%s_%s_pmc_summary.txt' % (tag, k))}
 J = json.load(open('profiles/roofline_traffic.json'))
 for row, (which, name) in ROWS.items():
     r, w = S[which][name]
+    J.setdefault(row, {})
     J[row]['read_bytes'], J[row]['write_bytes'] = int(round(r * 1e6)), int(round(w * 1e6))
     J[row]['note'] = 'round %s, profiles/%s_%s_pmc_summary.txt (FETCH_SIZE x2 gfx950 correction / WRITE_SIZE, MB = KB/1024 x 1e6 as the summary prints it)' % (tag[1:].lstrip('0'), tag, which)
     print(row, J[row]['read_bytes'], J[row]['write_bytes'])
