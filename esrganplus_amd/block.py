@@ -299,13 +299,28 @@ class _PlannedModule(nn.Module):
             self.__dict__['_gstore'] = gs
         return gs
 
-    def _deliver_flat_grads(self, flat_new):
+    def _deliver_flat_grads(self, flat_new, adopt=False):
         """What AccumulateGrad does for every parameter, on the flat buffer: `.grad` of every parameter becomes (stays) its
         view of the module's store, which receives `flat_new` — copied when the gradients were None (zero_grad
         (set_to_none=True)) or marked stale, added otherwise (autograd's accumulation).  Gradients somebody else put in
-        place are honoured tensor by tensor."""
+        place are honoured tensor by tensor.
+        adopt=True (the hand-written training loops, which own the gradients and consume them before the plan's next
+        backward: train.ESRGANPlusStep, bench.py's generator loop): when the delivery would OVERWRITE — gradients None
+        or marked stale — `.grad` becomes views of `flat_new` itself (the plan's buffer, cached per buffer) and nothing
+        is copied (67 MB per generator step); an accumulating delivery takes the copying route."""
         gs = self._grad_store(flat_new.device)
         params, views = gs['params'], gs['views']
+        if adopt:
+            ad = gs.get('adopted')
+            ours = all(p.grad is v for p, v in zip(params, views)) or (ad is not None and all(p.grad is v for p, v in zip(params, ad[1])))
+            if (ours and gs['stale']) or all(p.grad is None for p in params):
+                if ad is None or ad[0] is not flat_new:
+                    ad = gs['adopted'] = (flat_new, [t.view(p.shape) for t, p in zip(flat_new.split(gs['sizes']), params)])
+                if not all(p.grad is v for p, v in zip(params, ad[1])):
+                    for p_, v in zip(params, ad[1]):
+                        p_.grad = v
+                gs['stale'] = False
+                return
         if all(p.grad is v for p, v in zip(params, views)):
             if gs['stale']:
                 gs['flat'].copy_(flat_new)
@@ -329,7 +344,11 @@ class _PlannedModule(nn.Module):
         the next backward OVERWRITES the store instead of adding to it; `.grad` keeps pointing at the (old) values
         until then.  Returns False — nothing marked — when the parameters' gradients are not the store's views."""
         gs = self.__dict__.get('_gstore')
-        if gs is None or not all(p.grad is v for p, v in zip(gs['params'], gs['views'])):
+        if gs is None:
+            return False
+        ad = gs.get('adopted')
+        if not (all(p.grad is v for p, v in zip(gs['params'], gs['views']))
+                or (ad is not None and all(p.grad is v for p, v in zip(gs['params'], ad[1])))):
             return False
         gs['stale'] = True
         return True
@@ -341,6 +360,9 @@ class _PlannedModule(nn.Module):
         gs = self.__dict__.get('_gstore')
         if gs is not None and gs['stale']:
             gs['flat'].zero_()
+            ad = gs.get('adopted')
+            if ad is not None and all(p.grad is v for p, v in zip(gs['params'], ad[1])):
+                ad[0].zero_()                     # (the stale gradients live in an adopted plan buffer)
             gs['stale'] = False
 
     def _conv_list(self):

@@ -289,6 +289,9 @@ class TrainPass:
     __slots__ = ('lease', 'seed', 'noise', 'explicit', 'sync')
 
 
+_ADOPT = os.environ.get('ESR_ADOPT_GRADS', '1') != '0'     # A/B knob: 0 = always copy into the module's store (round 4)
+
+
 def rrdbnet_train_forward(net, x, z=None):
     """RRDBNet.forward in training form (every activation the backward needs is kept) WITHOUT an autograd node:
     returns (y, state) for ``rrdbnet_train_backward``.  Same plans, same launches as ``_RRDBNetFn``."""
@@ -319,7 +322,7 @@ def rrdbnet_train_backward(net, s, gy):
     if tp is None:
         raise RuntimeError('rrdbnet_train_backward called twice on one forward')
     _train_backward(tp, gy, E.current_stream(), s.noise, s.explicit, s.seed, False, s.sync)
-    net._deliver_flat_grads(tp.grad_flat)
+    net._deliver_flat_grads(tp.grad_flat, adopt=_ADOPT)
     s.lease.release()
 
 

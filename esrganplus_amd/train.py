@@ -134,8 +134,8 @@ class ESRGANPlusStep:
           * dL/d fake_H = d l_pix + d l_fea + d l_gan is never summed by a launch: the pixel loss writes the buffer, the
             last layout ops of netF's and netD's input-gradient passes ADD into it (esr_layout.accumulate);
           * netD's parameter gradients stay in its plan's flat buffer (the parameters' .grad are persistent views of
-            it: FusedAdam reads them in place); RRDBNet's leave the backward as one flat buffer and reach its module-owned
-            store with ONE 67 MB device copy (`_deliver_flat_grads`), which FusedAdam then reads in place."""
+            it: FusedAdam reads them in place); RRDBNet's leave the backward as one flat buffer which the parameters'
+            `.grad` alias (`_deliver_flat_grads(adopt=True)`: no copy) and FusedAdam reads in place."""
         from . import functional as Fn
         from . import convnet as CN
         netG, netD, netF = self.netG, self.netD, self.netF

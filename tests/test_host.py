@@ -345,6 +345,44 @@ def test_flat_gradient_store_follows_autograd_accumulation_rules():
     assert not net.mark_grads_stale()
 
 
+def test_adopted_plan_gradients_alias_without_a_copy_and_keep_the_accumulation_rules():
+    """`_deliver_flat_grads(adopt=True)` (the hand-written training loops): an OVERWRITING delivery — gradients None or
+    marked stale — makes `.grad` views of the plan's own buffer instead of copying 67 MB into the module's store; an
+    accumulating one (a second backward without zero_grad) still adds, through the copying route; another plan's buffer
+    is adopted in turn; FusedAdam's zero-copy test accepts the aliased views."""
+    from esrganplus_amd import architecture as arch
+    from esrganplus_amd.optim import FusedAdam
+    net = arch.RRDBNet(3, 3, 64, 1)
+    params = list(net.parameters())
+    n = sum(p.numel() for p in params)
+    a, b = torch.arange(n, dtype=torch.float32) / n, torch.ones(n)
+    net._deliver_flat_grads(a, adopt=True)              # None everywhere: adopted
+    assert params[0].grad.data_ptr() == a.data_ptr() and torch.equal(torch.cat([p.grad.reshape(-1) for p in params]), a)
+    views = [p.grad for p in params]
+    assert net.mark_grads_stale()
+    a.mul_(2.0)                                         # "the next backward wrote the plan's buffer"
+    net._deliver_flat_grads(a, adopt=True)              # stale + same buffer: nothing to do
+    assert all(p.grad is v for p, v in zip(params, views)) and not net._gstore['stale']
+    net._deliver_flat_grads(b, adopt=True)              # NOT stale: accumulate -> copying route, a + b, a untouched
+    got = torch.cat([p.grad.reshape(-1) for p in params])
+    assert torch.equal(got, a + b) and params[0].grad.data_ptr() not in (a.data_ptr(), b.data_ptr())
+    net.zero_grad(set_to_none=True)
+    net._deliver_flat_grads(b, adopt=True)              # another plan's buffer
+    assert params[0].grad.data_ptr() == b.data_ptr()
+    assert net.mark_grads_stale()
+    net._deliver_flat_grads(a, adopt=True)              # stale, other buffer: re-pointed
+    assert params[0].grad.data_ptr() == a.data_ptr() and all(p.grad.shape == p.shape for p in params)
+    opt = FusedAdam(params)
+    st, off = dict(goff=[0] * len(params), total=n), 0
+    for i, p in enumerate(params):
+        st['goff'][i] = off
+        off += p.numel()
+    assert opt._flat_grad(st, params).data_ptr() == a.data_ptr()
+    assert net.mark_grads_stale()
+    net._flush_stale_grads()                            # a per-tensor backward is about to ADD: the stale values go
+    assert float(a.abs().sum()) == 0.0 and not net._gstore['stale']
+
+
 def test_committed_traffic_numbers_belong_to_the_current_kernels():
     """bench.py quotes `roofline.traffic` from profiles/roofline_traffic.json (separate rocprofv3 --pmc passes): every
     row must have been measured on the kernel sources in the tree (tools/traffic_hashes.py: sha256 over the files that
