@@ -159,7 +159,7 @@ def _step_worker(rank, world, port, q):
         dev = torch.device('cuda', 0)
         netG, netD, netF = _make_nets(dev)
         st = train.ESRGANPlusStep(netG, netD, netF)
-        assert st.exG.inline and dp.world_size() == 2
+        assert st.exG.inline and dp.world_size() == world
         st.optimizer_G.step = lambda **kw: None            # keep the (averaged) gradients: they are what is compared
         st.optimizer_D.step = lambda **kw: None
         lr, hr = _shard(rank, dev)
@@ -176,31 +176,34 @@ def _step_worker(rank, world, port, q):
             dist.destroy_process_group()
 
 
-def test_train_step_two_ranks_equals_global_batch_loss(dev):
-    """train.ESRGANPlusStep under torch.distributed (2 ranks on cuda:0, gloo): the gradients that reach the
+@pytest.mark.parametrize('world', [2, 8])
+def test_train_step_two_ranks_equals_global_batch_loss(dev, world):
+    """train.ESRGANPlusStep under torch.distributed (2 — and 8, the node's shape: BASELINE configs[3] — ranks on cuda:0,
+    gloo): the gradients that reach the
     optimizers are the rank-average of a loss whose relativistic means run over the GLOBAL batch
     (SRRaGAN_model.py:136-137,151-152) with per-rank BatchNorm statistics — restated here in one
-    process with torch formulas over the two shards.  Exercises the fused global-mean RaGAN loss, the in-backward
+    process with torch formulas over the shards.  Exercises the fused global-mean RaGAN loss, the in-backward
     G exchange, the D exchange and both stream overlaps."""
     import torch.multiprocessing as mp
     import torch.nn.functional as F
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_step_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=900) for _ in procs), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == 'ok' for r in res), [r[1] for r in res]
-    # both ranks hold the same averaged gradients
-    assert np.abs(res[0][2] - res[1][2]).max() <= 1e-6 * np.abs(res[0][2]).max()
-    assert np.abs(res[0][3] - res[1][3]).max() <= 1e-6 * np.abs(res[0][3]).max()
+    # all ranks hold the same averaged gradients
+    for r in range(1, world):
+        assert np.abs(res[0][2] - res[r][2]).max() <= 1e-6 * np.abs(res[0][2]).max()
+        assert np.abs(res[0][3] - res[r][3]).max() <= 1e-6 * np.abs(res[0][3]).max()
 
     # ---- single-process restatement
     netG, netD, netF = _make_nets(dev)
-    shards = [_shard(r, dev) for r in range(2)]
+    shards = [_shard(r, dev) for r in range(world)]
     bce = lambda v, real: F.binary_cross_entropy_with_logits(v, torch.ones_like(v) if real else torch.zeros_like(v))
     for p in netD.parameters():
         p.requires_grad = False
@@ -215,9 +218,9 @@ def test_train_step_two_ranks_equals_global_batch_loss(dev):
         pg.append(a); pr.append(b.detach())
     m_fake, m_real = torch.cat(pg).mean(), torch.cat(pr).mean()
     tot = 0
-    for r in range(2):
+    for r in range(world):
         gan = 5e-3 * (bce(pr[r] - m_fake, False) + bce(pg[r] - m_real, True)) / 2
-        tot = tot + (pix[r] + fea[r] + gan) / 2
+        tot = tot + (pix[r] + fea[r] + gan) / world
     tot.backward()
     wantG = torch.cat([p.grad.reshape(-1) for p in netG.parameters()]).cpu().numpy()
     for p in netD.parameters():
@@ -229,8 +232,8 @@ def test_train_step_two_ranks_equals_global_batch_loss(dev):
         dr.append(a); df.append(b)
     m_real, m_fake = torch.cat(dr).mean(), torch.cat(df).mean()
     totd = 0
-    for r in range(2):
-        totd = totd + (bce(dr[r] - m_fake, True) + bce(df[r] - m_real, False)) / 2 / 2
+    for r in range(world):
+        totd = totd + (bce(dr[r] - m_fake, True) + bce(df[r] - m_real, False)) / 2 / world
     totd.backward()
     wantD = torch.cat([p.grad.reshape(-1) for p in netD.parameters()]).cpu().numpy()
     eG = np.linalg.norm(res[0][2] - wantG) / np.linalg.norm(wantG)
