@@ -182,6 +182,7 @@ class _SeqNet(B._PlannedModule):
                 plan.fwd.array()[plan.in_op].u.layout.nchw = plan.x_static.data_ptr()
                 plan.graph = True
             pool.append(plan)
+        plan.packs = (wp, dp)            # the lists hold raw pointers into the packs; a DataParallel replica dies before its backward
         lease = CN._Lease(plan) if need_bwd else None
         if own:
             plan.own_dp.ensure(st, force=True)

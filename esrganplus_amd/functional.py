@@ -228,11 +228,17 @@ def _train_plan(net, wp, dp, B, H, W, dev, noise, explicit):
     net._plans[key] = pool
     for tp in pool:
         if not tp.busy:
+            tp.packs = (wp, dp)
             return tp
     tp = E.build_rrdbnet_train_plan(net, wp, dp, net.nb, net.in_nc, net.out_nc, B, H, W,
                                     net.precision, dev, noise, net.variant, explicit, segmented=sync is not None)
     if not explicit and E.use_graphs() and sync is None:
         tp.enable_graph((B, net.in_nc, H, W), dev)
+    # The launch lists hold RAW pointers into the packed operands: the plan keeps the packs alive.  An autograd graph
+    # references the plan (through its lease), not the module — and a nn.DataParallel replica (networks.py:105-107) is
+    # gone when its forward returns: without this its input-gradient operands were freed memory by the time the backward
+    # ran (found in round 5 with two replicas on one GPU: wrong gradients whenever the allocator re-used the block)
+    tp.packs = (wp, dp)
     pool.append(tp)
     return tp
 
@@ -331,11 +337,13 @@ def _block_train_plan(mod, kind, wp, dp, B, H, W, dev, noise, explicit):
     pool = mod._plans.setdefault(key, [])
     for tp in pool:
         if not tp.busy:
+            tp.packs = (wp, dp)
             return tp
     tp = E.build_rrdbnet_train_plan(mod, wp, dp, 1, 64, 64, B, H, W, mod.precision, dev, noise,
                                     mod.variant, explicit, kind=kind)
     if not explicit and E.use_graphs():
         tp.enable_graph((B, 64, H, W), dev)
+    tp.packs = (wp, dp)              # (the lists hold raw pointers into the packs: see _train_plan)
     pool.append(tp)
     return tp
 
