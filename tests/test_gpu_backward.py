@@ -330,3 +330,25 @@ def test_data_parallel_two_replicas_on_one_gpu_end_to_end(dev, prec):
             assert got is not None, k
             err = (got - g).norm().item() / (g.norm().item() + 1e-20)
             assert err <= lim, (rep, k, err)
+
+
+def test_data_parallel_discriminator_two_replicas_on_one_gpu(dev):
+    """networks.py:136-137: `nn.DataParallel(netD, device_ids=[0, 0])`, BatchNorm in eval mode (batch statistics are per
+    replica under DataParallel — SURVEY 8e — so only the eval form equals the one-batch result): logits and every
+    parameter gradient against the plain module."""
+    from esrganplus_amd import architecture as arch
+    net = arch.Discriminator_VGG_128(3, 64).to(dev).eval()
+    net.load_state_dict(synth.discriminator_state_dict(seed=12), strict=True)
+    x = synth.image_batch(6, 4, 3, 128, 128, name='dpd2.x').to(dev)
+    ref = net(x)
+    ref.sum().backward()
+    g_ref = {k: p.grad.clone() for k, p in net.named_parameters()}
+    for rep in range(2):
+        net.zero_grad(set_to_none=True)
+        y = torch.nn.DataParallel(net, device_ids=[0, 0])(x)
+        y.sum().backward()
+        torch.cuda.synchronize()
+        assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6)
+        for k, g in g_ref.items():
+            got = net.get_parameter(k).grad
+            assert got is not None and (got - g).norm().item() <= 1e-4 * (g.norm().item() + 1e-12), (rep, k)
