@@ -151,12 +151,17 @@ class ESRGANPlusStep:
             self.optimizer_G.zero_grad(set_to_none=True)
         with torch.no_grad():
             if ov >= 1:
-                side.wait_stream(main)
+                ev0 = torch.cuda.Event()
+                ev0.record(main)                              # var_H (and whatever the caller did before the step)
+            # the generator's forward is enqueued FIRST: a loop that reads its losses every step has the host running
+            # behind the GPU, and the step's critical path starts with this launch list, not with netF(real)'s
+            fake, stG = Fn.rrdbnet_train_forward(netG, var_L, z)
+            self.fake_H = fake
+            if ov >= 1:
+                side.wait_event(ev0)
                 with torch.cuda.stream(side):
                     real_fea = netF._run_forward(var_H, need_bwd=False)[0]
                 real_fea.record_stream(main)
-            fake, stG = Fn.rrdbnet_train_forward(netG, var_L, z)
-            self.fake_H = fake
             gy = self.__dict__.get('_gy')
             if gy is None or gy.shape != fake.shape or gy.device != fake.device:
                 gy = self._gy = torch.empty_like(fake)
