@@ -135,3 +135,27 @@ def test_srresnet_x3_keeps_the_per_conv_modules(dev):
     x = synth.image_batch(92, 1, 3, 10, 12, name='sr3.x').to(dev)
     with torch.no_grad():
         assert net(x).shape == (1, 3, 30, 36)
+
+
+@pytest.mark.parametrize('mode', ['pixelshuffle', 'upconv'])
+def test_srresnet_plan_fp16_backward_close_to_fp32(dev, mode):
+    """The planned SRResNet in fp16 storage (tap-major fp16 weight gradients, the up-sampling / shuffle ops in fp16):
+    every parameter gradient and the input gradient within fp16 rounding of the fp32 plan's."""
+    from esrganplus_amd import architecture as arch
+    nb = 2
+    sd = synth.srresnet_state_dict(nb=nb, seed=93, upsample_mode=mode)
+    x = synth.image_batch(93, 2, 3, 24, 32, name='sr16.x').to(dev)
+    gy = synth.normal_like(93, 'sr16.gy', (2, 3, 96, 128)).to(dev)
+    res = {}
+    for prec in ('fp32', 'fp16'):
+        net = arch.SRResNet(3, 3, 64, nb, upsample_mode=mode).to(dev).set_precision(prec)
+        net.load_state_dict(sd, strict=True)
+        xr = x.clone().requires_grad_(True)
+        (net(xr) * gy).sum().backward()
+        res[prec] = (xr.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()})
+    rel = lambda a, b: (a - b).norm().item() / (b.norm().item() + 1e-20)
+    assert rel(res['fp16'][0], res['fp32'][0]) <= 2e-2
+    worst = max((rel(res['fp16'][1][k], g), k) for k, g in res['fp32'][1].items())
+    print('SRResNet %s fp16 vs fp32: input gradient %.2e, worst parameter gradient %.2e (%s)'
+          % (mode, rel(res['fp16'][0], res['fp32'][0]), worst[0], worst[1]))
+    assert worst[0] <= 3e-2, worst
