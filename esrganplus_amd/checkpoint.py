@@ -6,7 +6,12 @@ Appendix B).  What the reference does around them lives here:
 * ``save_network`` — tensors moved to the CPU before ``torch.save`` (base_model.py:55-58);
 * ``interpolate`` — the network-interpolation script (codes/scripts/net_interp.py:16-18);
 * ``save_training_state`` / ``resume_training`` — the ``.state`` files (base_model.py:66-85);
-  ``optim.FusedAdam.state_dict()`` emits torch.optim.Adam's layout, so resume files interchange."""
+  ``optim.FusedAdam.state_dict()`` emits torch.optim.Adam's layout, so resume files interchange;
+* ``save_step`` / ``resume_step`` — what ``model.save(step)`` + ``model.save_training_state(epoch, step)``
+  (codes/train.py:162-165) and the resume branch (train.py:27-28, 86-91; options.py:106-120) do for a
+  ``train.ESRGANPlusStep``: ``{step}_G.pth`` / ``{step}_D.pth`` / ``{step}.state`` in the reference's layouts, taken
+  behind whatever a pipelined step left in flight, plus — new, the reference trains in fp32 — the dynamic loss
+  scaler's state, so that a resumed fp16 run continues bit for bit (tests/test_gpu_train_step.py)."""
 from collections import OrderedDict
 
 import torch
@@ -47,3 +52,41 @@ def resume_training(resume_state, optimizers, schedulers):
         o.load_state_dict(sd)
     for s, sd in zip(schedulers, rs):
         s.load_state_dict(sd)
+
+
+def save_step(step, directory, epoch, iter_step, schedulers=()):
+    """models/{iter}_G.pth, models/{iter}_D.pth, training_state/{iter}.state of a ``train.ESRGANPlusStep`` (the file
+    names and dict layouts of base_model.py:50-74; `directory` plays opt['path']['models'] / ['training_state']).
+    The step's side-stream tail (D's Adam, weight packs) is ordered first; the networks' ``state_dict()`` join it too.
+    Returns the three paths."""
+    import os
+    step.finish()
+    os.makedirs(directory, exist_ok=True)
+    pg = os.path.join(directory, '%s_G.pth' % iter_step)
+    pd = os.path.join(directory, '%s_D.pth' % iter_step)
+    ps = os.path.join(directory, '%s.state' % iter_step)
+    save_network(step.netG, pg)
+    save_network(step.netD, pd)
+    state = {'epoch': epoch, 'iter': iter_step,
+             'schedulers': [s.state_dict() for s in schedulers],
+             'optimizers': [step.optimizer_G.state_dict(), step.optimizer_D.state_dict()]}
+    if step.scaler is not None:
+        # fp16 path only (no counterpart in the reference): {scale, -, good steps, -, found flags}
+        state['loss_scaler'] = step.scaler.state.detach().cpu()
+    torch.save(state, ps)
+    return pg, pd, ps
+
+
+def resume_step(step, directory, iter_step, schedulers=()):
+    """The inverse of ``save_step``: weights into the step's networks (their packed copies are refreshed at the next
+    forward: load_state_dict marks them), Adam moments and step counts into its optimizers, schedulers, the loss
+    scaler.  Returns (epoch, iter) as train.py:86-91 reads them."""
+    import os
+    step.finish()
+    load_network(os.path.join(directory, '%s_G.pth' % iter_step), step.netG)
+    load_network(os.path.join(directory, '%s_D.pth' % iter_step), step.netD)
+    state = torch.load(os.path.join(directory, '%s.state' % iter_step), map_location='cpu')
+    resume_training(state, [step.optimizer_G, step.optimizer_D], list(schedulers))
+    if step.scaler is not None and 'loss_scaler' in state:
+        step.scaler.state.copy_(state['loss_scaler'].to(step.scaler.state.device))
+    return state['epoch'], state['iter']

@@ -1,5 +1,7 @@
 """One full ESRGAN+ optimisation step on the HIP path vs the golden captured from the reference's
 ``SRRaGANModel.optimize_parameters`` (nb=2, batch 4; oracle/gen_golden.py: gen_train_step)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -581,3 +583,67 @@ def test_optimize_parameters_step_at_full_depth_matches_reference(dev, prec):
         floor = 0.95 if prec == 'fp32' else float(g['D_sign_agree_fp16emu'][i]) - 0.03
         print('D %-40s sign agreement %.4f (floor %.4f)' % (k, agree, floor))
         assert agree >= floor, (k, agree)
+
+
+@pytest.mark.parametrize('scale', [1024.0, 'dynamic'])
+def test_resumed_training_continues_bit_for_bit(dev, tmp_path, scale):
+    """codes/train.py:162-165 + the resume branch (27-28, 86-91) on the fp16 production step: 3 steps, `save_step`
+    ({iter}_G.pth / _D.pth / .state in the reference's layouts + the loss scaler), a FRESH set of networks, optimizers
+    and schedulers, `resume_step`, 3 more steps — against 6 uninterrupted steps: every weight, BatchNorm buffer and Adam
+    moment bit-identical (fixed noise seeds per step; pipelined calls, so the checkpoint is taken behind work in flight)."""
+    from esrganplus_amd import architecture as arch, train, checkpoint as ck
+    sdG, sdD = synth.rrdbnet_state_dict(nb=2, seed=81), synth.discriminator_state_dict(seed=82)
+
+    def make():
+        netG = arch.RRDBNet(3, 3, 64, 2).to(dev).train().set_precision('fp16')
+        netD = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision('fp16')
+        netF = arch.VGGFeatureExtractor(34, False, True, dev).to(dev).eval().set_precision('fp16')
+        netF.load_state_dict(synth.vgg19_state_dict(6, 34), strict=False)
+        st = train.ESRGANPlusStep(netG, netD, netF, loss_scale=scale)
+        scheds = [torch.optim.lr_scheduler.MultiStepLR(o, [2, 4], 0.5) for o in (st.optimizer_G, st.optimizer_D)]
+        return netG, netD, st, scheds
+
+    def steps(st, scheds, lo, hi):
+        import warnings
+        for it in range(lo, hi):
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                for sch in scheds:
+                    sch.step()                              # train.py:102: the schedulers first
+            torch.manual_seed(9000 + it)                    # the Philox seeds of the noise layers come from torch's generator
+            lr = synth.image_batch(900 + it, 4, 3, 32, 32, name='resume.lr').to(dev)
+            hr = synth.image_batch(950 + it, 4, 3, 128, 128, name='resume.hr').to(dev)
+            st.step(lr, hr, sync_log=False)
+
+    def snapshot(netG, netD, st):
+        st.finish()
+        torch.cuda.synchronize()
+        out = {'G.' + k: v.detach().clone() for k, v in netG.state_dict().items()}
+        out.update({'D.' + k: v.detach().clone() for k, v in netD.state_dict().items()})
+        for tag, opt in (('oG', st.optimizer_G), ('oD', st.optimizer_D)):
+            for i, e in opt.state_dict()['state'].items():
+                out['%s.%s.m' % (tag, i)], out['%s.%s.v' % (tag, i)], out['%s.%s.t' % (tag, i)] = e['exp_avg'], e['exp_avg_sq'], e['step']
+        return out
+
+    netG, netD, st, scheds = make()
+    netG.load_state_dict(sdG, strict=True)
+    netD.load_state_dict(sdD, strict=True)
+    steps(st, scheds, 0, 6)
+    want = snapshot(netG, netD, st)
+
+    netG, netD, st, scheds = make()
+    netG.load_state_dict(sdG, strict=True)
+    netD.load_state_dict(sdD, strict=True)
+    steps(st, scheds, 0, 3)
+    paths = ck.save_step(st, str(tmp_path), epoch=0, iter_step=3, schedulers=scheds)     # no finish() by the caller
+    assert [os.path.basename(p) for p in paths] == ['3_G.pth', '3_D.pth', '3.state']
+    state = torch.load(paths[2], map_location='cpu')
+    assert set(state) >= {'epoch', 'iter', 'schedulers', 'optimizers'} and len(state['optimizers']) == 2
+    del netG, netD, st, scheds
+    netG, netD, st, scheds = make()                         # default-initialised networks: everything comes from the files
+    assert ck.resume_step(st, str(tmp_path), 3, schedulers=scheds) == (0, 3)
+    steps(st, scheds, 3, 6)
+    got = snapshot(netG, netD, st)
+    assert want.keys() == got.keys()
+    bad = [k for k in want if not torch.equal(want[k].cpu(), got[k].cpu())]
+    assert not bad, bad[:8]
