@@ -647,3 +647,49 @@ def test_resumed_training_continues_bit_for_bit(dev, tmp_path, scale):
     assert want.keys() == got.keys()
     bad = [k for k in want if not torch.equal(want[k].cpu(), got[k].cpu())]
     assert not bad, bad[:8]
+
+
+def test_validation_between_pipelined_steps_does_not_disturb_training(dev):
+    """codes/train.py:121-159: every `val_freq` iterations the loop runs `model.test()` — netG.eval(), a no_grad forward,
+    netG.train() (SRRaGAN_model.py:188-192) — between two optimisation steps.  In a pipelined loop that forward lands
+    between a step whose D-side tail is still in flight and the next one, and the train <-> eval flips re-pack weights:
+    the trajectory must be the one without validation (bit for bit), and what validation sees must be the eval forward of
+    the weights after exactly that many steps."""
+    from esrganplus_amd import architecture as arch, train
+    sdG, sdD = synth.rrdbnet_state_dict(nb=2, seed=85), synth.discriminator_state_dict(seed=86)
+    val_lr = synth.image_batch(990, 1, 3, 40, 24, name='val.lr').to(dev)
+
+    def run(validate_at):
+        netG = arch.RRDBNet(3, 3, 64, 2).to(dev).train().set_precision('fp16')
+        netD = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision('fp16')
+        netF = arch.VGGFeatureExtractor(34, False, True, dev).to(dev).eval().set_precision('fp16')
+        netG.load_state_dict(sdG, strict=True)
+        netD.load_state_dict(sdD, strict=True)
+        netF.load_state_dict(synth.vgg19_state_dict(6, 34), strict=False)
+        st = train.ESRGANPlusStep(netG, netD, netF, loss_scale=1024.0)
+        seen = {}
+        for it in range(4):
+            torch.manual_seed(7000 + it)
+            lr = synth.image_batch(970 + it, 4, 3, 32, 32, name='valrun.lr').to(dev)
+            hr = synth.image_batch(980 + it, 4, 3, 128, 128, name='valrun.hr').to(dev)
+            st.step(lr, hr, sync_log=False)
+            if it + 1 in validate_at:
+                netG.eval()
+                with torch.no_grad():
+                    seen[it + 1] = (netG(val_lr).clone(), {k: v.detach().clone() for k, v in netG.state_dict().items()})
+                netG.train()
+        st.finish()
+        torch.cuda.synchronize()
+        out = {'G.' + k: v.detach().clone() for k, v in netG.state_dict().items()}
+        out.update({'D.' + k: v.detach().clone() for k, v in netD.state_dict().items()})
+        return out, seen
+
+    plain, _ = run(())
+    withval, seen = run((2, 3))
+    bad = [k for k in plain if not torch.equal(plain[k], withval[k])]
+    assert not bad, bad[:8]
+    for n, (y, sd) in seen.items():
+        ref = arch.RRDBNet(3, 3, 64, 2).to(dev).eval().set_precision('fp16')
+        ref.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            assert torch.equal(ref(val_lr), y), n
