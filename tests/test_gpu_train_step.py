@@ -693,3 +693,69 @@ def test_validation_between_pipelined_steps_does_not_disturb_training(dev):
         ref.load_state_dict(sd, strict=True)
         with torch.no_grad():
             assert torch.equal(ref(val_lr), y), n
+
+
+def test_reference_loop_transcribed_over_the_drop_in_modules_matches_the_golden(dev):
+    """INTEGRATION.md section 1 taken literally: `SRRaGANModel.optimize_parameters` (SRRaGAN_model.py:113-168) transcribed
+    line by line — torch.optim.Adam, nn.L1Loss, BCEWithLogitsLoss, requires_grad toggles on netD, FOUR separate netD calls,
+    two netF calls, loss.backward() — with nothing of this repository but the three drop-in modules.  Against the golden
+    step of the imported reference (train_step.npz): losses, fake_H, the weights after Adam, and BatchNorm's
+    `num_batches_tracked` = 4."""
+    from esrganplus_amd import architecture as arch
+    from oracle import ref_torch as RT
+    g = dict(np.load('tests/golden/train_step.npz'))
+    sdG, sdD = synth.rrdbnet_state_dict(nb=2, seed=30), synth.discriminator_state_dict(seed=31)
+    netG = arch.RRDBNet(3, 3, 64, 2).to(dev).train()
+    netD = arch.Discriminator_VGG_128(3, 64).to(dev).train()
+    netF = arch.VGGFeatureExtractor(34, False, True, dev).to(dev).eval()
+    netG.load_state_dict(sdG, strict=True)
+    netD.load_state_dict(sdD, strict=True)
+    netF.load_state_dict(synth.vgg19_state_dict(6, 34), strict=False)
+    var_L = synth.image_batch(30, 4, 3, 32, 32, name='step.lr').to(dev)
+    var_H = synth.image_batch(30, 4, 3, 128, 128, name='step.hr').to(dev)
+    var_ref = var_H
+    z = [synth.normal_like(9, 'step.z.%d' % i, s).to(dev) for i, s in enumerate(RT.noise_shapes(var_L.shape, 2, 'codes'))]
+    cri_pix, cri_fea, bce = torch.nn.L1Loss(), torch.nn.L1Loss(), torch.nn.BCEWithLogitsLoss()
+    gan = lambda x, real: bce(x, torch.ones_like(x) if real else torch.zeros_like(x))      # loss.py:6-38, 'vanilla'
+    optimizer_G = torch.optim.Adam([p for p in netG.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.999))
+    optimizer_D = torch.optim.Adam(netD.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    # ---- G (SRRaGAN_model.py:114-141)
+    for p in netD.parameters():
+        p.requires_grad = False
+    optimizer_G.zero_grad()
+    fake_H = netG(var_L, z=z)                       # (z: the golden's injected normal_() draws)
+    l_g_pix = 1e-2 * cri_pix(fake_H, var_H)
+    real_fea = netF(var_H).detach()
+    fake_fea = netF(fake_H)
+    l_g_fea = 1.0 * cri_fea(fake_fea, real_fea)
+    pred_g_fake = netD(fake_H)
+    pred_d_real = netD(var_ref).detach()
+    l_g_gan = 5e-3 * (gan(pred_d_real - torch.mean(pred_g_fake), False) + gan(pred_g_fake - torch.mean(pred_d_real), True)) / 2
+    (l_g_pix + l_g_fea + l_g_gan).backward()
+    optimizer_G.step()
+    # ---- D (143-168)
+    for p in netD.parameters():
+        p.requires_grad = True
+    optimizer_D.zero_grad()
+    pred_d_real = netD(var_ref)
+    pred_d_fake = netD(fake_H.detach())
+    l_d_real = gan(pred_d_real - torch.mean(pred_d_fake), True)
+    l_d_fake = gan(pred_d_fake - torch.mean(pred_d_real), False)
+    ((l_d_real + l_d_fake) / 2).backward()
+    optimizer_D.step()
+    log = dict(l_g_pix=l_g_pix.item(), l_g_fea=l_g_fea.item(), l_g_gan=l_g_gan.item(), l_d_real=l_d_real.item(),
+               l_d_fake=l_d_fake.item(), D_real=torch.mean(pred_d_real.detach()).item(), D_fake=torch.mean(pred_d_fake.detach()).item())
+    for k, v in log.items():
+        ref = float(g['log_' + k])
+        print('%-9s drop-in %.6e  ref %.6e' % (k, v, ref))
+        assert abs(v - ref) <= 2e-4 * max(1.0, abs(ref)), k
+    assert np.abs(fake_H.detach().cpu().numpy()[:, :, ::4, ::4] - g['fake_H_sub4']).max() <= 1e-4
+    pg, pd = dict(netG.named_parameters()), dict(netD.named_parameters())
+    chk = np.stack([checks(pg[k]) for k in sdG.keys()])
+    assert np.abs(chk - g['G_new_chk']).max() <= 2e-3 * np.abs(g['G_new_chk']).max()
+    chk = np.stack([checks(pd[k]) for k in pd.keys()])
+    assert np.abs(chk - g['D_new_chk']).max() <= 2e-3 * np.abs(g['D_new_chk']).max()
+    d = (pg['model.0.weight'].detach().cpu() - sdG['model.0.weight']).numpy()
+    assert np.mean(np.sign(d) == np.sign(g['G_delta_model.0.weight'])) >= 0.97
+    nbt = [int(v) for k, v in netD.named_buffers() if k.endswith('num_batches_tracked')]
+    assert nbt and all(n == 4 for n in nbt), nbt
