@@ -695,9 +695,9 @@ def test_validation_between_pipelined_steps_does_not_disturb_training(dev):
             assert torch.equal(ref(val_lr), y), n
 
 
-def test_reference_loop_transcribed_over_the_drop_in_modules_matches_the_golden(dev):
-    """INTEGRATION.md section 1 taken literally: `SRRaGANModel.optimize_parameters` (SRRaGAN_model.py:113-168) transcribed
-    line by line — torch.optim.Adam, nn.L1Loss, BCEWithLogitsLoss, requires_grad toggles on netD, FOUR separate netD calls,
+def test_reference_call_pattern_over_the_drop_in_modules_matches_the_golden(dev):
+    """INTEGRATION.md section 1 taken literally: the call pattern of `SRRaGANModel.optimize_parameters`
+    (SRRaGAN_model.py:113-168) restated call by call with stock torch pieces — torch.optim.Adam, nn.L1Loss, BCEWithLogitsLoss, requires_grad toggles on netD, FOUR separate netD calls,
     two netF calls, loss.backward() — with nothing of this repository but the three drop-in modules.  Against the golden
     step of the imported reference (train_step.npz): losses, fake_H, the weights after Adam, and BatchNorm's
     `num_batches_tracked` = 4."""
