@@ -103,11 +103,14 @@ def _train_forward(tp, xin, st, seed, zs):
     return out
 
 
-def _train_backward(tp, gy, st, noise, explicit, seed, want_gx, sync=None):
-    """Runs the backward launch list; returns dL/dx (stand-alone blocks) or None."""
-    tp.grad_flat.zero_()
-    if tp.tapmajor is not None:
-        tp.tapmajor.tm.zero_()
+def _train_backward(tp, gy, st, noise, explicit, seed, want_gx, sync=None, prepared=False):
+    """Runs the backward launch list; returns dL/dx (stand-alone blocks) or None.
+    prepared: the gradient buffers are zeroed and the backward chain's weight streams gathered already
+    (`rrdbnet_train_prepare`, on another stream the caller has ordered in front of this one)."""
+    if not prepared:
+        tp.grad_flat.zero_()
+        if tp.tapmajor is not None:
+            tp.tapmajor.tm.zero_()
     if tp.graph:
         tp.gy_static.copy_(gy)
         if tp.bwd_streams is not None:
@@ -138,7 +141,7 @@ def _train_backward(tp, gy, st, noise, explicit, seed, want_gx, sync=None):
     for i in tp.bwd_chain_ops:                      # fused backward chain (esr_rdb_backward): same Philox key as the forward
         arr[i].u.rdb_chain.noise_mode = L.NOISE_PHILOX if noise else L.NOISE_OFF
         arr[i].u.rdb_chain.seed = seed
-    if tp.bwd_streams is not None:
+    if tp.bwd_streams is not None and not prepared:
         tp.bwd_streams.ensure(st)
     if tp.segments is None or sync is None:
         tp.bwd.run_range(st, 0, n_ops)
@@ -292,7 +295,7 @@ class _RRDBNetFn(torch.autograd.Function):
 
 class TrainPass:
     """State of one RRDBNet training forward outside autograd (train.ESRGANPlusStep's hand-written step)."""
-    __slots__ = ('lease', 'seed', 'noise', 'explicit', 'sync')
+    __slots__ = ('lease', 'seed', 'noise', 'explicit', 'sync', 'prepared')
 
 
 _ADOPT = os.environ.get('ESR_ADOPT_GRADS', '1') != '0'     # A/B knob: 0 = always copy into the module's store (round 4)
@@ -318,7 +321,25 @@ def rrdbnet_train_forward(net, x, z=None):
     s.lease = _PlanLease(tp)
     s.seed = _draw_seed() if (noise and zs is None) else 0
     s.noise, s.explicit, s.sync = noise, zs is not None, getattr(net, '_grad_sync', None)
+    s.prepared = False
     return _train_forward(tp, xin, st, s.seed, zs), s
+
+
+def rrdbnet_train_prepare(net, s):
+    """What the backward of the forward state `s` needs before its first launch and that depends on nothing of this
+    step — the flat gradient buffer and the tap-major arena zeroed (67 + 67 MB of fills), the backward chain's weight
+    streams gathered from the input-gradient packs — enqueued on the CURRENT stream: the train step runs it on its side
+    stream under the generator's forward and makes the main stream wait for it in front of the backward (three launches
+    and their dispatch gaps off the step's critical path)."""
+    tp = s.lease.tp
+    if tp is None or tp.graph or s.prepared:
+        return
+    tp.grad_flat.zero_()
+    if tp.tapmajor is not None:
+        tp.tapmajor.tm.zero_()
+    if tp.bwd_streams is not None:
+        tp.bwd_streams.ensure(E.current_stream())
+    s.prepared = True
 
 
 def rrdbnet_train_backward(net, s, gy):
@@ -327,7 +348,7 @@ def rrdbnet_train_backward(net, s, gy):
     tp = s.lease.tp
     if tp is None:
         raise RuntimeError('rrdbnet_train_backward called twice on one forward')
-    _train_backward(tp, gy, E.current_stream(), s.noise, s.explicit, s.seed, False, s.sync)
+    _train_backward(tp, gy, E.current_stream(), s.noise, s.explicit, s.seed, False, s.sync, prepared=s.prepared)
     net._deliver_flat_grads(tp.grad_flat, adopt=_ADOPT)
     s.lease.release()
 

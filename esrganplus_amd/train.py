@@ -75,6 +75,7 @@ class ESRGANPlusStep:
         # host enqueue order of netD's forward vs netF(fake)
         self.order = self._knob('ESR_TRAIN_ORDER', 'main_first', ('main_first', 'side_first'))
         self.tail_side = os.environ.get('ESR_TRAIN_TAIL_SIDE', '1') == '1'
+        self.prep_side = os.environ.get('ESR_TRAIN_PREP_SIDE', '1') == '1'      # A/B knob (round 5)
         self.overlap_d_step = self.overlap >= 1
 
     @staticmethod
@@ -157,10 +158,17 @@ class ESRGANPlusStep:
             # behind the GPU, and the step's critical path starts with this launch list, not with netF(real)'s
             fake, stG = Fn.rrdbnet_train_forward(netG, var_L, z)
             self.fake_H = fake
+            ev_prep = None
             if ov >= 1:
                 side.wait_event(ev0)
                 with torch.cuda.stream(side):
                     real_fea = netF._run_forward(var_H, need_bwd=False)[0]
+                    if self.prep_side:
+                        # the G backward's step-independent preliminaries (zero fills of the gradient buffers, the backward
+                        # chain's weight-stream gather) under the generator's forward instead of in front of the backward
+                        Fn.rrdbnet_train_prepare(netG, stG)
+                        ev_prep = torch.cuda.Event()
+                        ev_prep.record(side)
                 real_fea.record_stream(main)
             gy = self.__dict__.get('_gy')
             if gy is None or gy.shape != fake.shape or gy.device != fake.device:
@@ -265,6 +273,8 @@ class ESRGANPlusStep:
             if ov >= 1 and d_when == 'mid':
                 with torch.cuda.stream(side):
                     aux = d_step()
+            if ev_prep is not None:
+                main.wait_event(ev_prep)
             Fn.rrdbnet_train_backward(netG, stG, gy)
             self.exG.start()
             if ov >= 1:
