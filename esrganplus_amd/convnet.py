@@ -16,11 +16,6 @@ from . import engine as E
 
 BN_MOMENTUM, BN_EPS = 0.1, 1e-5      # nn.BatchNorm2d defaults (block.py:31)
 # ESR_FUSE_BN=0: the five-launch BatchNorm of round 3 (stats, finalize, apply / reduce, final, apply) for A/B runs
-def stats_in_epilogue():
-    # ESR_BN_STATS_IN_CONV=0: a separate ESR_BN_STATS pass behind every plain conv -> BatchNorm layer (round 4)
-    return os.environ.get('ESR_BN_STATS_IN_CONV', '1') != '0'
-
-
 def fuse_bn():
     return os.environ.get('ESR_FUSE_BN', '1') != '0'
 
@@ -224,11 +219,6 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
                 if training and fuse_bn():
                     cv.stat_sums, cv.stat_groups, cv.stat_C = P.sums_f.data_ptr() + 8 * base, groups, cout
                     stats_in_conv = True
-            elif training and fuse_bn() and stats_in_epilogue() and dt_e == L.ESR_F16:
-                # round 5: plain conv -> BatchNorm layers take the statistics in the conv's epilogue (esr_conv.stat_sums
-                # without ksplit): one launch less per layer on the train step's critical path (netD's forward)
-                cv.stat_sums, cv.stat_groups, cv.stat_C = P.sums_f.data_ptr() + 8 * base, groups, cout
-                stats_in_conv = True
             f.add_conv(cv)
             mk = dict(sums_f=P.sums_f.data_ptr() + 8 * base, base=base,
                       mean=stats.data_ptr() + 4 * base, invstd=stats.data_ptr() + 4 * (base + maxc * groups))

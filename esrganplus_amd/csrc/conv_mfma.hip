@@ -38,7 +38,7 @@ namespace {
 // per SIMD a load->use->store chain per row would expose R full memory latencies.
 template <typename T, int R, int NCW, int CW, bool HAS1X1, bool BWD, int RS = 1>
 __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc8& acc1, int b, int cb, int h,
-                                               int oyb, int ox, const bool col_ok = true) {
+                                               int oyb, int ox) {
   const bool n1 = (p.noise_mode == ESR_NOISE_PHILOX && p.layer1 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z1.ptr);
   const bool n2 = (p.noise_mode == ESR_NOISE_PHILOX && p.layer2 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z2.ptr);
   const bool n3 = (p.noise_mode == ESR_NOISE_PHILOX && p.layer3 != ESR_NO_LAYER) || (p.noise_mode == ESR_NOISE_EXPLICIT && p.z3.ptr);
@@ -56,13 +56,6 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
         !(p.debug_flags & 0x18)) {
       const bool relu = p.act == ESR_ACT_RELU;
       const float slope = p.act == ESR_ACT_LRELU ? ESR_LRELU_SLOPE : 1.f;
-      // round 5: the BatchNorm statistics of the stored tensor (ESR_BN_STATS: per channel sum / sum of squares over the
-      // group's images) taken HERE, from the values as they are stored — the discriminator's conv -> BatchNorm layers
-      // lose one launch each on the train step's critical path (esr_conv.stat_sums without ksplit)
-      const bool stats = p.stat_sums != nullptr && p.ksplit <= 1;
-      float s0[16], s1[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
       sfor<R>([&](auto RR) __attribute__((always_inline)) {
         constexpr int r = decltype(RR)::value;
         const int oy = oyb + RS * r;
@@ -79,11 +72,6 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
             v[e] = fmaxf(x, x * slope);
           }
         }
-        if (stats && col_ok) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) { const float q = (float)(T)v[e]; s0[e] += q; s1[e] += q * q; }
-        }
-        if (!col_ok) return;
         if (g32_only) Px16<T>::store(p.out, b, cb, h, (int64_t)(oy + 1) * p.out.wp + ox + 1, v);
         else {
           const int c0 = cb * 32 + 16 * h;
@@ -93,23 +81,6 @@ __device__ __forceinline__ void epilogue_block(const esr_conv& p, Acc8& acc, Acc
             if (c0 + e < p.nchw_out_c) o[(int64_t)e * p.H * p.W] = v[e];
         }
       });
-      if (stats) {
-        // the 32 pixel lanes of a half-wave hold the same 16 channels: butterfly over them, lane 0 / 32 adds to the sums
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-#pragma unroll
-          for (int o = 16; o > 0; o >>= 1) { s0[e] += __shfl_xor(s0[e], o); s1[e] += __shfl_xor(s1[e], o); }
-        }
-        if ((__lane_id() & 31) == 0) {
-          const int ngrp = p.stat_groups > 1 ? p.stat_groups : 1, grp = b / (p.B / ngrp);
-          double* const sums = p.stat_sums + (int64_t)grp * 2 * p.stat_C;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int c = cb * 32 + 16 * h + e;
-            if (c < p.stat_C) { atomicAdd(sums + c, (double)s0[e]); atomicAdd(sums + p.stat_C + c, (double)s1[e]); }
-          }
-        }
-      }
       return;
     }
   }
@@ -794,17 +765,13 @@ __device__ __forceinline__ void conv_body(const esr_conv& p, char* const smem, c
     return;
   }
   const int ox = UPS == 2 ? ox0 + 2 * j + wc : UPS == 3 ? 2 * (ox0 + wc * 32 + j) + pdx : ox0 + wc * 32 + j;
-  // (statistics in the epilogue — esr_conv.stat_sums, plain layers — need every lane of the wave in the butterfly: the
-  //  lanes beyond the image's last column stay, contribute nothing and store nothing)
-  const bool col_ok = ox < p.W;
-  const bool stat_epi = !BWD && !HAS1X1 && !PACK && UPS == 0 && p.stat_sums != nullptr && p.ksplit <= 1;
-  if ((!col_ok && !stat_epi) || (dbg & 1)) return;
+  if (ox >= p.W || (dbg & 1)) return;
   const int oyb = UPS == 3 ? 2 * (oy0 + wr * R) + pdy : oy0 + wr * R;
   sfor<NCW>([&](auto CW) __attribute__((always_inline)) {
     constexpr int cw = decltype(CW)::value;
     const int cb = cb0 + cw;
     if (cb >= p.cout_blocks) return;
-    epilogue_block<T, R, NCW, cw, HAS1X1, BWD, (UPS == 3 ? 2 : 1)>(p, acc, acc1, b, cb, h, oyb, ox, col_ok);
+    epilogue_block<T, R, NCW, cw, HAS1X1, BWD, (UPS == 3 ? 2 : 1)>(p, acc, acc1, b, cb, h, oyb, ox);
   });
 }
 
@@ -1042,12 +1009,7 @@ extern "C" int esr_conv_forward(const esr_conv* p, esr_stream_t stream) {
     return ESR_ERR_INVALID;
   }
   if (p->mask.ptr && !p->out2.ptr) { esr_set_error("esr_conv_forward: mask without out2"); return ESR_ERR_INVALID; }
-  if (p->stat_sums && p->ksplit <= 1 &&
-      (p->upsample || p->w1x1 || p->res1.ptr || p->res2.ptr || p->aux_out.ptr || p->mask.ptr || p->noise_mode != ESR_NOISE_OFF ||
-       !p->out.ptr || p->nchw_out_c > 0 || p->stat_C <= 0 || (p->stat_groups > 1 && p->B % p->stat_groups))) {
-    esr_set_error("esr_conv_forward: stat_sums without ksplit is for plain layers (bias [+ act], one G32 output)");
-    return ESR_ERR_INVALID;
-  }
+  if (p->stat_sums && p->ksplit <= 1) { esr_set_error("esr_conv_forward: stat_sums rides on the split-K finishing pass (ksplit > 1)"); return ESR_ERR_INVALID; }
 
   hipStream_t st = (hipStream_t)stream;
   if (p->dtype == ESR_F16) return dispatch<_Float16>(*p, st);
