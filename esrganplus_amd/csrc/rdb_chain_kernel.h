@@ -1039,7 +1039,7 @@ __device__ __forceinline__ void run_units_fat(Acc24& acc, const WStream& s, char
       // top of unit I+1: its successor's weights, the barrier, hook(I)
       hook(std::integral_constant<int, I>{}, PhC<PH_END>{});
       if constexpr (!(ESR_ABL & 256)) {
-        if constexpr (STRICT0 && I == I0) wait_units<T, S::wait_fat_strict(I + 1, true), S::wait_fat_strict(I + 1, false)>(s);
+        if constexpr (STRICT0 && I == I0 && !(ESR_ABL & 2048)) wait_units<T, S::wait_fat_strict(I + 1, true), S::wait_fat_strict(I + 1, false)>(s);
         else wait_units<T, S::wait_fat(I + 1, true), S::wait_fat(I + 1, false)>(s);
       }
       dbg_stamp<I0>(s, 3 + 3 * (I - I0));
@@ -1093,7 +1093,7 @@ __device__ __forceinline__ void run_units_s(Acc24& acc, const WStream& s, char* 
     auto mid = [&]() __attribute__((always_inline)) {
       hook(std::integral_constant<int, I>{}, PhC<PH_END>{});
       if constexpr (!(ESR_ABL & 256)) {
-      if constexpr (STRICT0 && I == I0) wait_units<T, S::wait_mid_strict(I, true), S::wait_mid_strict(I, false)>(s);
+      if constexpr (STRICT0 && I == I0 && !(ESR_ABL & 2048)) wait_units<T, S::wait_mid_strict(I, true), S::wait_mid_strict(I, false)>(s);
       else wait_units<T, S::wait_mid(I, true), S::wait_mid(I, false)>(s);   // the next unit's weights
       }
       dbg_stamp<I0>(s, 3 + 3 * (I - I0));
@@ -1219,7 +1219,7 @@ template <typename PT = esr_rdb_chain>
 __device__ __forceinline__ void publish(unsigned* flags, int tile, unsigned epoch, const Tile& t,
                                         const PT* tp = nullptr, int* ev = nullptr) {
   if (tp) trace_ev(*tp, tile, *ev);                      // epilogue done (stores issued)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its sc1 stores
+  if constexpr (!(ESR_ABL & 1024)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its sc1 stores
   if (tp) trace_ev(*tp, tile, *ev);                      // own stores drained
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store((gu32*)(flags + tile), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1230,6 +1230,7 @@ __device__ __forceinline__ void publish(unsigned* flags, int tile, unsigned epoc
 template <typename PT = esr_rdb_chain>
 __device__ __forceinline__ bool wait_neighbours(unsigned* ws, unsigned epoch, char* smem, const Tile& t,
                                                 const PT* tp = nullptr, int* ev = nullptr, int tile_ = 0) {
+  if constexpr ((ESR_ABL & 1024) != 0) { if (tp) trace_ev(*tp, tile_, *ev); __syncthreads(); return true; }   // "free hand-off" bound
   if (t.wave == 0) {
     // the neighbour this lane polls (lanes 0..7)
     const int lane = t.lane();
@@ -1844,7 +1845,7 @@ if constexpr (DIR == 2) {
             }
             if constexpr (ph == PH_IN) {
               lds_old2(pr.tag, pr.hsrc);
-              early = __builtin_amdgcn_readfirstlane((int)(pr.tag == epoch));
+              early = (ESR_ABL & 1024) ? 1 : __builtin_amdgcn_readfirstlane((int)(pr.tag == epoch));
               if (early) halo_issue<CF::KD>(dblk, g0, (int)pr.hsrc, hq);
             }
           }
@@ -2004,7 +2005,7 @@ if constexpr (DIR == 2) {
             }
             if constexpr (ph == PH_IN) {
               lds_old2(pr.tag, pr.hsrc);
-              early = __builtin_amdgcn_readfirstlane((int)(pr.tag == epoch));
+              early = (ESR_ABL & 1024) ? 1 : __builtin_amdgcn_readfirstlane((int)(pr.tag == epoch));
               if (early) halo_issue<CF::KD>(dblk, g0, (int)pr.hsrc, hq);
             }
           }

@@ -36,6 +36,12 @@
 
 namespace {
 
+#ifndef ESR_WGRAD_NBF
+#define ESR_WGRAD_NBF 3
+#endif
+#ifndef ESR_WGRAD_ABL
+#define ESR_WGRAD_ABL 0      // timing ablations (development only; results are wrong when non-zero): 1 = no staging DMA after a
+#endif                       // task's first batch, 2 = no fragment reads, 4 = no MFMAs, 8 = no step barrier / DMA wait
 constexpr int NWV = 8, NTH = NWV * 64;
 constexpr int RS = 4;                       // output rows per step
 constexpr int INB = 34 * 64;                // one in-block row: [34 px][2 groups][32 B]
@@ -63,7 +69,13 @@ __device__ __host__ constexpr int conv_slot_off(int k) {
 constexpr int SLOT_ELEMS = conv_slot_off(5) + conv_slot_elems(5);      // 241 664 weights + 192 bias sums
 static_assert(SLOT_ELEMS == 241664 + 192, "slot");
 
-struct WaveJob { int g, i, kind; };         // staged g-block index, staged in-block index; kind 0 = 3x3, 1 = 1x1, 2 = idle
+// staged g-block index, staged in-block index; kind 0 = 3x3, 1 = 1x1, 2 = idle; bias: mask of the staged g-blocks whose
+// bias gradient (the sum of the gradient over the pixels) this wave accumulates.  The sums ride on the waves with the
+// least matrix work — the 1x1 pairs of set A (8 MFMAs per step against 72), the idle wave of sets C and D — not on the
+// 3x3 pairs that happen to read the block: 128 dot-product instructions per step on two of eight waves kept the other six
+// waiting at the step barrier (round 5).  Every conv's bias comes from exactly one set (conv5: A; conv4, conv1: C;
+// conv3, conv2: D).
+struct WaveJob { int g, i, kind, bias; };
 struct SetDesc {
   int nib, ngb;
   int inb[MAX_NIB];                         // in-block ids staged
@@ -72,13 +84,13 @@ struct SetDesc {
 };
 constexpr SetDesc kSets[4] = {
     // A: conv5 x in blocks 0..2, + the 1x1 (g_x2 x in blocks 0,1)
-    {3, 3, {0, 1, 2, 0, 0}, {0, 1, 6}, {{0, 0, 0}, {0, 1, 0}, {0, 2, 0}, {1, 0, 0}, {1, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 1, 1}}},
+    {3, 3, {0, 1, 2, 0, 0}, {0, 1, 6}, {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 2, 0, 0}, {1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 0, 0}, {2, 0, 1, 1}, {2, 1, 1, 2}}},
     // B: conv5 x in blocks 3..5
-    {3, 2, {3, 4, 5, 0, 0}, {0, 1, 0}, {{0, 0, 0}, {0, 1, 0}, {0, 2, 0}, {1, 0, 0}, {1, 1, 0}, {1, 2, 0}, {0, 0, 2}, {0, 0, 2}}},
+    {3, 2, {3, 4, 5, 0, 0}, {0, 1, 0}, {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 2, 0, 0}, {1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 0, 0}, {0, 0, 2, 0}, {0, 0, 2, 0}}},
     // C: conv4 x in blocks 0..4, conv1 x in blocks 0,1
-    {5, 2, {0, 1, 2, 3, 4}, {2, 5, 0}, {{0, 0, 0}, {0, 1, 0}, {0, 2, 0}, {0, 3, 0}, {0, 4, 0}, {1, 0, 0}, {1, 1, 0}, {0, 0, 2}}},
+    {5, 2, {0, 1, 2, 3, 4}, {2, 5, 0}, {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 2, 0, 0}, {0, 3, 0, 0}, {0, 4, 0, 0}, {1, 0, 0, 0}, {1, 1, 0, 0}, {0, 0, 2, 3}}},
     // D: conv3 x in blocks 0..3, conv2 x in blocks 0..2
-    {4, 2, {0, 1, 2, 3, 0}, {3, 4, 0}, {{0, 0, 0}, {0, 1, 0}, {0, 2, 0}, {0, 3, 0}, {1, 0, 0}, {1, 1, 0}, {1, 2, 0}, {0, 0, 2}}},
+    {4, 2, {0, 1, 2, 3, 0}, {3, 4, 0}, {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 2, 0, 0}, {0, 3, 0, 0}, {1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 0, 0}, {0, 0, 2, 3}}},
 };
 
 // Fragment reads are inline asm: with a compiler-visible LDS read after an LDS-DMA in flight hipcc waits `vmcnt(0)`
@@ -88,6 +100,7 @@ constexpr SetDesc kSets[4] = {
 // statements that name the registers they release (cdna guide 5.7, form ii).
 struct Frag { u32x2 lo, hi; };
 template <int OFF> __device__ __forceinline__ void tr_issue(Frag& f, uint32_t a) {
+  if constexpr ((ESR_WGRAD_ABL & 2) != 0) { asm volatile("" : "=v"(f.lo), "=v"(f.hi) : "v"(a)); return; }
   asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
                : "=&v"(f.lo), "=&v"(f.hi) : "v"(a), "n"(OFF), "n"(OFF + 4 * 64));
 }
@@ -185,8 +198,7 @@ __device__ __forceinline__ void pace_prefetch(Pace& pc) {
 // (in-row ir, column tap kw) stream through three registers sets, two reads ahead of the MFMAs that consume them —
 // B(ir, kw) feeds the output rows ir - kh, kh = 0..2.
 template <int KIND, int NIB_ROW, int NGB_ROW>
-__device__ __forceinline__ void step_mma(Acc9& acc, float& bsum, const bool want_bias, const uint32_t lg, const uint32_t lp0,
-                                         const uint32_t lp1, const uint32_t lp2) {
+__device__ __forceinline__ void step_mma(Acc9& acc, const uint32_t lg, const uint32_t lp0, const uint32_t lp1, const uint32_t lp2) {
   sfor<2>([&](auto HF) __attribute__((always_inline)) {
     constexpr int hf = decltype(HF)::value;
     Frag A[RS];
@@ -208,44 +220,62 @@ __device__ __forceinline__ void step_mma(Acc9& acc, float& bsum, const bool want
         acc.a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_val(A[r]), frag_val(B[r]), acc.a0, 0, 0, 0);
       });
     } else {
-      Frag B[3];
+      // NBF register sets, NBF - 1 fragments ahead (ESR_WGRAD_NBF: 3 = two ahead, the round-2 form)
+      constexpr int NBF = ESR_WGRAD_NBF, AHD = NBF - 1;
+      Frag B[NBF];
       auto issue_b = [&](auto J) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value, ir = j / 3, kw = j % 3;
-        tr_issue<(ir & 1) * NIB_ROW + hf * (16 * 64) + kw * 64>(B[j % 3], ir < 2 ? lp0 : (ir < 4 ? lp1 : lp2));
+        tr_issue<(ir & 1) * NIB_ROW + hf * (16 * 64) + kw * 64>(B[j % NBF], ir < 2 ? lp0 : (ir < 4 ? lp1 : lp2));
       };
-      issue_b(std::integral_constant<int, 0>{});
-      issue_b(std::integral_constant<int, 1>{});
-      wait_frag5<2>(A[0], A[1], A[2], A[3], B[0]);              // everything but B1's two reads
-      if (want_bias) {
-        // the lane's 8 pixels of cout row lane % 32, four fragments: v_dot2_f32_f16 against (1, 1) — exact products,
-        // fp32 accumulation, one instruction per two pixels
-        typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-        const half2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
-#pragma unroll
-        for (int r = 0; r < RS; ++r) {
-          const half8 hv = frag_val(A[r]);
-#pragma unroll
-          for (int e = 0; e < 8; e += 2) bsum = __builtin_amdgcn_fdot2(half2_t{hv[e], hv[e + 1]}, ones, bsum, false);
-        }
-      }
+      sfor<AHD>([&](auto J) __attribute__((always_inline)) { issue_b(J); });
+      wait_frag5<2 * (AHD - 1)>(A[0], A[1], A[2], A[3], B[0]);   // everything but the reads of B1 .. B(AHD - 1)
       sfor<18>([&](auto J) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value, ir = j / 3, kw = j % 3;
-        if constexpr (j + 2 < 18) issue_b(std::integral_constant<int, j + 2>{});
+        if constexpr (j + AHD < 18) issue_b(std::integral_constant<int, j + AHD>{});
         sfor<3>([&](auto KH) __attribute__((always_inline)) {
           constexpr int kh = decltype(KH)::value;
           constexpr int r = ir - kh;
           if constexpr (r >= 0 && r < RS) {
             f32x16& d = acc_t<kh * 3 + kw>(acc);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_val(A[r]), frag_val(B[j % 3]), d, 0, 0, 0);
+            if constexpr (!(ESR_WGRAD_ABL & 4)) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_val(A[r]), frag_val(B[j % NBF]), d, 0, 0, 0);
+            else d[0] += (float)frag_val(A[r])[0] * (float)frag_val(B[j % NBF])[7];      // (keeps the reads alive)
           }
         });
-        if constexpr (j + 1 < 18) wait_frag<(j + 2 < 18) ? 2 : 0>(B[(j + 1) % 3]);
+        // B(j + 1): everything issued behind it may stay in flight (fragments j + 2 .. min(j + AHD, 17), two reads each)
+        if constexpr (j + 1 < 18) wait_frag<2 * ((j + AHD < 17 ? j + AHD : 17) - (j + 1))>(B[(j + 1) % NBF]);
       });
     }
   });
 }
 
-template <int SET>
+// bias sums of one staged gradient block over a step: the lane's 8 pixels of cout row lane % 32, four row fragments per
+// 16-pixel half run: v_dot2_f32_f16 against (1, 1) — exact products, fp32 accumulation, one instruction per two pixels.
+// Order per lane: (half run, row, pixel pair) — the order the 3x3 pairs used to sum in, so the results are unchanged.
+template <int NGB_ROW>
+__device__ __forceinline__ void step_bias(float& bsum, const uint32_t lg) {
+  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  const half2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
+  Frag A[2][RS];
+  sfor<2>([&](auto HF) __attribute__((always_inline)) {
+    constexpr int hf = decltype(HF)::value;
+    sfor<RS>([&](auto RR) __attribute__((always_inline)) {
+      constexpr int r = decltype(RR)::value;
+      tr_issue<r * NGB_ROW + hf * (16 * 64)>(A[hf][r], lg);
+    });
+  });
+  wait_frag5<0>(A[0][0], A[0][1], A[0][2], A[0][3], A[1][0]);
+  wait_frag5<0>(A[1][1], A[1][2], A[1][3], A[1][0], A[0][0]);
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+      const half8 hv = frag_val(A[hf][r]);
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) bsum = __builtin_amdgcn_fdot2(half2_t{hv[e], hv[e + 1]}, ones, bsum, false);
+    }
+}
+
+template <int SET, bool PACED>
 __device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const int chunk, char* const smem, Pace& pc) {
   constexpr SetDesc sd = kSets[SET];
   constexpr int nib = sd.nib, ngb = sd.ngb;
@@ -326,9 +356,9 @@ __device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const 
   };
 
   // ---- this wave's pair
-  int jg = 0, ji = 0, kind = 2;
+  int jg = 0, ji = 0, kind = 2, bmask = 0;
 #pragma unroll
-  for (int w = 0; w < NWV; ++w) if (wave == w) { jg = sd.wave[w].g; ji = sd.wave[w].i; kind = sd.wave[w].kind; }
+  for (int w = 0; w < NWV; ++w) if (wave == w) { jg = sd.wave[w].g; ji = sd.wave[w].i; kind = sd.wave[w].kind; bmask = sd.wave[w].bias; }
   int gbid = sd.gbk[0], ibid = sd.inb[0];
 #pragma unroll
   for (int u = 1; u < ngb; ++u) if (jg == u) gbid = sd.gbk[u];
@@ -336,7 +366,9 @@ __device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const 
   for (int u = 1; u < nib; ++u) if (ji == u) ibid = sd.inb[u];
   const int conv = conv_of_gblock(gbid);
   const int cb = gbid == 1 ? 1 : 0;                     // cout block inside the conv (conv5's second half)
-  const bool want_bias = kind == 0 && ibid == 0 && bd.db[conv] != nullptr;   // one wave per gradient block sums it
+  // bias sums: staged g-blocks 0 / 1 of the set (a wave takes one or both), skipped where the caller wants no db
+  const bool bias0 = (bmask & 1) && bd.db[conv_of_gblock(sd.gbk[0])] != nullptr;
+  const bool bias1 = (bmask & 2) && bd.db[conv_of_gblock(sd.gbk[1])] != nullptr;
   // per-lane transposed-read geometry (wgrad.hip): lane -> pixel-in-run, 8-byte quarter, 16-channel half
   const int i16 = lane & 15, jrow = i16 >> 2, q = i16 & 3, ghalf = (lane >> 4) & 1, kg = lane >> 5;
   const uint32_t lane_off = (uint32_t)((8 * kg + jrow) * 64 + ghalf * 32 + q * 8);
@@ -348,7 +380,7 @@ __device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const 
     for (int e = 0; e < 16; ++e) z[e] = 0.f;
     acc.a0 = z; acc.a1 = z; acc.a2 = z; acc.a3 = z; acc.a4 = z; acc.a5 = z; acc.a6 = z; acc.a7 = z; acc.a8 = z;
   }
-  float bsum = 0.f;
+  float bsum0 = 0.f, bsum1 = 0.f;
 
   const int T = (p.H + RS - 1) / RS;
   const int b_begin = ig * ka.ipw, b_end = min(p.B, b_begin + ka.ipw);
@@ -364,23 +396,37 @@ __device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const 
     issue_pair(2);
     issue_gquad(0);
     for (int t = 0; t < T; ++t) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // batch t (issued a whole step ago) has landed
-      if (wave == 0) pace_step(pc);                // lock step with the chunk's other sets (a late sibling: bounded spin)
-      __builtin_amdgcn_s_barrier();                // ... for every wave; every wave is done reading step t - 1
-      if (wave == 0) pace_prefetch(pc);
-      if (t + 1 < T) {
+      if constexpr (!(ESR_WGRAD_ABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // batch t (issued a whole step ago) has landed
+      if constexpr (PACED) { if (wave == 0) pace_step(pc); }   // lock step with the chunk's other sets (a late sibling: bounded spin)
+      if constexpr (!(ESR_WGRAD_ABL & 8)) __builtin_amdgcn_s_barrier();                // ... for every wave; every wave is done reading step t - 1
+      if constexpr (PACED) { if (wave == 0) pace_prefetch(pc); }
+      if (t + 1 < T && !(ESR_WGRAD_ABL & 1)) {
         issue_pair(2 * t + 3);
         issue_pair(2 * t + 4);
         issue_gquad(t + 1);
       }
+      if (bias0) step_bias<NGB_ROW>(bsum0, lds_g + (t & 1) * GQB + lane_off);
+      if (bias1) step_bias<NGB_ROW>(bsum1, lds_g + (t & 1) * GQB + GBB + lane_off);
       if (kind == 2) continue;
       const uint32_t lg = lds_g + (t & 1) * GQB + jg * GBB + lane_off;
       const uint32_t lp0 = lds0 + ((2 * t) % NPAIR) * PAIRB + ji * INB + lane_off;
       const uint32_t lp1 = lds0 + ((2 * t + 1) % NPAIR) * PAIRB + ji * INB + lane_off;
       const uint32_t lp2 = lds0 + ((2 * t + 2) % NPAIR) * PAIRB + ji * INB + lane_off;
-      if (kind == 0) step_mma<0, NIB_ROW, NGB_ROW>(acc, bsum, want_bias, lg, lp0, lp1, lp2);
-      else step_mma<1, NIB_ROW, NGB_ROW>(acc, bsum, false, lg, lp0, lp1, lp2);
+      if (kind == 0) step_mma<0, NIB_ROW, NGB_ROW>(acc, lg, lp0, lp1, lp2);
+      else step_mma<1, NIB_ROW, NGB_ROW>(acc, lg, lp0, lp1, lp2);
     }
+  }
+  // ---- bias sums -> behind the weights of their conv's slot ([9][cout][cin] | [cout])
+  {
+    float* const slot0 = p.partial + ((int64_t)blk * nchunk + chunk) * ka.slot_stride;
+    auto put_bias = [&](const float bsum, const int gb) __attribute__((always_inline)) {
+      const int cv = conv_of_gblock(gb), half = gb == 1 ? 1 : 0;
+      const float scb = p.scale * (cv == 4 ? p.scale5 : 1.f);
+      const float other = __shfl_xor(bsum, 32);          // lanes l and l + 32 hold the two k halves of cout row l % 32
+      if (lane < 32) slot0[conv_slot_off(cv) + (int64_t)9 * conv_cout(cv) * conv_cin(cv) + half * 32 + lane] = (bsum + other) * scb;
+    };
+    if (bias0) put_bias(bsum0, sd.gbk[0]);
+    if (bias1) put_bias(bsum1, sd.gbk[1]);
   }
   if (kind == 2) return;
 
@@ -401,13 +447,13 @@ __device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const 
   } else {
     put(acc.a0, 0); put(acc.a1, 1); put(acc.a2, 2); put(acc.a3, 3); put(acc.a4, 4);
     put(acc.a5, 5); put(acc.a6, 6); put(acc.a7, 7); put(acc.a8, 8);
-    if (want_bias) {
-      const float other = __shfl_xor(bsum, 32);          // lanes l and l + 32 hold the two k halves of cout row l % 32
-      if (lane < 32) slot[(int64_t)9 * cout * cin + cb * 32 + lane] = (bsum + other) * sc;
-    }
   }
 }
 
+// PACED: the lock-step experiment's instantiation.  The default one carries no Pace state at all: the struct is passed by
+// reference through the set switch, lives in scratch, and a test of `pc.mine` in front of every step's barrier was a
+// scratch load on wave 0 — a memory round trip per row step that every wave then waited for at the barrier.
+template <bool PACED>
 __global__ __launch_bounds__(NTH, 2) void rdb_wgrad_kernel(const KArgs ka) {
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   // ---- task decode: linear id -> (block, chunk, set) with a chunk's four sets on ONE XCD (ids 8 apart: the
@@ -422,7 +468,7 @@ __global__ __launch_bounds__(NTH, 2) void rdb_wgrad_kernel(const KArgs ka) {
   pc.mine = nullptr;
   pc.count = 0;
   pc.seen[0] = pc.seen[1] = pc.seen[2] = 0;
-  if (ka.pace) {                                          // (host: only when every task sits in a complete group)
+  if (PACED && ka.pace) {                                 // (host: only when every task sits in a complete group)
     const int w = blockIdx.x, me = (w >> 3) & 3;
     pc.mine = ka.pace + w;
     int k = 0;
@@ -437,10 +483,10 @@ __global__ __launch_bounds__(NTH, 2) void rdb_wgrad_kernel(const KArgs ka) {
     if (l < full) { const int grp = l >> 5, w = l & 31; chunk = grp * 8 + (w & 7); set = w >> 3; }
     else { const int rem = nchunk & 7, w = l - full; chunk = (nchunk / 8) * 8 + w % rem; set = w / rem; }
     switch (set) {
-      case 0: wgrad_set<0>(ka, blk, chunk, smem, pc); break;
-      case 1: wgrad_set<1>(ka, blk, chunk, smem, pc); break;
-      case 2: wgrad_set<2>(ka, blk, chunk, smem, pc); break;
-      default: wgrad_set<3>(ka, blk, chunk, smem, pc); break;
+      case 0: wgrad_set<0, PACED>(ka, blk, chunk, smem, pc); break;
+      case 1: wgrad_set<1, PACED>(ka, blk, chunk, smem, pc); break;
+      case 2: wgrad_set<2, PACED>(ka, blk, chunk, smem, pc); break;
+      default: wgrad_set<3, PACED>(ka, blk, chunk, smem, pc); break;
     }
   }
 }
@@ -562,7 +608,8 @@ extern "C" int esr_rdb_wgrad_run(const esr_rdb_wgrad* p, esr_stream_t stream) {
       return ESR_ERR_LAUNCH;
     }
   }
-  hipLaunchKernelGGL(rdb_wgrad_kernel, dim3((unsigned)grid), dim3(NTH), 0, st, ka);
+  if (ka.pace) hipLaunchKernelGGL(rdb_wgrad_kernel<true>, dim3((unsigned)grid), dim3(NTH), 0, st, ka);
+  else hipLaunchKernelGGL(rdb_wgrad_kernel<false>, dim3((unsigned)grid), dim3(NTH), 0, st, ka);
   int rc = esr_check_launch("rdb_wgrad_kernel");
   if (rc) return rc;
   const int64_t total = (int64_t)p->n_blocks * SLOT_ELEMS;

@@ -13,8 +13,9 @@ H = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 W = int(sys.argv[4]) if len(sys.argv) > 4 else 128
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
-ins = [E.G32(B, 192, H, W, 'fp16', dev) for _ in range(nb)]
-qs = [E.G32(B, 224, H, W, 'fp16', dev) for _ in range(nb)]
+SHARED = os.environ.get('ESR_PROBE_SHARED') == '1'     # every block reads the SAME two tensors (cache-resident operands)
+ins = [E.G32(B, 192, H, W, 'fp16', dev) for _ in range(1 if SHARED else nb)]
+qs = [E.G32(B, 224, H, W, 'fp16', dev) for _ in range(1 if SHARED else nb)]
 for g in ins + qs:
     g.t[:, :, 1:H + 1, 1:W + 1].normal_()
 flat = torch.zeros(nb * (241664 + 192), dtype=torch.float32, device=dev)
@@ -22,7 +23,7 @@ blocks = (L.esr_rdb_wgrad_block * nb)()
 couts, cins = [32, 32, 32, 32, 64, 32], [64, 96, 128, 160, 192, 64]
 for i in range(nb):
     b = blocks[i]
-    b.in_, b.q = ins[i].view(0, 192), qs[i].view(0, 224)
+    b.in_, b.q = ins[0 if SHARED else i].view(0, 192), qs[0 if SHARED else i].view(0, 224)
     off = i * (241664 + 192)
     for k in range(6):
         b.dw[k] = flat.data_ptr() + 4 * off
@@ -50,5 +51,7 @@ ev[1].record()
 torch.cuda.synchronize()
 ms = ev[0].elapsed_time(ev[1]) / reps
 fl = 2.0 * 241664 * B * H * W * nb
+steps = nb * 4 * B * ((W + 31) // 32) * ((H + 3) // 4)
+print('  %s operands; %d workgroup-steps, %.2f us per step on 256 CUs' % ('shared' if SHARED else 'distinct', steps, ms * 1e3 / (steps / 256.0)))
 print('rdb_wgrad: %d blocks, %dx%dx%d: %.3f ms per launch pair = %.1f us per block, %.1f TFLOP/s (%.3f of fp16 peak); arena %.2f GB'
       % (nb, B, H, W, ms, ms * 1e3 / nb, fl / ms / 1e9, fl / ms / 1e9 / 2500.0, need * 4 / 1e9))
