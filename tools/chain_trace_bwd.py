@@ -38,3 +38,12 @@ for i, n in enumerate(names):
     tot += col.mean()
     print('  %-10s %7.2f  [%6.2f .. %6.2f]' % (n, col.mean(), col.min(), col.max()))
 print('  total      %7.2f' % tot)
+if os.environ.get('ESR_TRACE_UNITS'):          # build with -DESR_ABL=32 [-DESR_DBG_SEG=<first unit>]: s_memtime stamps of one segment
+    u = t[:, 32:64]
+    n = int((u[0] != 0).sum())
+    du = np.diff(u[:, :n], axis=1).astype(np.float64)
+    lab = ['wait+bar', 'first loads'] + sum([['u%d mfma+wait' % k, 'u%d barrier' % k, 'u%d hook' % k] for k in range(20)], [])
+    print('unit stamps of the traced segment (shader ticks), mean over tiles [min..max]; %d stamps' % n)
+    for i in range(n - 1):
+        print('  %-14s %7.0f  [%6.0f .. %6.0f]' % (lab[i], du[:, i].mean(), du[:, i].min(), du[:, i].max()))
+    print('  total          %7.0f' % du.sum(axis=1).mean())
