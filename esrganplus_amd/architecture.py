@@ -204,6 +204,50 @@ class _SeqNet(B._PlannedModule):
             order.leave(cur)
         return y, lease
 
+    # ---- the dual pair forward in two stages (train step, round 5): ``_pair_begin(b)`` runs the SECOND operand's half
+    # (group 1: the train step's ``real``, known at the start of the step) and ``_pair_finish(handle, a)`` the first
+    # operand's half once it exists; together they are ``_run_forward(cat([a, b]), need_bwd=True, groups=2, dual=n)``:
+    # the same plan (same pool key), the same launches on half the batch each, the running-statistics updates in the
+    # reference's order (the early half's update is deferred to plan.restat1, which the caller runs after the late half).
+    def _pair_begin(self, b):
+        E.require_cuda(b, 'input')
+        xb = b.detach().contiguous().float()
+        n, C_, H, W = xb.shape
+        dev = xb.device
+        st = E.current_stream()
+        wp = self._weights(dev)
+        dp = self._dgrad_weights(dev)
+        dp.ensure(st, force=not self.__dict__.get('_weights_clean', False) and not self._dgrad_fresh())
+        training = bool(self.training) and self._has_bn
+        if not training or getattr(self, '_per_call_weights', False) or E.use_graphs():
+            raise L.HipExtensionError('_pair_begin: BatchNorm network in train mode only')
+        key = ('seq', 2 * n, H, W, self.precision, training, True, True, wp.generation, str(dev), 2, None, n)
+        pool = self._plans.setdefault(key, [])
+        plan = next((p for p in pool if not p.busy), None)
+        if plan is None:
+            plan = CN.build_seq_plan(self._spec(), wp, dp, self._pspec(), True, 2 * n, H, W, self.precision,
+                                     dev, training, True, self._input_affine(), self._head(), groups=2, bwd_B=None, dual=n)
+            plan.own_dp, plan.own_head = None, None
+            pool.append(plan)
+        if getattr(plan, 'fwd_half', None) is None:
+            CN.split_forward_groups(plan, n)
+        plan.packs = (wp, dp)
+        lease = CN._Lease(plan)
+        plan.sums_f.zero_()
+        half = plan.fwd_half[1]
+        half.array()[plan.in_op].u.layout.nchw = xb.data_ptr()
+        half.run(st)
+        plan.keep_x = (xb,)
+        return plan, lease
+
+    def _pair_finish(self, plan, a):
+        xa = a.detach().contiguous().float()
+        half = plan.fwd_half[0]
+        half.array()[plan.in_op].u.layout.nchw = xa.data_ptr()
+        half.run(E.current_stream())
+        plan.keep_x = plan.keep_x + (xa,)
+        return plan.out_tensor.clone()
+
     def forward(self, x):
         self._join_pending()
         need = torch.is_grad_enabled() and (x.requires_grad or self._wants_param_grads())

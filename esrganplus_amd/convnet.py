@@ -477,6 +477,74 @@ def build_seq_plan(spec, wp, dp, pspec, want_wgrad, B, H, W, dtype, dev, trainin
     return P
 
 
+def split_forward_groups(P, n):
+    """The forward launch list of a two-group pair plan (batch 2n, BatchNorm groups (0, 1)) as TWO lists over the halves,
+    so that the half whose input is known early (the train step's ``real`` operand, group 1) can run long before the
+    other one exists (round 5: netD(real) under the generator's forward instead of behind it).  Every launch of the
+    full list is copied with B = n, its buffers advanced to the half's images, BatchNorm launches with groups = 1 and
+    the statistics arrays advanced to the group's [C] rows.  The reference's order of running-statistics updates is
+    (group 0, group 1): the EARLY half (group 1) therefore leaves the running buffers alone and the update it owes is a
+    third list, ``P.restat1`` (ESR_BN_RESTAT on group 1's sums), to be run once after the late half.
+    Returns nothing; fills P.fwd_half = [list of group 0, list of group 1] and P.restat1."""
+    import ctypes as C_
+    src = P.fwd.array()
+    halves = [L.OpList(), L.OpList()]
+    restat1 = L.OpList()
+    g32_fields = {L.OP_CONV: ('conv', ('in_', 'out', 'aux_out', 'res1', 'res2', 'z1', 'z2', 'z3', 'mask', 'out2', 'out3')),
+                  L.OP_BN: ('bn', ('x', 'y', 'g', 'gx')), L.OP_POOL: ('pool', ('x', 'y', 'g', 'gx')),
+                  L.OP_LAYOUT: ('layout', ('g32',))}
+
+    def adv(v, g):
+        if v.ptr:
+            v.ptr = v.ptr + g * n * v.batch_stride
+
+    for g in (0, 1):
+        for i in range(len(P.fwd.ops)):
+            o = L.esr_op.from_buffer_copy(src[i])
+            k = o.kind
+            if k in g32_fields:
+                st = getattr(o.u, g32_fields[k][0])
+                for fld in g32_fields[k][1]:
+                    adv(getattr(st, fld), g)
+                assert st.B == 2 * n, 'pair plan: every launch covers both halves'
+                st.B = n
+                if k == L.OP_CONV:
+                    if st.nchw_out:
+                        raise L.HipExtensionError('split pair forward: NCHW conv outputs are not supported')
+                    if st.stat_sums:
+                        assert st.stat_groups == 2
+                        st.stat_sums = st.stat_sums + g * 2 * st.stat_C * 8
+                        st.stat_groups = 1
+                elif k == L.OP_BN:
+                    assert st.groups == 2
+                    st.groups = 1
+                    st.sums = st.sums + g * 2 * st.C * 8
+                    st.mean = st.mean + g * st.C * 4
+                    st.invstd = st.invstd + g * st.C * 4
+                    if g == 1:
+                        st.running_mean = st.running_var = st.num_batches_tracked = None
+                elif k == L.OP_LAYOUT:
+                    if st.nchw and i != P.in_op:
+                        st.nchw = st.nchw + g * n * st.C * st.H * st.W * 4
+            elif k == L.OP_LINEAR:
+                st = o.u.linear
+                assert st.B == 2 * n and st.mode == 0
+                st.B = n
+                st.x = st.x + g * n * st.I * 4
+                st.y = st.y + g * n * st.O * 4
+            else:
+                raise L.HipExtensionError('split pair forward: launch kind %d is not supported' % k)
+            halves[g].ops.append(o)
+    for i in range(len(P.restat.ops)):
+        o = L.esr_op.from_buffer_copy(P.restat.array()[i])
+        st = o.u.bn
+        assert o.kind == L.OP_BN and st.groups == 2 and st.B == 2 * n
+        st.B, st.groups = n, 1
+        st.sums = st.sums + 2 * st.C * 8
+        restat1.ops.append(o)
+    P.fwd_half, P.restat1 = halves, restat1
+
+
 def _run_pass(Q, graph, gy, n_total, want_gx, needs):
     """Replay one backward pass (a SeqPlan's own or its BwdPass) for the upstream gradient gy; returns
     (gx or None, [parameter gradients or None])."""

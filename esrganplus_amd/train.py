@@ -76,6 +76,10 @@ class ESRGANPlusStep:
         self.order = self._knob('ESR_TRAIN_ORDER', 'main_first', ('main_first', 'side_first'))
         self.tail_side = os.environ.get('ESR_TRAIN_TAIL_SIDE', '1') == '1'
         self.prep_side = os.environ.get('ESR_TRAIN_PREP_SIDE', '1') == '1'      # A/B knob (round 5)
+        # netD's forward in two stages: the `real` half on the side stream under the generator's forward (its input is
+        # known when the step starts), the `fake` half alone behind the generator (A/B knob, round 5)
+        self.d_split = os.environ.get('ESR_TRAIN_DSPLIT', '1') == '1'
+
         self.overlap_d_step = self.overlap >= 1
 
     @staticmethod
@@ -159,6 +163,9 @@ class ESRGANPlusStep:
             fake, stG = Fn.rrdbnet_train_forward(netG, var_L, z)
             self.fake_H = fake
             ev_prep = None
+            dsplit = (self.d_split and ov >= 1 and netD._has_bn and netD.training and not E.use_graphs()
+                      and not getattr(netD, '_per_call_weights', False))
+            d_early = None
             if ov >= 1:
                 side.wait_event(ev0)
                 with torch.cuda.stream(side):
@@ -169,6 +176,11 @@ class ESRGANPlusStep:
                         Fn.rrdbnet_train_prepare(netG, stG)
                         ev_prep = torch.cuda.Event()
                         ev_prep.record(side)
+                    if dsplit:
+                        # netD(real): the previous step's D-side tail (Adam, packs) sits on this stream, in front of it
+                        var_ref.record_stream(side)
+                        d_early = netD._pair_begin(var_ref) + (torch.cuda.Event(),)
+                        d_early[2].record(side)
                 real_fea.record_stream(main)
             gy = self.__dict__.get('_gy')
             if gy is None or gy.shape != fake.shape or gy.device != fake.device:
@@ -188,8 +200,13 @@ class ESRGANPlusStep:
                 if ev is not None:
                     main.wait_event(ev)                       # the previous step's D step, D's Adam and packs (side stream)
                 # ONE netD forward for the step's four calls (forward_shared): groups (fake, real)
-                out, leaseD = netD._run_forward(torch.cat([fake, var_ref]), need_bwd=True, groups=2 if netD._has_bn else 1, dual=n)
-                PD = leaseD.plan
+                if d_early is not None:
+                    PD, leaseD = d_early[0], d_early[1]
+                    main.wait_event(d_early[2])               # the real half (side stream)
+                    out = netD._pair_finish(PD, fake)
+                else:
+                    out, leaseD = netD._run_forward(torch.cat([fake, var_ref]), need_bwd=True, groups=2 if netD._has_bn else 1, dual=n)
+                    PD = leaseD.plan
                 if side is not None:
                     out.record_stream(side)                   # (the D step reads it there)
                 box['leaseD'], box['PD'], box['pg'], box['pr'] = leaseD, PD, out[:n], out[n:]
@@ -231,6 +248,8 @@ class ESRGANPlusStep:
 
             def d_step():
                 # D step (SRRaGAN_model.py:143-168): the second pair of calls sees the first pair's values
+                if d_early is not None and PD.restat1.ops:
+                    PD.restat1.run(E.current_stream())            # the running-statistics update the early half still owes
                 if PD.restat is not None and PD.restat.ops:
                     PD.restat.run(E.current_stream())
                 gyt = PD.gy_tensor                                # plan order [fake; real]

@@ -252,6 +252,51 @@ def test_discriminator_forward_pair_matches_two_calls(dev, mode, prec, tol):
             assert (x - y).abs().max().item() <= tol * max(y.abs().max().item(), 1e-3 * gmax)
 
 
+@pytest.mark.parametrize('prec', ['fp32', 'fp16'])
+def test_two_stage_pair_forward_is_the_one_pass_pair_forward(dev, prec):
+    """``_pair_begin(real)`` + ``_pair_finish(plan, fake)`` (the train step runs netD's `real` half on the side stream
+    under the generator's forward and the `fake` half behind it) against ONE dual pair forward over ``cat([fake, real])``:
+    the same launches on half the batch each, so logits, both backward passes (the D step's parameter gradients over
+    the whole batch, the G step's input gradient of the fake half) and the BatchNorm buffers after the deferred update
+    (plan.restat1) and the second pair's replay (plan.restat) must agree BIT FOR BIT."""
+    from esrganplus_amd import architecture as arch, convnet as CN, engine as E
+    sd = synth.discriminator_state_dict(9)
+    n = 3
+    fake = synth.image_batch(91, n, 3, 128, 128, name='two.f').to(dev)
+    real = synth.image_batch(92, n, 3, 128, 128, name='two.r').to(dev)
+    gy = synth.image_batch(93, 2 * n, 1, 1, 1, name='two.g').to(dev).reshape(2 * n, 1)
+    res = {}
+    for how in ('one', 'two'):
+        net = arch.Discriminator_VGG_128(3, 64).to(dev).train().set_precision(prec)
+        net.load_state_dict(sd)
+        with torch.no_grad():
+            if how == 'one':
+                out, lease = net._run_forward(torch.cat([fake, real]), need_bwd=True, groups=2, dual=n)
+                P = lease.plan
+            else:
+                P, lease = net._pair_begin(real)
+                out = net._pair_finish(P, fake)
+                P.restat1.run(E.current_stream())
+            P.restat.run(E.current_stream())
+            P.gy_tensor.copy_(gy)
+            P.second.gy_tensor.copy_(gy[:n])
+            CN.run_pass_into(P)
+            CN.run_pass_into(P.second)
+            torch.cuda.synchronize()
+            bn = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+            res[how] = dict(out=out.clone(), grads=P.grad_flat.clone(), gx=P.second.gx_tensor.clone(),
+                            rm=[m.running_mean.clone() for m in bn], rv=[m.running_var.clone() for m in bn],
+                            nbt=[int(m.num_batches_tracked) for m in bn])
+        lease.release()
+    one, two = res['one'], res['two']
+    assert two['nbt'] == one['nbt'] == [4] * len(one['nbt'])
+    assert torch.equal(one['out'], two['out'])
+    assert torch.equal(one['gx'], two['gx'])
+    assert torch.equal(one['grads'], two['grads'])
+    for x, y in zip(one['rm'] + one['rv'], two['rm'] + two['rv']):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize('prec,tol', [('fp32', 2e-4), ('fp16', 3e-2)])
 def test_discriminator_forward_shared_matches_four_calls(dev, prec, tol):
     """The train step calls netD four times with unchanged weights — G step: netD(fake), netD(real).detach() with D
