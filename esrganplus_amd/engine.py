@@ -1566,12 +1566,20 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             # (block n reads its g_t from Qs[n], which the previous launch's last block wrote: launch boundaries are
             # free of semantics).  Only the last run's weight gradients are left behind the chain.
             per_run = (nb + nsplit - 1) // nsplit
-            warena = torch.empty(int(L.lib().esr_rdb_wgrad_workspace_elems(B, H, W, per_run * nj)), dtype=torch.float32, device=device)
+            # run boundaries (RRDB indices).  ESR_BWD_SPLIT_FIRST = n: two runs, the first of n RRDBs (A/B: the LAST run's
+            # weight gradients are the ones left behind the chain, the first run's must fit under the second chain)
+            first = int(os.environ.get('ESR_BWD_SPLIT_FIRST', '0'))
+            bounds = list(range(0, nb, per_run)) + [nb]
+            if nsplit == 2 and 0 < first < nb:
+                bounds = [0, first, nb]
+            # (the arena of a pass is not monotonic in its block count: fewer blocks -> fewer images per task -> more slots)
+            need = max(int(L.lib().esr_rdb_wgrad_workspace_elems(B, H, W, (b1 - b0) * nj)) for b0, b1 in zip(bounds[:-1], bounds[1:]))
+            warena = torch.empty(need, dtype=torch.float32, device=device)
             TP.bufs.append(warena)
             cus = L.lib().esr_rdb_max_tiles_per_image()
             spare = max(32, cus - B * ((H + 3) // 4) * ((W + 31) // 32))     # CUs the chain's grid leaves free
-            for r0 in range(0, nb, per_run):
-                k0, k1 = r0 * nj, min(nb, r0 + per_run) * nj
+            for r0, r1 in zip(bounds[:-1], bounds[1:]):
+                k0, k1 = r0 * nj, r1 * nj
                 chain_op(k0, k1)
                 # every run but the last shares the chip with the next run's chain: its pass keeps to the spare CUs
                 # (a persistent grid of that many workgroups) so that the chain's workgroups find theirs free
