@@ -196,9 +196,15 @@ def test_backward_chain_split_into_runs_is_bit_identical(dev, monkeypatch, cls_n
     x = synth.image_batch(71, 16, 3, 32, 32, name='split.x').to(dev)
     gy = synth.normal_like(72, 'split.gy', (16, 3, 128, 128)).to(dev)
     res = {}
-    for split in ('1', '4', '5', 'auto'):
+    for split in ('1', '4', '5', 'auto', 'first4'):
+        monkeypatch.delenv('ESR_BWD_SPLIT_FIRST', raising=False)
         if split == 'auto':
             monkeypatch.delenv('ESR_BWD_SPLIT', raising=False)
+        elif split == 'first4':
+            # two UNEQUAL runs (4 + 1 RRDBs): the shared weight-gradient arena must fit the run that needs the most slots,
+            # which is not the longest one
+            monkeypatch.delenv('ESR_BWD_SPLIT', raising=False)
+            monkeypatch.setenv('ESR_BWD_SPLIT_FIRST', '4')
         else:
             monkeypatch.setenv('ESR_BWD_SPLIT', split)
         net = getattr(arch, cls_name)(3, 3, 64, nb).to(dev).train().set_precision('fp16')
@@ -210,6 +216,7 @@ def test_backward_chain_split_into_runs_is_bit_identical(dev, monkeypatch, cls_n
         assert len(tps) == 1
         res[split] = (len(tps[0].bwd_chain_ops), {k: p.grad.clone() for k, p in net.named_parameters()})
     assert res['1'][0] == 1 and res['4'][0] == 3 and res['5'][0] == 5 and res['auto'][0] == 2     # '4': runs of ceil(5 / 4) = 2 RRDBs
-    for split in ('4', '5', 'auto'):
+    assert res['first4'][0] == 2
+    for split in ('4', '5', 'auto', 'first4'):
         bad = [k for k, g in res['1'][1].items() if not torch.equal(g, res[split][1][k])]
         assert not bad, (split, bad[:6])
