@@ -708,11 +708,7 @@ __device__ __forceinline__ void unit_steps(Acc24& acc, UFrags& f, const uint32_t
         if constexpr (s + 1 < NS) {
           if constexpr (newset && !(ESR_ABL & 4))
             sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<decltype(IR2)::value * IW * 32>(bf[decltype(IR2)::value], lb[newset ? kwi + 1 : 0]); });
-          if constexpr (newset && (ESR_ABL & 8192) != 0)     // .. and the B rows of a new column tap twice
-            sfor<3>([&](auto IR2) __attribute__((always_inline)) { lds_read16<decltype(IR2)::value * IW * 32>(bf[decltype(IR2)::value], lb[newset ? kwi + 1 : 0]); });
           if constexpr (!(ESR_ABL & 2))
-            sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<((s + 1) * 3 + decltype(KH)::value) * 1024>(an[decltype(KH)::value], lw); });
-          if constexpr ((ESR_ABL & 4096) != 0)     // every A refill twice (same data): what a fragment read costs
             sfor<3>([&](auto KH) __attribute__((always_inline)) { lds_read16<((s + 1) * 3 + decltype(KH)::value) * 1024>(an[decltype(KH)::value], lw); });
         } else if constexpr (NXT) {
           if constexpr (!(ESR_ABL & 8)) mid();
