@@ -10,8 +10,8 @@ watch_run() {
     sleep 0.5
   done
 }
-echo "== forward: python bench.py --steps 2500 --no-fwd-bwd --no-cpu-baseline"
-watch_run python bench.py --steps 2500 --warmup 10 --no-fwd-bwd --no-cpu-baseline
+echo "== forward: python bench.py --steps 2500 --no-fwd-bwd --no-cpu-baseline --no-train"
+watch_run python bench.py --steps 2500 --warmup 10 --no-fwd-bwd --no-cpu-baseline --no-train
 tail -1 /tmp/cw_out.txt | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('forward ms/step', d['ms_per_step'], 'whole-net frac', d['whole_net_frac_of_f16_mfma_peak'])"
 echo "== fwd+bwd: python tools/fwd_bwd_probe.py 600"
 watch_run python tools/fwd_bwd_probe.py 600
