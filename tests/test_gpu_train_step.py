@@ -57,6 +57,7 @@ def test_optimize_parameters_step_matches_reference():
 
 @pytest.mark.parametrize('knobs', [{}, {'PIPELINED': '1'}, {'ESR_TRAIN_NETF_SIDE': '0', 'ESR_TRAIN_DSTEP': 'first'}, {'ESR_TRAIN_MANUAL': '0'},
                                    {'ESR_TRAIN_DSPLIT': '0'}, {'ESR_TRAIN_DSPLIT': '1', 'ESR_TRAIN_DSTEP': 'mid', 'PIPELINED': '1'},
+                                   {'ESR_FUSE_BN': '0', 'ESR_S2_SPLIT': '0'},      # two-stage netD forward over the unfused BatchNorm launches
                                    {'ESR_TRAIN_MANUAL': '0', 'ESR_SHARED_D': '0', 'ESR_TRAIN_OVERLAP': '0', 'ESR_FLAT_GRADS': '0',
                                     'ESR_FUSE_BN': '0', 'ESR_S2_SPLIT': '0'}])
 def test_three_training_iterations_match_the_reference(monkeypatch, knobs):
