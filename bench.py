@@ -108,6 +108,44 @@ def host_cores():
     return max(1, min(n, 64))
 
 
+def mfma_sustained_probe(dev, seconds=1.6):
+    """What the matrix pipe of THIS box sustains under the package power limit: every SIMD issues independent
+    v_mfma_f32_32x32x16_f16 back to back from registers (esr_debug_mfma_probe), operands = random fp16 (weights-like A,
+    activation-like B: the toggle rate of real data).  The quoted 2.5 PFLOP/s is reached with ZERO operands at 2.4 GHz;
+    with real data the power management settles near 1.65-1.7 GHz (profiles/r05_mfma_power_probe.txt).  Context for
+    `roofline.frac`, not a replacement of its peak."""
+    import ctypes as C
+    from esrganplus_amd import _lib as L, engine as E
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    g = torch.Generator(device='cpu').manual_seed(11)
+    ops = torch.cat([torch.randn(4 * 256 * 8, generator=g) * 0.02, torch.randn(4 * 256 * 8, generator=g)]).half().to(dev)
+    clk = torch.zeros(2, dtype=torch.int64, device=dev)
+    sink = torch.zeros(1, dtype=torch.float32, device=dev)
+    st = E.current_stream()
+    iters = 60000                                    # ~20 ms per launch
+
+    def launch():
+        L.check(L.lib().esr_debug_mfma_probe(C.c_void_p(ops.data_ptr()), C.c_int32(iters), C.c_void_p(clk.data_ptr()),
+                                             C.c_void_p(sink.data_ptr()), C.c_int32(cus), C.c_void_p(st)), 'esr_debug_mfma_probe')
+    launch()
+    torch.cuda.synchronize()
+    t_end = time.perf_counter() + seconds            # load until the clock has settled, keep the last launches
+    ms = []
+    while time.perf_counter() < t_end:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        e1.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    last = sorted(ms[-5:])[len(ms[-5:]) // 2]
+    c = clk.tolist()
+    tf = cus * 4 * iters * 16 * 32768.0 / (last * 1e-3) / 1e12
+    return {'tflops': round(tf, 1), 'shader_clock_ghz': round(c[0] / max(c[1], 1) * 0.1, 3), 'seconds_of_load': seconds,
+            'what': 'independent v_mfma_f32_32x32x16_f16 from registers on every SIMD, random fp16 operands, after %.1f s of '
+                    'load (esr_debug_mfma_probe): the sustained dense fp16 rate of this box under its power limit' % seconds}
+
+
 def cpu_baseline(seconds_budget=25.0):
     """Oracle (torch restatement == reference bit-for-bit, oracle/gen_golden.py) on the host cores:
     RRDBNet x4 fp32 eval forward.  Calibrates on a 32x32 LR tile, then times the largest LR tile
@@ -558,6 +596,7 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--lr', type=int, default=LR)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-mfma-probe', action='store_true', help='forward mode: skip the sustained-MFMA-rate probe (1.6 s)')
     ap.add_argument('--no-fwd-bwd', action='store_true', help='forward mode: skip the fwd+bwd side measurement')
     ap.add_argument('--dp-steps', type=int, default=20, help='timed steps of the dp_train object (N > 1); 3 warm-up steps')
     ap.add_argument('--no-train', action='store_true',
@@ -688,6 +727,10 @@ def main():
         res['kernels'] = {k: {'launches': a[2] // reps, 'ms_per_step': round(a[0] / reps, 3),
                               'tflops': round(a[1] / (a[0] * 1e-3) / 1e12, 1) if a[1] else 0.0}
                           for k, a in sorted(agg.items())}
+        if world == 1 and not args.no_mfma_probe:
+            pr = mfma_sustained_probe(dev)
+            res['mfma_sustained_probe'] = pr
+            res['roofline']['frac_of_sustained_probe'] = round(ach / pr['tflops'], 4)
         if world == 1 and not args.no_fwd_bwd:
             del y
             net = None

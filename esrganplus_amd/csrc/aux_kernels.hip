@@ -320,3 +320,44 @@ extern "C" int esr_fill_noise(const esr_noise_fill* p, esr_stream_t stream) {
   hipLaunchKernelGGL(noise_fill_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
   return esr_check_launch("noise_fill_kernel");
 }
+
+// ---- diagnostic: what the matrix pipe sustains under the package power limit (bench.py's `mfma_sustained_probe`) ----
+// Every SIMD runs ONE wave issuing independent v_mfma_f32_32x32x16_f16 back to back from registers (no LDS, no memory
+// in the loop); the operands are the caller's (random fp16 = the toggle rate of real data; zeros reach the quoted peak).
+// clk2[0] / clk2[1]: shader-clock ticks / 100 MHz ticks the loop took on workgroup 0 (-> the clock it ran at).
+namespace {
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const half8* __restrict__ ops, float* sink, uint64_t* clk2, int iters) {
+  __shared__ char pad[120 * 1024];                        // one workgroup per CU
+  pad[threadIdx.x] = 0;
+  const int lane = threadIdx.x;
+  half8 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = ops[i * 256 + lane]; b[i] = ops[(4 + i) * 256 + lane]; }
+  probe_f32x16 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  uint64_t t0 = 0, r0 = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { clk2[0] = __builtin_amdgcn_s_memtime() - t0; clk2[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][lane & 15];
+  if (s == 123.456f) sink[0] = s + pad[5];
+}
+}  // namespace
+
+extern "C" int esr_debug_mfma_probe(const void* operands, int32_t iters, uint64_t* clk2, float* sink, int32_t n_workgroups, esr_stream_t stream) {
+  if (!operands || !clk2 || !sink || iters <= 0 || n_workgroups <= 0) {
+    esr_set_error("esr_debug_mfma_probe: invalid arguments");
+    return ESR_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3((unsigned)n_workgroups), dim3(256), 0, (hipStream_t)stream, (const half8*)operands, sink, clk2, (int)iters);
+  return esr_check_launch("mfma_probe_kernel");
+}

@@ -622,6 +622,12 @@ int esr_rdb_check_abort(void);
  * sleep until *release (device-visible memory) becomes non-zero or max_ms (<= 10000) have passed; every workgroup
  * that has started adds 1 to *started (optional). */
 int esr_debug_hold_cus(int32_t n_workgroups, const uint32_t* release, uint32_t max_ms, uint32_t* started, esr_stream_t stream);
+/* Diagnostic (bench.py `mfma_sustained_probe`; tools/experiments/mfma_power_probe.hip is the stand-alone form): what the
+ * matrix pipe sustains under the package power limit.  n_workgroups workgroups of four waves (one per SIMD; one workgroup
+ * per CU) each issue iters x 16 independent v_mfma_f32_32x32x16_f16 from registers; operands: 8 x 256 x 16 bytes of fp16
+ * (four A and four B fragments per lane: zeros reach the quoted 2.5 PFLOP/s, random values ~1.65 on MI355X).  clk2[0] /
+ * clk2[1] = shader-clock / 100 MHz ticks the loop took on workgroup 0; sink: 4 bytes nothing is written to. */
+int esr_debug_mfma_probe(const void* operands, int32_t iters, uint64_t* clk2, float* sink, int32_t n_workgroups, esr_stream_t stream);
 /* Library state and devices.  What the library keeps between calls — the chain launches in flight (the ordering above),
  * the abort word, the side streams of ESR_OPF_SIDE runs — is keyed by the CURRENT DEVICE of the calling thread:
  * nn.DataParallel's one-thread-per-device replicas (networks.py:105-107) never wait for, or report the aborts of, each
