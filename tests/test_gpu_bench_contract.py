@@ -35,6 +35,10 @@ def test_forward_line_follows_the_contract():
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'HR-Mpix/s' and c['cores'] >= 1 and c['value'] > 0 and c['sample']
     assert 'settle_steps' not in d
+    # round 5: the sustained dense fp16 rate of this box (register-resident MFMA loop, random operands) as context
+    pr = d['mfma_sustained_probe']
+    assert 800 < pr['tflops'] < 2600 and 1.0 < pr['shader_clock_ghz'] < 2.6
+    assert d['roofline']['frac'] < d['roofline']['frac_of_sustained_probe'] < 1
     # BASELINE configs[2] / configs[4] ride in the same line
     t = d['train_step']
     assert t['ms_per_step'] > 0 and 0 < t['frac_of_f16_mfma_peak'] < 1 and t['roofline']['kernel'].startswith('rdb_')
