@@ -749,6 +749,9 @@ def main():
             pr = mfma_sustained_probe(dev)
             res['mfma_sustained_probe'] = pr
             res['roofline']['frac_of_sustained_probe'] = round(ach / pr['tflops'], 4)
+            fb = res.get('fwd_bwd', {}).get('roofline')
+            if fb and fb.get('unit') == 'TFLOP/s':       # (the training chains fill the chip as well; the train step's do not)
+                fb['frac_of_sustained_probe'] = round(fb['achieved'] / pr['tflops'], 4)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
     if world > 1 and not args.no_train:
