@@ -490,9 +490,15 @@ def test_chains_make_progress_next_to_a_resident_kernel(dev):
     # (a) inference chain at the bench shape
     net = _net('RRDBNet', nb, sd, dev, 'fp16')
     x = synth.image_batch(61, 16, 3, 128, 128, name='hold.x').to(dev)
+    # (wall-clock ratios of 5-call loops: the better of two measurements each — a host hiccup in one loop is not a
+    #  property of the schedule)
     with torch.no_grad():
         good, t_free = free(lambda: net(x), 5)
+        t_free = min(t_free, free(lambda: net(x), 5)[1])
         got, t_held = held(lambda: net(x), 5)
+        assert torch.equal(got, good)
+        got, t2 = held(lambda: net(x), 5)
+        t_held = min(t_held, t2)
     assert L.lib().esr_rdb_check_abort() == 0
     assert torch.equal(got, good)
     print('inference chain 16x128^2, nb=%d: %.3f ms free, %.3f ms next to %d held CUs (x%.2f)'
@@ -513,11 +519,15 @@ def test_chains_make_progress_next_to_a_resident_kernel(dev):
         return y.detach(), torch.cat([p.grad.reshape(-1) for p in tnet.parameters()])
 
     (y0, g0), t_free = free(fb, 5)
+    t_free = min(t_free, free(fb, 5)[1])
     # (the backward also runs weight gradients on the library's side streams: the hold kernel must not sit in THEIR queue)
     side = _concurrent_stream(dev, words, p_release, p_started, work=fb)
     if side is None:
         pytest.skip('no stream that runs concurrently with the training pass')
     (y1, g1), t_held = held(fb, 5)
+    assert torch.equal(y1, y0) and torch.equal(g1, g0)
+    (y1, g1), t2 = held(fb, 5)
+    t_held = min(t_held, t2)
     assert L.lib().esr_rdb_check_abort() == 0
     assert torch.equal(y1, y0) and torch.equal(g1, g0)
     print('training chains 16x32^2, nb=%d: %.3f ms free, %.3f ms next to %d held CUs (x%.2f)'
