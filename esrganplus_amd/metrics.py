@@ -95,6 +95,7 @@ def calculate_ssim(img1, img2):
             return float(np.mean([_ssim_plane(img1[..., c], img2[..., c]) for c in range(3)]))
         if img1.shape[2] == 1:
             return _ssim_plane(np.squeeze(img1), np.squeeze(img2))
+        return None             # util.py:151-156 falls off the end for 2- or 4-channel images: None, as the reference
     raise ValueError('Wrong input image dimensions.')
 
 

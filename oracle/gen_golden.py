@@ -867,10 +867,8 @@ def gen_psnr():
 
 
 def gen_metrics():
-    """Y-channel conversion (codes/data/util.py:123-168) from the imported reference.  SSIM
-    (codes/utils/util.py:117-158) needs cv2, absent here: it is pinned in tests/test_metrics.py
-    against a scipy restatement of cv2.filter2D's valid region instead ("parity unpinned by the
-    reference" for SSIM)."""
+    """Y-channel conversion (codes/data/util.py:123-168) from the imported reference.  (SSIM,
+    codes/utils/util.py:117-158: gen_ssim below, the reference's own lines over a two-function cv2 shim.)"""
     U = RI.data_util()
     rng = np.random.RandomState(7)
     u8 = rng.randint(0, 256, (12, 10, 3)).astype(np.uint8)
@@ -886,7 +884,7 @@ def gen_metrics():
 def gen_metrics_y():
     """PSNR on the Y channel exactly as the reference's test script forms it (codes/test.py:69-90): tensor2img both
     images, /255 (float64), bgr2ycbcr(only_y) on the FLOAT images (the unrounded branch of data/util.py:150-168),
-    crop, x255, calculate_psnr.  (SSIM_Y needs cv2 — absent: pinned against the host restatement only.)"""
+    crop, x255, calculate_psnr.  (SSIM / SSIM_Y of the same flow: gen_ssim.)"""
     sys.modules.setdefault('cv2', types.ModuleType('cv2'))
     RI._stub_torchvision()
     p = os.path.join(RI.REF, 'codes')
@@ -912,6 +910,54 @@ def gen_metrics_y():
             res['y_sr0'] = (sr_y * 255).astype(np.float64)
         print('  metrics_y case %d: PSNR %.6f dB, PSNR_Y %.6f dB' % (i, psnr, psnr_y))
     np.savez_compressed(os.path.join(OUT, 'metrics_y.npz'), **res)
+
+
+def gen_ssim():
+    """SSIM from the reference's OWN lines (codes/utils/util.py:117-158: ``ssim``, ``calculate_ssim`` incl. the
+    three-fold loop over the full (H, W, 3) arrays at 152-153), run over ``ref_import.cv2_shim`` (cv2 is absent: the
+    shim supplies OpenCV's getGaussianKernel / filter2D semantics, nothing of the reference's).  Cases: the
+    reference's validation flow (codes/test.py:69-90: tensor2img, /255, crop, x255 -> SSIM on 3 channels and on the
+    unrounded Y plane), a 2-D plane, an (H, W, 1) image, and raw float planes.  Inputs are seeded (synth): the
+    tests regenerate them; the fixture keeps sizes, results and one SSIM input pair in full."""
+    util = RI.utils_util()
+    U = RI.data_util()
+    res = {}
+    for i, (h, w, crop) in enumerate(((40, 52, 4), (33, 47, 2), (128, 96, 4), (30, 27, 0))):
+        hr = synth.image_batch(90 + i, 1, 3, h, w, name='ssim.hr')[0]
+        sr = hr + 0.06 * synth.normal_like(90 + i, 'ssim.n', (3, h, w))
+        sr_img = util.tensor2img(sr.clone()) / 255.
+        gt_img = util.tensor2img(hr.clone()) / 255.
+        sl = slice(crop, -crop) if crop else slice(None)
+        c_sr, c_gt = sr_img[sl, sl, :], gt_img[sl, sl, :]
+        ssim = util.calculate_ssim(c_sr * 255, c_gt * 255)
+        sr_y, gt_y = U.bgr2ycbcr(sr_img, only_y=True), U.bgr2ycbcr(gt_img, only_y=True)    # scales its input in place
+        ssim_y = util.calculate_ssim(sr_y[sl, sl] * 255, gt_y[sl, sl] * 255)
+        res['shape%d' % i], res['crop%d' % i] = np.array([h, w]), np.array(crop)
+        res['ssim%d' % i], res['ssim_y%d' % i] = np.array(ssim), np.array(ssim_y)
+        print('  ssim case %d: SSIM %.12f  SSIM_Y %.12f' % (i, ssim, ssim_y))
+    # grey: a 1-channel tensor -> tensor2img gives (H, W); and the (H, W, 1) branch of calculate_ssim
+    g_hr = synth.image_batch(95, 1, 1, 24, 30, name='ssim.g')[0]
+    g_sr = g_hr + 0.05 * synth.normal_like(95, 'ssim.gn', (1, 24, 30))
+    ia, ib = util.tensor2img(g_sr.clone()), util.tensor2img(g_hr.clone())
+    res['grey'] = np.array(util.calculate_ssim(ia[2:-2, 2:-2].astype(np.float64), ib[2:-2, 2:-2].astype(np.float64)))
+    res['grey_hw1'] = np.array(util.calculate_ssim(ia[..., None], ib[..., None]))
+    # raw float planes / 3-channel arrays in full (host-restatement pin, no tensor2img in between)
+    rng = np.random.RandomState(3)
+    a = rng.rand(40, 33) * 255
+    b = np.clip(a + rng.randn(40, 33) * 12, 0, 255)
+    a3, b3 = np.stack([a, a * 0.5, 255 - a], -1), np.stack([b, b * 0.5, 255 - b], -1)
+    res['raw_a'], res['raw_b'] = a, b
+    res['raw_ssim'] = np.array(util.calculate_ssim(a, b))
+    res['raw_ssim3'] = np.array(util.calculate_ssim(a3, b3))
+    res['raw_same'] = np.array(util.calculate_ssim(a, a))
+    print('  raw %.12f  raw3 %.12f  same %.12f  grey %.12f' % (res['raw_ssim'], res['raw_ssim3'], res['raw_same'], res['grey']))
+    for bad in ((a, a[:-1]), (a3[..., :2], b3[..., :2])):
+        try:
+            r = util.calculate_ssim(*bad)
+            print('  (reference returns %r for shapes %s)' % (r, bad[0].shape))
+        except ValueError as e:
+            print('  reference raises:', e)
+    np.savez_compressed(os.path.join(OUT, 'ssim.npz'), **res)
 
 
 def gen_imresize():
@@ -952,7 +998,7 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     which = sys.argv[1:] or ['rdb', 'rrdbnet_small', 'rrdbnet_full', 'disc', 'disc_variants', 'vgg', 'train_step',
                              'psnr', 'imresize', 'metrics', 'metrics_y', 'srresnet', 'rrdbnet_full_grad', 'disc_sn', 'train_steps3', 'rrdbnet_full_grad_fp16emu', 'disc_sn_two', 'rrdbnet_small_fp16emu',
-                             'train_step_full', 'sr_infer']
+                             'train_step_full', 'sr_infer', 'ssim']
     for w in which:
         print('[gen_golden]', w)
         globals()['gen_' + w]()

@@ -18,7 +18,10 @@ import types
 import torch
 
 REF = os.environ.get('ESRGAN_REFERENCE', '/root/reference')
+# Nothing may ever be written under /root/reference: no bytecode at all, and should some later import switch bytecode
+# back on, it goes to a scratch prefix instead of the source tree's __pycache__.
 sys.dont_write_bytecode = True
+sys.pycache_prefix = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'esr_ref_pycache')
 
 
 def available():
@@ -112,6 +115,46 @@ def build_discriminator(size=128):
 def build_discriminator_sn():
     arch, _ = codes_arch()
     return arch.Discriminator_VGG_128_SN()
+
+
+def cv2_shim():
+    """The two cv2 entry points codes/utils/util.py:117-137 (``ssim``) calls, registered on the ``cv2`` module object the
+    reference's ``import cv2`` binds (cv2 is absent from this image).  NOT a restatement of the reference: these are
+    OpenCV's documented semantics for exactly the call forms the reference uses —
+      * ``getGaussianKernel(ksize, sigma)``: (ksize, 1) float64 column ``exp(-(i-(ksize-1)/2)^2 / (2 sigma^2))``
+        normalised to sum 1 (OpenCV's formula whenever sigma > 0 and ksize > 7: no fixed small-kernel table);
+      * ``filter2D(src, -1, kernel)``: correlation (no kernel flip), anchor at the kernel centre, output depth = source
+        depth, border ``BORDER_REFLECT_101`` (``gfedcb|abcdefgh|gfedcba`` = scipy's ``mode='mirror'``), every channel
+        of an H x W x C image filtered with the same 2-D kernel.
+    With it the reference's own ``ssim`` / ``calculate_ssim`` lines run (oracle/gen_golden.py: gen_ssim)."""
+    import numpy as np
+    from scipy.ndimage import correlate
+    cv2 = sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+
+    def getGaussianKernel(ksize, sigma, ktype=None):
+        assert sigma > 0 and ksize % 2 == 1 and ksize > 7, 'shim covers the reference\'s call form only'
+        i = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
+        k = np.exp(-(i * i) / (2.0 * sigma * sigma))
+        return (k / k.sum()).reshape(ksize, 1)
+
+    def filter2D(src, ddepth, kernel):
+        assert ddepth == -1 and src.dtype == np.float64 and kernel.shape[0] % 2 == 1 and kernel.shape[1] % 2 == 1
+        if src.ndim == 2:
+            return correlate(src, kernel, mode='mirror')
+        return np.stack([correlate(src[..., c], kernel, mode='mirror') for c in range(src.shape[2])], axis=-1)
+
+    cv2.getGaussianKernel, cv2.filter2D = getGaussianKernel, filter2D
+    return cv2
+
+
+def utils_util():
+    """codes/utils/util.py of the reference (tensor2img, calculate_psnr, ssim, calculate_ssim), cv2 as ``cv2_shim``."""
+    cv2_shim()
+    _stub_torchvision()
+    p = os.path.join(REF, 'codes')
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    return importlib.import_module('utils.util')
 
 
 def data_util():

@@ -73,3 +73,22 @@ def test_device_psnr_y_matches_reference_test_script(dev):
         assert abs(psnr - float(g['psnr%d' % i])) < 1e-9
         assert abs(psnr_y - float(g['psnr_y%d' % i])) < 1e-7, (psnr_y, float(g['psnr_y%d' % i]))
         assert 0.0 < ssim_y <= 1.0
+
+
+def test_device_ssim_matches_reference_lines(dev):
+    """SSIM / SSIM_Y on the device against the outputs of the reference's own ``calculate_ssim`` (codes/utils/util.py:
+    117-158 over oracle/ref_import.cv2_shim; tests/golden/ssim.npz) in the validation flow of codes/test.py:69-90."""
+    g = dict(np.load('tests/golden/ssim.npz'))
+    for i in range(4):
+        h, w = (int(v) for v in g['shape%d' % i])
+        crop = int(g['crop%d' % i])
+        hr = synth.image_batch(90 + i, 1, 3, h, w, name='ssim.hr')[0]
+        sr = hr + 0.06 * synth.normal_like(90 + i, 'ssim.n', (3, h, w))
+        _, ssim = M.device_psnr_ssim(sr.to(dev), hr.to(dev), crop=crop)
+        _, ssim_y = M.device_psnr_ssim(sr.to(dev), hr.to(dev), crop=crop, y_only=True)
+        assert abs(ssim - float(g['ssim%d' % i])) < 1e-9, (i, ssim, float(g['ssim%d' % i]))
+        assert abs(ssim_y - float(g['ssim_y%d' % i])) < 1e-9, (i, ssim_y, float(g['ssim_y%d' % i]))
+    g_hr = synth.image_batch(95, 1, 1, 24, 30, name='ssim.g')[0]
+    g_sr = g_hr + 0.05 * synth.normal_like(95, 'ssim.gn', (1, 24, 30))
+    _, ssim = M.device_psnr_ssim(g_sr.to(dev), g_hr.to(dev), crop=2)
+    assert abs(ssim - float(g['grey'])) < 1e-9
