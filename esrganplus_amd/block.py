@@ -211,9 +211,23 @@ class _PlannedModule(nn.Module):
         self.__dict__['_pending_ev'] = event
 
     def _join_pending(self):
-        ev = self.__dict__.pop('_pending_ev', None)
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+        # The event STAYS until the next step replaces it: a second forward / state_dict on ANOTHER stream has to be
+        # ordered behind the same tail (round 5 popped it: only the first caller's stream was).  A stream waits once.
+        pend = self.__dict__.get('_pending_ev')
+        if pend is None:
+            return
+        if not isinstance(pend, tuple):
+            pend = self.__dict__['_pending_ev'] = (pend, set())
+        ev, joined = pend
+        cur = torch.cuda.current_stream()
+        key = (cur.device.index, cur.cuda_stream)
+        if key not in joined:
+            cur.wait_event(ev)
+            joined.add(key)
+
+    # (nn.DataParallel's replicate() broadcasts the weights on the caller's stream before any hook of a module runs, and
+    # `parameters()` is on the train step's own fast path, so it cannot join here: a loop that hands the networks of a
+    # PIPELINED step to DataParallel calls ESRGANPlusStep.finish() first.  Replicas keep the event: their forwards wait.)
 
     def state_dict(self, *a, **k):
         self._join_pending()
@@ -256,7 +270,6 @@ class _PlannedModule(nn.Module):
         replica = super()._replicate_for_data_parallel()
         replica.__dict__['_conv_cache'] = None
         replica.__dict__['_gstore'] = None
-        replica.__dict__.pop('_pending_ev', None)
         replica.__dict__.pop('_grad_proxy', None)     # its weights are non-leaf copies: per-tensor gradient outputs
         replica.__dict__['_wp'] = {}
         replica.__dict__['_plans'] = {}
@@ -307,37 +320,79 @@ class _PlannedModule(nn.Module):
         adopt=True (the hand-written training loops, which own the gradients and consume them before the plan's next
         backward: train.ESRGANPlusStep, bench.py's generator loop): when the delivery would OVERWRITE — gradients None
         or marked stale — `.grad` becomes views of `flat_new` itself (the plan's buffer, cached per buffer) and nothing
-        is copied (67 MB per generator step); an accumulating delivery takes the copying route."""
+        is copied (67 MB per generator step); an accumulating delivery takes the copying route.
+        Adopted views ALIAS the plan's buffer, which the plan's next backward rewrites: whoever is about to rewrite it
+        calls `_release_adopted(buf)` first (functional.py does), so an accumulating delivery finds the old values in
+        the module's own store; every branch below leaves `.grad` on the store's views unless it adopts."""
         gs = self._grad_store(flat_new.device)
         params, views = gs['params'], gs['views']
-        if adopt:
-            ad = gs.get('adopted')
-            ours = all(p.grad is v for p, v in zip(params, views)) or (ad is not None and all(p.grad is v for p, v in zip(params, ad[1])))
-            if (ours and gs['stale']) or all(p.grad is None for p in params):
-                if ad is None or ad[0] is not flat_new:
-                    ad = gs['adopted'] = (flat_new, [t.view(p.shape) for t, p in zip(flat_new.split(gs['sizes']), params)])
-                if not all(p.grad is v for p, v in zip(params, ad[1])):
-                    for p_, v in zip(params, ad[1]):
-                        p_.grad = v
-                gs['stale'] = False
-                return
-        if all(p.grad is v for p, v in zip(params, views)):
+        ad = gs.get('adopted')
+        on_store = all(p.grad is v for p, v in zip(params, views))
+        on_adopted = (not on_store) and ad is not None and all(p.grad is v for p, v in zip(params, ad[1]))
+        none = (not on_store) and (not on_adopted) and all(p.grad is None for p in params)
+
+        def to_store():
+            for p_, v in zip(params, views):
+                p_.grad = v
+
+        if on_adopted and not gs['stale']:
+            # accumulate onto gradients that live in a plan's buffer
+            if ad[0] is flat_new or ad[0].data_ptr() == flat_new.data_ptr():
+                raise RuntimeError(
+                    'gradient accumulation onto a plan buffer that its own backward has just rewritten: the earlier '
+                    'gradients are gone (call net._release_adopted(buf) before the backward overwrites the buffer — '
+                    'functional.rrdbnet_train_backward / _RRDBNetFn do — or zero_grad / mark_grads_stale between steps)')
+            torch.add(ad[0], flat_new, out=gs['flat'])
+            to_store()
+            return
+        if adopt and (none or ((on_store or on_adopted) and gs['stale'])):
+            if ad is None or ad[0] is not flat_new:
+                ad = gs['adopted'] = (flat_new, [t.view(p.shape) for t, p in zip(flat_new.split(gs['sizes']), params)])
+            if not all(p.grad is v for p, v in zip(params, ad[1])):
+                for p_, v in zip(params, ad[1]):
+                    p_.grad = v
+            gs['stale'] = False
+            return
+        if on_adopted:          # stale, and the caller does not vouch for the buffer's lifetime: overwrite the STORE
+            gs['flat'].copy_(flat_new)
+            gs['stale'] = False
+            to_store()
+            return
+        if on_store:
             if gs['stale']:
                 gs['flat'].copy_(flat_new)
                 gs['stale'] = False
             else:
                 gs['flat'].add_(flat_new)
             return
-        if all(p.grad is None for p in params):
+        if none:
             gs['flat'].copy_(flat_new)
             gs['stale'] = False
-            for p_, v in zip(params, views):
-                p_.grad = v
+            to_store()
             return
         new = flat_new.clone().split(gs['sizes'])
         for p_, g, v in zip(params, new, views):
             g = g.view(v.shape)
             p_.grad = g if p_.grad is None else p_.grad + g
+
+    def _release_adopted(self, buf=None):
+        """Called by whoever is about to REWRITE a plan's flat gradient buffer (the zero fill in front of a backward):
+        when the parameters' `.grad` are adopted views of that buffer (`buf=None`: of any buffer) and hold gradients
+        that still count — not marked stale — they move into the module's own store first, so that the coming delivery
+        accumulates onto them (a second backward without zero_grad, zero_grad(set_to_none=False), a loop that falls
+        back from the hand-written step to autograd).  Stale gradients stay where they are: the delivery overwrites."""
+        gs = self.__dict__.get('_gstore')
+        if gs is None:
+            return False
+        ad = gs.get('adopted')
+        if ad is None or (buf is not None and ad[0] is not buf and ad[0].data_ptr() != buf.data_ptr()):
+            return False
+        if gs['stale'] or not all(p.grad is v for p, v in zip(gs['params'], ad[1])):
+            return False
+        gs['flat'].copy_(ad[0])
+        for p_, v in zip(gs['params'], gs['views']):
+            p_.grad = v
+        return True
 
     def mark_grads_stale(self):
         """Cheap stand-in for ``zero_grad`` in a training loop that owns this module's gradients (train.ESRGANPlusStep):
@@ -356,13 +411,25 @@ class _PlannedModule(nn.Module):
     def _flush_stale_grads(self):
         """A backward through the per-tensor autograd route ADDS into `.grad` (AccumulateGrad): a store that was only
         marked stale — `mark_grads_stale()` stood in for `zero_grad()` — must really be zeroed first, or the old
-        gradients pile up (a parameter frozen after the first step, `flat_param_grads` switched off)."""
+        gradients pile up (a parameter frozen after the first step, `flat_param_grads` switched off).  Adopted views
+        are given up here as well: that backward rewrites the plan's buffer BEFORE AccumulateGrad adds to `.grad`, so
+        `.grad` must not alias it — the gradients move to (stale: are zeroed in) the module's own store."""
         gs = self.__dict__.get('_gstore')
-        if gs is not None and gs['stale']:
-            gs['flat'].zero_()
-            ad = gs.get('adopted')
-            if ad is not None and all(p.grad is v for p, v in zip(gs['params'], ad[1])):
+        if gs is None:
+            return
+        ad = gs.get('adopted')
+        if ad is not None and all(p.grad is v for p, v in zip(gs['params'], ad[1])):
+            if gs['stale']:
                 ad[0].zero_()                     # (the stale gradients live in an adopted plan buffer)
+                gs['flat'].zero_()
+            else:
+                gs['flat'].copy_(ad[0])
+            for p_, v in zip(gs['params'], gs['views']):
+                p_.grad = v
+            gs['stale'] = False
+            return
+        if gs['stale']:
+            gs['flat'].zero_()
             gs['stale'] = False
 
     def _conv_list(self):

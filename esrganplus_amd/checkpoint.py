@@ -87,6 +87,13 @@ def resume_step(step, directory, iter_step, schedulers=()):
     load_network(os.path.join(directory, '%s_D.pth' % iter_step), step.netD)
     state = torch.load(os.path.join(directory, '%s.state' % iter_step), map_location='cpu')
     resume_training(state, [step.optimizer_G, step.optimizer_D], list(schedulers))
-    if step.scaler is not None and 'loss_scaler' in state:
-        step.scaler.state.copy_(state['loss_scaler'].to(step.scaler.state.device))
+    if step.scaler is not None:
+        if 'loss_scaler' in state:
+            step.scaler.state.copy_(state['loss_scaler'].to(step.scaler.state.device))
+        else:
+            import warnings
+            warnings.warn('resume_step: %s.state holds no "loss_scaler" (written by the reference, or by a run with a '
+                          'static loss scale): the dynamic loss scale restarts from its initial value, so the first '
+                          'steps after the resume are not bit-identical to the uninterrupted run' % iter_step,
+                          RuntimeWarning, stacklevel=2)
     return state['epoch'], state['iter']

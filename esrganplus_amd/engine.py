@@ -889,13 +889,29 @@ class StreamOrder:
         self.last = cur.cuda_stream
 
 
+def env_int(name, default, lo, hi):
+    """An integer schedule knob from the environment, validated: a misspelt or out-of-range value is an error that
+    names the knob and its range, not an opaque ValueError in the middle of a plan build or a silently ignored
+    setting."""
+    v = os.environ.get(name)
+    if v is None or v == '':
+        return default
+    try:
+        n = int(v)
+    except ValueError:
+        raise ValueError('%s=%r: expected an integer in [%d, %d]' % (name, v, lo, hi)) from None
+    if not lo <= n <= hi:
+        raise ValueError('%s=%d: expected an integer in [%d, %d]' % (name, n, lo, hi))
+    return n
+
+
 def bwd_chain_split(B, H, W, nb):
     """Launches the fused backward chain of a training plan is cut into (runs of whole RRDBs; 1 = one launch).  More
     than one only when the chain's grid leaves at least half of the CUs idle (4-row tiles, at most cus / 2 of them):
     the weight gradients of a run then execute under the next run's chain.  ESR_BWD_SPLIT = n forces n (1: off)."""
-    env = os.environ.get('ESR_BWD_SPLIT')
+    env = env_int('ESR_BWD_SPLIT', None, 1, max(1, nb))
     if env is not None:
-        return max(1, min(int(env), nb))
+        return env
     cus = L.lib().esr_rdb_max_tiles_per_image()
     tiles4 = B * ((H + 3) // 4) * ((W + 31) // 32)
     return min(2, nb) if 2 * tiles4 <= cus else 1      # (train step, same box: 1 run 7.09 ms, 2 runs 7.01, 4 runs 7.06)
@@ -1568,7 +1584,7 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             per_run = (nb + nsplit - 1) // nsplit
             # run boundaries (RRDB indices).  ESR_BWD_SPLIT_FIRST = n: two runs, the first of n RRDBs (A/B: the LAST run's
             # weight gradients are the ones left behind the chain, the first run's must fit under the second chain)
-            first = int(os.environ.get('ESR_BWD_SPLIT_FIRST', '0'))
+            first = env_int('ESR_BWD_SPLIT_FIRST', 0, 0, nb)          # 0 / nb: equal runs
             bounds = list(range(0, nb, per_run)) + [nb]
             if nsplit == 2 and 0 < first < nb:
                 bounds = [0, first, nb]

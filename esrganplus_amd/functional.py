@@ -279,6 +279,8 @@ class _RRDBNetFn(torch.autograd.Function):
             raise RuntimeError('RRDBNet backward called twice (retain_graph is not supported: the '
                                'saved activations live in a reusable launch plan)')
         gy = gy.detach().contiguous().float()
+        if ctx.net is not None:
+            ctx.net._release_adopted(tp.grad_flat)      # `.grad` may alias the buffer this backward is about to rewrite
         gx = _train_backward(tp, gy, E.current_stream(), ctx.noise, ctx.explicit, ctx.seed,
                              bool(ctx.needs_input_grad[0]), ctx.sync)
         gx = gx if ctx.needs_input_grad[0] else None
@@ -295,7 +297,7 @@ class _RRDBNetFn(torch.autograd.Function):
 
 class TrainPass:
     """State of one RRDBNet training forward outside autograd (train.ESRGANPlusStep's hand-written step)."""
-    __slots__ = ('lease', 'seed', 'noise', 'explicit', 'sync', 'prepared')
+    __slots__ = ('lease', 'seed', 'noise', 'explicit', 'sync', 'prepared', 'pack_ev')
 
 
 _ADOPT = os.environ.get('ESR_ADOPT_GRADS', '1') != '0'     # A/B knob: 0 = always copy into the module's store (round 4)
@@ -315,9 +317,19 @@ def rrdbnet_train_forward(net, x, z=None):
     zs = _zs_list(z, per * net.nb, (B, 64, H, W), dev) if noise else None
     wp = net._weights(dev)
     dp = net._dgrad_weights(dev)
+    n_packs = getattr(dp, 'pack_count', 0)
     dp.ensure(st, force=not net._dgrad_fresh())
+    pack_ev = None
+    if getattr(dp, 'pack_count', 0) != n_packs and not torch.cuda.is_current_stream_capturing():
+        # the input-gradient operands were re-packed on THIS stream just now (first step, ESR_PREPACK=0, after
+        # load_state_dict / resume): whoever gathers the backward chain's weight streams from dp.arena on another
+        # stream (`rrdbnet_train_prepare` on the train step's side stream) has to wait for it — recorded here, in
+        # front of the forward's launches, so that the wait does not cover the forward
+        pack_ev = torch.cuda.Event()
+        pack_ev.record(torch.cuda.current_stream())
     tp = _train_plan(net, wp, dp, B, H, W, dev, noise, zs is not None)
     s = TrainPass()
+    s.pack_ev = pack_ev
     s.lease = _PlanLease(tp)
     s.seed = _draw_seed() if (noise and zs is None) else 0
     s.noise, s.explicit, s.sync = noise, zs is not None, getattr(net, '_grad_sync', None)
@@ -334,6 +346,9 @@ def rrdbnet_train_prepare(net, s):
     tp = s.lease.tp
     if tp is None or tp.graph or s.prepared:
         return
+    if s.pack_ev is not None:
+        torch.cuda.current_stream().wait_event(s.pack_ev)     # the operands the gather below reads (see the forward)
+    net._release_adopted(tp.grad_flat)
     tp.grad_flat.zero_()
     if tp.tapmajor is not None:
         tp.tapmajor.tm.zero_()
@@ -348,6 +363,8 @@ def rrdbnet_train_backward(net, s, gy):
     tp = s.lease.tp
     if tp is None:
         raise RuntimeError('rrdbnet_train_backward called twice on one forward')
+    if not s.prepared:
+        net._release_adopted(tp.grad_flat)
     _train_backward(tp, gy, E.current_stream(), s.noise, s.explicit, s.seed, False, s.sync, prepared=s.prepared)
     net._deliver_flat_grads(tp.grad_flat, adopt=_ADOPT)
     s.lease.release()
@@ -395,6 +412,8 @@ class _BlockFn(torch.autograd.Function):
             raise RuntimeError('backward called twice (retain_graph is not supported: the saved '
                                'activations live in a reusable launch plan)')
         gy = gy.detach().contiguous().float()
+        if ctx.net is not None:
+            ctx.net._release_adopted(tp.grad_flat)      # `.grad` may alias the buffer this backward is about to rewrite
         gx = _train_backward(tp, gy, E.current_stream(), ctx.noise, ctx.explicit, ctx.seed, True)
         grads = _grad_views(tp)
         ctx.lease.release()

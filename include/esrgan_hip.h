@@ -535,9 +535,10 @@ typedef struct esr_rdb_wgrad {
   float* partial;           /* esr_rdb_wgrad_workspace_elems() floats: per-task partial sums, reduced in a fixed order
                                (+ the step counters that keep the four channel sets of a row band in lock step) */
   int64_t partial_elems;
-  int32_t max_workgroups;   /* 0: the pass takes every CU (persistent grid, one workgroup per CU); n > 0: at most n
-                               workgroups — the caller runs the pass NEXT TO other work (the train plan: a run of RRDBs'
-                               weight gradients on the side stream under the next run's backward chain) */
+  int32_t max_workgroups;   /* 0 (default): one workgroup per task, a plain non-persistent grid; n > 0: a persistent
+                               grid of at most n workgroups striding over the tasks — the caller runs the pass NEXT TO
+                               other work (the train plan: a run of RRDBs' weight gradients on the side stream under the
+                               next run's backward chain) */
   int32_t _pad;
 } esr_rdb_wgrad;
 

@@ -506,7 +506,16 @@ def test_networks_join_a_pipelined_steps_tail_at_their_public_entry_points(monke
         # no finish(): the reads below are on the current stream, the tail is on the side stream
         sd = {k: v.detach().clone() for k, v in netD.state_dict().items()}
         if not explicit_finish:
-            assert netD.__dict__.get('_pending_ev') is None
+            # the event stays for callers on OTHER streams; this stream has joined it once
+            pend = netD.__dict__.get('_pending_ev')
+            cur = torch.cuda.current_stream()
+            assert isinstance(pend, tuple) and (cur.device.index, cur.cuda_stream) in pend[1]
+            other = torch.cuda.Stream()
+            with torch.cuda.stream(other):              # NOT ordered behind the current stream: only the join orders it
+                sd2 = {k: v.detach().clone() for k, v in netD.state_dict().items()}
+            other.synchronize()
+            assert (other.device.index, other.cuda_stream) in pend[1]
+            assert all(torch.equal(sd[k], sd2[k]) for k in sd)
         netD.eval()
         with torch.no_grad():
             y = netD(hr).clone()

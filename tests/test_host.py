@@ -381,6 +381,65 @@ def test_adopted_plan_gradients_alias_without_a_copy_and_keep_the_accumulation_r
     assert net.mark_grads_stale()
     net._flush_stale_grads()                            # a per-tensor backward is about to ADD: the stale values go
     assert float(a.abs().sum()) == 0.0 and not net._gstore['stale']
+    assert params[0].grad.data_ptr() == net._gstore['flat'].data_ptr()     # ... and `.grad` no longer aliases the plan
+
+
+def test_adopted_gradients_survive_the_plan_buffer_being_rewritten():
+    """adopted `.grad` views alias the plan's buffer, which the plan's NEXT backward zeroes and rewrites
+    before it delivers.  The three sequences that gave 2 * g (expected 4 / 3 / 3, got 6):
+    (a) a second backward on the same plan without zero_grad -> g1 + g2;
+    (b) mark_grads_stale() and then a delivery with adopt=False (the train step falling back to autograd) -> g2;
+    (c) zero_grad(set_to_none=False) after an adopted step -> g2; and (d) the per-tensor route (AccumulateGrad)."""
+    from esrganplus_amd import architecture as arch
+    net = arch.RRDBNet(3, 3, 64, 1)
+    params = list(net.parameters())
+    n = sum(p.numel() for p in params)
+
+    def cat():
+        return torch.cat([p.grad.reshape(-1) for p in params])
+
+    def backward(buf, g, adopt):                        # what functional.rrdbnet_train_backward / _RRDBNetFn.backward do
+        net._release_adopted(buf)
+        buf.zero_()
+        buf.add_(g)
+        net._deliver_flat_grads(buf, adopt=adopt)
+    buf = torch.zeros(n)
+    backward(buf, 1.0, True)                            # (a)
+    assert params[0].grad.data_ptr() == buf.data_ptr()
+    backward(buf, 3.0, True)
+    assert torch.equal(cat(), torch.full((n,), 4.0)) and params[0].grad.data_ptr() != buf.data_ptr()
+    net.zero_grad(set_to_none=True)
+    backward(buf, 1.0, True)                            # (b)
+    assert net.mark_grads_stale()
+    backward(buf, 3.0, False)
+    assert torch.equal(cat(), torch.full((n,), 3.0)) and not net._gstore['stale']
+    assert params[0].grad.data_ptr() != buf.data_ptr()
+    net.zero_grad(set_to_none=True)
+    backward(buf, 1.0, True)                            # (c)
+    net.zero_grad(set_to_none=False)
+    backward(buf, 3.0, True)
+    assert torch.equal(cat(), torch.full((n,), 3.0))
+    net.zero_grad(set_to_none=True)
+    backward(buf, 1.0, True)                            # (d) per-tensor route: forward flushes, backward rewrites, AccumulateGrad adds
+    assert net.mark_grads_stale()
+    net._flush_stale_grads()
+    buf.zero_(), buf.add_(3.0)
+    for p_, g in zip(params, buf.clone().split([p.numel() for p in params])):
+        p_.grad.add_(g.view_as(p_))
+    assert torch.equal(cat(), torch.full((n,), 3.0))
+    net.zero_grad(set_to_none=True)
+    backward(buf, 1.0, True)                            # (d'), not stale: the old gradients count
+    net._flush_stale_grads()
+    buf.zero_(), buf.add_(3.0)
+    for p_, g in zip(params, buf.clone().split([p.numel() for p in params])):
+        p_.grad.add_(g.view_as(p_))
+    assert torch.equal(cat(), torch.full((n,), 4.0))
+    # without the release hook the aliasing is refused loudly instead of returning 2 * g
+    net.zero_grad(set_to_none=True)
+    backward(buf, 1.0, True)
+    buf.zero_(), buf.add_(3.0)
+    with pytest.raises(RuntimeError, match='rewritten'):
+        net._deliver_flat_grads(buf, adopt=True)
 
 
 def test_committed_traffic_numbers_belong_to_the_current_kernels():
@@ -398,3 +457,21 @@ def test_committed_traffic_numbers_belong_to_the_current_kernels():
     for k in rows:
         assert tj[k]['read_bytes'] > 0 and tj[k]['write_bytes'] > 0
         assert TH.fresh(tj, k), '%s: traffic was measured on other sources (re-run the PMC pass, then tools/traffic_hashes.py --update)' % k
+
+
+def test_integer_schedule_knobs_are_validated(monkeypatch):
+    """ESR_BWD_SPLIT / ESR_BWD_SPLIT_FIRST were parsed with a bare int(): a misspelt value raised an opaque
+    ValueError in the middle of a plan build, an out-of-range one was silently ignored."""
+    from esrganplus_amd import engine as E
+    assert E.env_int('ESR_NO_SUCH_KNOB', 7, 0, 9) == 7
+    monkeypatch.setenv('ESR_BWD_SPLIT_FIRST', 'ten')
+    with pytest.raises(ValueError, match='ESR_BWD_SPLIT_FIRST'):
+        E.env_int('ESR_BWD_SPLIT_FIRST', 0, 0, 23)
+    monkeypatch.setenv('ESR_BWD_SPLIT_FIRST', '24')
+    with pytest.raises(ValueError, match=r'\[0, 23\]'):
+        E.env_int('ESR_BWD_SPLIT_FIRST', 0, 0, 23)
+    monkeypatch.setenv('ESR_BWD_SPLIT_FIRST', '14')
+    assert E.env_int('ESR_BWD_SPLIT_FIRST', 0, 0, 23) == 14
+    monkeypatch.setenv('ESR_BWD_SPLIT', '0')
+    with pytest.raises(ValueError, match='ESR_BWD_SPLIT'):
+        E.env_int('ESR_BWD_SPLIT', None, 1, 23)
