@@ -46,6 +46,22 @@ def committed_traffic(kernel):
         return None, None
 
 
+def committed_profile(kernel):
+    """The committed rocprofv3 --kernel-trace --stats figure of `kernel` (average launch duration on the PROFILED box,
+    tools/update_traffic.py), or None: printed next to this run's own HIP-event figure so that the line itself says the
+    two fractions come from different boxes."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import traffic_hashes as TH
+        tj = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')))
+        row = tj.get(kernel, {})
+        if 'profiled_avg_launch_us' not in row or not TH.fresh(tj, kernel):
+            return None
+        return row
+    except (OSError, ValueError, KeyError, ImportError):
+        return None
+
+
 def conv_flops(c):
     """Algorithmic FLOPs of one fused-conv launch: 2 * MACs of the convolution(s) it replaces
     (true Cin/Cout, not the padded GEMM the kernel runs)."""
@@ -629,7 +645,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    # ESR_DP_FORCE=1 (esrganplus_amd.dp.forced): a ONE-rank process group over the real RCCL backend, and the dp_train /
+    # dp_gtrain objects at N = 1 — every data-parallel branch runs (AVG all-reduce of the gradient buckets inside the
+    # segmented backward, global RaGAN means, stream-side waits), only the wire is missing
+    dp_forced = world == 1 and os.environ.get('ESR_DP_FORCE', '0') == '1'
+    if dp_forced:
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('MASTER_PORT', '29543')
+    if world > 1 or dp_forced:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -677,7 +701,7 @@ def main():
     value = hr_mpix_per_step / (elapsed / args.steps)
     step_flops = 2.0 * MAC_PER_LR_PIXEL * args.batch * args.lr * args.lr
 
-    res = {'metric': 'HR megapixels/sec (x4 SR) RRDBNet forward', 'value': round(value, 2),
+    res = {'metric': 'HR megapixels/sec (x4 SR) RRDBNet forward (fwd+bwd: the fwd_bwd object of this line)', 'value': round(value, 2),
            'unit': 'HR-Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
            'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
@@ -719,6 +743,13 @@ def main():
                            'traffic_source': traffic_src,
                            'launches_per_step': n // reps, 'avg_launch_us': round(t_ms / n * 1e3, 2),
                            'share_of_step_time': round(t_ms / reps / tot_ms, 3)}
+        prow = committed_profile(dom) if (args.batch == BATCH and args.lr == LR) else None
+        if prow:
+            # the committed rocprofv3 figure of the same command — ANOTHER box than this run's (box spread +-3.5 %)
+            res['roofline']['profiled_avg_launch_us'] = prow['profiled_avg_launch_us']
+            res['roofline']['profiled_frac'] = round(fl / n / (prow['profiled_avg_launch_us'] * 1e-6) / 1e12 / PEAK_F16_TFLOPS, 4)
+            res['roofline']['profiled_source'] = '%s (rocprofv3 --kernel-trace --stats, %d launches incl. the cold one; a different box than this line)' % (
+                prow.get('profiled_source', 'profiles/'), prow.get('profiled_calls', 0))
         if traffic:
             # secondary bound: HBM-side bytes of that launch over its duration vs 8 TB/s
             gbps = traffic / (t_ms / n * 1e-3) / 1e9
@@ -732,6 +763,9 @@ def main():
             net = None
             torch.cuda.empty_cache()
             res['fwd_bwd'] = fwd_bwd_probe(args, dev)
+            # BASELINE.json's metric string says "fwd+bwd": the same figure at the top level of the line
+            res['fwd_bwd_value'] = res['fwd_bwd'].get('value')
+            res['fwd_bwd_ms_per_step'] = res['fwd_bwd'].get('ms_per_step')
         if world == 1 and not args.no_train:
             # BASELINE configs[2] and configs[4] next to the headline, so that the driver's line carries them
             torch.cuda.empty_cache()
@@ -754,7 +788,12 @@ def main():
                 fb['frac_of_sustained_probe'] = round(fb['achieved'] / pr['tflops'], 4)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
-    if world > 1 and not args.no_train:
+    if dist is not None:
+        # proof of what ran: ranks in the group, backend, the RCCL the collectives went through
+        res['dist'] = {'world_size': dist.get_world_size(), 'backend': dist.get_backend(),
+                       'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == 'nccl' else None,
+                       'forced_one_rank': bool(dp_forced)}
+    if (world > 1 or dp_forced) and not args.no_train:
         # BASELINE configs[3]: every rank runs the data-parallel train step (the collective path of this repo); the
         # forward headline above has no data-path collective (independent tiles)
         net = None

@@ -27,11 +27,30 @@ import torch
 import torch.distributed as dist
 
 
+def forced():
+    """ESR_DP_FORCE=1: take every data-parallel branch (bucketed exchange inside the segmented backward, global RaGAN
+    means, async handles + stream-side waits) even at world size 1, over whatever backend the process group has.  On
+    the ONE GPU a box here has this is the only way the real RCCL backend ('nccl') ever runs under this code:
+    ``ReduceOp.AVG``, ``device_id=``, the Work handles' stream semantics and RCCL's launch path next to the resident
+    chains are exercised — everything except the wire (tests/test_gpu_dp.py, bench.py with the knob set)."""
+    return os.environ.get('ESR_DP_FORCE', '0') == '1'
+
+
+def active():
+    """True when the data-parallel paths run: a process group of more than one rank, or a forced one (``forced``)."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
 def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)."""
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  World size 1 needs
+    no process group — unless ESR_DP_FORCE=1 asks for the data-parallel paths anyway (a one-rank group)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world == 1 or dist.is_initialized():
+    if dist.is_initialized() or (world == 1 and not forced()):
         return world
+    if world == 1:
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('MASTER_PORT', '29541')
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -52,7 +71,7 @@ def world_size():
 def broadcast_parameters(module, src=0):
     """One-time parameter/buffer sync at start-up (replicas then stay identical because every rank
     applies the same averaged gradients) — replaces DataParallel's per-forward broadcast."""
-    if world_size() == 1:
+    if not active():
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
@@ -108,14 +127,14 @@ class GradExchange:
         # start() / wait() skip them.
         self.inline = False
         self.bucket_elems = max(1, bucket_bytes // 4)
-        if overlap and world_size() > 1 and hasattr(module, 'attach_grad_sync'):
+        if overlap and active() and hasattr(module, 'attach_grad_sync'):
             module.attach_grad_sync(self)
             self.inline = True
 
     def __call__(self, flat_slice):
         """Mean all-reduce of one finished slice (called from inside the backward node, stream-ordered after
         the kernels that wrote it).  Returns the work handle (None on one rank)."""
-        if world_size() == 1:
+        if not active():
             return None
         self.calls += 1
         self.bytes += flat_slice.numel() * flat_slice.element_size()
@@ -161,7 +180,7 @@ class GradExchange:
     def start(self):
         """Issue the all-reduces (async).  Call right after ``loss.backward()``."""
         self.handles, self._staged = [], []
-        if world_size() == 1 or self.inline or not self.enabled:
+        if not active() or self.inline or not self.enabled:
             return
         ws = float(world_size())
         for _, ps in self._flat_groups().items():
@@ -222,7 +241,7 @@ class _GlobalMean(torch.autograd.Function):
     def forward(ctx, x):
         # torch.full, not new_tensor(scalar): the latter is a synchronous host->device copy (2 ms stall)
         s = torch.stack([x.sum(), torch.full((), float(x.numel()), dtype=x.dtype, device=x.device)])
-        if world_size() > 1:
+        if active():
             dist.all_reduce(s)
         ctx.save_for_backward(s[1:2])
         ctx.shape = x.shape
@@ -235,7 +254,7 @@ class _GlobalMean(torch.autograd.Function):
         # on the mean, so the upstream gradient is summed over ranks first.  With per-rank losses =
         # local means and parameter gradients averaged over ranks (GradExchange) this reproduces the
         # gradient of the reference's single global-batch loss.
-        if world_size() > 1:
+        if active():
             g = g.clone()
             dist.all_reduce(g)
         return (g / n).expand(ctx.shape)

@@ -15,6 +15,7 @@ import torch
 
 from . import _lib as L
 from . import engine as E
+from . import dp as DP
 
 _scratch = {}
 
@@ -110,7 +111,7 @@ def ragan_raw(x, y, x_is_real, y_is_real, weight, grad_x=None, grad_y=None, grad
     _scale_args(p, grad_scale, scale_dev)
     gx = grad_x.data_ptr() if grad_x is not None else None
     gy = grad_y.data_ptr() if grad_y is not None else None
-    if not (global_mean and dist.is_initialized() and dist.get_world_size() > 1):
+    if not (global_mean and DP.active()):
         p.grad_x, p.grad_y = gx, gy
         L.check(L.lib().esr_ragan_loss_forward(C.byref(p), st), 'esr_ragan_loss_forward')
         return loss, out
@@ -188,7 +189,7 @@ class _RaGANGlobalFn(torch.autograd.Function):
         p.tx, p.ty, p.weight = tx, ty, weight
         p.mode, p.sums = 1, ext.data_ptr()
         L.check(L.lib().esr_ragan_loss_forward(C.byref(p), st), 'esr_ragan_loss_forward')
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if DP.active():
             dist.all_reduce(ext[0:3])
         loss = torch.empty((), dtype=torch.float32, device=dev)
         out = torch.empty(4, dtype=torch.float32, device=dev)
@@ -206,7 +207,7 @@ class _RaGANGlobalFn(torch.autograd.Function):
     def backward(ctx, g, _unused):
         import torch.distributed as dist
         x_, y_, ext, dsum, tx, ty, weight, sx, sy = ctx.keep
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if DP.active():
             dist.all_reduce(dsum)
         ext[3:5] = dsum
         gx = torch.empty_like(x_) if ctx.need[0] else None

@@ -31,7 +31,7 @@ class ESRGANPlusStep:
         self.l_pix_w, self.l_fea_w, self.l_gan_w = pixel_weight, feature_weight, gan_weight
         # data_parallel: None = follow torch.distributed (world size > 1); False inside a multi-rank job = this rank's
         # own step without any exchange (bench.py's no-exchange figure next to the data-parallel one)
-        self.data_parallel = (DP.world_size() > 1) if data_parallel is None else bool(data_parallel)
+        self.data_parallel = DP.active() if data_parallel is None else bool(data_parallel)
         # fp16 path: 'dynamic' (default policy of the scaler: start at 1024, halve on overflow and skip that step,
         # double after 2000 clean steps) or a fixed number (1.0 for fp32).  Nothing here synchronises with the host.
         self.scaler = None

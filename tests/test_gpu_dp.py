@@ -279,3 +279,142 @@ def test_bench_two_ranks_prints_the_dp_train_object(N):
     assert all(v > 0 for v in g['buckets_ms'].values()) and g['ms_per_step'] > 0 and g['ms_per_step_no_exchange'] > 0
     lr_pix = 2 * 32 * 32 + 48 * 48 + 64 * 64
     assert abs(g['value'] - N * 16 * lr_pix / 1e6 / (g['ms_per_step'] / 1e3)) <= 1e-2 * g['value']
+
+
+# ---- the REAL RCCL backend on the one GPU a box has: a forced one-rank group (ESR_DP_FORCE=1, dp.forced) -------------
+def _rccl_one_rank_worker(port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', ESR_DP_FORCE='1')
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import ctypes as C
+    import torch.distributed as dist
+    from esrganplus_amd import dp, train, _lib as L, functional as Fn, losses as LS
+    from esrganplus_amd.optim import FusedAdam
+    from esrganplus_amd import architecture as arch
+    try:
+        out = {}
+        dev = torch.device('cuda', 0)
+
+        def run_step(dp_on, steps=3):
+            torch.manual_seed(77)
+            netG, netD, netF = _make_nets(dev, 'fp16')
+            st = train.ESRGANPlusStep(netG, netD, netF, loss_scale=1024.0, data_parallel=dp_on)
+            assert st.exG.inline == dp_on
+            logs = []
+            for it in range(steps):
+                lr = synth.image_batch(900 + it, 4, 3, 32, 32, name='rccl1.lr').to(dev)
+                hr = synth.image_batch(950 + it, 4, 3, 128, 128, name='rccl1.hr').to(dev)
+                logs.append({k: float(v) for k, v in st.step(lr, hr).items()})
+            st.finish()
+            torch.cuda.synchronize()
+            assert L.lib().esr_rdb_check_abort() == 0, 'a chain gave up next to RCCL work'
+            g = torch.cat([p.grad.reshape(-1).float() for p in netG.parameters()]).cpu()
+            w = {k: v.detach().float().cpu() for k, v in list(netG.state_dict().items()) + [('D.' + k, v) for k, v in netD.state_dict().items()]}
+            return g, w, logs, st
+
+        g0, w0, l0, _ = run_step(False)            # BEFORE the process group exists: the plain single-GPU step
+        assert not dp.active()
+        assert dp.init_from_env('nccl') == 1       # one-rank group over RCCL (device_id= path)
+        assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1 and dp.active() and dp.forced()
+        g1, w1, l1, st = run_step(True)
+        rep = st.comm_report()
+        out['calls_per_step'], out['bytes_per_step'] = rep['calls_per_step'], rep['bytes_per_step']
+        nG = sum(p.numel() for p in st.netG.parameters())
+        nD = sum(p.numel() for p in st.netD.parameters())
+        out['expected_bytes'] = 4 * (nG + nD)
+        out['grad_equal'] = bool(torch.equal(g0, g1))
+        out['weights_equal'] = all(torch.equal(w0[k], w1[k]) for k in w0)
+        out['logs_equal'] = l0 == l1
+        out['max_grad_diff'] = float((g0 - g1).abs().max())
+
+        # the generator-only bucket loop (bench.py measure_gtrain's form) with the exchange inside each backward
+        def run_gtrain(dp_on):
+            torch.manual_seed(78)
+            netG = arch.RRDBNet(3, 3, 64, 2).to(dev).train().set_precision('fp16')
+            netG.load_state_dict(synth.rrdbnet_state_dict(nb=2, seed=43, gain=0.5))
+            opt = FusedAdam(netG.parameters(), lr=1e-4, betas=(0.9, 0.999))
+            ex = dp.GradExchange(netG, enabled=dp_on, measure=dp_on)
+            assert ex.inline == dp_on
+            scale = torch.full((), 1024.0, device=dev)
+            for it in range(2):
+                for k, (n, sz) in enumerate(((2, 32), (1, 48))):
+                    lr = synth.image_batch(600 + 10 * it + k, n, 3, sz, sz, name='rccl1.glr').to(dev)
+                    hr = synth.image_batch(700 + 10 * it + k, n, 3, 4 * sz, 4 * sz, name='rccl1.ghr').to(dev)
+                    if not netG.mark_grads_stale():
+                        opt.zero_grad(set_to_none=True)
+                    with torch.no_grad():
+                        fake, stG = Fn.rrdbnet_train_forward(netG, lr)
+                        gy = torch.empty_like(fake)
+                        LS.l1_raw(fake, hr, 1.0, grad_out=gy, grad_scale=1024.0)
+                        Fn.rrdbnet_train_backward(netG, stG, gy)
+                    ex.start(); ex.wait()
+                    opt.step(grad_scale=1.0 / 1024.0)
+            torch.cuda.synchronize()
+            assert L.lib().esr_rdb_check_abort() == 0, 'a chain gave up next to RCCL work'
+            return {k: v.detach().float().cpu() for k, v in netG.state_dict().items()}, ex
+        wa, _ = run_gtrain(False)
+        wb, exg = run_gtrain(True)
+        out['gtrain_weights_equal'] = all(torch.equal(wa[k], wb[k]) for k in wa)
+        out['gtrain_calls'], out['gtrain_bytes'] = exg.calls, exg.bytes
+        out['gtrain_expected_bytes'] = 4 * sum(p.numel() for p in exg.params) * 4        # 2 iterations x 2 buckets
+        maps = open('/proc/self/maps').read()
+        out['librccl_mapped'] = 'librccl' in maps
+        out['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        q.put(('ok', out))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q.put((repr(e) + traceback.format_exc(), None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_forced_one_rank_rccl_step_equals_the_plain_step():
+    """the data-parallel branches of dp.GradExchange (AVG all-reduce of flat-gradient slices inside
+    the segmented RRDBNet backward, D's buckets under it, stream-side Work.wait()), of losses' global RaGAN means and of
+    train.ESRGANPlusStep over the REAL RCCL backend ('nccl', device_id=) with a forced one-rank group: three train steps
+    and the generator-only bucket loop must leave exactly the gradients / weights / losses of the plain step (the mean
+    over one rank is the identity), the byte counts are the networks' gradient bytes, librccl is in the process's maps,
+    and no chain reports an abort with RCCL work enqueued next to it."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    status, out = q.get(timeout=900)
+    p.join(timeout=60)
+    assert status == 'ok', status
+    print(out)
+    assert out['librccl_mapped'], 'RCCL was not loaded: the nccl backend did not run'
+    assert out['bytes_per_step'] == out['expected_bytes'] and out['calls_per_step'] >= 2
+    assert out['gtrain_bytes'] == out['gtrain_expected_bytes'] and out['gtrain_calls'] >= 4
+    assert out['logs_equal'] and out['grad_equal'] and out['weights_equal'], out
+    assert out['gtrain_weights_equal']
+
+
+def test_bench_forced_one_rank_rccl_prints_the_dp_objects():
+    """`ESR_DP_FORCE=1 python bench.py --gpus 1`: the dp_train / dp_gtrain objects over a one-rank RCCL group — n_ranks 1,
+    backend nccl, the all-reduce volume of BASELINE configs[3] (125 MB) and configs[4] (3 x 67.4 MB) — and the `dist`
+    object that proves which backend / RCCL version / world size a line was measured under."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ESR_DP_FORCE='1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('ESR_BENCH_BACKEND', None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '2',
+                          '--dp-steps', '4', '--no-cpu-baseline', '--no-fwd-bwd', '--no-mfma-probe'],
+                         cwd=root, env=env, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=1500).stdout.decode()
+    line = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
+    d = line['dist']
+    assert d['world_size'] == 1 and d['backend'] == 'nccl' and d['forced_one_rank'] and d['rccl_version']
+    dpo, dpg = line['dp_train'], line['dp_gtrain']
+    assert dpo['n_ranks'] == 1 and dpo['backend'] == 'nccl' and dpg['n_ranks'] == 1
+    assert abs(dpo['allreduce_bytes_per_step'] - 125.4e6) < 0.5e6, dpo['allreduce_bytes_per_step']
+    assert dpg['allreduce_bytes_per_step'] == dpg['expected_allreduce_bytes_per_step'] == 3 * 4 * 16839299
+    assert dpo['allreduce_calls_per_step'] >= 2 and dpg['allreduce_calls_per_step'] >= 3
+    # one rank: the exchange is RCCL's bookkeeping only — the DP step may not cost more than a few percent
+    print('dp_train %.3f ms (no exchange %.3f), exposed %.3f ms; dp_gtrain %.2f (%.2f)' % (
+        dpo['ms_per_step'], dpo['ms_per_step_no_exchange'], dpo['exposed_comm_ms_per_step'],
+        dpg['ms_per_step'], dpg['ms_per_step_no_exchange']))
+    assert dpo['ms_per_step'] <= 1.25 * dpo['ms_per_step_no_exchange'] + 0.5

@@ -1,3 +1,4 @@
+// EXPERIMENT — not product code, not part of libesrgan_hip.so (see tools/experiments/README.md).
 // issue_probe.hip — what one wave per SIMD pays per MFMA for the instructions between its MFMAs (gfx950).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/issue_probe.hip -o gpurun_out/issue_probe
 // Every variant: 128 workgroups x 4 waves, N MFMAs (v_mfma_f32_32x32x16_f16) per wave; prints ns and shader cycles per MFMA.

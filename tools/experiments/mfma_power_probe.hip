@@ -1,3 +1,4 @@
+// EXPERIMENT — not product code, not part of libesrgan_hip.so (see tools/experiments/README.md).
 // mfma_power_probe.hip — what the matrix pipe sustains under the package power limit (round 5).
 // Every SIMD of the chip runs ONE wave that issues independent v_mfma_f32_32x32x16_f16 back to back from registers
 // (no LDS, no memory in the loop): the only limits are the MFMA issue rate and the clock the power management allows.

@@ -1,3 +1,4 @@
+// EXPERIMENT — not product code, not part of libesrgan_hip.so (see tools/experiments/README.md).
 // Flag ping-pong between two workgroups of one launch: same XCD vs different XCDs, with the load policies a
 // cross-workgroup hand-off could use on gfx950 (sc1 = device scope, sc0 = group scope, none = wave scope).
 // Build: hipcc --offload-arch=gfx950 -O3 -o xcd_pingpong xcd_pingpong.hip ;  run on the GPU box.

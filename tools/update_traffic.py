@@ -32,5 +32,19 @@ for row, (which, name) in ROWS.items():
     J[row]['read_bytes'], J[row]['write_bytes'] = int(round(r * 1e6)), int(round(w * 1e6))
     J[row]['note'] = 'round %s, profiles/%s_%s_pmc_summary.txt (FETCH_SIZE x2 gfx950 correction / WRITE_SIZE, MB = KB/1024 x 1e6 as the summary prints it)' % (tag[1:].lstrip('0'), tag, which)
     print(row, J[row]['read_bytes'], J[row]['write_bytes'])
+J['_source'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, round %s: profiles/%s_fwd_pmc_summary.txt (forward kernels), '
+                'profiles/%s_fwdbwd_pmc_summary.txt (training kernels); tools/profile_all.sh %s') % (tag[1:].lstrip('0'), tag, tag, tag)
+# the profiled box's average launch duration of the dominant forward kernel (rocprofv3 --kernel-trace --stats of the same
+# command): bench.py prints it next to its own HIP-event figure — the two come from DIFFERENT boxes (+-3.5 %)
+import csv
+st = 'profiles/%s_fwd_kernel_stats.csv' % tag
+if os.path.exists(st):
+    for r in csv.DictReader(open(st)):
+        if 'rdb_chain_kernel' in r['Name']:
+            J['rdb_chain']['profiled_avg_launch_us'] = round(float(r['AverageNs']) / 1e3, 2)
+            J['rdb_chain']['profiled_min_launch_us'] = round(float(r['MinNs']) / 1e3, 2)
+            J['rdb_chain']['profiled_calls'] = int(r['Calls'])
+            J['rdb_chain']['profiled_source'] = st
+            break
 json.dump(J, open('profiles/roofline_traffic.json', 'w'), indent=2)
 subprocess.check_call([sys.executable, 'tools/traffic_hashes.py', '--update'])
