@@ -412,8 +412,7 @@ class _BlockFn(torch.autograd.Function):
             raise RuntimeError('backward called twice (retain_graph is not supported: the saved '
                                'activations live in a reusable launch plan)')
         gy = gy.detach().contiguous().float()
-        if ctx.net is not None:
-            ctx.net._release_adopted(tp.grad_flat)      # `.grad` may alias the buffer this backward is about to rewrite
+        # (a stand-alone block never adopts the plan's gradient buffer: autograd accumulates copies of the views)
         gx = _train_backward(tp, gy, E.current_stream(), ctx.noise, ctx.explicit, ctx.seed, True)
         grads = _grad_views(tp)
         ctx.lease.release()
