@@ -320,6 +320,7 @@ def packed_weight_bytes(cout, cin, ks, dtype):
 
 
 OPF_SIDE = 1   # esr_op.flags: run of wgrad ops on the library's side stream (include/esrgan_hip.h)
+OPF_FOLLOW = 4   # on an OP_RDB_WGRAD op right behind its OP_RDB_CHAIN_BWD op: launched with the chain, one block behind it
 OPF_SIDE_FREE = 2   # with OPF_SIDE: independent run (own partial region, inputs never overwritten): no waits between runs
 
 

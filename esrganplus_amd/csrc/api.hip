@@ -83,6 +83,8 @@ SideState* side_state(hipStream_t owner) {
 }
 }  // namespace
 
+int esr_rdb_backward_with_follower(const esr_rdb_chain* ch, const esr_rdb_wgrad* wg, hipStream_t stream, hipStream_t side, hipEvent_t fork);   // rdb_fused.hip
+
 // consecutive weight-gradient ops handed to one esr_conv_wgrad_multi call (an RRDB: 3 x 6)
 constexpr int ESR_WGRAD_RUN_MAX = 24;
 
@@ -164,7 +166,29 @@ extern "C" int esr_run_ops(const esr_op* ops, int32_t n, esr_stream_t stream) {
         break;
       case ESR_OP_PACK_BATCH: rc = esr_pack_conv_weights_batch(&ops[i].u.pack_batch, stream); break;
       case ESR_OP_RDB_CHAIN: rc = esr_rdb_forward(&ops[i].u.rdb_chain, stream); break;
-      case ESR_OP_RDB_CHAIN_BWD: rc = esr_rdb_backward(&ops[i].u.rdb_chain, stream); break;
+      case ESR_OP_RDB_CHAIN_BWD: {
+        // a follower pass (ESR_OPF_FOLLOW on the ESR_OP_RDB_WGRAD op right behind): chain and weight gradients launched
+        // together — the pass on the side stream, behind the clearing of the chain's flags, one block behind the chain
+        if (i + 1 < n && ops[i + 1].kind == ESR_OP_RDB_WGRAD && (ops[i + 1].flags & ESR_OPF_FOLLOW)) {
+          SideState* ss = side_state((hipStream_t)stream);
+          if (!ss) return ESR_ERR_LAUNCH;
+          hipStream_t main_st = (hipStream_t)stream;
+          if (nside > 0) ESR_HIP(hipStreamWaitEvent(main_st, ss->join[(nside - 1) & 1], 0));
+          {
+            std::lock_guard<std::mutex> lk(ss->mu);
+            rc = esr_rdb_backward_with_follower(&ops[i].u.rdb_chain, &ops[i + 1].u.rdb_wgrad, main_st, ss->stream, ss->fork[nside & 1]);
+          }
+          if (rc == ESR_OK) {
+            ESR_HIP(hipEventRecord(ss->join[nside & 1], ss->stream));
+            ++nside;
+            joined = false;
+            ++i;
+          }
+          break;
+        }
+        rc = esr_rdb_backward(&ops[i].u.rdb_chain, stream);
+        break;
+      }
       case ESR_OP_FRAG_GATHER: rc = esr_gather_fragments(&ops[i].u.frag_gather, stream); break;
       case ESR_OP_RDB_WGRAD: {
         // dense-block weight gradients: like a run of wgrad ops — on the side stream when flagged ESR_OPF_SIDE

@@ -218,7 +218,11 @@ extern "C" size_t esr_rdb_mask_bytes(int32_t B, int32_t H, int32_t W) {
 extern "C" int esr_rdb_max_tiles_per_image(void) { return num_cus_dev(); }
 
 namespace {
-int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, int want_mode) {
+// ChainFollow (api.hip, follower weight gradients): `after_clear` is recorded on the stream between the clearing of the
+// workspace and the kernel launch — what polls the launch's flags from another stream waits for it, not for the launch;
+// the launch's tile grid and the CUs it leaves free come back.
+struct ChainFollow { hipEvent_t after_clear; int tiles_x, tiles_y, rows, grid, cus; };
+int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, int want_mode, ChainFollow* fol = nullptr) {
   if (!p || !p->blocks || p->n_blocks <= 0 || !p->workspace || p->B <= 0 || p->H <= 0 || p->W <= 0 ||
       (p->mode == 0 && !p->dense.ptr)) {
     esr_set_error("%s: invalid arguments", who);
@@ -278,6 +282,13 @@ int chain_launch(const esr_rdb_chain* p, esr_stream_t stream, const char* who, i
     esr_set_error("%s: hipMemsetAsync failed", who);
     return ESR_ERR_LAUNCH;
   }
+  if (fol) {
+    fol->tiles_x = tiles_x; fol->tiles_y = tiles_y; fol->rows = rows; fol->grid = grid; fol->cus = cus;
+    if (fol->after_clear && hipEventRecord(fol->after_clear, st) != hipSuccess) {
+      esr_set_error("%s: hipEventRecord failed", who);
+      return ESR_ERR_LAUNCH;
+    }
+  }
   auto dispatch = [&]() -> int {
     if (p->band_rows != 0) {
       if (p->dtype != ESR_F16 && p->dtype != ESR_F32) { esr_set_error("%s: bad dtype %d", who, p->dtype); return ESR_ERR_INVALID; }
@@ -336,6 +347,25 @@ void esr_chain_graph_after(hipStream_t st, int cus) { chain_record_launch(st, cu
 
 extern "C" int esr_rdb_forward(const esr_rdb_chain* p, esr_stream_t stream) { return chain_launch(p, stream, "esr_rdb_forward", 0); }
 extern "C" int esr_rdb_backward(const esr_rdb_chain* p, esr_stream_t stream) { return chain_launch(p, stream, "esr_rdb_backward", 2); }
+
+// esr_run_ops (api.hip): the backward chain with a follower pass of weight gradients on `side` (rdb_wgrad.hip:
+// esr_rdb_wgrad_run_follow).  Order on the device: [clear of the chain's flags] -> chain kernel (stream) and, behind the
+// clear only, the follower (side): it polls the flags of the launch that runs next to it.
+int esr_rdb_wgrad_run_follow(const esr_rdb_wgrad* p, esr_stream_t stream, const uint32_t* flags, int tiles_x, int tiles_y, unsigned* host_abort);
+int esr_rdb_backward_with_follower(const esr_rdb_chain* ch, const esr_rdb_wgrad* wg, hipStream_t stream, hipStream_t side, hipEvent_t fork) {
+  ChainFollow fol{};
+  fol.after_clear = fork;
+  int rc = chain_launch(ch, (esr_stream_t)stream, "esr_rdb_backward", 2, &fol);
+  if (rc != ESR_OK) return rc;
+  if (hipStreamWaitEvent(side, fork, 0) != hipSuccess) { esr_set_error("esr_rdb_backward (follower): hipStreamWaitEvent failed"); return ESR_ERR_LAUNCH; }
+  esr_rdb_wgrad w = *wg;
+  // the follower keeps to the CUs the chain's grid leaves free (a workgroup of either kernel takes a whole CU's LDS)
+  const int spare = fol.cus - fol.grid;
+  if (spare < 32) { esr_set_error("esr_rdb_backward (follower): the chain launch leaves %d CUs free (< 32): run the weight gradients behind it", spare); return ESR_ERR_UNSUPPORTED; }
+  if (w.max_workgroups <= 0 || w.max_workgroups > spare) w.max_workgroups = spare;
+  return esr_rdb_wgrad_run_follow(&w, (esr_stream_t)side, (const uint32_t*)ch->workspace + WS_HDR, fol.tiles_x, fol.tiles_y,
+                                  abort_word_dev(esr_bookkeeping_device()));
+}
 
 // Fused weight stream of a block = 1 KB fragments gathered from the per-conv packed weights
 // (esr_pack_conv_weights order [cout_block][cin_group][kh][kw][lane][16 B]).

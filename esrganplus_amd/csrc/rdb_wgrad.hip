@@ -141,7 +141,59 @@ struct KArgs {
   int64_t slot_stride;            // floats per slot (SLOT_ELEMS rounded up to 4)
   int total;                      // tasks of the launch (n_blocks x ntasks): workgroup w runs w, w + grid, w + 2 grid, ...
   uint32_t* pace;                 // NULL, or one step counter per workgroup (zero at launch): see Pace
+  // ---- follower form (esr_rdb_wgrad_run_follow): the pass runs NEXT TO the backward-chain launch that produces its
+  // gradient slices, one block behind it
+  const uint32_t* follow;         // NULL, or the chain's per-tile flags (its workspace behind the header words)
+  int f_tx, f_ty;                 // the chain launch's tiles per image row / column (tile width = a column strip: 32)
+  uint32_t* done;                 // follower: compute tasks finished per block (zero at launch); done[n_blocks] = "a wait timed
+                                  // out": every later wait of the launch returns at once
+  unsigned* host_abort;           // pinned host word raised when a bounded wait timed out (may be NULL)
+  int rdelay;                     // follower: a block's reduce tasks stand this many blocks further down the task list
 };
+
+// ---- follower (round 6) -------------------------------------------------------------------------------------------
+// Training crops leave the backward chain half of the chip (16 x 32^2 LR = 128 four-row tiles on 256 CUs).  Up to round
+// 5 the chain ran as two launches so that the first run's weight gradients could execute under the second run — and the
+// second run's were left behind the chain on the step's critical path (0.4 ms + a 0.08 ms reduction).  A follower pass
+// is launched TOGETHER with ONE chain launch over all blocks, on the side stream, as a persistent grid on the CUs the
+// chain leaves free: a task of block k (the chain's k-th block; the pass lists its blocks in the chain's order) starts
+// when every tile it reads has published the end of block k — the chain's own hand-off flags, value 5 (k + 1), read
+// with agent-scope loads; the gradient slices were written through to the L2 in front of the flag (rdb_chain_kernel.h:
+// publish) and are staged here with sc1 loads.  The reduction of a block's task slots is done by whichever workgroup
+// finishes the block's last task (arrival counter, release / acquire at agent scope) in the same slot order as the
+// reduce kernel: results are bit-identical to the two-launch form, and what is left behind the chain is the last
+// block's tasks.  Waits are bounded (a chain that aborted never raises its flags): a time-out raises the library's
+// abort word and lets the pass run to its end on whatever is there — the next library call reports it.
+__device__ __forceinline__ void follow_wait(const KArgs& ka, const int blk, const int chunk) {
+  // wave 0: one flag per lane, 64 at a time
+  const int sx = chunk % ka.strips, ig = chunk / ka.strips;
+  const int b_begin = ig * ka.ipw, b_end = min(ka.p.B, b_begin + ka.ipw);
+  const int nflag = (b_end - b_begin) * ka.f_ty;
+  const uint32_t need = 5u * (uint32_t)(blk + 1);
+  const int lane = threadIdx.x & 63;
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  const uint32_t* const dead = ka.done + ka.p.n_blocks;
+  for (int base = 0; base < nflag; base += 64) {
+    const int i = base + lane;
+    const bool mine = i < nflag;
+    const int b = b_begin + (mine ? i / ka.f_ty : 0), ty = mine ? i % ka.f_ty : 0;
+    const uint32_t* const f = ka.follow + ((int64_t)b * ka.f_ty + ty) * ka.f_tx + sx;
+    bool ok = !mine;
+    for (;;) {
+      if (!ok) ok = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+      if (__all(ok)) break;
+      const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull;          // 2 s of the 100 MHz counter
+      if (late || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        if (late && lane == 0) {
+          __hip_atomic_store(ka.done + ka.p.n_blocks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (ka.host_abort) __hip_atomic_store(ka.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+  }
+}
 
 // ---- lock step of the four sets of a chunk (round 5; an EXPERIMENT, off by default: ESR_RDB_WGRAD_PACE=1) -----------
 // The four workgroups that run the four channel sets of one (block, image group, column strip) read the same rows of
@@ -275,7 +327,7 @@ __device__ __forceinline__ void step_bias(float& bsum, const uint32_t lg) {
     }
 }
 
-template <int SET, bool PACED>
+template <int SET, bool PACED, bool FOLLOW = false>
 __device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const int chunk, char* const smem, Pace& pc) {
   constexpr SetDesc sd = kSets[SET];
   constexpr int nib = sd.nib, ngb = sd.ngb;
@@ -350,8 +402,9 @@ __device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const 
 #pragma unroll
     for (int k = 0; k < NRG; ++k) {
       if ((k + 1) * NTH > gq_slots && wave * 64 + NTH * k >= gq_slots) continue;
+      // (follower: the slices were written by the chain launch that is still running — L1 bypassed, sc1)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(r_q, (__attribute__((address_space(3))) void*)(dst0 + k * (NTH * 16)), 16,
-                                               (int)entg[k], rowadv, 0, 0);
+                                               (int)entg[k], rowadv, 0, FOLLOW ? 16 : 0);
     }
   };
 
@@ -416,6 +469,13 @@ __device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const 
       else step_mma<1, NIB_ROW, NGB_ROW>(acc, lg, lp0, lp1, lp2);
     }
   }
+  // a slot element.  Follower: read by ANOTHER workgroup of the same launch (possibly on another XCD) — a write-through
+  // (sc1) store, as the chains publish their slices; no fence: an agent-scope release / acquire pair writes back and
+  // invalidates the XCD's whole L2, i.e. the weight stream of the chain that runs next to this pass
+  auto put_f = [](float* q, const float v) __attribute__((always_inline)) {
+    if constexpr (FOLLOW) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *q = v;
+  };
   // ---- bias sums -> behind the weights of their conv's slot ([9][cout][cin] | [cout])
   {
     float* const slot0 = p.partial + ((int64_t)blk * nchunk + chunk) * ka.slot_stride;
@@ -423,7 +483,7 @@ __device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const 
       const int cv = conv_of_gblock(gb), half = gb == 1 ? 1 : 0;
       const float scb = p.scale * (cv == 4 ? p.scale5 : 1.f);
       const float other = __shfl_xor(bsum, 32);          // lanes l and l + 32 hold the two k halves of cout row l % 32
-      if (lane < 32) slot0[conv_slot_off(cv) + (int64_t)9 * conv_cout(cv) * conv_cin(cv) + half * 32 + lane] = (bsum + other) * scb;
+      if (lane < 32) put_f(&slot0[conv_slot_off(cv) + (int64_t)9 * conv_cout(cv) * conv_cin(cv) + half * 32 + lane], (bsum + other) * scb);
     };
     if (bias0) put_bias(bsum0, sd.gbk[0]);
     if (bias1) put_bias(bsum1, sd.gbk[1]);
@@ -439,7 +499,7 @@ __device__ __forceinline__ void wgrad_set(const KArgs& ka, const int blk, const 
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
-      slot[((int64_t)t * cout + co) * cin + ci] = a[e] * sc;
+      put_f(&slot[((int64_t)t * cout + co) * cin + ci], a[e] * sc);
     }
   };
   if (kind == 1) {
@@ -492,14 +552,11 @@ __global__ __launch_bounds__(NTH, 2) void rdb_wgrad_kernel(const KArgs ka) {
 }
 
 // ---- stage 2: dw / db += sum over a block's task slots, in slot order (deterministic)
-__global__ __launch_bounds__(256) void rdb_wgrad_reduce_kernel(const KArgs ka) {
-  const esr_rdb_wgrad& p = ka.p;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int blk = (int)(idx / SLOT_ELEMS);
-  if (blk >= p.n_blocks) return;
-  const int k = (int)(idx - (int64_t)blk * SLOT_ELEMS);
+// element k of block blk's slot.  NT: the slots were written by other workgroups of the SAME launch (follower form):
+// loads that bypass the L1
+__device__ __forceinline__ float reduce_sum(const KArgs& ka, const int blk, const int k) {
   const int nchunk = ka.strips * ka.igroups;
-  const float* src = p.partial + (int64_t)blk * nchunk * ka.slot_stride + k;
+  const float* src = ka.p.partial + (int64_t)blk * nchunk * ka.slot_stride + k;
   float s = 0.f;
   int sp = 0;
   for (; sp + 8 <= nchunk; sp += 8) {
@@ -510,6 +567,10 @@ __global__ __launch_bounds__(256) void rdb_wgrad_reduce_kernel(const KArgs ka) {
     for (int u = 0; u < 8; ++u) s += v[u];
   }
   for (; sp < nchunk; ++sp) s += src[(int64_t)sp * ka.slot_stride];
+  return s;
+}
+__device__ __forceinline__ void reduce_apply(const KArgs& ka, const int blk, const int k, const float s) {
+  const esr_rdb_wgrad& p = ka.p;
   int conv = 0;
 #pragma unroll
   for (int c = 1; c < 6; ++c) if (k >= conv_slot_off(c)) conv = c;
@@ -523,6 +584,125 @@ __global__ __launch_bounds__(256) void rdb_wgrad_reduce_kernel(const KArgs ka) {
   if (p.tap_major || ntap == 1) { dw[e] += s; return; }
   const int ci = e % cin, r = e / cin, co = r % cout, t = r / cout;
   dw[((int64_t)co * cin + ci) * ntap + t] += s;
+}
+// four consecutive elements (k a multiple of 4: a group never straddles a conv's weights / bias sums — every region of
+// the slot is a multiple of 4 long): the same sums in the same slot order, 16-byte accesses.  Follower form only (the
+// slots come from other workgroups of the same launch: `nt` loads go past the L1 like sc1 ones, profiles/r02_experiments)
+__device__ __forceinline__ f32x4 reduce_sum4(const KArgs& ka, const int blk, const int k) {
+  const int nchunk = ka.strips * ka.igroups;
+  const f32x4* src = (const f32x4*)(ka.p.partial + (int64_t)blk * nchunk * ka.slot_stride + k);
+  const int64_t st4 = ka.slot_stride / 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int sp = 0;
+  for (; sp + 8 <= nchunk; sp += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (int64_t)(sp + u) * st4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; sp + 4 <= nchunk; sp += 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(src + (int64_t)(sp + u) * st4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += v[u];
+  }
+  for (; sp < nchunk; ++sp) s += __builtin_nontemporal_load(src + (int64_t)sp * st4);
+  return s;
+}
+__device__ __forceinline__ void reduce_apply4(const KArgs& ka, const int blk, const int k, const f32x4 s) {
+  const esr_rdb_wgrad& p = ka.p;
+  int conv = 0;
+#pragma unroll
+  for (int c = 1; c < 6; ++c) if (k >= conv_slot_off(c)) conv = c;
+  const int e = k - conv_slot_off(conv);
+  const esr_rdb_wgrad_block& bd = p.blocks[blk];
+  const int ntap = conv_ntap(conv), nw = ntap * conv_cout(conv) * conv_cin(conv);
+  if (e >= nw) { if (bd.db[conv]) { f32x4* q = (f32x4*)(bd.db[conv] + (e - nw)); *q = *q + s; } return; }
+  if (!bd.dw[conv]) return;
+  if (p.tap_major || ntap == 1) { f32x4* q = (f32x4*)(bd.dw[conv] + e); *q = *q + s; return; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) reduce_apply(ka, blk, k + j, s[j]);
+}
+__global__ __launch_bounds__(256) void rdb_wgrad_reduce_kernel(const KArgs ka) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int blk = (int)(idx / SLOT_ELEMS);
+  if (blk >= ka.p.n_blocks) return;
+  const int k = (int)(idx - (int64_t)blk * SLOT_ELEMS);
+  reduce_apply(ka, blk, k, reduce_sum(ka, blk, k));
+}
+
+// ---- follower form: persistent grid next to the chain launch (see follow_wait).  Task (vb, l) of the list = compute
+// task l of block vb, then the l-th slice of the REDUCTION of block vb - rdelay (a whole round of the grid earlier: its
+// compute tasks are done, or all but, when a workgroup gets there; arrival counter per block, write-through stores in
+// front of it, L1-bypassing loads behind it) — the reduce kernel's arithmetic, slot order and all, so the results are
+// bit-identical to the pass that runs behind the chain.  rdelay extra list positions at the end carry the last
+// blocks' reductions.  (Tried first: the block's last task reduces the whole block — 472 dependent rounds of loads per
+// thread, ~1 ms per block; reduce tasks of their own right behind the block's compute tasks — a third of the
+// workgroups idle for a task's length, every block.)  Every workgroup walks the list in order and a compute task never
+// waits for a reduction: no cycle of waits.
+__global__ __launch_bounds__(NTH, 2) void rdb_wgrad_follow_kernel(const KArgs ka) {
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const int per_block = ka.ntasks;
+  const int nchunk = ka.strips * ka.igroups;
+  const int full = (nchunk / 8) * 32;
+  const int rspan = ((SLOT_ELEMS + per_block - 1) / per_block + 8 * NTH - 1) / (8 * NTH) * (8 * NTH);   // elements per reduction slice
+  Pace pc;
+  pc.mine = nullptr;
+  pc.count = 0;
+  pc.seen[0] = pc.seen[1] = pc.seen[2] = 0;
+  for (int task = blockIdx.x; task < ka.total; task += gridDim.x) {
+    const int vb = task / per_block;
+    const int l = task - vb * per_block;
+    if (vb < ka.p.n_blocks) {
+      const int blk = vb;
+      int chunk, set;
+      if (l < full) { const int grp = l >> 5, w = l & 31; chunk = grp * 8 + (w & 7); set = w >> 3; }
+      else { const int rem = nchunk & 7, w = l - full; chunk = (nchunk / 8) * 8 + w % rem; set = w / rem; }
+      if (threadIdx.x < 64) follow_wait(ka, blk, chunk);
+      __syncthreads();
+      switch (set) {
+        case 0: wgrad_set<0, false, true>(ka, blk, chunk, smem, pc); break;
+        case 1: wgrad_set<1, false, true>(ka, blk, chunk, smem, pc); break;
+        case 2: wgrad_set<2, false, true>(ka, blk, chunk, smem, pc); break;
+        default: wgrad_set<3, false, true>(ka, blk, chunk, smem, pc); break;
+      }
+      // arrival: every storing wave has drained its write-through stores (the slot is complete at the coherent level)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(ka.done + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int rblk = vb - ka.rdelay;
+    if (rblk >= 0) {
+      // ---- slice l of block rblk's reduction
+      if (threadIdx.x == 0) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(ka.done + rblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)per_block) {
+          const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull;      // 2 s: the chain never got there
+          if (late || __hip_atomic_load(ka.done + ka.p.n_blocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            if (late) {
+              __hip_atomic_store(ka.done + ka.p.n_blocks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (ka.host_abort) __hip_atomic_store(ka.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            break;
+          }
+          __builtin_amdgcn_s_sleep(32);
+        }
+      }
+      __syncthreads();
+      const int k0 = l * rspan, k1 = min(SLOT_ELEMS, k0 + rspan);
+      for (int k = k0 + 4 * (int)threadIdx.x; k < k1; k += 8 * NTH) {
+        // two groups of four elements per round: their loads are in flight together, the read-modify-writes follow
+        const int kb = k + 4 * NTH;
+        const f32x4 sa = reduce_sum4(ka, rblk, k);
+        f32x4 sb = {0.f, 0.f, 0.f, 0.f};
+        if (kb < k1) sb = reduce_sum4(ka, rblk, kb);
+        reduce_apply4(ka, rblk, k, sa);
+        if (kb < k1) reduce_apply4(ka, rblk, kb, sb);
+      }
+    }
+  }
 }
 
 int images_per_task(int B, int strips, int n_blocks) {
@@ -561,7 +741,22 @@ static int wgrad_cus() {
   return cached[dev];
 }
 
-extern "C" int esr_rdb_wgrad_run(const esr_rdb_wgrad* p, esr_stream_t stream) {
+static int rdb_wgrad_launch(const esr_rdb_wgrad* p, esr_stream_t stream, const uint32_t* follow, int f_tx, int f_ty, unsigned* host_abort);
+
+extern "C" int esr_rdb_wgrad_run(const esr_rdb_wgrad* p, esr_stream_t stream) { return rdb_wgrad_launch(p, stream, nullptr, 0, 0, nullptr); }
+
+// Follower form (api.hip: an ESR_OP_RDB_WGRAD op flagged ESR_OPF_FOLLOW right behind the ESR_OP_RDB_CHAIN_BWD op whose
+// blocks it lists, in the chain's order): `flags` = the chain launch's per-tile flags (cleared, on a stream this one
+// waits for), tiles_x / tiles_y = that launch's tile grid.  p->max_workgroups = the CUs the chain leaves free.
+int esr_rdb_wgrad_run_follow(const esr_rdb_wgrad* p, esr_stream_t stream, const uint32_t* flags, int tiles_x, int tiles_y, unsigned* host_abort) {
+  if (!flags || tiles_x <= 0 || tiles_y <= 0 || !p || p->max_workgroups <= 0 || tiles_x != (p->W + 31) / 32) {
+    esr_set_error("esr_rdb_wgrad_run_follow: invalid arguments (needs the chain's flags, its tile grid and max_workgroups > 0)");
+    return ESR_ERR_INVALID;
+  }
+  return rdb_wgrad_launch(p, stream, flags, tiles_x, tiles_y, host_abort);
+}
+
+static int rdb_wgrad_launch(const esr_rdb_wgrad* p, esr_stream_t stream, const uint32_t* follow, int f_tx, int f_ty, unsigned* host_abort) {
   if (!p || !p->blocks || p->n_blocks <= 0 || p->B <= 0 || p->H <= 0 || p->W <= 0 || !p->partial) {
     esr_set_error("esr_rdb_wgrad_run: invalid arguments");
     return ESR_ERR_INVALID;
@@ -596,11 +791,25 @@ extern "C" int esr_rdb_wgrad_run(const esr_rdb_wgrad* p, esr_stream_t stream) {
     grid = wgrad_cus();
     if (p->max_workgroups > 0 && p->max_workgroups < grid) grid = p->max_workgroups;
     if (env_grid > 0) grid = env_grid;
-    if (grid >= 32) grid &= ~31;                 // a multiple of 32 keeps every workgroup on its XCD and with its set
+    if (follow) { if (grid >= 8) grid &= ~7; }   // (a follower's tasks are bound to the chain's progress, not to each other: whole XCD rounds)
+    else if (grid >= 32) grid &= ~31;            // a multiple of 32 keeps every workgroup on its XCD and with its set
     if (grid > ka.total) grid = ka.total;
   }
   const int nchunk = ka.strips * ka.igroups;
   ka.pace = nullptr;
+  ka.follow = follow; ka.f_tx = f_tx; ka.f_ty = f_ty; ka.done = nullptr; ka.host_abort = host_abort; ka.rdelay = 0;
+  if (follow) {
+    if (p->n_blocks >= PACE_WORDS) { esr_set_error("esr_rdb_wgrad_run_follow: at most %d blocks per pass", PACE_WORDS); return ESR_ERR_UNSUPPORTED; }
+    ka.done = (uint32_t*)(p->partial + slot_floats(p->B, p->W, p->n_blocks));
+    if (hipMemsetAsync(ka.done, 0, (size_t)(p->n_blocks + 1) * sizeof(uint32_t), st) != hipSuccess) {
+      esr_set_error("esr_rdb_wgrad_run_follow: hipMemsetAsync failed");
+      return ESR_ERR_LAUNCH;
+    }
+    ka.rdelay = (grid + ka.ntasks - 1) / ka.ntasks;
+    ka.total = (p->n_blocks + ka.rdelay) * ka.ntasks;
+    hipLaunchKernelGGL(rdb_wgrad_follow_kernel, dim3((unsigned)grid), dim3(NTH), 0, st, ka);
+    return esr_check_launch("rdb_wgrad_follow_kernel");
+  }
   if (pace_on && nchunk % 8 == 0 && grid % 32 == 0 && grid <= PACE_WORDS) {
     ka.pace = (uint32_t*)(p->partial + slot_floats(p->B, p->W, p->n_blocks));
     if (hipMemsetAsync(ka.pace, 0, (size_t)grid * sizeof(uint32_t), st) != hipSuccess) {

@@ -917,6 +917,14 @@ def bwd_chain_split(B, H, W, nb):
     return min(2, nb) if 2 * tiles4 <= cus else 1      # (train step, same box: 1 run 7.09 ms, 2 runs 7.01, 4 runs 7.06)
 
 
+def bwd_follow():
+    """Training crops: the backward chain's weight gradients as a follower pass next to ONE chain launch (ESR_OPF_FOLLOW)
+    instead of the two-launch form of bwd_chain_split.  ESR_BWD_FOLLOW=0: the round-5 form (A/B)."""
+    if os.environ.get('ESR_BWD_SPLIT'):            # an explicit split asks for the multi-launch form
+        return False
+    return os.environ.get('ESR_BWD_FOLLOW', '1') != '0'
+
+
 def use_rdb_wgrad():
     """fp16 training plans: the six weight gradients of a dense block as ONE esr_rdb_wgrad pass over its saved
     concat buffer and gradient concat (csrc/rdb_wgrad.hip) instead of six esr_conv_wgrad problems
@@ -1574,7 +1582,23 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
 
         TP.bwd_chain_ws = bws
         nsplit = 1 if segmented else bwd_chain_split(B, H, W, nb)
-        if nsplit > 1:
+        cus_ = L.lib().esr_rdb_max_tiles_per_image()
+        spare_ = cus_ - B * ((H + 3) // 4) * ((W + 31) // 32)           # CUs a 4-row-tile launch leaves free
+        if nsplit > 1 and _SIDE and bwd_follow() and spare_ >= 32:
+            # Round 6: ONE chain launch and, launched with it on the side stream, the weight gradients of ALL blocks as
+            # a follower pass on the CUs the chain leaves free — a block's tasks start when the chain has published the
+            # block (csrc/rdb_wgrad.hip: follow_wait), its partial sums are reduced by its last task.  Behind the chain
+            # only the last block's tasks are left (the two-launch form below left the second run's pass + reduction:
+            # 0.4 + 0.08 ms of the step's critical path).
+            warena = torch.empty(int(L.lib().esr_rdb_wgrad_workspace_elems(B, H, W, len(border))), dtype=torch.float32, device=device)
+            TP.bufs.append(warena)
+            chain_op(0, len(border))
+            # (the follower's workgroups each hold a whole CU's LDS for the length of the chain: what else runs next to
+            # the G backward — the D step on the caller's second stream — needs CUs too.  Train step, same box, two runs
+            # each: round-5 form 6.52 ms; follower on 40 / 48 / 56 / 64 / 72 / 80 / 88 / 96 / 128 workgroups 7.33 / 6.86 /
+            # 6.52 / 6.28 / 6.29 / 6.26 / 6.27 / 6.23* / 6.57* (* another box: 6.42 without).  ESR_BWD_FOLLOW_WGS: A/B knob)
+            wgrad_op(wblocks, warena, flags=_SIDE | L.OPF_FOLLOW, max_wg=env_int('ESR_BWD_FOLLOW_WGS', min(spare_, 80), 32, max(32, spare_)))
+        elif nsplit > 1:
             # Small grids (the reference's training crops: 16 x 32^2 LR = 128 four-row tiles on 256 CUs): the chain leaves
             # half of the chip idle and the weight gradients — 0.7 ms behind a 1.9 ms chain — sit on the step's critical
             # path.  The chain runs as `nsplit` launches over runs of whole RRDBs, and the weight gradients of a run go

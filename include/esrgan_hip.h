@@ -562,6 +562,14 @@ enum esr_op_kind { ESR_OP_CONV = 1, ESR_OP_PACK = 2, ESR_OP_LAYOUT = 3, ESR_OP_N
                             completes.  (The discriminator's backward: ten independent, latency-bound weight
                             gradients next to the dgrad chain.) */
 
+#define ESR_OPF_FOLLOW 4   /* on an ESR_OP_RDB_WGRAD op that stands right behind the ESR_OP_RDB_CHAIN_BWD op whose blocks it
+                            lists (same blocks, the chain's order): the pass is launched TOGETHER with the chain, on the
+                            library's side stream, as a persistent grid on the CUs the chain's grid leaves free (at least
+                            32; esr_rdb_wgrad.max_workgroups caps it further) — a task of block k starts when the chain's
+                            tiles it reads have published the end of block k, a block's partial sums are reduced by
+                            its last task.  Results are bit-identical to the pass run behind the chain; completion as for
+                            ESR_OPF_SIDE.  For launches that leave CUs free (training crops); refused otherwise. */
+
 typedef struct esr_op {
   int32_t kind;
   int32_t flags;

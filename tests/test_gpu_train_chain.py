@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from esrganplus_amd import synth
+from esrganplus_amd import synth, _lib as L
 
 pytestmark = pytest.mark.gpu
 
@@ -186,26 +186,28 @@ def test_fp16_noise_on_training_chains_match_the_oracle(dev, monkeypatch, cls_na
 
 @pytest.mark.parametrize('cls_name', ['RRDBNet', 'RRDB_Net'])
 def test_backward_chain_split_into_runs_is_bit_identical(dev, monkeypatch, cls_name):
-    """Training crops (16 x 32^2 LR: 128 four-row tiles) run the fused backward as several chain launches over runs of
-    RRDBs, each followed by its weight-gradient pass on the side stream under the next run's chain
-    (engine.bwd_chain_split).  Launch boundaries carry no semantics: every gradient equals the one-launch form bit for
-    bit, noise on (same Philox key)."""
+    """Training crops (16 x 32^2 LR: 128 four-row tiles) leave the fused backward half of the chip.  Round 6 (the
+    default): ONE chain launch with the weight gradients of all blocks as a FOLLOWER pass launched with it on the side
+    stream — a block's tasks start when the chain has published the block, its partial sums are reduced by its last
+    task (ESR_OPF_FOLLOW, csrc/rdb_wgrad.hip).  Round 5 (ESR_BWD_FOLLOW=0 / an explicit ESR_BWD_SPLIT): several chain
+    launches over runs of RRDBs, each followed by its weight-gradient pass under the next run's chain
+    (engine.bwd_chain_split).  Neither launch boundaries nor the follower's schedule carry semantics: every gradient
+    equals the one-launch, pass-behind-the-chain form bit for bit, noise on (same Philox key)."""
     from esrganplus_amd import architecture as arch
     nb = 5
     sd = synth.rrdbnet_state_dict(nb=nb, seed=71, gain=0.7)
     x = synth.image_batch(71, 16, 3, 32, 32, name='split.x').to(dev)
     gy = synth.normal_like(72, 'split.gy', (16, 3, 128, 128)).to(dev)
     res = {}
-    for split in ('1', '4', '5', 'auto', 'first4'):
+    for split in ('1', '4', '5', 'follow', 'auto', 'first4'):
         monkeypatch.delenv('ESR_BWD_SPLIT_FIRST', raising=False)
-        if split == 'auto':
-            monkeypatch.delenv('ESR_BWD_SPLIT', raising=False)
-        elif split == 'first4':
+        monkeypatch.delenv('ESR_BWD_SPLIT', raising=False)
+        monkeypatch.setenv('ESR_BWD_FOLLOW', '1' if split == 'follow' else '0')
+        if split == 'first4':
             # two UNEQUAL runs (4 + 1 RRDBs): the shared weight-gradient arena must fit the run that needs the most slots,
             # which is not the longest one
-            monkeypatch.delenv('ESR_BWD_SPLIT', raising=False)
             monkeypatch.setenv('ESR_BWD_SPLIT_FIRST', '4')
-        else:
+        elif split not in ('auto', 'follow'):
             monkeypatch.setenv('ESR_BWD_SPLIT', split)
         net = getattr(arch, cls_name)(3, 3, 64, nb).to(dev).train().set_precision('fp16')
         net.load_state_dict(sd, strict=True)
@@ -214,9 +216,11 @@ def test_backward_chain_split_into_runs_is_bit_identical(dev, monkeypatch, cls_n
         torch.cuda.synchronize()
         tps = [tp for pool in net._plans.values() if isinstance(pool, list) for tp in pool if getattr(tp, 'bwd_chain_ops', None)]
         assert len(tps) == 1
-        res[split] = (len(tps[0].bwd_chain_ops), {k: p.grad.clone() for k, p in net.named_parameters()})
+        nfollow = sum(1 for o in tps[0].bwd.ops if o.kind == L.OP_RDB_WGRAD and (o.flags & L.OPF_FOLLOW))
+        res[split] = (len(tps[0].bwd_chain_ops), nfollow, {k: p.grad.clone() for k, p in net.named_parameters()})
     assert res['1'][0] == 1 and res['4'][0] == 3 and res['5'][0] == 5 and res['auto'][0] == 2     # '4': runs of ceil(5 / 4) = 2 RRDBs
     assert res['first4'][0] == 2
-    for split in ('4', '5', 'auto', 'first4'):
-        bad = [k for k, g in res['1'][1].items() if not torch.equal(g, res[split][1][k])]
+    assert res['follow'][:2] == (1, 1) and all(res[k][1] == 0 for k in res if k != 'follow')
+    for split in ('4', '5', 'follow', 'auto', 'first4'):
+        bad = [k for k, g in res['1'][2].items() if not torch.equal(g, res[split][2][k])]
         assert not bad, (split, bad[:6])
