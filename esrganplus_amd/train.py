@@ -154,6 +154,14 @@ class ESRGANPlusStep:
         side = self._side(dev, 0) if ov >= 1 else None
         if not netG.mark_grads_stale():
             self.optimizer_G.zero_grad(set_to_none=True)
+        marks = self.__dict__.get('_marks')          # measurement (tools/train_marks.py): timed events on the main stream
+
+        def mark(name):
+            if marks is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(main)
+                marks.append((name, e))
+        mark('start')
         with torch.no_grad():
             if ov >= 1:
                 ev0 = torch.cuda.Event()
@@ -162,6 +170,7 @@ class ESRGANPlusStep:
             # behind the GPU, and the step's critical path starts with this launch list, not with netF(real)'s
             fake, stG = Fn.rrdbnet_train_forward(netG, var_L, z)
             self.fake_H = fake
+            mark('G forward')
             ev_prep = None
             dsplit = (self.d_split and ov >= 1 and netD._has_bn and netD.training and not E.use_graphs()
                       and not getattr(netD, '_per_call_weights', False))
@@ -241,6 +250,7 @@ class ESRGANPlusStep:
                 netd_fwd()
             leaseF, PF, l_g_fea = box['leaseF'], box['PF'], box['l_g_fea']
             leaseD, PD, pg, pr, l_g_gan = box['leaseD'], box['PD'], box['pg'], box['pr'], box['l_g_gan']
+            mark('pixel loss, netD(fake) forward, GAN loss')
             ev_glog = None
             if sync_log and ov >= 1:
                 ev_glog = torch.cuda.Event()          # the G step's three losses are enqueued (main; l_g_fea maybe on side)
@@ -284,9 +294,11 @@ class ESRGANPlusStep:
                         aux = d_step()
             # dL/d fake_H: + d l_gan (netD, first pair) + d l_fea (netF), added by the passes' last layout ops
             CN.run_pass_into(PD.second, gx_into=gy, accumulate=True)
+            mark('netD input-gradient pass (G step)')
             if nf_side:
                 main.wait_event(ev_f)
                 gy.add_(gy2)
+                mark('wait for netF(fake) pass, add')
             else:
                 CN.run_pass_into(PF, gx_into=gy, accumulate=True)
             if ov >= 1 and d_when == 'mid':
@@ -295,6 +307,7 @@ class ESRGANPlusStep:
             if ev_prep is not None:
                 main.wait_event(ev_prep)
             Fn.rrdbnet_train_backward(netG, stG, gy)
+            mark('G backward (tail, chain, weight gradients, unpermute)')
             self.exG.start()
             if ov >= 1:
                 if d_when == 'last':
@@ -357,6 +370,7 @@ class ESRGANPlusStep:
                 self.optimizer_G.step(grad_scale=inv, scaler=None)
                 if self.prepack:
                     netG.prepack(fwd=True, dgrad=False)
+                mark('Adam(G), forward weight pack')
                 side.wait_stream(main)                        # G's new weights (its input-gradient packs read them)
                 with torch.cuda.stream(side):
                     self.exD.wait()
