@@ -234,7 +234,7 @@ EXPORTS = ['esr_packed_weight_bytes', 'esr_g32_dims', 'esr_conv_forward', 'esr_p
            'esr_rdb_max_tiles_per_image', 'esr_gather_fragments', 'esr_image_metrics', 'esr_wgrad_workspace_elems',
            'esr_l1_loss_forward', 'esr_ragan_loss_forward', 'esr_rdb_wgrad_run', 'esr_rdb_wgrad_workspace_elems', 'esr_rdb_backward',
            'esr_rdb_mask_bytes', 'esr_rdb_check_abort', 'esr_debug_hold_cus', 'esr_debug_device_alias', 'esr_debug_chain_order_waits',
-           'esr_debug_mfma_probe']
+           'esr_debug_mfma_probe', 'esr_debug_rdb_wgrad_follow']
 
 _lib = None
 _lock = threading.Lock()

@@ -37,7 +37,7 @@ int esr_check_launch(const char* what) {
   } while (0)
 
 extern "C" const char* esr_last_error(void) { return g_err; }
-extern "C" int esr_abi_version(void) { return 5; }   // 5: round 5 (esr_rdb_wgrad.max_workgroups, per-device bookkeeping diagnostics); 4: round 4 (esr_conv.ksplit ..., BN_FIN_APPLY / BN_RESTAT); 3: round 3 (esr_ragan_loss modes, esr_rdb_backward, esr_rdb_wgrad)
+extern "C" int esr_abi_version(void) { return 6; }   // 6: round 6 (ESR_OPF_FOLLOW, esr_debug_rdb_wgrad_follow); 5: round 5 (esr_rdb_wgrad.max_workgroups, per-device bookkeeping diagnostics); 4: round 4 (esr_conv.ksplit ..., BN_FIN_APPLY / BN_RESTAT); 3: round 3 (esr_ragan_loss modes, esr_rdb_backward, esr_rdb_wgrad)
 extern "C" size_t esr_sizeof_op(void) { return sizeof(esr_op); }
 
 extern "C" void esr_g32_dims(int32_t H, int32_t W, int32_t* Hp, int32_t* Wp) {

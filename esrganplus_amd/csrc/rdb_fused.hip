@@ -5,6 +5,7 @@
 #include <atomic>
 #include <mutex>
 
+int esr_rdb_wgrad_run_follow(const esr_rdb_wgrad* p, esr_stream_t stream, const uint32_t* flags, int tiles_x, int tiles_y, unsigned* host_abort);   // rdb_wgrad.hip
 // defined next to their kernels
 int esr_rdb_launch_train(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
 int esr_rdb_launch_bwd(const esr_rdb_chain& p, int grid, int ntiles, int tiles_x, int tiles_y, unsigned* host_abort, hipStream_t st);
@@ -348,10 +349,13 @@ void esr_chain_graph_after(hipStream_t st, int cus) { chain_record_launch(st, cu
 extern "C" int esr_rdb_forward(const esr_rdb_chain* p, esr_stream_t stream) { return chain_launch(p, stream, "esr_rdb_forward", 0); }
 extern "C" int esr_rdb_backward(const esr_rdb_chain* p, esr_stream_t stream) { return chain_launch(p, stream, "esr_rdb_backward", 2); }
 
+extern "C" int esr_debug_rdb_wgrad_follow(const esr_rdb_wgrad* p, const uint32_t* flags, int32_t tiles_x, int32_t tiles_y, esr_stream_t stream) {
+  return esr_rdb_wgrad_run_follow(p, stream, flags, tiles_x, tiles_y, abort_word_dev(esr_bookkeeping_device()));
+}
+
 // esr_run_ops (api.hip): the backward chain with a follower pass of weight gradients on `side` (rdb_wgrad.hip:
 // esr_rdb_wgrad_run_follow).  Order on the device: [clear of the chain's flags] -> chain kernel (stream) and, behind the
 // clear only, the follower (side): it polls the flags of the launch that runs next to it.
-int esr_rdb_wgrad_run_follow(const esr_rdb_wgrad* p, esr_stream_t stream, const uint32_t* flags, int tiles_x, int tiles_y, unsigned* host_abort);
 int esr_rdb_backward_with_follower(const esr_rdb_chain* ch, const esr_rdb_wgrad* wg, hipStream_t stream, hipStream_t side, hipEvent_t fork) {
   ChainFollow fol{};
   fol.after_clear = fork;

@@ -622,8 +622,8 @@ int esr_rdb_forward(const esr_rdb_chain* p, esr_stream_t stream);
  * launches; the weight gradients follow with esr_rdb_wgrad_run over the Q buffers this launch leaves complete. */
 int esr_rdb_backward(const esr_rdb_chain* p, esr_stream_t stream);
 size_t esr_rdb_mask_bytes(int32_t B, int32_t H, int32_t W);   /* esr_rdb_block.mask of one block */
-/* Sticky abort report: 1 if a chain launch since the last call gave up on a bounded spin (its results are invalid;
- * e.g. another kernel held CUs for > 1 s), else 0.  Reads a pinned host word: no synchronisation, but only meaningful
+/* Sticky abort report: 1 if a chain launch — or a follower pass of weight gradients (ESR_OPF_FOLLOW) waiting for one —
+ * since the last call gave up on a bounded spin (its results are invalid; e.g. another kernel held CUs for > 1 s), else 0.  Reads a pinned host word: no synchronisation, but only meaningful
  * for launches that have completed.  esr_run_ops / esr_rdb_forward / esr_rdb_backward check it on entry and fail with
  * ESR_ERR_LAUNCH, so an aborted launch cannot go unnoticed past the next call. */
 int esr_rdb_check_abort(void);
@@ -637,6 +637,11 @@ int esr_debug_hold_cus(int32_t n_workgroups, const uint32_t* release, uint32_t m
  * (four A and four B fragments per lane: zeros reach the quoted 2.5 PFLOP/s, random values ~1.65 on MI355X).  clk2[0] /
  * clk2[1] = shader-clock / 100 MHz ticks the loop took on workgroup 0; sink: 4 bytes nothing is written to. */
 int esr_debug_mfma_probe(const void* operands, int32_t iters, uint64_t* clk2, float* sink, int32_t n_workgroups, esr_stream_t stream);
+/* Diagnostic (tests/test_gpu_train_chain.py: a follower without its chain): the follower form of esr_rdb_wgrad_run
+ * (ESR_OPF_FOLLOW) against `flags` — tiles_x * tiles_y words per image that the caller controls instead of a chain
+ * launch.  A follower whose flags never rise gives up after 2 s, raises the abort word (esr_rdb_check_abort) and runs
+ * to its end on whatever is in its inputs. */
+int esr_debug_rdb_wgrad_follow(const struct esr_rdb_wgrad* p, const uint32_t* flags, int32_t tiles_x, int32_t tiles_y, esr_stream_t stream);
 /* Library state and devices.  What the library keeps between calls — the chain launches in flight (the ordering above),
  * the abort word, the side streams of ESR_OPF_SIDE runs — is keyed by the CURRENT DEVICE of the calling thread:
  * nn.DataParallel's one-thread-per-device replicas (networks.py:105-107) never wait for, or report the aborts of, each
@@ -690,7 +695,7 @@ int esr_graph_destroy(esr_graph_t g);
 int esr_run_ops_timed(const esr_op* ops, int32_t n, esr_stream_t stream, float* ms_out);
 
 const char* esr_last_error(void);
-int esr_abi_version(void);   /* 5 (round 5: esr_rdb_wgrad.max_workgroups, esr_debug_device_alias / esr_debug_chain_order_waits); 4 (round 4: esr_conv.ksplit / split_ws / stat_sums, ESR_BN_FIN_APPLY / ESR_BN_RESTAT); 3 (round 3: esr_ragan_loss.mode / sums / ext, ...; 2 = round 2: esr_bn.groups / num_batches_tracked,
+int esr_abi_version(void);   /* 6 (round 6: ESR_OPF_FOLLOW, esr_debug_rdb_wgrad_follow); 5 (round 5: esr_rdb_wgrad.max_workgroups, esr_debug_device_alias / esr_debug_chain_order_waits); 4 (round 4: esr_conv.ksplit / split_ws / stat_sums, ESR_BN_FIN_APPLY / ESR_BN_RESTAT); 3 (round 3: esr_ragan_loss.mode / sums / ext, ...; 2 = round 2: esr_bn.groups / num_batches_tracked,
                                 esr_l1_loss, esr_ragan_loss, ESR_OPF_SIDE_FREE) */
 size_t esr_sizeof_op(void);
 

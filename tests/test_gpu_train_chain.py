@@ -224,3 +224,46 @@ def test_backward_chain_split_into_runs_is_bit_identical(dev, monkeypatch, cls_n
     for split in ('4', '5', 'follow', 'auto', 'first4'):
         bad = [k for k, g in res['1'][2].items() if not torch.equal(g, res[split][2][k])]
         assert not bad, (split, bad[:6])
+
+
+def test_follower_without_its_chain_gives_up_and_is_reported(dev, monkeypatch):
+    """The follower pass of weight gradients (ESR_OPF_FOLLOW) polls the flags of the chain launch that runs next to it.
+    If that chain never raises them (it aborted, or never got its CUs) the follower must not hang the device: every wait
+    is bounded (2 s, once per launch: a `dead` word lets all later waits return at once), the pass runs to its end, and
+    the library's abort word makes the NEXT library call fail loudly.  Here the pass of a real training plan is
+    launched through esr_debug_rdb_wgrad_follow against flags that stay zero."""
+    import ctypes as C
+    import time
+    from esrganplus_amd import architecture as arch
+    monkeypatch.setenv('ESR_BWD_FOLLOW', '1')
+    monkeypatch.delenv('ESR_BWD_SPLIT', raising=False)
+    nb = 2                                   # (one RRDB runs the chain as one launch with the pass behind it: nothing to follow)
+    sd = synth.rrdbnet_state_dict(nb=nb, seed=81, gain=0.7)
+    x = synth.image_batch(81, 16, 3, 32, 32, name='fol.x').to(dev)
+    gy = synth.normal_like(82, 'fol.gy', (16, 3, 128, 128)).to(dev)
+    net = arch.RRDBNet(3, 3, 64, nb).to(dev).train().set_precision('fp16')
+    net.load_state_dict(sd, strict=True)
+
+    def grads():
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(5)
+        (net(x) * gy).sum().backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in net.named_parameters()}
+    g0 = grads()
+    tp = [t for pool in net._plans.values() if isinstance(pool, list) for t in pool if getattr(t, 'bwd_chain_ops', None)][0]
+    fol = [o for o in tp.bwd.ops if o.kind == L.OP_RDB_WGRAD and (o.flags & L.OPF_FOLLOW)]
+    assert len(fol) == 1
+    rw = fol[0].u.rdb_wgrad
+    flags = torch.zeros(16 * 8, dtype=torch.int32, device=dev)          # 16 images x 8 four-row tiles, never raised
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    L.check(L.lib().esr_debug_rdb_wgrad_follow(C.byref(rw), C.c_void_p(flags.data_ptr()), 1, 8,
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'esr_debug_rdb_wgrad_follow')
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert 1.5 <= dt <= 8.0, dt                                          # one bounded wait, not one per task
+    with pytest.raises(RuntimeError, match='aborted'):
+        net(x)
+    g1 = grads()                                                         # the call after that works again, same results
+    assert all(torch.equal(g0[k], g1[k]) for k in g0)

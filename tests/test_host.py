@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_struct_mirror_sizes(built):
     L = built.lib()
     assert L.esr_sizeof_op() == ctypes.sizeof(built.esr_op)
-    assert L.esr_abi_version() == 5
+    assert L.esr_abi_version() == 6
     assert built.packed_weight_bytes(32, 64, 3, built.ESR_F16) == 1 * 4 * 9 * 1024
     assert built.packed_weight_bytes(64, 192, 3, built.ESR_F32) == 2 * 24 * 9 * 1024
     assert built.g32_dims(128, 128) == (134, 130)
