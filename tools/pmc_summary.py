@@ -18,7 +18,7 @@ def short(name):
     m = re.search(r'rdb_chain_kernelI(DF16_|f)(?:Li(\d)E)?', name)
     if m:
         return 'rdb_chain<%s,%s>' % ('f16' if m.group(1) != 'f' else 'f32', {'0': 'forward', '1': 'train-forward', '2': 'backward'}.get(m.group(2) or '0'))
-    m = re.search(r'(rdb_wgrad_reduce_kernel|rdb_wgrad_kernel|wgrad_reduce_kernel)', name)
+    m = re.search(r'(rdb_wgrad_reduce_kernel|rdb_wgrad_follow_kernel|rdb_wgrad_kernel|wgrad_reduce_kernel)', name)
     if m:
         return m.group(1)
     m = re.search(r'(wgrad16_kernel<[^>]*>|wgrad_kernel\w*|pack_batch_kernel|unpermute_kernel|bn_\w+|pool_kernel\w*|linear_\w+)', name)

@@ -23,7 +23,7 @@ def parse(path):
 import os
 if os.path.exists('profiles/%s_train_pmc_summary.txt' % tag):      # tools/pmc_train.sh: the train step's shape
     ROWS.update({'rdb_chain_train@train': ('train', 'rdb_chain<f16,train-forward>'), 'rdb_chain_bwd@train': ('train', 'rdb_chain<f16,backward>'),
-                 'rdb_wgrad@train': ('train', 'rdb_wgrad_kernel')})
+                 'rdb_wgrad@train': ('train', 'rdb_wgrad_follow_kernel')})     # round 6: the follower form of the pass (csrc/rdb_wgrad.hip)
 S = {k: parse('profiles/%s_%s_pmc_summary.txt' % (tag, k)) for k in ('fwd', 'fwdbwd', 'train') if os.path.exists('profiles/%s_%s_pmc_summary.txt' % (tag, k))}
 J = json.load(open('profiles/roofline_traffic.json'))
 for row, (which, name) in ROWS.items():
