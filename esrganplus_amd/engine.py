@@ -1148,6 +1148,9 @@ class TrainPlan:
         self.segments = None         # segmented backward: [(op_end, elem_lo, elem_hi)] — after ops [.., op_end) the
                                      # gradients in flat[elem_lo:elem_hi] are final (see build_rrdbnet_train_plan)
         self.graph = False           # hipGraph replay with I/O bound to the static tensors below
+        self.follow_op = None        # index of the ESR_OPF_FOLLOW weight-gradient op of the backward list (follow_spare: the CUs its
+        self.follow_spare = 0        # chain leaves free; follow_wgs: the plan's default grid)
+        self.follow_wgs = 0
         self.bwd_chain_ops = []      # indices of OP_RDB_CHAIN_BWD ops in the backward list (noise mode / seed per run)
         self.bwd_streams = None      # RdbBwdStreams feeding them
 
@@ -1598,6 +1601,9 @@ def build_rrdbnet_train_plan(net, wp, dp, nb, in_nc, out_nc, B, H, W, dtype, dev
             # each: round-5 form 6.52 ms; follower on 40 / 48 / 56 / 64 / 72 / 80 / 88 / 96 / 128 workgroups 7.33 / 6.86 /
             # 6.52 / 6.28 / 6.29 / 6.26 / 6.27 / 6.23* / 6.57* (* another box: 6.42 without).  ESR_BWD_FOLLOW_WGS: A/B knob)
             wgrad_op(wblocks, warena, flags=_SIDE | L.OPF_FOLLOW, max_wg=env_int('ESR_BWD_FOLLOW_WGS', min(spare_, 80), 32, max(32, spare_)))
+            # (functional._train_backward: a caller may size the follower per run — the train step's logging form)
+            TP.follow_op, TP.follow_spare = len(Bk.ops) - 1, spare_
+            TP.follow_wgs = Bk.ops[TP.follow_op].u.rdb_wgrad.max_workgroups
         elif nsplit > 1:
             # Small grids (the reference's training crops: 16 x 32^2 LR = 128 four-row tiles on 256 CUs): the chain leaves
             # half of the chip idle and the weight gradients — 0.7 ms behind a 1.9 ms chain — sit on the step's critical

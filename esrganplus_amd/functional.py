@@ -103,8 +103,10 @@ def _train_forward(tp, xin, st, seed, zs):
     return out
 
 
-def _train_backward(tp, gy, st, noise, explicit, seed, want_gx, sync=None, prepared=False):
+def _train_backward(tp, gy, st, noise, explicit, seed, want_gx, sync=None, prepared=False, follow_wgs=None):
     """Runs the backward launch list; returns dL/dx (stand-alone blocks) or None.
+    follow_wgs: workgroups of the follower pass of weight gradients for THIS run (None: the plan's default); the
+    results do not depend on it.
     prepared: the gradient buffers are zeroed and the backward chain's weight streams gathered already
     (`rrdbnet_train_prepare`, on another stream the caller has ordered in front of this one)."""
     if not prepared:
@@ -138,6 +140,9 @@ def _train_backward(tp, gy, st, noise, explicit, seed, want_gx, sync=None, prepa
     for i in tp.bwd_noise_ops:
         arr[i].u.conv.noise_mode = mode
         arr[i].u.conv.seed = seed
+    if tp.follow_op is not None:
+        arr[tp.follow_op].u.rdb_wgrad.max_workgroups = (max(32, min(int(follow_wgs), tp.follow_spare)) if follow_wgs
+                                                        else tp.follow_wgs)
     for i in tp.bwd_chain_ops:                      # fused backward chain (esr_rdb_backward): same Philox key as the forward
         arr[i].u.rdb_chain.noise_mode = L.NOISE_PHILOX if noise else L.NOISE_OFF
         arr[i].u.rdb_chain.seed = seed
@@ -357,7 +362,7 @@ def rrdbnet_train_prepare(net, s):
     s.prepared = True
 
 
-def rrdbnet_train_backward(net, s, gy):
+def rrdbnet_train_backward(net, s, gy, follow_wgs=None):
     """The backward of ``rrdbnet_train_forward``: parameter gradients into the module's flat store (every parameter's
     ``.grad`` = its view of it, block._PlannedModule._deliver_flat_grads); dL/dx is not formed."""
     tp = s.lease.tp
@@ -365,7 +370,8 @@ def rrdbnet_train_backward(net, s, gy):
         raise RuntimeError('rrdbnet_train_backward called twice on one forward')
     if not s.prepared:
         net._release_adopted(tp.grad_flat)
-    _train_backward(tp, gy, E.current_stream(), s.noise, s.explicit, s.seed, False, s.sync, prepared=s.prepared)
+    _train_backward(tp, gy, E.current_stream(), s.noise, s.explicit, s.seed, False, s.sync, prepared=s.prepared,
+                    follow_wgs=follow_wgs)
     net._deliver_flat_grads(tp.grad_flat, adopt=_ADOPT)
     s.lease.release()
 

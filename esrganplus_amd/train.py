@@ -72,6 +72,15 @@ class ESRGANPlusStep:
         # G-step pass on the main stream (both hang off fake_H only; their two contributions to dL/d fake_H meet in one add)
         self.netf_side = os.environ.get('ESR_TRAIN_NETF_SIDE', '1') == '1'
         self.d_when = self._knob('ESR_TRAIN_DSTEP', 'last', ('first', 'mid', 'last'))       # see _step_manual
+        # The logging form (sync_log=True: the host reads the losses every step and the call returns with the D-side tail
+        # ordered on the caller's stream) wants the D step EARLY and the follower pass of G's weight gradients BIG: the main
+        # stream waits for the side stream's tail at the end of the call, so what the D step gains by running late under the
+        # backward chain is lost again.  Round 6, same box, ms per logging-form step (tools/train_marks.py sync, two runs):
+        # last / 80 workgroups 7.06 / 7.02; first / 96: 6.90 / 7.02; first / 112: 6.65 / 6.68; mid / 112: 6.66 / 6.63; first /
+        # 128: 6.59 / 6.66; mid / 128: 6.60 / 6.58.  An explicit ESR_TRAIN_DSTEP / ESR_BWD_FOLLOW_WGS rules both forms.
+        self.d_when_sync = self._knob('ESR_TRAIN_DSTEP_SYNC', os.environ.get('ESR_TRAIN_DSTEP', 'mid'), ('first', 'mid', 'last'))
+        fw = os.environ.get('ESR_TRAIN_SYNC_FOLLOW_WGS', '' if os.environ.get('ESR_BWD_FOLLOW_WGS') else '128')
+        self.follow_wgs_sync = int(fw) if fw else None
         # host enqueue order of netD's forward vs netF(fake)
         self.order = self._knob('ESR_TRAIN_ORDER', 'main_first', ('main_first', 'side_first'))
         self.tail_side = os.environ.get('ESR_TRAIN_TAIL_SIDE', '1') == '1'
@@ -286,7 +295,7 @@ class ESRGANPlusStep:
             # Where the HOST enqueues it matters as much: the D step is ~60 launches (~1 ms of host time) during which the
             # main stream gets nothing new.  'mid': the main stream's netD / netF input-gradient passes (two C calls,
             # ~0.9 ms of GPU work) go out first and run while the host enqueues the D step; the G backward follows.
-            d_when = self.d_when
+            d_when = self.d_when_sync if sync_log else self.d_when
             if ov >= 1:
                 side.wait_stream(main)
                 if d_when == 'first':
@@ -306,7 +315,7 @@ class ESRGANPlusStep:
                     aux = d_step()
             if ev_prep is not None:
                 main.wait_event(ev_prep)
-            Fn.rrdbnet_train_backward(netG, stG, gy)
+            Fn.rrdbnet_train_backward(netG, stG, gy, follow_wgs=self.follow_wgs_sync if sync_log else None)
             mark('G backward (tail, chain, weight gradients, unpermute)')
             self.exG.start()
             if ov >= 1:
