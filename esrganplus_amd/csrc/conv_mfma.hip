@@ -965,7 +965,14 @@ int dispatch(const esr_conv& p, hipStream_t st) {
       }
       return cbk == 1 ? launch_ts2_packed<T, 1>(p, st) : launch_ts2_packed<T, 2>(p, st);
     }
-    return cbk == 1 ? launch<T, 4, 1, 2, 4, 2, 1, 1, true, false>(p, st) : launch<T, 4, 1, 2, 4, 2, 1, 2, true, false>(p, st);
+    // several cout blocks: ONE per workgroup while that still leaves the grid below one workgroup per CU (the input
+    // gradients of the discriminators' deep stride-2 layers at training batches: 128 workgroups streamed 512 x 512 x 16
+    // weights for two blocks each — 75 us; as the 3x3 dispatch above does), two per wave otherwise
+    const int64_t tiles_t = (int64_t)((p.W + Geo<4, 1, 2, 4, 2, 1, 2, true, false, false, 4>::TW - 1) / Geo<4, 1, 2, 4, 2, 1, 2, true, false, false, 4>::TW) *
+                            ((p.H + Geo<4, 1, 2, 4, 2, 1, 2, true, false, false, 4>::TH - 1) / Geo<4, 1, 2, 4, 2, 1, 2, true, false, false, 4>::TH) * p.B;
+    static const bool ts2_one = [] { const char* e = getenv("ESR_TS2_ONE"); return !e || atoi(e) != 0; }();
+    if (cbk == 1 || (ts2_one && tiles_t * ((cbk + 1) / 2) < 256)) return launch<T, 4, 1, 2, 4, 2, 1, 1, true, false>(p, st);
+    return launch<T, 4, 1, 2, 4, 2, 1, 2, true, false>(p, st);
   }
   if (p.ks == 3 && p.stride == 1 && p.upsample == 1) {
     if ((p.H | p.W) & 1) { esr_set_error("conv: upsample needs even output size"); return ESR_ERR_INVALID; }
