@@ -267,3 +267,30 @@ def test_follower_without_its_chain_gives_up_and_is_reported(dev, monkeypatch):
         net(x)
     g1 = grads()                                                         # the call after that works again, same results
     assert all(torch.equal(g0[k], g1[k]) for k in g0)
+
+
+@pytest.mark.parametrize('shape', [(4, 3, 32, 64), (3, 3, 20, 40), (2, 3, 64, 96)])
+def test_follower_on_several_column_strips_and_ragged_tiles(dev, monkeypatch, shape):
+    """The follower reads the chain's flags of exactly the tiles a task covers: column strip sx of its images, every tile
+    row.  Shapes with two / three column strips, ragged last tiles and fewer images than a task takes — every gradient
+    equals the two-launch form (ESR_BWD_FOLLOW=0) bit for bit, noise on."""
+    from esrganplus_amd import architecture as arch
+    nb = 2
+    sd = synth.rrdbnet_state_dict(nb=nb, seed=91, gain=0.7)
+    x = synth.image_batch(91, *shape, name='folshape.x').to(dev)
+    gy = synth.normal_like(92, 'folshape.gy', (shape[0], 3, 4 * shape[2], 4 * shape[3])).to(dev)
+    res = {}
+    for follow in ('0', '1'):
+        monkeypatch.setenv('ESR_BWD_FOLLOW', follow)
+        monkeypatch.delenv('ESR_BWD_SPLIT', raising=False)
+        net = arch.RRDBNet(3, 3, 64, nb).to(dev).train().set_precision('fp16')
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(7)
+        (net(x) * gy).sum().backward()
+        torch.cuda.synchronize()
+        tp = [t for pool in net._plans.values() if isinstance(pool, list) for t in pool if getattr(t, 'bwd_chain_ops', None)][0]
+        nfol = sum(1 for o in tp.bwd.ops if o.kind == L.OP_RDB_WGRAD and (o.flags & L.OPF_FOLLOW))
+        res[follow] = (nfol, {k: p.grad.clone() for k, p in net.named_parameters()})
+    assert res['0'][0] == 0 and res['1'][0] == 1, (res['0'][0], res['1'][0])
+    bad = [k for k, g in res['0'][1].items() if not torch.equal(g, res['1'][1][k])]
+    assert not bad, bad[:6]
