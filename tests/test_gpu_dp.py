@@ -187,14 +187,21 @@ def test_train_step_two_ranks_equals_global_batch_loss(dev, world):
     import torch.multiprocessing as mp
     import torch.nn.functional as F
     ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_step_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted((q.get(timeout=900) for _ in procs), key=lambda r: r[0])
-    for p in procs:
-        p.join(timeout=60)
+    # `world` processes on one GPU over a loopback rendezvous: a rank that dies of the INFRASTRUCTURE (rendezvous, a
+    # context that does not come up next to seven others — seen once in ~20 runs on a fresh box) gets one more
+    # attempt; what the ranks computed is never retried
+    for attempt in range(2):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_step_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted((q.get(timeout=900) for _ in procs), key=lambda r: r[0])
+        for p in procs:
+            p.join(timeout=60)
+        if all(r[1] == 'ok' for r in res) or attempt == 1:
+            break
+        print('attempt 1 failed on the worker side, retrying once:', [r[1][:300] for r in res if r[1] != 'ok'])
     assert all(r[1] == 'ok' for r in res), [r[1] for r in res]
     # all ranks hold the same averaged gradients
     for r in range(1, world):
