@@ -159,10 +159,10 @@ struct KArgs {
 // chain leaves free: a task of block k (the chain's k-th block; the pass lists its blocks in the chain's order) starts
 // when every tile it reads has published the end of block k — the chain's own hand-off flags, value 5 (k + 1), read
 // with agent-scope loads; the gradient slices were written through to the L2 in front of the flag (rdb_chain_kernel.h:
-// publish) and are staged here with sc1 loads.  The reduction of a block's task slots is done by whichever workgroup
-// finishes the block's last task (arrival counter, release / acquire at agent scope) in the same slot order as the
-// reduce kernel: results are bit-identical to the two-launch form, and what is left behind the chain is the last
-// block's tasks.  Waits are bounded (a chain that aborted never raises its flags): a time-out raises the library's
+// publish) and are staged here with sc1 loads.  The reduction of a block's task slots rides on the compute tasks one
+// grid round later (rdb_wgrad_follow_kernel: arrival counter per block, write-through slot stores in front of it,
+// L1-bypassing loads behind it — no fences) in the same slot order as the reduce kernel: results are bit-identical to
+// the two-launch form, and what is left behind the chain is the last block's tasks.  Waits are bounded (a chain that aborted never raises its flags): a time-out raises the library's
 // abort word and lets the pass run to its end on whatever is there — the next library call reports it.
 __device__ __forceinline__ void follow_wait(const KArgs& ka, const int blk, const int chunk) {
   // wave 0: one flag per lane, 64 at a time
